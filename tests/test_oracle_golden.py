@@ -1,0 +1,132 @@
+"""Pin the CPU oracle (oracle/) against golden vectors produced by the reference's own Python
+(tools/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import assert_rank_close, canonicalise
+from oracle import oracle as orc
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _block_list(g):
+    ptr, idx = g["block_ptr"], g["block_idx"]
+    return [idx[ptr[i]:ptr[i + 1]].tolist() for i in range(len(ptr) - 1)]
+
+
+@pytest.mark.parametrize("name,sim,trunc", [
+    ("g1_ranking_dot.npz", "dot", False),
+    ("g4_ranking_trunc.npz", "dot", True),
+])
+def test_canonical_ranking_matches_reference_dot(golden_dir, name, sim, trunc):
+    g = _load(golden_dir, name)
+    ids, sc = orc.canonical_ranking(g["Eq"], g["Ed"], sim)
+    assert ids.shape[1] == min(1001, g["Ed"].shape[0])
+    # inputs are bf16-exact, so the only difference is fp32 (MKL) vs fp64 accumulation
+    assert_rank_close(ids, sc, g["ids"], g["scores"], tol=2e-6, truncated=trunc)
+
+
+def test_reference_faithful_restatement_dot(golden_dir):
+    g = _load(golden_dir, "g1_ranking_dot.npz")
+    ids, sc = orc.reference_ranking(g["Eq"], g["Ed"], int(g["batch_size"]), "dot")
+    ci, cs = canonicalise(ids, sc)
+    assert_rank_close(ci, cs, g["ids"], g["scores"], tol=1e-6)
+
+
+def test_cos_ranking(golden_dir):
+    g = _load(golden_dir, "g2_ranking_cos.npz")
+    # faithful fp32 restatement reproduces the reference to fp32 noise
+    ids, sc = orc.reference_ranking(g["Eq"], g["Ed"], int(g["batch_size"]), "cos")
+    ci, cs = canonicalise(ids, sc)
+    assert_rank_close(ci, cs, g["ids"], g["scores"], tol=1e-6)
+    # canonical path rounds the normalised rows to bf16: scores within the 1e-3 bf16 tolerance
+    ids2, sc2 = orc.canonical_ranking(g["Eq"], g["Ed"], "cos")
+    assert_rank_close(ids2, sc2, g["ids"], g["scores"], tol=1e-3)
+    assert orc.recall_at_k(g["ids"][:, :12], ids2[:, :10]) > 0.95  # our top-10 inside the reference top-12
+
+
+def test_block_dict(golden_dir):
+    g = _load(golden_dir, "g3_ranking_block.npz")
+    block = _block_list(g)
+    ids, sc = orc.canonical_ranking(g["Eq"], g["Ed"], "dot", block=block)
+    ref_i, ref_s = g["ids"], g["scores"]
+    for q, b in enumerate(block):
+        nb = len(b)
+        # blocked ids are kept, scored -1e6, and sort last
+        assert set(ids[q, -nb:].tolist()) == set(b)
+        assert np.all(sc[q, -nb:] == np.float32(-1e6))
+        assert set(ref_i[q, -nb:].tolist()) == set(b)
+        assert q in b  # self-block as in prime_pantry
+    ri, rs = canonicalise(ref_i, ref_s)
+    assert_rank_close(ids, sc, ri, rs, tol=2e-6)
+    with pytest.raises(AssertionError, match="block id not found"):
+        orc.canonical_ranking(g["Eq"][:1], g["Ed"], "dot", block=[[10 ** 6]])
+
+
+def test_exact_arithmetic_ties(golden_dir):
+    g = _load(golden_dir, "g5_ranking_exact_ties.npz")
+    ids, sc = orc.canonical_ranking(g["Eq"], g["Ed"], "dot")
+    ri, rs = canonicalise(g["ids"], g["scores"])
+    # every partial sum is exactly representable: bit-for-bit agreement, ties by ascending id
+    assert np.array_equal(sc.view(np.uint32), rs.view(np.uint32))
+    assert np.array_equal(ids, ri)
+    # the engineered 31-way tie is present and ordered by index
+    for q in range(ids.shape[0]):
+        pos = np.nonzero(np.isin(ids[q], np.r_[100, 200:230]))[0]
+        assert len(pos) == 31 and np.all(np.diff(pos) == 1)
+        assert np.all(np.diff(ids[q][pos]) > 0)
+
+
+def test_item_tower_pooling(golden_dir):
+    g = _load(golden_dir, "g6_item_tower.npz")
+    mp = orc.meanpool(g["hidden"], g["mask"])
+    np.testing.assert_allclose(mp, g["mean_pooling"], rtol=2e-6, atol=2e-6)
+    np.testing.assert_array_equal(g["hidden"][:, 0], g["cls"])
+    np.testing.assert_allclose(orc.layer_norm(g["hidden"][:, 0]), g["mean_layer_norm"], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag,B,sim", [("b8_dot", 8, "dot"), ("b32_dot", 32, "dot"), ("b8_cos", 8, "cos"), ("b32_cos", 32, "cos")])
+def test_contrastive_loss_and_grads(golden_dir, tag, B, sim):
+    g = _load(golden_dir, "g7_contrastive.npz")
+    E = g[f"{tag}_E"]
+    loss, dQ, dP, dN = orc.inbatch_ce(E[:B], E[B:2 * B], E[2 * B:], 20.0, sim)
+    assert abs(loss - float(g[f"{tag}_loss"])) < 2e-5 * max(1.0, abs(loss))
+    grad = np.concatenate([dQ, dP, dN], 0)
+    np.testing.assert_allclose(grad, g[f"{tag}_grad"], rtol=2e-4, atol=2e-6)
+
+
+def test_assign_topk(golden_dir):
+    g = _load(golden_dir, "g8_assign_topk.npz")
+    k = int(g["k"])
+    ids, sc = orc.canonical_search(orc.pack_bf16(g["U"]), orc.pack_bf16(g["V"]), k)
+    ref = g["indices"]
+    ref_sc = np.take_along_axis((g["U"].astype(np.float64) @ g["V"].astype(np.float64).T), ref, 1).astype(np.float32)
+    assert_rank_close(ids, sc, ref, ref_sc, tol=2e-6, truncated=True)
+    assert np.array_equal(g["indptr"], np.arange(0, ref.size + 1, k))
+
+
+def test_pack_bf16_bits(golden_dir):
+    g = _load(golden_dir, "g9_pack_bf16.npz")
+    bits = orc.pack_bf16(g["x"])
+    assert np.array_equal(bits, g["bits"])
+    np.testing.assert_array_equal(orc.unpack_bf16(bits).view(np.uint32) >> 16, bits.astype(np.uint32))
+
+
+def test_merge_topk_is_topk_of_union():
+    rs = np.random.RandomState(0)
+    R, nq, k = 3, 5, 16
+    sc = rs.randint(-50, 50, size=(R, nq, k)).astype(np.float32)   # many ties
+    ids = np.stack([rs.permutation(1000)[: nq * k].reshape(nq, k) + 1000 * r for r in range(R)]).astype(np.int64)
+    for r in range(R):
+        for q in range(nq):
+            o = np.lexsort((ids[r, q], -sc[r, q]))
+            sc[r, q], ids[r, q] = sc[r, q][o], ids[r, q][o]
+    ms, mi = orc.merge_topk(sc, ids)
+    for q in range(nq):
+        alls, alli = sc[:, q].ravel(), ids[:, q].ravel()
+        o = np.lexsort((alli, -alls))[:k]
+        assert np.array_equal(mi[q], alli[o]) and np.array_equal(ms[q], alls[o])

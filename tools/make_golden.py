@@ -1,0 +1,272 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by RUNNING the reference's own Python.
+
+Dev-container only: needs /root/reference (never present on the GPU box).  The
+fixtures written to tests/golden/*.npz contain arrays only (inputs + the outputs
+the reference produced); no reference source travels.
+
+Recipe:
+  * inert stub modules for the four third-party packages the reference imports
+    but this image lacks (pytorch_lightning, tensorboard, shap, beir);
+  * /root/reference/{src,scripts} on sys.path, CCREC_* env set before import;
+  * Tensor.cuda / cuda.synchronize no-op'd (that *is* the reference CPU path).
+
+Fixtures:
+  G1 ranking() dot                G2 ranking() cos
+  G3 ranking() with block_dict    G4 ranking() N>1001 (truncation to 1001)
+  G5 exact-arithmetic corpus with engineered ties
+  G6 NaiveItemTower.forward (mean_pooling / cls / mean_layer_norm)
+  G7 multiple_nrl in-batch-negative loss + autograd grads
+  G8 _assign_topk on a MatMulExpression
+  G9 fp32->bf16 RNE bit patterns (torch, not the reference)
+"""
+import contextlib
+import importlib.abc
+import importlib.machinery
+import io
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+STUB_ROOTS = {"pytorch_lightning", "tensorboard", "shap", "beir"}
+
+
+class _Dummy:
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return None
+
+
+class _LightningModule(torch.nn.Module):
+    hparams = {}
+
+    def save_hyperparameters(self, *a, **k):
+        pass
+
+    def log(self, *a, **k):
+        pass
+
+
+class _StubModule(types.ModuleType):
+    __path__ = []
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        if name == "LightningModule":
+            return _LightningModule
+        if name == "LightningDataModule":
+            return type("LightningDataModule", (object,), {})
+        return type(name, (_Dummy,), {})
+
+
+class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    def find_spec(self, fullname, path=None, target=None):
+        if fullname.split(".")[0] in STUB_ROOTS:
+            return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        return _StubModule(spec.name)
+
+    def exec_module(self, module):
+        pass
+
+
+def _import_reference(sim_type="dot"):
+    os.environ["CCREC_SIM_TYPE"] = sim_type
+    os.environ.setdefault("CCREC_EMBEDDING_TYPE", "mean_pooling")
+    os.environ.setdefault("CCREC_MAX_LENGTH", "256")
+    os.environ.setdefault("CCREC_BBPR_INV_TEMPERATURE", "20")
+    if not any(isinstance(f, _StubFinder) for f in sys.meta_path):
+        sys.meta_path.insert(0, _StubFinder())
+    for p in (f"{REF}/src", f"{REF}/scripts"):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.cuda.synchronize = lambda *a, **k: None
+    with contextlib.redirect_stdout(io.StringIO()):
+        import ms_marco_eval  # noqa: F401
+        import ccrec.models.item_tower  # noqa: F401
+        import ccrec.models.bbpr  # noqa: F401
+        import rime_lite.util  # noqa: F401
+        import rime_lite.util.score_array  # noqa: F401
+    return sys.modules["ms_marco_eval"]
+
+
+def bf16_exact(x: torch.Tensor) -> torch.Tensor:
+    """fp32 tensor whose values are exactly representable in bf16."""
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def _run_ranking(mod, Eq, Ed, batch_size, sim, block=None):
+    """Call the reference ranking() with integer 'texts' that index embedding tables."""
+    os.environ["CCREC_SIM_TYPE"] = sim
+    nq, nd = Eq.shape[0], Ed.shape[0]
+    table = torch.cat([Eq, Ed], 0)
+    queries = {f"q{i}": i for i in range(nq)}
+    corpus = {f"p{j}": nq + j for j in range(nd)}
+
+    def embedding_func(rows):
+        return table[torch.as_tensor(rows, dtype=torch.long)]
+
+    block_dict = None
+    if block is not None:
+        block_dict = {f"q{i}": [f"p{j}" for j in block[i]] for i in range(nq)}
+    with contextlib.redirect_stdout(io.StringIO()):
+        prof = mod.ranking(corpus, queries, embedding_func, batch_size, block_dict)
+    L = min(1001, nd)
+    ids = np.zeros((nq, L), np.int64)
+    sc = np.zeros((nq, L), np.float32)
+    for i in range(nq):
+        items = list(prof[f"q{i}"].items())
+        assert len(items) == L, (len(items), L)
+        ids[i] = [int(p[1:]) for p, _ in items]
+        sc[i] = [s for _, s in items]
+    return ids, sc
+
+
+def g_ranking(mod):
+    g = torch.Generator().manual_seed(1234)
+    d = 768
+    Ed = bf16_exact(torch.randn(300, d, generator=g) / d ** 0.5)
+    Eq = bf16_exact(torch.randn(7, d, generator=g) / d ** 0.5)
+    ids, sc = _run_ranking(mod, Eq, Ed, 64, "dot")
+    np.savez_compressed(f"{OUT}/g1_ranking_dot.npz", Eq=Eq.numpy(), Ed=Ed.numpy(), ids=ids, scores=sc, batch_size=64)
+
+    # G2: cos on raw (non-normalised, scaled) embeddings; reference normalises in fp32
+    Ed2 = bf16_exact(Ed * (0.5 + torch.rand(300, 1, generator=g) * 3))
+    Eq2 = bf16_exact(Eq * (0.5 + torch.rand(7, 1, generator=g) * 3))
+    ids, sc = _run_ranking(mod, Eq2, Ed2, 64, "cos")
+    np.savez_compressed(f"{OUT}/g2_ranking_cos.npz", Eq=Eq2.numpy(), Ed=Ed2.numpy(), ids=ids, scores=sc, batch_size=64)
+
+    # G3: block_dict (queries == corpus as in prime_pantry; self-block + ragged lists)
+    E = bf16_exact(torch.randn(200, d, generator=g) / d ** 0.5)
+    rs = np.random.RandomState(7)
+    groups = rs.randint(0, 23, size=200)
+    block = [np.nonzero(groups == groups[i])[0].tolist() for i in range(200)]
+    Eq3 = E[:40]
+    ids, sc = _run_ranking(mod, Eq3, E, 64, "dot", block=block[:40])
+    flat = np.concatenate([np.asarray(b, np.int64) for b in block[:40]])
+    ptr = np.cumsum([0] + [len(b) for b in block[:40]]).astype(np.int64)
+    np.savez_compressed(f"{OUT}/g3_ranking_block.npz", Eq=Eq3.numpy(), Ed=E.numpy(), ids=ids, scores=sc,
+                        block_ptr=ptr, block_idx=flat, batch_size=64)
+
+    # G4: N > 1001 pins the truncation to 1001 entries
+    Ed4 = bf16_exact(torch.randn(1500, d, generator=g) / d ** 0.5)
+    Eq4 = bf16_exact(torch.randn(5, d, generator=g) / d ** 0.5)
+    ids, sc = _run_ranking(mod, Eq4, Ed4, 512, "dot")
+    np.savez_compressed(f"{OUT}/g4_ranking_trunc.npz", Eq=Eq4.numpy(), Ed=Ed4.numpy(), ids=ids, scores=sc, batch_size=512)
+
+    # G5: exact arithmetic (multiples of 1/8 in [-4,4]; every partial sum exact in fp32)
+    # with engineered ties: duplicate corpus rows, incl. duplicates of top scorers.
+    rs = np.random.RandomState(11)
+    Ed5 = rs.randint(-32, 33, size=(400, d)).astype(np.float32) / 8
+    Eq5 = rs.randint(-32, 33, size=(6, d)).astype(np.float32) / 8
+    Ed5[50] = Ed5[10]
+    Ed5[350] = Ed5[10]
+    Ed5[399] = Ed5[0]
+    Ed5[200:230] = Ed5[100]       # a 31-way tie (rows 100, 200..229)
+    ids, sc = _run_ranking(mod, torch.from_numpy(Eq5), torch.from_numpy(Ed5), 128, "dot")
+    np.savez_compressed(f"{OUT}/g5_ranking_exact_ties.npz", Eq=Eq5, Ed=Ed5, ids=ids, scores=sc, batch_size=128)
+
+
+def g_item_tower():
+    from ccrec.models.item_tower import NaiveItemTower
+
+    g = torch.Generator().manual_seed(99)
+    B, L, d = 3, 16, 768
+    hidden = torch.randn(B, L, d, generator=g)
+    mask = torch.zeros(B, L, dtype=torch.long)
+    for b, n in enumerate([16, 5, 1]):
+        mask[b, :n] = 1
+
+    class FakeCls(torch.nn.Module):
+        device = torch.device("cpu")
+
+        def forward(self, **inputs):
+            return types.SimpleNamespace(last_hidden_state=hidden)
+
+    ln = torch.nn.LayerNorm(d, elementwise_affine=False)
+    tower = NaiveItemTower(FakeCls(), ln)
+    inputs = {"input_ids": torch.ones(B, L, dtype=torch.long), "attention_mask": mask}
+    out = {}
+    with torch.no_grad():
+        for step in ["mean_pooling", "cls", "mean_layer_norm"]:
+            out[step] = tower(**inputs, output_step=step).numpy()
+    np.savez_compressed(f"{OUT}/g6_item_tower.npz", hidden=hidden.numpy(), mask=mask.numpy(), **out)
+
+
+def g_contrastive():
+    from ccrec.models.bbpr import _BertBPR
+
+    res = {}
+    for tag, B, sim in [("b8_dot", 8, "dot"), ("b32_dot", 32, "dot"), ("b8_cos", 8, "cos"), ("b32_cos", 32, "cos")]:
+        os.environ["CCREC_SIM_TYPE"] = sim
+        os.environ["CCREC_BBPR_INV_TEMPERATURE"] = "20"
+        g = torch.Generator().manual_seed(5 + B)
+        d = 768
+        scale = 1 / d ** 0.5 if sim == "dot" else 1.0
+        E = (torch.randn(3 * B, d, generator=g) * scale).requires_grad_(True)
+        m = _BertBPR.__new__(_BertBPR)
+        torch.nn.Module.__init__(m)
+        m.objective = "multiple_nrl"
+        m.i_to_ptr = torch.arange(0, B)
+        m.j_to_ptr = torch.arange(B, 3 * B)          # j-space: [pos(0..B-1), neg(B..2B-1)]
+        m.user_to_negs = {u: [B + u] for u in range(B)}
+        m.forward = lambda ptr: E[ptr]
+        batch = torch.stack([torch.arange(B), torch.arange(B), torch.ones(B, dtype=torch.long)], 1)
+        loss = m.training_and_validation_step(batch, 0)
+        loss.backward()
+        res[f"{tag}_E"] = E.detach().numpy()
+        res[f"{tag}_loss"] = np.float32(loss.item())
+        res[f"{tag}_grad"] = E.grad.numpy()
+    np.savez_compressed(f"{OUT}/g7_contrastive.npz", **res)
+
+
+def g_assign_topk():
+    from rime_lite.util import _assign_topk
+    from rime_lite.util.score_array import auto_cast_lazy_score
+
+    g = torch.Generator().manual_seed(21)
+    d = 768
+    U = bf16_exact(torch.randn(50, d, generator=g) / d ** 0.5).numpy()
+    V = bf16_exact(torch.randn(4000, d, generator=g) / d ** 0.5).numpy()
+    S = auto_cast_lazy_score(U) @ auto_cast_lazy_score(V).T
+    with contextlib.redirect_stdout(io.StringIO()):
+        csr = _assign_topk(S, 10)
+    np.savez_compressed(f"{OUT}/g8_assign_topk.npz", U=U, V=V, indices=csr.indices.reshape(50, 10).astype(np.int64),
+                        indptr=csr.indptr.astype(np.int64), k=10)
+
+
+def g_pack():
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(64, 768, generator=g)
+    x[0, :8] = torch.tensor([0.0, -0.0, float("inf"), -float("inf"), 1e-40, -1e-40, 3.3895314e38, 1.0])
+    # exact half-way cases: bf16 ulp at 1.0 is 2^-7; 1 + 2^-8 ties to even (1.0), 1 + 3*2^-8 ties to 1+2^-6
+    x[1, :4] = torch.tensor([1 + 2.0 ** -8, 1 + 3 * 2.0 ** -8, -(1 + 2.0 ** -8), 1 + 2.0 ** -8 + 2.0 ** -20])
+    bits = x.to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+    np.savez_compressed(f"{OUT}/g9_pack_bf16.npz", x=x.numpy(), bits=bits)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    mod = _import_reference("dot")
+    g_ranking(mod)
+    g_item_tower()
+    g_contrastive()
+    g_assign_topk()
+    g_pack()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()
