@@ -1,0 +1,78 @@
+"""ctypes binding of libccr_hip.so (include/ccr_retrieval.h).  No CPU fallback: if the library or a
+ROCm device is missing, every op raises -- the product path never routes through oracle/ or torch math."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libccr_hip.so")
+
+CCR_OK = 0
+CCR_ERR_INVALID, CCR_ERR_HIP, CCR_ERR_WORKSPACE, CCR_ERR_BLOCK_ID = -1, -2, -3, -4
+DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
+SEARCH_DEFAULT, SEARCH_FORCE_DENSE, SEARCH_FORCE_FUSED = 0, 1, 2
+
+EXPORTS = [
+    "ccr_last_error", "ccr_version", "ccr_pack_bf16", "ccr_meanpool_pack_bf16", "ccr_index_create", "ccr_index_destroy",
+    "ccr_index_rows", "ccr_index_dim", "ccr_search_workspace_bytes", "ccr_search", "ccr_search_last_stats",
+    "ccr_merge_topk", "ccr_apply_block", "ccr_inbatch_ce_fwd", "ccr_inbatch_ce_bwd", "ccr_debug_mfma_scores",
+    "ccr_debug_canonical_scores",
+]
+
+
+class SearchStats(ctypes.Structure):
+    _fields_ = [("path", ctypes.c_int32), ("n_fallback", ctypes.c_int32), ("sample_tiles", ctypes.c_int32),
+                ("ranges", ctypes.c_int32), ("cap", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("n_candidates", ctypes.c_int64)]
+
+
+class CcrError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library and declare every prototype."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise CcrError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       f"(or make -C crowd-coachable-recommendations_amd/csrc)")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64, f32, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
+    lib.ccr_last_error.restype = ctypes.c_char_p
+    lib.ccr_last_error.argtypes = []
+    lib.ccr_version.restype = i32
+    lib.ccr_pack_bf16.argtypes = [vp, vp, vp, i64, i32, i32, vp]
+    lib.ccr_meanpool_pack_bf16.argtypes = [vp, i32, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.ccr_index_create.argtypes = [vp, i64, i32, i64, vp, ctypes.POINTER(vp)]
+    lib.ccr_index_destroy.argtypes = [vp]
+    lib.ccr_index_rows.argtypes = [vp]
+    lib.ccr_index_rows.restype = i64
+    lib.ccr_index_dim.argtypes = [vp]
+    lib.ccr_search_workspace_bytes.argtypes = [vp, i32, i32]
+    lib.ccr_search_workspace_bytes.restype = sz
+    lib.ccr_search.argtypes = [vp, vp, i32, i32, vp, vp, vp, sz, i32, vp]
+    lib.ccr_search_last_stats.argtypes = [vp, ctypes.POINTER(SearchStats)]
+    lib.ccr_merge_topk.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
+    lib.ccr_apply_block.argtypes = [vp, vp, i32, i32, vp, vp, i64, vp, vp, i32, vp]
+    lib.ccr_inbatch_ce_fwd.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp, vp]
+    lib.ccr_inbatch_ce_bwd.argtypes = [vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp, vp]
+    lib.ccr_debug_mfma_scores.argtypes = [vp, vp, i32, vp, vp]
+    lib.ccr_debug_canonical_scores.argtypes = [vp, vp, i32, vp, vp]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if fn.restype is ctypes.c_int and name not in ("ccr_version", "ccr_index_dim"):
+            fn.restype = i32
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != CCR_OK:
+        msg = load().ccr_last_error().decode("utf-8", "replace")
+        if rc == CCR_ERR_BLOCK_ID:
+            raise AssertionError("block id not found")
+        raise CcrError(f"{what} failed ({rc}): {msg}")

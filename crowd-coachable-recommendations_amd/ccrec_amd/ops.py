@@ -1,0 +1,189 @@
+"""Tensor-level wrappers over the C ABI.  torch is plumbing here (device memory, streams); every
+arithmetic step runs in libccr_hip.so.  All ops raise if there is no ROCm device."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+_DTYPES = {torch.float32: _lib.DTYPE_F32, torch.float16: _lib.DTYPE_F16, torch.bfloat16: _lib.DTYPE_BF16}
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise _lib.CcrError("ccrec_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+    return _lib.load()
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _on(t):
+    """Run the call with t's device current (HIP kernels launch on the current device)."""
+    return torch.cuda.device(t.device)
+
+
+def pack_bf16(x, normalize=False, out=None, return_norms=False):
+    """fp32 [rows, dim] (cuda) -> bf16 [rows, dim]; normalize=True applies x / max(||x||, 1e-12) first
+    (the cos_sim rule, ms_marco_eval.py:160-161).  `out` may be a slice of a preallocated shard."""
+    lib = require_gpu()
+    assert x.is_cuda and x.dim() == 2, "pack_bf16 expects a 2-d cuda tensor"
+    x = x.contiguous()
+    if x.dtype != torch.float32:
+        x = x.float()  # autocast may hand over fp16 encoder outputs (al_0_rank.py:125)
+    rows, dim = x.shape
+    if out is None:
+        out = torch.empty(rows, dim, dtype=torch.bfloat16, device=x.device)
+    assert out.is_contiguous() and out.dtype == torch.bfloat16 and tuple(out.shape) == (rows, dim)
+    norms = torch.empty(rows, dtype=torch.float32, device=x.device) if return_norms else None
+    with _on(x):
+        _lib.check(lib.ccr_pack_bf16(_ptr(x), _ptr(out), _ptr(norms), rows, dim, int(bool(normalize)), _stream(x)),
+                   "ccr_pack_bf16")
+    return (out, norms) if return_norms else out
+
+
+def meanpool_pack(hidden, mask, normalize=False, want_f32=True, want_bf16=True):
+    """Fused masked mean pooling (item_tower.py:141-146) + bf16 pack of [B, L, dim] hidden states.
+    Returns (pooled_f32 or None, packed_bf16 or None)."""
+    lib = require_gpu()
+    assert hidden.is_cuda and hidden.dim() == 3 and hidden.dtype in _DTYPES
+    hidden = hidden.contiguous()
+    mask = mask.to(device=hidden.device, dtype=torch.int64).contiguous()
+    B, L, dim = hidden.shape
+    assert tuple(mask.shape) == (B, L)
+    f32 = torch.empty(B, dim, dtype=torch.float32, device=hidden.device) if want_f32 else None
+    b16 = torch.empty(B, dim, dtype=torch.bfloat16, device=hidden.device) if want_bf16 else None
+    with _on(hidden):
+        _lib.check(lib.ccr_meanpool_pack_bf16(_ptr(hidden), _DTYPES[hidden.dtype], _ptr(mask), _ptr(b16), _ptr(f32), B, L,
+                                              dim, int(bool(normalize)), _stream(hidden)), "ccr_meanpool_pack_bf16")
+    return f32, b16
+
+
+class CorpusIndex:
+    """A resident bf16 corpus shard + its search state (ccr_index).  Build once per AL step, query many.
+
+    corpus_bf16: [n_rows, dim] bf16 cuda tensor (kept alive by this object; the C index borrows it).
+    global_row_offset: id of row 0 in the whole corpus (row-sharded multi-GPU search).
+    """
+
+    def __init__(self, corpus_bf16, global_row_offset=0):
+        self._lib = require_gpu()
+        assert corpus_bf16.is_cuda and corpus_bf16.dtype == torch.bfloat16 and corpus_bf16.dim() == 2
+        self.corpus = corpus_bf16.contiguous()
+        self.n_rows, self.dim = self.corpus.shape
+        self.offset = int(global_row_offset)
+        self._h = ctypes.c_void_p()
+        self._ws = None
+        with _on(self.corpus):
+            _lib.check(self._lib.ccr_index_create(_ptr(self.corpus), self.n_rows, self.dim, self.offset,
+                                                  _stream(self.corpus), ctypes.byref(self._h)), "ccr_index_create")
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.ccr_index_destroy(h)
+
+    def _workspace(self, n_q, k):
+        need = int(self._lib.ccr_search_workspace_bytes(self._h, n_q, k))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.corpus.device)
+        return self._ws
+
+    def search(self, queries_bf16, k, flags=_lib.SEARCH_DEFAULT):
+        """-> (scores [n_q, k] fp32, ids [n_q, k] int64 global), canonical order."""
+        q = queries_bf16
+        assert q.is_cuda and q.dtype == torch.bfloat16 and q.dim() == 2 and q.shape[1] == self.dim
+        q = q.contiguous()
+        n_q = q.shape[0]
+        scores = torch.empty(n_q, k, dtype=torch.float32, device=q.device)
+        ids = torch.empty(n_q, k, dtype=torch.int64, device=q.device)
+        if n_q == 0:
+            return scores, ids
+        ws = self._workspace(n_q, k)
+        with _on(q):
+            _lib.check(self._lib.ccr_search(self._h, _ptr(q), n_q, k, _ptr(scores), _ptr(ids), _ptr(ws), ws.numel(),
+                                            int(flags), _stream(q)), "ccr_search")
+        return scores, ids
+
+    def last_stats(self):
+        st = _lib.SearchStats()
+        _lib.check(self._lib.ccr_search_last_stats(self._h, ctypes.byref(st)), "ccr_search_last_stats")
+        return {f: getattr(st, f) for f, _ in st._fields_ if f != "reserved"}
+
+    def debug_scores(self, queries_bf16, canonical):
+        q = queries_bf16.contiguous()
+        out = torch.empty(q.shape[0], self.n_rows, dtype=torch.float32, device=q.device)
+        fn = self._lib.ccr_debug_canonical_scores if canonical else self._lib.ccr_debug_mfma_scores
+        with _on(q):
+            _lib.check(fn(self._h, _ptr(q), q.shape[0], _ptr(out), _stream(q)), "ccr_debug_scores")
+        return out
+
+
+def merge_topk(scores, ids):
+    """[R, n_q, k] per-shard canonical lists -> global ([n_q, k], [n_q, k])."""
+    lib = require_gpu()
+    assert scores.is_cuda and scores.dtype == torch.float32 and ids.dtype == torch.int64 and scores.shape == ids.shape
+    scores, ids = scores.contiguous(), ids.contiguous()
+    R, n_q, k = scores.shape
+    os_ = torch.empty(n_q, k, dtype=torch.float32, device=scores.device)
+    oi = torch.empty(n_q, k, dtype=torch.int64, device=scores.device)
+    with _on(scores):
+        _lib.check(lib.ccr_merge_topk(_ptr(scores), _ptr(ids), R, n_q, k, _ptr(os_), _ptr(oi), _stream(scores)), "ccr_merge_topk")
+    return os_, oi
+
+
+def apply_block(scores, ids, block_ptr, block_idx, k_out, n_rows_total):
+    """Post-filter an over-fetched canonical list with per-query blocked ids (ms_marco_eval.py:224-227)."""
+    lib = require_gpu()
+    n_q, k_in = scores.shape
+    os_ = torch.empty(n_q, k_out, dtype=torch.float32, device=scores.device)
+    oi = torch.empty(n_q, k_out, dtype=torch.int64, device=scores.device)
+    block_ptr = block_ptr.to(device=scores.device, dtype=torch.int64).contiguous()
+    block_idx = block_idx.to(device=scores.device, dtype=torch.int64).contiguous()
+    if block_idx.numel() == 0:
+        block_idx = torch.zeros(1, dtype=torch.int64, device=scores.device)
+    with _on(scores):
+        _lib.check(lib.ccr_apply_block(_ptr(scores.contiguous()), _ptr(ids.contiguous()), n_q, k_in, _ptr(block_ptr),
+                                       _ptr(block_idx), int(n_rows_total), _ptr(os_), _ptr(oi), k_out, _stream(scores)),
+                   "ccr_apply_block")
+    return os_, oi
+
+
+class _InBatchCE(torch.autograd.Function):
+    """loss = CE([Q P^T | Q N^T] * inv_T, arange(B)).mean()   (bbpr.py:205-212), bf16 operands, fp32 accumulate."""
+
+    @staticmethod
+    def forward(ctx, q, p, n, inv_temperature):
+        lib = require_gpu()
+        qb, pb, nb = (t.detach().to(torch.bfloat16).contiguous() for t in (q, p, n))
+        B, dim = qb.shape
+        loss = torch.empty(1, dtype=torch.float32, device=q.device)
+        lse = torch.empty(B, dtype=torch.float32, device=q.device)
+        with _on(qb):
+            _lib.check(lib.ccr_inbatch_ce_fwd(_ptr(qb), _ptr(pb), _ptr(nb), B, dim, float(inv_temperature), _ptr(loss),
+                                              _ptr(lse), _stream(qb)), "ccr_inbatch_ce_fwd")
+        ctx.save_for_backward(qb, pb, nb, lse)
+        ctx.inv_t = float(inv_temperature)
+        ctx.dtypes = (q.dtype, p.dtype, n.dtype)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = require_gpu()
+        qb, pb, nb, lse = ctx.saved_tensors
+        B, dim = qb.shape
+        dq, dp, dn = (torch.empty(B, dim, dtype=torch.float32, device=qb.device) for _ in range(3))
+        with _on(qb):
+            _lib.check(lib.ccr_inbatch_ce_bwd(_ptr(qb), _ptr(pb), _ptr(nb), _ptr(lse), B, dim, ctx.inv_t, float(grad_out),
+                                              _ptr(dq), _ptr(dp), _ptr(dn), _stream(qb)), "ccr_inbatch_ce_bwd")
+        return dq.to(ctx.dtypes[0]), dp.to(ctx.dtypes[1]), dn.to(ctx.dtypes[2]), None
+
+
+def inbatch_ce(q, p, n, inv_temperature):
+    return _InBatchCE.apply(q, p, n, inv_temperature)

@@ -1,0 +1,312 @@
+// ccr_api.hip -- host side of the C ABI: index object, planner, ccr_search orchestration.
+#include <stdarg.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "ccr_common.h"
+#include "ccr_topk_device.h"
+
+namespace ccr {
+
+// ------------------------------------------------------------------ error text (thread-local)
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ------------------------------------------------------------------ kernels implemented elsewhere
+int launch_gemm_filter(const GemmArgs &a, int grid, hipStream_t s);
+int launch_gemm_gmax(const GemmArgs &a, int grid, hipStream_t s);
+int launch_gemm_store(const GemmArgs &a, int grid, hipStream_t s);
+int launch_row_norms_bf16(const uint16_t *X, int64_t rows, int dim, float *norms, uint32_t *max_bits, hipStream_t s);
+int launch_threshold(const float *gmax, int64_t n_groups, int n_q, int nq_pad, int k, const float *qnorm,
+                     const uint32_t *dmax_bits, int dim, float *thr, float *delta, hipStream_t s);
+size_t select_lds_bytes(int dim, int ranges, int rescore_cap);
+int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, int n_q, int nq_pad, int cap, int k,
+                          int rescore_cap, const float *delta, const uint16_t *Q, const uint16_t *D, int dim,
+                          int64_t id_offset, float *out_scores, int64_t *out_ids, uint32_t *flag_count,
+                          uint32_t *flag_list, unsigned long long *stat_cand, hipStream_t s);
+int launch_dense_scores(const uint16_t *D, int64_t n_rows, int dim, const uint16_t *Q, const uint32_t *qlist,
+                        int q_begin, int nq_chunk, float *out, hipStream_t s);
+int launch_dense_select(const float *scores, int64_t n_rows, int k, const uint32_t *qlist, int q_begin, int nq_chunk,
+                        int64_t id_offset, float *out_scores, int64_t *out_ids, hipStream_t s);
+
+// ------------------------------------------------------------------ planner
+static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+constexpr size_t DENSE_SCRATCH_TARGET = (size_t)1 << 30;  // ~1 GiB of score rows per dense chunk
+constexpr int FALLBACK_ROWS = 16;                         // score rows reserved for flagged queries
+
+Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu) {
+    Plan p;
+    memset(&p, 0, sizeof(p));
+    p.nq_pad = (int)round_up(n_q, TILE_Q);
+    p.qblocks = p.nq_pad / TILE_Q;
+    p.tiles = (n_rows + TILE_DOCS - 1) / TILE_DOCS;
+    p.full_tiles = n_rows / TILE_DOCS;
+    p.grid = std::max(NUM_XCD, num_cu / NUM_XCD * NUM_XCD);
+    p.rescore_cap = std::min(8192, std::max(256, 2 * pow2_ceil(k)));
+
+    // sample pass: group maxima of 16 rows; need comfortably more groups than k
+    const int64_t min_sample = (2 * (int64_t)k + GROUPS_PER_TILE - 1) / GROUPS_PER_TILE;
+    int64_t sample = std::max<int64_t>({(p.tiles + 31) / 32, min_sample, 4});
+    bool fused = (dim % TILE_K == 0) && dim >= TILE_K && (sample * 4 <= p.full_tiles) && k <= MAX_K;
+    if ((flags & CCR_SEARCH_FORCE_FUSED) && (dim % TILE_K == 0) && p.full_tiles >= 1) {
+        // honour the request where at all possible: the sample may be the whole corpus
+        if (!fused) sample = std::min<int64_t>(std::max<int64_t>(sample, 1), p.full_tiles);
+        fused = sample * GROUPS_PER_TILE >= k;
+    }
+    if (flags & CCR_SEARCH_FORCE_DENSE) fused = false;
+    p.fused = fused ? 1 : 0;
+
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off = (size_t)round_up((int64_t)(off + bytes), 256);
+        return o;
+    };
+    if (p.fused) {
+        p.sample_tiles = (int)sample;
+        p.sample_stride = std::max<int64_t>(1, p.full_tiles / sample);
+        // main-pass ranges: ~6 work items per workgroup, each at least 8 tiles, multiple of 8 (XCDs)
+        int64_t R = round_up(std::max<int64_t>(NUM_XCD, (int64_t)p.grid * 6 / p.qblocks), NUM_XCD);
+        R = std::min<int64_t>(R, round_up(std::max<int64_t>(1, p.tiles / 8), NUM_XCD));
+        R = std::min<int64_t>(R, 1024);
+        p.ranges = (int)R;
+        const double ratio = (double)p.tiles / (double)sample;
+        const double expect = (double)k * ratio * 1.3 + 64.0;  // survivors per query
+        int64_t cap = (int64_t)(4.0 * expect / (double)R) + 32;
+        cap = round_up(std::min<int64_t>(std::max<int64_t>(cap, 32), 8192), 8);
+        p.cap = (int)cap;
+        p.off_qnorm = take((size_t)p.nq_pad * 4);
+        p.off_thr = take((size_t)p.nq_pad * 4 * 2);  // thr then delta
+        p.off_gmax = take((size_t)p.sample_tiles * GROUPS_PER_TILE * p.nq_pad * 4);
+        p.off_cnt = take((size_t)p.ranges * p.nq_pad * 4);
+        p.off_cand = take((size_t)p.ranges * p.nq_pad * p.cap * 8);
+        p.off_flag = take(64 + (size_t)n_q * 4);
+        p.dense_rows_per_chunk = FALLBACK_ROWS;
+        p.off_dense = take((size_t)FALLBACK_ROWS * n_rows * 4);
+    } else {
+        int64_t rows = (int64_t)(DENSE_SCRATCH_TARGET / ((size_t)n_rows * 4));
+        rows = std::min<int64_t>(std::max<int64_t>(rows, 1), n_q);
+        if (rows >= 64) rows = rows / 64 * 64;
+        p.dense_rows_per_chunk = rows;
+        p.off_flag = take(64);
+        p.off_dense = take((size_t)rows * n_rows * 4);
+    }
+    p.total = off;
+    return p;
+}
+
+}  // namespace ccr
+
+using namespace ccr;
+
+struct ccr_index {
+    const uint16_t *D;
+    int64_t n_rows;
+    int dim;
+    int64_t offset;
+    uint32_t *dmax_bits;  // device: bits of the max row norm
+    int num_cu;
+    int device;
+    ccr_search_stats stats;
+};
+
+extern "C" const char *ccr_last_error(void) { return g_err; }
+extern "C" int ccr_version(void) { return 100; }
+
+extern "C" int ccr_index_create(const uint16_t *D_bf16, int64_t n_rows, int dim, int64_t global_row_offset, void *stream,
+                                ccr_index **out) {
+    CCR_REQUIRE(D_bf16 && out, "ccr_index_create: null pointer");
+    CCR_REQUIRE(n_rows >= 1 && n_rows < ((int64_t)1 << 32), "ccr_index_create: n_rows=%lld out of range [1, 2^32)",
+                (long long)n_rows);
+    CCR_REQUIRE(dim >= 8 && dim % 8 == 0 && dim <= 4096, "ccr_index_create: dim=%d must be a multiple of 8 in [8, 4096]", dim);
+    CCR_REQUIRE((uintptr_t)D_bf16 % 16 == 0, "ccr_index_create: corpus pointer must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    ccr_index *ix = new ccr_index();
+    memset(ix, 0, sizeof(*ix));
+    ix->D = D_bf16;
+    ix->n_rows = n_rows;
+    ix->dim = dim;
+    ix->offset = global_row_offset;
+    CCR_HIP_CHECK(hipGetDevice(&ix->device));
+    hipDeviceProp_t prop;
+    CCR_HIP_CHECK(hipGetDeviceProperties(&prop, ix->device));
+    ix->num_cu = prop.multiProcessorCount;
+    CCR_HIP_CHECK(hipMalloc((void **)&ix->dmax_bits, 256));
+    CCR_HIP_CHECK(hipMemsetAsync(ix->dmax_bits, 0, 256, s));
+    int rc = launch_row_norms_bf16(D_bf16, n_rows, dim, nullptr, ix->dmax_bits, s);
+    if (rc != CCR_OK) return rc;
+    CCR_HIP_CHECK(hipStreamSynchronize(s));
+    *out = ix;
+    return CCR_OK;
+}
+
+extern "C" int ccr_index_destroy(ccr_index *ix) {
+    if (!ix) return CCR_OK;
+    if (ix->dmax_bits) (void)hipFree(ix->dmax_bits);
+    delete ix;
+    return CCR_OK;
+}
+
+extern "C" int64_t ccr_index_rows(const ccr_index *ix) { return ix ? ix->n_rows : -1; }
+extern "C" int ccr_index_dim(const ccr_index *ix) { return ix ? ix->dim : -1; }
+
+extern "C" size_t ccr_search_workspace_bytes(const ccr_index *ix, int n_q, int k) {
+    if (!ix || n_q <= 0 || k <= 0) return 0;
+    // the larger of the two plans, so that flags may be chosen at call time
+    Plan a = make_plan(ix->n_rows, ix->dim, n_q, k, CCR_SEARCH_DEFAULT, ix->num_cu);
+    Plan b = make_plan(ix->n_rows, ix->dim, n_q, k, CCR_SEARCH_FORCE_DENSE, ix->num_cu);
+    Plan c = make_plan(ix->n_rows, ix->dim, n_q, k, CCR_SEARCH_FORCE_FUSED, ix->num_cu);
+    return std::max({a.total, b.total, c.total}) + 256;
+}
+
+extern "C" int ccr_search_last_stats(const ccr_index *ix, ccr_search_stats *stats) {
+    CCR_REQUIRE(ix && stats, "ccr_search_last_stats: null pointer");
+    *stats = ix->stats;
+    return CCR_OK;
+}
+
+static int dense_for_list(const ccr_index *ix, const uint16_t *Q, const uint32_t *d_qlist, int q_begin, int n, int k,
+                          float *scratch, int64_t rows_per_chunk, float *out_scores, int64_t *out_ids, hipStream_t s) {
+    for (int lo = 0; lo < n; lo += (int)rows_per_chunk) {
+        const int m = std::min<int64_t>(rows_per_chunk, n - lo);
+        int rc = launch_dense_scores(ix->D, ix->n_rows, ix->dim, Q, d_qlist ? d_qlist + lo : nullptr, q_begin + lo, m,
+                                     scratch, s);
+        if (rc != CCR_OK) return rc;
+        rc = launch_dense_select(scratch, ix->n_rows, k, d_qlist ? d_qlist + lo : nullptr, q_begin + lo, m, ix->offset,
+                                 out_scores, out_ids, s);
+        if (rc != CCR_OK) return rc;
+    }
+    return CCR_OK;
+}
+
+extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k, float *out_scores, int64_t *out_ids,
+                          void *workspace, size_t ws_bytes, int flags, void *stream) {
+    CCR_REQUIRE(ix && Q_bf16 && out_scores && out_ids, "ccr_search: null pointer");
+    CCR_REQUIRE(n_q >= 0, "ccr_search: n_q=%d", n_q);
+    CCR_REQUIRE(k >= 1 && k <= MAX_K && (int64_t)k <= ix->n_rows, "ccr_search: k=%d must be in [1, min(n_rows=%lld, %d)]", k,
+                (long long)ix->n_rows, MAX_K);
+    CCR_REQUIRE((uintptr_t)Q_bf16 % 16 == 0, "ccr_search: query pointer must be 16-byte aligned");
+    memset(&ix->stats, 0, sizeof(ix->stats));
+    if (n_q == 0) return CCR_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const Plan p = make_plan(ix->n_rows, ix->dim, n_q, k, flags, ix->num_cu);
+    if (!workspace || ws_bytes < p.total || (uintptr_t)workspace % 256 != 0) {
+        set_error("ccr_search: workspace %zu bytes (256-byte aligned) required, got %zu at %p", p.total, ws_bytes, workspace);
+        return CCR_ERR_WORKSPACE;
+    }
+    char *ws = (char *)workspace;
+    float *dense_scratch = (float *)(ws + p.off_dense);
+
+    if (!p.fused) {
+        ix->stats.path = 0;
+        return dense_for_list(ix, Q_bf16, nullptr, 0, n_q, k, dense_scratch, p.dense_rows_per_chunk, out_scores, out_ids, s);
+    }
+
+    float *qnorm = (float *)(ws + p.off_qnorm);
+    float *thr = (float *)(ws + p.off_thr);
+    float *delta = thr + p.nq_pad;
+    float *gmax = (float *)(ws + p.off_gmax);
+    uint32_t *cnt = (uint32_t *)(ws + p.off_cnt);
+    uint2 *cand = (uint2 *)(ws + p.off_cand);
+    uint32_t *flag_count = (uint32_t *)(ws + p.off_flag);
+    unsigned long long *stat_cand = (unsigned long long *)(ws + p.off_flag + 8);
+    uint32_t *flag_list = (uint32_t *)(ws + p.off_flag + 64);
+
+    CCR_HIP_CHECK(hipMemsetAsync(flag_count, 0, 64, s));
+    CCR_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)p.ranges * p.nq_pad * 4, s));  // ranges with no tiles write nothing
+    int rc = launch_row_norms_bf16(Q_bf16, n_q, ix->dim, qnorm, nullptr, s);
+    if (rc != CCR_OK) return rc;
+
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.D = ix->D;
+    g.n_rows = ix->n_rows;
+    g.dim = ix->dim;
+    g.Q = Q_bf16;
+    g.n_q = n_q;
+    g.nq_pad = p.nq_pad;
+    g.qblocks = p.qblocks;
+
+    // sample pass -> group maxima -> thresholds
+    GemmArgs gs = g;
+    gs.n_vt = p.sample_tiles;
+    gs.tile_stride = p.sample_stride;
+    gs.ranges = (int)round_up(std::min<int64_t>(p.ranges, std::max<int64_t>(NUM_XCD, p.sample_tiles / 4)), NUM_XCD);
+    gs.gmax = gmax;
+    rc = launch_gemm_gmax(gs, p.grid, s);
+    if (rc != CCR_OK) return rc;
+    rc = launch_threshold(gmax, (int64_t)p.sample_tiles * GROUPS_PER_TILE, n_q, p.nq_pad, k, qnorm, ix->dmax_bits, ix->dim,
+                          thr, delta, s);
+    if (rc != CCR_OK) return rc;
+
+    // main pass -> candidates
+    GemmArgs gm = g;
+    gm.n_vt = p.tiles;
+    gm.tile_stride = 1;
+    gm.ranges = p.ranges;
+    gm.thr = thr;
+    gm.cand = cand;
+    gm.cnt = cnt;
+    gm.cap = p.cap;
+    rc = launch_gemm_filter(gm, p.grid, s);
+    if (rc != CCR_OK) return rc;
+
+    rc = launch_select_rescore(cand, cnt, p.ranges, n_q, p.nq_pad, p.cap, k, p.rescore_cap, delta, Q_bf16, ix->D, ix->dim,
+                               ix->offset, out_scores, out_ids, flag_count, flag_list, stat_cand, s);
+    if (rc != CCR_OK) return rc;
+
+    // one small readback: how many queries need the exact fallback
+    struct {
+        uint32_t nflag, pad;
+        unsigned long long ncand;
+    } host;
+    CCR_HIP_CHECK(hipMemcpyAsync(&host, flag_count, sizeof(host), hipMemcpyDeviceToHost, s));
+    CCR_HIP_CHECK(hipStreamSynchronize(s));
+    ix->stats.path = 1;
+    ix->stats.n_fallback = (int32_t)host.nflag;
+    ix->stats.sample_tiles = p.sample_tiles;
+    ix->stats.ranges = p.ranges;
+    ix->stats.cap = p.cap;
+    ix->stats.n_candidates = (int64_t)host.ncand;
+    if (host.nflag > 0) {
+        rc = dense_for_list(ix, Q_bf16, flag_list, 0, (int)host.nflag, k, dense_scratch, p.dense_rows_per_chunk, out_scores,
+                            out_ids, s);
+        if (rc != CCR_OK) return rc;
+        CCR_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    return CCR_OK;
+}
+
+// ------------------------------------------------------------------ diagnostics
+extern "C" int ccr_debug_mfma_scores(const ccr_index *ix, const uint16_t *Q_bf16, int n_q, float *out, void *stream) {
+    CCR_REQUIRE(ix && Q_bf16 && out && n_q > 0, "ccr_debug_mfma_scores: bad argument");
+    CCR_REQUIRE(ix->dim % TILE_K == 0, "ccr_debug_mfma_scores: dim %% 64 != 0");
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.D = ix->D;
+    g.n_rows = ix->n_rows;
+    g.dim = ix->dim;
+    g.Q = Q_bf16;
+    g.n_q = n_q;
+    g.nq_pad = (int)round_up(n_q, TILE_Q);
+    g.qblocks = g.nq_pad / TILE_Q;
+    g.n_vt = (ix->n_rows + TILE_DOCS - 1) / TILE_DOCS;
+    g.tile_stride = 1;
+    g.ranges = (int)round_up(std::min<int64_t>(64, g.n_vt), NUM_XCD);
+    g.store = out;
+    const int grid = std::max(NUM_XCD, ix->num_cu / NUM_XCD * NUM_XCD);
+    return launch_gemm_store(g, grid, (hipStream_t)stream);
+}
+
+extern "C" int ccr_debug_canonical_scores(const ccr_index *ix, const uint16_t *Q_bf16, int n_q, float *out, void *stream) {
+    CCR_REQUIRE(ix && Q_bf16 && out && n_q > 0, "ccr_debug_canonical_scores: bad argument");
+    return launch_dense_scores(ix->D, ix->n_rows, ix->dim, Q_bf16, nullptr, 0, n_q, out, (hipStream_t)stream);
+}

@@ -1,0 +1,106 @@
+// ccr_common.h -- shared host/device helpers for the gfx950 retrieval library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "ccr_retrieval.h"
+
+namespace ccr {
+
+void set_error(const char *fmt, ...);
+
+#define CCR_HIP_CHECK(expr)                                                                   \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            ccr::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return CCR_ERR_HIP;                                                               \
+        }                                                                                     \
+    } while (0)
+
+#define CCR_REQUIRE(cond, ...)            \
+    do {                                  \
+        if (!(cond)) {                    \
+            ccr::set_error(__VA_ARGS__);  \
+            return CCR_ERR_INVALID;       \
+        }                                 \
+    } while (0)
+
+#define CCR_LAUNCH_CHECK()                                                              \
+    do {                                                                                \
+        hipError_t _e = hipGetLastError();                                              \
+        if (_e != hipSuccess) {                                                         \
+            ccr::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+            return CCR_ERR_HIP;                                                         \
+        }                                                                               \
+    } while (0)
+
+// ---- geometry of the fused MFMA path (one definition for kernels and planner)
+constexpr int TILE_DOCS = 256;      // corpus rows per GEMM tile
+constexpr int TILE_Q = 256;         // queries per GEMM tile
+constexpr int TILE_K = 64;          // K step (bf16 elements) = 128 B per row
+constexpr int GEMM_THREADS = 512;   // 8 waves: 2 (doc halves) x 4 (query quarters)
+constexpr int GROUPS_PER_TILE = 16; // group maxima per (sample tile, query): 2 wave rows x 4 MFMA tiles x 2 lane halves
+constexpr int MAX_K = 4096;
+constexpr int NUM_XCD = 8;
+
+struct Plan {
+    int fused;            // 1 = fused MFMA path usable
+    int nq_pad;           // n_q rounded up to TILE_Q
+    int qblocks;          // nq_pad / TILE_Q
+    int64_t tiles;        // ceil(n_rows / TILE_DOCS)
+    int64_t full_tiles;   // floor(n_rows / TILE_DOCS)
+    int sample_tiles;     // tiles scored by the threshold pass
+    int64_t sample_stride;
+    int ranges;           // corpus ranges of the main pass (multiple of NUM_XCD)
+    int cap;              // candidate slots per (range, query)
+    int grid;             // persistent workgroups (multiple of NUM_XCD)
+    int rescore_cap;      // max candidates re-scored per query (power of two)
+    // workspace layout (byte offsets)
+    size_t off_qnorm, off_thr, off_gmax, off_cnt, off_cand, off_flag, off_dense, total;
+    int64_t dense_rows_per_chunk;  // queries per dense chunk
+};
+
+// arguments of the fused GEMM kernel (ccr_fused.hip)
+struct GemmArgs {
+    const uint16_t *D;
+    int64_t n_rows;
+    int dim;
+    const uint16_t *Q;
+    int n_q;
+    int nq_pad;
+    int qblocks;
+    int64_t n_vt;         // virtual tiles; real tile = vt * tile_stride
+    int64_t tile_stride;
+    int ranges;           // item (r, qb) covers virtual tiles r, r + ranges, ...
+    // EPI_FILTER
+    const float *thr;     // [nq_pad]
+    uint2 *cand;          // [ranges][nq_pad][cap] {score bits, local row}
+    uint32_t *cnt;        // [ranges][nq_pad]
+    int cap;
+    // EPI_GMAX
+    float *gmax;          // [n_vt * 16][nq_pad]
+    // EPI_STORE (debug)
+    float *store;         // [n_q][n_rows]
+};
+
+Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu);
+
+// ---- device helpers
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// monotone map float -> uint32 (larger float <-> larger uint); NaN maps above +inf (never produced here)
+__device__ __forceinline__ uint32_t f32_orderable(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float orderable_to_f32(uint32_t u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+// worst-case |mfma fp32 score - exact| <= gamma(dim) * ||q|| * ||d||  (any summation order, each
+// fp32 add within 2^-23 relative: see DESIGN.md "filter margins")
+__host__ __device__ __forceinline__ float mfma_gamma(int dim) { return (float)dim * 1.1920929e-7f * 1.02f; }
+
+}  // namespace ccr

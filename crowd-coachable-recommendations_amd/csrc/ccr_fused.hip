@@ -1,0 +1,437 @@
+// ccr_fused.hip -- the fused MFMA path: S^T = D . Q^T on the matrix cores with the top-k filter
+// in the epilogue, so the [Q, N] score matrix never exists in HBM.
+//
+//   sample pass  (EPI_GMAX)  : score every `stride`-th 256-row corpus tile, reduce each 16-row MFMA
+//                              fragment to its maximum -> gmax[group][query]
+//   threshold    (threshold_kernel): tau_q = k-th largest group maximum (a lower bound of the k-th
+//                              largest score: k disjoint groups hold a score >= tau_q), minus the
+//                              MFMA error margin delta_q
+//   main pass    (EPI_FILTER): score the whole shard; accumulators >= thr_q are appended to the
+//                              (range, query) candidate list (LDS counter, 8-byte records)
+//   select       (select_rescore_kernel): per query radix-select the k-th largest MFMA score among
+//                              the candidates, keep everything within delta_q of it, re-score those
+//                              canonically (fp64 ordered) and sort by (score desc, id asc).
+//
+// GEMM geometry (gfx950): 256 docs x 256 queries per workgroup tile, K step 64, 512 threads =
+// 8 waves as 2 (doc halves) x 4 (query quarters); each wave owns 128 docs x 64 queries =
+// 4 x 2 tiles of v_mfma_f32_32x32x16_bf16 (docs on the accumulator rows/registers, queries on
+// the lanes, so a lane compares its 16 registers against ONE per-lane threshold).
+// Staging: global_load_lds_dwordx4 into a double-buffered LDS image (2 x 64 KiB), rows of 128 B,
+// 16-byte chunk index XOR-swizzled with (row>>1)&7 on the SOURCE address and on the fragment read
+// (conflict-free ds_read_b128, cdna guide T2 / rule 21).
+#include "ccr_common.h"
+#include "ccr_topk_device.h"
+
+namespace ccr {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { EPI_FILTER = 0, EPI_GMAX = 1, EPI_STORE = 2 };
+
+constexpr int STAGE_BYTES = (TILE_DOCS + TILE_Q) * TILE_K * 2;  // 65536
+constexpr int Q_REGION = TILE_DOCS * TILE_K * 2;                 // 32768
+
+__device__ __forceinline__ void glds16(const void *gsrc, char *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t *lds_cnt = reinterpret_cast<uint32_t *>(smem + 2 * STAGE_BYTES);  // [TILE_Q]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wd = wv >> 2;  // doc half
+    const int wq = wv & 3;   // query quarter
+    const int l31 = lane & 31;
+    const int h = lane >> 5;
+    const int KS = a.dim / TILE_K;
+
+    // ---- staging roles: 8 x 16-byte chunks per thread per stage (4 doc rows, 4 query rows)
+    const int srow = wv * 8 + (lane >> 3);                       // + i*64
+    const int schunk = (lane & 7) ^ ((srow >> 1) & 7);           // logical chunk fetched into physical slot lane&7
+    // ---- fragment read offsets (bytes inside a stage buffer)
+    const int swz = (lane >> 1) & 7;
+    int cofs[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) cofs[ks] = (((2 * ks + h) ^ swz) << 4);
+    const int a_base = (wd * 128 + l31) * 128;             // + dt*32*128
+    const int b_base = Q_REGION + (wq * 64 + l31) * 128;   // + qt*32*128
+
+    // ---- work items of this workgroup (XCD-aware: blocks b and b+8 share an XCD / L2)
+    const int xcd = blockIdx.x & (NUM_XCD - 1);
+    const int jx = blockIdx.x >> 3;
+    const int per_x = gridDim.x >> 3;
+    const int rl_x = (a.ranges - xcd + NUM_XCD - 1) / NUM_XCD;  // ranges r with r % 8 == xcd
+    const int count_x = rl_x * a.qblocks;
+
+    for (int item = jx; item < count_x; item += per_x) {
+        const int rl = item / a.qblocks;
+        const int qb = item - rl * a.qblocks;
+        const int r = xcd + NUM_XCD * rl;
+        const int64_t ntile = (a.n_vt - r + a.ranges - 1) / a.ranges;  // virtual tiles r, r+R, ...
+        if (ntile <= 0) continue;
+        const int q0 = qb * TILE_Q;
+
+        // per-lane thresholds for the two query columns this lane owns
+        float thr[2];
+        if (EPI == EPI_FILTER) {
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const int q = q0 + wq * 64 + qt * 32 + l31;
+                thr[qt] = (q < a.n_q) ? a.thr[q] : __builtin_nanf("");
+            }
+            if (tid < TILE_Q) lds_cnt[tid] = 0;
+        }
+
+        // query source pointers are fixed for the item
+        const uint16_t *qsrc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int qrow = q0 + i * 64 + srow;
+            if (qrow > a.n_q - 1) qrow = a.n_q - 1;
+            qsrc[i] = a.Q + (int64_t)qrow * a.dim + schunk * 8;
+        }
+
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[dt][qt][e] = 0.f;
+
+        const int64_t total = ntile * KS;
+
+        auto stage = [&](int64_t step) {
+            const int64_t t = step / KS;
+            const int ks = (int)(step - t * KS);
+            const int64_t tile = (r + t * a.ranges) * a.tile_stride;
+            const int64_t row0 = tile * TILE_DOCS;
+            char *buf = smem + (step & 1) * STAGE_BYTES;
+            const int k0 = ks * TILE_K;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int64_t drow = row0 + i * 64 + srow;
+                if (drow > a.n_rows - 1) drow = a.n_rows - 1;
+                const uint16_t *src = a.D + drow * a.dim + k0 + schunk * 8;
+                glds16(src, buf + (i * 512 + wv * 64) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) glds16(qsrc[i] + k0, buf + Q_REGION + (i * 512 + wv * 64) * 16);
+        };
+
+        stage(0);
+        for (int64_t step = 0; step < total; ++step) {
+            __syncthreads();  // stage `step` landed (vmcnt(0) + barrier); everyone is done with the other buffer
+            if (step + 1 < total) stage(step + 1);
+            const char *buf = smem + (step & 1) * STAGE_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 af[4], bfr[2];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    af[dt] = *reinterpret_cast<const bf16x8 *>(buf + a_base + dt * 4096 + cofs[ks]);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+                    bfr[qt] = *reinterpret_cast<const bf16x8 *>(buf + b_base + qt * 4096 + cofs[ks]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt)
+                        acc[dt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[dt], bfr[qt], acc[dt][qt], 0, 0, 0);
+            }
+
+            const int64_t t = step / KS;
+            if (step - t * KS != KS - 1) continue;
+
+            // ------------------------------------------------------------ epilogue of one 256x256 tile
+            const int64_t vt = r + t * a.ranges;
+            const int64_t row_base = vt * a.tile_stride * TILE_DOCS + wd * 128 + 4 * h;  // + dt*32 + (e&3) + 8*(e>>2)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const int ql = wq * 64 + qt * 32 + l31;
+                float mdt[4];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    float m = acc[dt][qt][0];
+#pragma unroll
+                    for (int e = 1; e < 16; ++e) m = fmaxf(m, acc[dt][qt][e]);
+                    mdt[dt] = m;
+                }
+                if (EPI == EPI_GMAX) {
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+                        a.gmax[(vt * GROUPS_PER_TILE + wd * 8 + dt * 2 + h) * a.nq_pad + q0 + ql] = mdt[dt];
+                } else if (EPI == EPI_FILTER) {
+                    const float mall = fmaxf(fmaxf(mdt[0], mdt[1]), fmaxf(mdt[2], mdt[3]));
+                    if (__ballot(mall >= thr[qt]) != 0ull) {
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt) {
+                            if (__ballot(mdt[dt] >= thr[qt]) == 0ull) continue;
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) {
+                                const float v = acc[dt][qt][e];
+                                if (v >= thr[qt]) {
+                                    const int64_t doc = row_base + dt * 32 + (e & 3) + 8 * (e >> 2);
+                                    if (doc < a.n_rows) {
+                                        const uint32_t slot = atomicAdd(&lds_cnt[ql], 1u);
+                                        if (slot < (uint32_t)a.cap)
+                                            a.cand[((int64_t)r * a.nq_pad + q0 + ql) * a.cap + slot] =
+                                                make_uint2(__float_as_uint(v), (uint32_t)doc);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                } else {  // EPI_STORE
+                    const int q = q0 + ql;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int64_t doc = row_base + dt * 32 + (e & 3) + 8 * (e >> 2);
+                            if (q < a.n_q && doc < a.n_rows) a.store[(int64_t)q * a.n_rows + doc] = acc[dt][qt][e];
+                        }
+                }
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[dt][qt][e] = 0.f;
+        }
+
+        __syncthreads();  // all appends of the item done; LDS stage buffers free for the next item
+        if (EPI == EPI_FILTER) {
+            if (tid < TILE_Q) a.cnt[(int64_t)r * a.nq_pad + q0 + tid] = lds_cnt[tid];
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bf16 row norms (fp32 accumulate; used only for error margins, inflated by the caller)
+__global__ __launch_bounds__(256) void row_norms_bf16_kernel(const uint16_t *__restrict__ X, int64_t rows, int dim,
+                                                            float *__restrict__ norms, uint32_t *__restrict__ max_bits) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    float wmax = 0.f;
+    for (int64_t r = wave; r < rows; r += nwaves) {
+        const uint16_t *x = X + r * dim;
+        float s = 0.f;
+        for (int c = lane * 8; c < dim; c += 64 * 8) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(x + c);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
+                s = fmaf(lo, lo, s);
+                s = fmaf(hi, hi, s);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        const float n = sqrtf(s);
+        if (norms && lane == 0) norms[r] = n;
+        wmax = fmaxf(wmax, n);
+    }
+    if (max_bits && lane == 0) atomicMax(max_bits, __float_as_uint(wmax));  // non-negative floats order as uints
+}
+
+// thr[q] = (k-th largest group maximum) - delta[q];  grid = n_q, block = 256.
+__global__ __launch_bounds__(256) void threshold_kernel(const float *__restrict__ gmax, int64_t n_groups, int nq_pad,
+                                                       int k, const float *__restrict__ qnorm,
+                                                       const uint32_t *__restrict__ dmax_bits, float gamma,
+                                                       float *__restrict__ thr, float *__restrict__ delta) {
+    __shared__ uint32_t s_hist[256];
+    __shared__ uint32_t s_ctl[4];
+    const int q = blockIdx.x;
+    uint32_t kth;
+    int need_eq;
+    block_radix_select(
+        [&](int64_t i, bool &skip) -> uint32_t {
+            (void)skip;
+            return f32_orderable(gmax[i * nq_pad + q]);
+        },
+        n_groups, k, s_hist, s_ctl, kth, need_eq);
+    if (threadIdx.x == 0) {
+        const float tau = orderable_to_f32(kth);
+        const float dmax = __uint_as_float(*dmax_bits);
+        // |mfma - exact| <= gamma * ||q|| * ||d|| for both the threshold docs and the candidate
+        const float dl = 2.f * gamma * (qnorm[q] * 1.001f) * (dmax * 1.001f) + 1e-30f;
+        delta[q] = dl;
+        thr[q] = tau - dl;
+    }
+}
+
+// Stage-2: per query, candidates -> exact canonical top-k.  grid = n_q, block = 256.
+// dyn LDS: [dim bf16 query row][ranges uint32 counts][rescore_cap u64 keys]
+__global__ __launch_bounds__(256) void select_rescore_kernel(const uint2 *__restrict__ cand, const uint32_t *__restrict__ cnt,
+                                                            int ranges, int nq_pad, int cap, int k, int rescore_cap,
+                                                            const float *__restrict__ delta,
+                                                            const uint16_t *__restrict__ Q, const uint16_t *__restrict__ D,
+                                                            int dim, int64_t id_offset, float *__restrict__ out_scores,
+                                                            int64_t *__restrict__ out_ids, uint32_t *__restrict__ flag_count,
+                                                            uint32_t *__restrict__ flag_list,
+                                                            unsigned long long *__restrict__ stat_cand) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    uint16_t *s_q = reinterpret_cast<uint16_t *>(sm);
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(sm + (((size_t)dim * 2 + 15) & ~(size_t)15));
+    unsigned long long *s_keys =
+        reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(s_cnt) + (((size_t)ranges * 4 + 15) & ~(size_t)15));
+    __shared__ uint32_t s_hist[256];
+    __shared__ uint32_t s_ctl[4];
+    __shared__ int s_flag;
+    __shared__ uint32_t s_total;
+    __shared__ uint32_t s_ncoll;
+
+    const int tid = threadIdx.x;
+    const int q = blockIdx.x;
+    if (tid == 0) {
+        s_flag = 0;
+        s_total = 0;
+        s_ncoll = 0;
+    }
+    __syncthreads();
+    uint32_t my = 0;
+    for (int r = tid; r < ranges; r += blockDim.x) {
+        uint32_t c = cnt[(int64_t)r * nq_pad + q];
+        if (c > (uint32_t)cap) {
+            s_flag = 1;  // overflow: some survivors were dropped
+            c = (uint32_t)cap;
+        }
+        s_cnt[r] = c;
+        my += c;
+    }
+    if (my) atomicAdd(&s_total, my);
+    for (int c = tid; c < dim / 8; c += blockDim.x)
+        reinterpret_cast<uint4 *>(s_q)[c] = reinterpret_cast<const uint4 *>(Q + (int64_t)q * dim)[c];
+    __syncthreads();
+    if (tid == 0 && stat_cand) atomicAdd(stat_cand, (unsigned long long)s_total);
+    bool bad = (s_flag != 0) || (s_total < (uint32_t)k);
+
+    const int64_t slots = (int64_t)ranges * cap;
+    const uint2 *base = cand + (int64_t)q * cap;  // + r * nq_pad * cap
+    const int64_t rstride = (int64_t)nq_pad * cap;
+    uint32_t kth = 0;
+    int need_eq = 0;
+    if (!bad) {
+        block_radix_select(
+            [&](int64_t i, bool &skip) -> uint32_t {
+                const int r = (int)(i / cap);
+                const int s = (int)(i - (int64_t)r * cap);
+                if ((uint32_t)s >= s_cnt[r]) {
+                    skip = true;
+                    return 0u;
+                }
+                return f32_orderable(__uint_as_float(base[r * rstride + s].x));
+            },
+            slots, k, s_hist, s_ctl, kth, need_eq);
+        const float cut = orderable_to_f32(kth) - delta[q];
+        // collect everything within the margin of the k-th MFMA score
+        for (int64_t i = tid; i < slots; i += blockDim.x) {
+            const int r = (int)(i / cap);
+            const int s = (int)(i - (int64_t)r * cap);
+            if ((uint32_t)s >= s_cnt[r]) continue;
+            const uint2 e = base[r * rstride + s];
+            if (__uint_as_float(e.x) >= cut) {
+                const uint32_t p = atomicAdd(&s_ncoll, 1u);
+                if (p < (uint32_t)rescore_cap) s_keys[p] = (unsigned long long)e.y;  // local row for now
+            }
+        }
+        __syncthreads();
+        if (s_ncoll > (uint32_t)rescore_cap) bad = true;  // mass ties around the cut
+    }
+    if (bad) {
+        if (tid == 0) {
+            const uint32_t p = atomicAdd(flag_count, 1u);
+            flag_list[p] = (uint32_t)q;
+        }
+        return;
+    }
+    const int ncoll = (int)s_ncoll;
+    const int np2 = pow2_ceil(ncoll);
+    // canonical re-score
+    for (int i = tid; i < np2; i += blockDim.x) {
+        if (i < ncoll) {
+            const uint32_t row = (uint32_t)s_keys[i];
+            const float sc = canonical_dot(s_q, D + (int64_t)row * dim, dim);
+            s_keys[i] = make_key(sc, row);
+        } else {
+            s_keys[i] = 0ull;
+        }
+    }
+    block_bitonic_sort_desc(s_keys, np2);
+    for (int i = tid; i < k; i += blockDim.x) {
+        const unsigned long long key = s_keys[i];
+        out_scores[(int64_t)q * k + i] = key_score(key);
+        out_ids[(int64_t)q * k + i] = id_offset + (int64_t)key_idx(key);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+static size_t gemm_lds_bytes() { return 2 * (size_t)STAGE_BYTES + TILE_Q * sizeof(uint32_t); }
+
+template <int EPI>
+static int launch_gemm(const GemmArgs &a, int grid, hipStream_t s) {
+    static bool configured = false;
+    if (!configured) {
+        CCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_topk_kernel<EPI>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes()));
+        configured = true;
+    }
+    hipLaunchKernelGGL(gemm_topk_kernel<EPI>, dim3(grid), dim3(GEMM_THREADS), gemm_lds_bytes(), s, a);
+    CCR_LAUNCH_CHECK();
+    return CCR_OK;
+}
+
+int launch_gemm_filter(const GemmArgs &a, int grid, hipStream_t s) { return launch_gemm<EPI_FILTER>(a, grid, s); }
+int launch_gemm_gmax(const GemmArgs &a, int grid, hipStream_t s) { return launch_gemm<EPI_GMAX>(a, grid, s); }
+int launch_gemm_store(const GemmArgs &a, int grid, hipStream_t s) { return launch_gemm<EPI_STORE>(a, grid, s); }
+
+int launch_row_norms_bf16(const uint16_t *X, int64_t rows, int dim, float *norms, uint32_t *max_bits, hipStream_t s) {
+    if (rows <= 0) return CCR_OK;
+    int64_t blocks = (rows + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(row_norms_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, X, rows, dim, norms, max_bits);
+    CCR_LAUNCH_CHECK();
+    return CCR_OK;
+}
+
+int launch_threshold(const float *gmax, int64_t n_groups, int n_q, int nq_pad, int k, const float *qnorm,
+                     const uint32_t *dmax_bits, int dim, float *thr, float *delta, hipStream_t s) {
+    hipLaunchKernelGGL(threshold_kernel, dim3(n_q), dim3(256), 0, s, gmax, n_groups, nq_pad, k, qnorm, dmax_bits,
+                       mfma_gamma(dim), thr, delta);
+    CCR_LAUNCH_CHECK();
+    return CCR_OK;
+}
+
+size_t select_lds_bytes(int dim, int ranges, int rescore_cap) {
+    return (((size_t)dim * 2 + 15) & ~(size_t)15) + (((size_t)ranges * 4 + 15) & ~(size_t)15) + (size_t)rescore_cap * 8;
+}
+
+int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, int n_q, int nq_pad, int cap, int k,
+                          int rescore_cap, const float *delta, const uint16_t *Q, const uint16_t *D, int dim,
+                          int64_t id_offset, float *out_scores, int64_t *out_ids, uint32_t *flag_count,
+                          uint32_t *flag_list, unsigned long long *stat_cand, hipStream_t s) {
+    const size_t lds = select_lds_bytes(dim, ranges, rescore_cap);
+    static size_t configured = 0;
+    if (lds > 48 * 1024 && lds > configured) {
+        CCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&select_rescore_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+    }
+    hipLaunchKernelGGL(select_rescore_kernel, dim3(n_q), dim3(256), lds, s, cand, cnt, ranges, nq_pad, cap, k, rescore_cap,
+                       delta, Q, D, dim, id_offset, out_scores, out_ids, flag_count, flag_list, stat_cand);
+    CCR_LAUNCH_CHECK();
+    return CCR_OK;
+}
+
+}  // namespace ccr

@@ -1,0 +1,248 @@
+// ccr_pack.hip -- fp32 -> bf16 pack of encoder outputs (+ L2 normalise, + fused masked mean pooling).
+//
+// Pure HBM streaming kernels: 6 B per element (4 read + 2 written); the mean-pool variant reads
+// L * dim * sizeof(hidden) per row.  16 B per lane loads, 16 B per lane stores, one wave per row
+// where a row reduction is needed (fixed reduction order, mirrored by oracle/ccr_oracle.c).
+#include "ccr_common.h"
+
+namespace ccr {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ bf16x4 cvt4(float4 v) {
+    bf16x4 r;
+    r[0] = (__bf16)v.x;
+    r[1] = (__bf16)v.y;
+    r[2] = (__bf16)v.z;
+    r[3] = (__bf16)v.w;
+    return r;
+}
+
+// ---------------------------------------------------------------- plain elementwise pack
+// n8 = number of 8-element groups; tail handled by the scalar kernel below.
+__global__ __launch_bounds__(256) void pack_bf16_kernel(const float4 *__restrict__ src, bf16x8 *__restrict__ dst,
+                                                       int64_t n8) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n8; i += stride) {
+        float4 a = src[2 * i], b = src[2 * i + 1];
+        bf16x4 lo = cvt4(a), hi = cvt4(b);
+        bf16x8 r = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        dst[i] = r;
+    }
+}
+
+__global__ void pack_bf16_tail_kernel(const float *__restrict__ src, __bf16 *__restrict__ dst, int64_t begin,
+                                      int64_t n) {
+    int64_t i = begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (__bf16)src[i];
+}
+
+// ---------------------------------------------------------------- row-wise: norms / normalise + pack
+// One wave per row.  Lane l owns float4 chunks c with c % 64 == l; per-lane fp64 partial sum in
+// increasing index, then the butterfly p += shfl_xor(p, off) for off = 32..1 (every lane ends
+// with the same fp64 sum of squares).  This order is part of the canonical definition.
+__device__ __forceinline__ double wave_sumsq(const float *__restrict__ x, int dim, int lane) {
+    double p = 0.0;
+    const int nchunk = dim >> 2;
+    for (int c = lane; c < nchunk; c += 64) {
+        float4 v = reinterpret_cast<const float4 *>(x)[c];
+        p = p + (double)v.x * (double)v.x;
+        p = p + (double)v.y * (double)v.y;
+        p = p + (double)v.z * (double)v.z;
+        p = p + (double)v.w * (double)v.w;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) p = p + __shfl_xor(p, off, 64);
+    return p;
+}
+
+__global__ __launch_bounds__(256) void pack_rows_kernel(const float *__restrict__ src, __bf16 *__restrict__ dst,
+                                                       float *__restrict__ norms, int64_t rows, int dim,
+                                                       int normalize) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int nchunk = dim >> 2;
+    for (int64_t r = wave; r < rows; r += nwaves) {
+        const float *x = src + r * dim;
+        const double ss = wave_sumsq(x, dim, lane);
+        const double nrm = sqrt(ss);
+        if (norms && lane == 0) norms[r] = (float)nrm;
+        const double den = nrm > 1e-12 ? nrm : 1e-12;
+        bf16x4 *y = reinterpret_cast<bf16x4 *>(dst + r * dim);
+        for (int c = lane; c < nchunk; c += 64) {
+            float4 v = reinterpret_cast<const float4 *>(x)[c];
+            if (normalize) {
+                v.x = (float)((double)v.x / den);
+                v.y = (float)((double)v.y / den);
+                v.z = (float)((double)v.z / den);
+                v.w = (float)((double)v.w / den);
+            }
+            y[c] = cvt4(v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- fused masked mean pooling + pack
+// One workgroup of `dim/4` (<=256) threads... generalised: thread t owns float4 chunk columns
+// t, t+blockDim, ...; loop over tokens l ascending (fp32 adds in token order = the oracle's order);
+// divide by the mask count; optional normalise needs the row norm -> block reduction in fp64
+// (NOT the canonical wave order: normalised mean-pool output is tolerance-checked, not bit-checked).
+template <typename T>
+__device__ __forceinline__ float4 load4(const T *p);
+template <>
+__device__ __forceinline__ float4 load4<float>(const float *p) {
+    return *reinterpret_cast<const float4 *>(p);
+}
+template <>
+__device__ __forceinline__ float4 load4<_Float16>(const _Float16 *p) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    h4 v = *reinterpret_cast<const h4 *>(p);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+template <>
+__device__ __forceinline__ float4 load4<__bf16>(const __bf16 *p) {
+    bf16x4 v = *reinterpret_cast<const bf16x4 *>(p);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void meanpool_pack_kernel(const T *__restrict__ hidden,
+                                                           const int64_t *__restrict__ mask,
+                                                           __bf16 *__restrict__ dst_bf16,
+                                                           float *__restrict__ dst_f32, int L, int dim,
+                                                           int normalize) {
+    __shared__ double red[4];
+    __shared__ int s_cnt;
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int nchunk = dim >> 2;
+    const int64_t *m = mask + (int64_t)b * L;
+    if (tid == 0) {
+        long long c = 0;
+        for (int l = 0; l < L; ++l) c += m[l];
+        s_cnt = (int)c;
+    }
+    __syncthreads();
+    const float inv_is_div = (float)s_cnt;  // reference divides by the count (item_tower.py:145)
+    // pass 1: pooled fp32 value per owned chunk, kept in registers (<= 4 chunks per thread for dim <= 4096)
+    float4 acc[4];
+    int nown = 0;
+    double ss = 0.0;
+    for (int c = tid; c < nchunk && nown < 4; c += blockDim.x, ++nown) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        const T *h = hidden + (int64_t)b * L * dim + 4 * c;
+        for (int l = 0; l < L; ++l) {
+            if (m[l] != 0) {
+                float4 v = load4<T>(h + (int64_t)l * dim);
+                a.x += v.x;
+                a.y += v.y;
+                a.z += v.z;
+                a.w += v.w;
+            }
+        }
+        a.x /= inv_is_div;
+        a.y /= inv_is_div;
+        a.z /= inv_is_div;
+        a.w /= inv_is_div;
+        acc[nown] = a;
+        ss += (double)a.x * a.x + (double)a.y * a.y + (double)a.z * a.z + (double)a.w * a.w;
+    }
+    double den = 1.0;
+    if (normalize) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+        if ((tid & 63) == 0) red[tid >> 6] = ss;
+        __syncthreads();
+        double tot = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += red[w];
+        double nrm = sqrt(tot);
+        den = nrm > 1e-12 ? nrm : 1e-12;
+    }
+    nown = 0;
+    for (int c = tid; c < nchunk && nown < 4; c += blockDim.x, ++nown) {
+        float4 a = acc[nown];
+        if (dst_f32) reinterpret_cast<float4 *>(dst_f32 + (int64_t)b * dim)[c] = a;  // un-normalised pooled row
+        if (dst_bf16) {
+            if (normalize) {
+                a.x = (float)((double)a.x / den);
+                a.y = (float)((double)a.y / den);
+                a.z = (float)((double)a.z / den);
+                a.w = (float)((double)a.w / den);
+            }
+            reinterpret_cast<bf16x4 *>(dst_bf16 + (int64_t)b * dim)[c] = cvt4(a);
+        }
+    }
+}
+
+}  // namespace ccr
+
+using namespace ccr;
+
+extern "C" int ccr_pack_bf16(const float *src, uint16_t *dst, float *norms, int64_t rows, int dim, int normalize,
+                             void *stream) {
+    CCR_REQUIRE(src && dst, "ccr_pack_bf16: null pointer");
+    CCR_REQUIRE(rows >= 0 && dim > 0, "ccr_pack_bf16: bad shape rows=%lld dim=%d", (long long)rows, dim);
+    if (rows == 0) return CCR_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (!normalize && !norms) {
+        const int64_t n = rows * dim;
+        CCR_REQUIRE(((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0), "ccr_pack_bf16: buffers must be 16-byte aligned");
+        const int64_t n8 = n / 8;
+        if (n8 > 0) {
+            int64_t blocks = (n8 + 255) / 256;
+            if (blocks > 256 * 16) blocks = 256 * 16;
+            hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+                               reinterpret_cast<const float4 *>(src), reinterpret_cast<bf16x8 *>(dst), n8);
+            CCR_LAUNCH_CHECK();
+        }
+        if (n8 * 8 < n) {
+            hipLaunchKernelGGL(pack_bf16_tail_kernel, dim3(1), dim3(64), 0, s, src, reinterpret_cast<__bf16 *>(dst),
+                               n8 * 8, n);
+            CCR_LAUNCH_CHECK();
+        }
+        return CCR_OK;
+    }
+    CCR_REQUIRE(dim % 4 == 0, "ccr_pack_bf16: dim %% 4 != 0 (dim=%d) with normalize/norms", dim);
+    CCR_REQUIRE(((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 8 == 0), "ccr_pack_bf16: buffers must be 16-byte aligned");
+    int64_t blocks = (rows + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, reinterpret_cast<__bf16 *>(dst),
+                       norms, rows, dim, normalize);
+    CCR_LAUNCH_CHECK();
+    return CCR_OK;
+}
+
+extern "C" int ccr_meanpool_pack_bf16(const void *hidden, int hidden_dtype, const int64_t *mask, uint16_t *dst_bf16,
+                                      float *dst_f32, int B, int L, int dim, int normalize, void *stream) {
+    CCR_REQUIRE(hidden && mask && (dst_bf16 || dst_f32), "ccr_meanpool_pack_bf16: null pointer");
+    CCR_REQUIRE(B >= 0 && L > 0 && dim > 0 && dim % 4 == 0 && dim <= 4096,
+                "ccr_meanpool_pack_bf16: bad shape B=%d L=%d dim=%d (dim %% 4 == 0, dim <= 4096)", B, L, dim);
+    if (B == 0) return CCR_OK;
+    hipStream_t s = (hipStream_t)stream;
+    int threads = ((dim / 4 + 63) / 64) * 64;
+    if (threads > 256) threads = 256;
+    __bf16 *db = reinterpret_cast<__bf16 *>(dst_bf16);
+    switch (hidden_dtype) {
+        case CCR_DTYPE_F32:
+            hipLaunchKernelGGL(meanpool_pack_kernel<float>, dim3(B), dim3(threads), 0, s, (const float *)hidden, mask, db,
+                               dst_f32, L, dim, normalize);
+            break;
+        case CCR_DTYPE_F16:
+            hipLaunchKernelGGL(meanpool_pack_kernel<_Float16>, dim3(B), dim3(threads), 0, s, (const _Float16 *)hidden,
+                               mask, db, dst_f32, L, dim, normalize);
+            break;
+        case CCR_DTYPE_BF16:
+            hipLaunchKernelGGL(meanpool_pack_kernel<__bf16>, dim3(B), dim3(threads), 0, s, (const __bf16 *)hidden, mask,
+                               db, dst_f32, L, dim, normalize);
+            break;
+        default:
+            set_error("ccr_meanpool_pack_bf16: unknown hidden_dtype %d", hidden_dtype);
+            return CCR_ERR_INVALID;
+    }
+    CCR_LAUNCH_CHECK();
+    return CCR_OK;
+}

@@ -1,0 +1,104 @@
+// ccr_topk_device.h -- workgroup-level selection primitives shared by the dense and fused paths.
+//   * block_radix_select : exact k-th largest of M 32-bit orderable keys (4 x 8-bit MSB-first passes,
+//                          256-bin LDS histogram);
+//   * block_bitonic_sort_desc : in-LDS bitonic sort of 64-bit keys, descending.
+// 64-bit result keys are (orderable(score) << 32) | ~local_idx : unique per document, so "score
+// descending, index ascending" is plain descending key order.
+#pragma once
+#include "ccr_common.h"
+
+namespace ccr {
+
+// All threads of the block must call.  get(i) -> uint32 orderable key of item i (0 <= i < M) or
+// skip == true to ignore the slot.  On return (uniform across the block):
+//   kth      = key of the k-th largest item
+//   need_eq  = how many items equal to kth belong to the top-k (1 <= need_eq)
+// Requires the number of non-skipped items >= k.  s_hist: 256 uint32, s_ctl: 4 uint32 (LDS).
+template <class Get>
+__device__ __forceinline__ void block_radix_select(Get get, int64_t M, int k, uint32_t *s_hist, uint32_t *s_ctl,
+                                                   uint32_t &kth, int &need_eq) {
+    const int tid = threadIdx.x;
+    const int nt = blockDim.x;
+    uint32_t prefix = 0, mask = 0;
+    int remaining = k;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int b = tid; b < 256; b += nt) s_hist[b] = 0;
+        __syncthreads();
+        for (int64_t i = tid; i < M; i += nt) {
+            bool skip = false;
+            uint32_t o = get(i, skip);
+            if (!skip && (o & mask) == prefix) atomicAdd(&s_hist[(o >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int cum = 0, d = 255;
+            for (; d > 0; --d) {
+                int h = (int)s_hist[d];
+                if (cum + h >= remaining) break;
+                cum += h;
+            }
+            s_ctl[0] = (uint32_t)d;
+            s_ctl[1] = (uint32_t)(remaining - cum);
+        }
+        __syncthreads();
+        prefix |= s_ctl[0] << shift;
+        mask |= 0xffu << shift;
+        remaining = (int)s_ctl[1];
+        __syncthreads();
+    }
+    kth = prefix;
+    need_eq = remaining;
+}
+
+// keys[0..n) in LDS, n a power of two; all threads of the block must call.
+__device__ __forceinline__ void block_bitonic_sort_desc(unsigned long long *keys, int n) {
+    const int tid = threadIdx.x;
+    const int nt = blockDim.x;
+    for (int size = 2; size <= n; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int i = tid; i < (n >> 1); i += nt) {
+                const int pos = 2 * i - (i & (stride - 1));
+                const unsigned long long a = keys[pos], b = keys[pos + stride];
+                const bool desc = ((pos & size) == 0);
+                if ((a < b) == desc) {
+                    keys[pos] = b;
+                    keys[pos + stride] = a;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ unsigned long long make_key(float score, uint32_t local_idx) {
+    return ((unsigned long long)f32_orderable(score) << 32) | (unsigned long long)(~local_idx);
+}
+__device__ __forceinline__ float key_score(unsigned long long key) { return orderable_to_f32((uint32_t)(key >> 32)); }
+__device__ __forceinline__ uint32_t key_idx(unsigned long long key) { return ~(uint32_t)key; }
+
+__host__ __device__ __forceinline__ int pow2_ceil(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// canonical score of one (query, doc) pair: fp64 accumulate in increasing element order.
+// q: bf16 row in LDS (or global), d: bf16 row in global; dim % 8 == 0; both 16-byte aligned.
+__device__ __forceinline__ float canonical_dot(const uint16_t *__restrict__ q, const uint16_t *__restrict__ d, int dim) {
+    double acc = 0.0;
+    for (int c = 0; c < dim; c += 8) {
+        const uint4 dv = *reinterpret_cast<const uint4 *>(d + c);
+        const uint4 qv = *reinterpret_cast<const uint4 *>(q + c);
+        const uint32_t dw[4] = {dv.x, dv.y, dv.z, dv.w};
+        const uint32_t qw[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc = fma((double)__uint_as_float(qw[e] << 16), (double)__uint_as_float(dw[e] << 16), acc);
+            acc = fma((double)__uint_as_float(qw[e] & 0xffff0000u), (double)__uint_as_float(dw[e] & 0xffff0000u), acc);
+        }
+    }
+    return (float)acc;
+}
+
+}  // namespace ccr

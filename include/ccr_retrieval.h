@@ -1,0 +1,151 @@
+/*
+ * ccr_retrieval.h -- C ABI of the MI355X-native retrieval hot path
+ *                    (encode output -> bf16 pack -> exhaustive Q.D^T -> top-k -> shard merge).
+ *
+ * The reference (awslabs/crowd-coachable-recommendations) has no FFI for this path: it is plain
+ * Python over torch ops.  Each entry point below names the reference code it replaces
+ * (file:line under the reference tree); INTEGRATION.md shows the ctypes stub a maintainer adds.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every data pointer is DEVICE memory unless marked host;
+ *   - the caller owns every buffer; an index BORROWS the corpus pointer it was created on;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - return value: CCR_OK (0) or a negative CCR_ERR_* code; ccr_last_error() gives the text
+ *     (thread-local);
+ *   - embeddings are bf16 bit patterns (uint16_t), row-major [rows][dim];
+ *   - canonical arithmetic: score(q,d) = (float) sum_{i ascending} (double)q_i*(double)d_i,
+ *     rank order = score descending, id ascending on equal scores.  Results of ccr_search are
+ *     exactly that ordering for ANY input (near-ties and exact ties included).
+ */
+#ifndef CCR_RETRIEVAL_H
+#define CCR_RETRIEVAL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CCR_OK 0
+#define CCR_ERR_INVALID (-1)     /* bad argument (null pointer, dim not supported, k > rows, ...) */
+#define CCR_ERR_HIP (-2)         /* a HIP runtime call failed */
+#define CCR_ERR_WORKSPACE (-3)   /* workspace too small: see ccr_search_workspace_bytes */
+#define CCR_ERR_BLOCK_ID (-4)    /* a blocked id is outside the corpus ("block id not found") */
+
+#define CCR_DTYPE_F32 0
+#define CCR_DTYPE_F16 1
+#define CCR_DTYPE_BF16 2
+
+/* ccr_search flags */
+#define CCR_SEARCH_DEFAULT 0
+#define CCR_SEARCH_FORCE_DENSE 1   /* exact brute-force path for every query (tests, tiny corpora) */
+#define CCR_SEARCH_FORCE_FUSED 2   /* MFMA fused path even where the planner would pick dense */
+
+typedef struct ccr_index ccr_index;
+
+/* statistics of the last ccr_search on an index (host struct, filled after the call returns) */
+typedef struct ccr_search_stats {
+    int32_t path;              /* 0 = dense exact, 1 = fused MFMA */
+    int32_t n_fallback;        /* queries re-done by the dense path (candidate overflow / mass ties) */
+    int32_t sample_tiles;      /* 256-row corpus tiles scored by the threshold (sample) pass */
+    int32_t ranges;            /* corpus ranges of the main pass */
+    int32_t cap;               /* candidate slots per (range, query) */
+    int32_t reserved;
+    int64_t n_candidates;      /* total stage-1 survivors over all queries */
+} ccr_search_stats;
+
+const char *ccr_last_error(void);
+int ccr_version(void);
+
+/*
+ * fp32 -> bf16 pack of encoder outputs, optionally L2-normalising each row first.
+ * Replaces: the fp32 host copy + vstack of scripts/ms_marco_eval.py:141-149 (embeddings stay on
+ * device as a packed bf16 shard) and, with normalize=1, the F.normalize calls of cos_sim
+ * (scripts/ms_marco_eval.py:160-161; twin src/ccrec/models/bbpr.py:490-491).
+ *   src   [rows][dim] fp32          dst  [rows][dim] bf16 (RNE; NaN stays NaN)
+ *   norms [rows] fp32 or NULL: L2 norm of the fp32 row (before normalisation)
+ * dim % 4 == 0.  normalize: y = x / max(||x||, 1e-12), fixed reduction order (oracle/ccr_oracle.c).
+ */
+int ccr_pack_bf16(const float *src, uint16_t *dst, float *norms, int64_t rows, int dim, int normalize, void *stream);
+
+/*
+ * Fused masked mean pooling (+ optional normalise) + pack of the encoder's last hidden state.
+ * Replaces: src/ccrec/models/item_tower.py:137-147 (masked_fill, sum(dim=1), divide) followed by the pack.
+ *   hidden [B][L][dim] of hidden_dtype (CCR_DTYPE_*), mask [B][L] int64 (0/1)
+ *   dst_bf16 [B][dim] or NULL, dst_f32 [B][dim] or NULL (the un-rounded fp32 pooled rows)
+ */
+int ccr_meanpool_pack_bf16(const void *hidden, int hidden_dtype, const int64_t *mask, uint16_t *dst_bf16,
+                           float *dst_f32, int B, int L, int dim, int normalize, void *stream);
+
+/*
+ * Build a search index over a resident bf16 corpus shard (borrowed pointer, no copy).
+ * Replaces: the host-resident fp32 passage matrix of scripts/ms_marco_eval.py:199-201,208-210.
+ *   global_row_offset: id of row 0 of this shard in the whole corpus (multi-GPU row sharding).
+ * Synchronises `stream` once (computes the shard's max row norm for the filter margins).
+ */
+int ccr_index_create(const uint16_t *D_bf16, int64_t n_rows, int dim, int64_t global_row_offset, void *stream,
+                     ccr_index **out);
+int ccr_index_destroy(ccr_index *index);
+int64_t ccr_index_rows(const ccr_index *index);
+int ccr_index_dim(const ccr_index *index);
+
+/*
+ * Exhaustive inner-product top-k of n_q queries against the shard.
+ * Replaces: the score loop, the host [Q,N] matrix and the per-row full sort of
+ * scripts/ms_marco_eval.py:203-218,228-230, and the per-batch topk of
+ * src/rime_lite/util/__init__.py:136-142.
+ *   Q_bf16 [n_q][dim]; out_scores [n_q][k] fp32; out_ids [n_q][k] int64 (global ids)
+ *   1 <= k <= min(n_rows, 4096).
+ * The call returns after the results are complete on `stream` (it synchronises the stream once
+ * to read the fallback count).
+ */
+size_t ccr_search_workspace_bytes(const ccr_index *index, int n_q, int k);
+int ccr_search(ccr_index *index, const uint16_t *Q_bf16, int n_q, int k, float *out_scores, int64_t *out_ids,
+               void *workspace, size_t ws_bytes, int flags, void *stream);
+int ccr_search_last_stats(const ccr_index *index, ccr_search_stats *stats /* host */);
+
+/*
+ * Merge R per-shard top-k lists (after the RCCL all-gather) into the global top-k.
+ * New (the reference scores on one GPU only: SURVEY 2a); order rule as above.
+ *   scores [R][n_q][k], ids [R][n_q][k] -> out_scores [n_q][k], out_ids [n_q][k];  k <= 4096.
+ */
+int ccr_merge_topk(const float *scores, const int64_t *ids, int R, int n_q, int k, float *out_scores,
+                   int64_t *out_ids, void *stream);
+
+/*
+ * Apply per-query blocked ids to an over-fetched result list.
+ * Replaces: scripts/ms_marco_eval.py:224-227 (scores[block_ind] = -1e6, kept not removed).
+ *   in_* [n_q][k_in] canonical top-k_in with k_in >= min(n_rows, k_out + max block length);
+ *   block_ptr [n_q+1], block_idx [block_ptr[n_q]] int64 global ids, ascending inside each query;
+ *   out_* [n_q][k_out]: unblocked entries in order, then (only if fewer than k_out remain)
+ *   blocked ids ascending with score -1e6.  n_rows_total bounds valid ids (CCR_ERR_BLOCK_ID).
+ */
+int ccr_apply_block(const float *in_scores, const int64_t *in_ids, int n_q, int k_in, const int64_t *block_ptr,
+                    const int64_t *block_idx, int64_t n_rows_total, float *out_scores, int64_t *out_ids, int k_out,
+                    void *stream);
+
+/*
+ * In-batch-negative contrastive loss ("multiple_nrl"), forward and backward.
+ * Replaces: src/ccrec/models/bbpr.py:205-212 (two mm + cat + scale + CrossEntropyLoss mean).
+ *   Qe, Pe, Ne [B][dim] bf16; logits = [Qe Pe^T | Qe Ne^T] * inv_temperature (fp32 accumulate)
+ *   fwd: loss (1 float, mean CE with labels arange(B)), lse [B] (saved for bwd)
+ *   bwd: dQ, dP, dN [B][dim] fp32 = grad_out * dloss/d(.)
+ */
+int ccr_inbatch_ce_fwd(const uint16_t *Qe, const uint16_t *Pe, const uint16_t *Ne, int B, int dim,
+                       float inv_temperature, float *loss, float *lse, void *stream);
+int ccr_inbatch_ce_bwd(const uint16_t *Qe, const uint16_t *Pe, const uint16_t *Ne, const float *lse, int B, int dim,
+                       float inv_temperature, float grad_out, float *dQ, float *dP, float *dN, void *stream);
+
+/*
+ * Test/diagnostic entry points (not part of the drop-in surface).
+ *   ccr_debug_mfma_scores: the raw MFMA (bf16 x bf16 -> fp32) score matrix [n_q][n_rows] the filter sees.
+ *   ccr_debug_canonical_scores: the canonical fp64-ordered scores [n_q][n_rows].
+ */
+int ccr_debug_mfma_scores(const ccr_index *index, const uint16_t *Q_bf16, int n_q, float *out, void *stream);
+int ccr_debug_canonical_scores(const ccr_index *index, const uint16_t *Q_bf16, int n_q, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CCR_RETRIEVAL_H */

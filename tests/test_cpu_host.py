@@ -1,0 +1,133 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/ccr_retrieval.h declares
+(no compute calls without a GPU), the host mirror keeps the reference's config/error behaviour, and the
+multi-process exchange path (all-gather of per-shard top-k + merge) is correct under gloo, world_size 2."""
+import os
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, PKG, has_gpu
+
+
+def test_header_symbols_are_exported():
+    from ccrec_amd import _lib
+    header = open(os.path.join(ROOT, "include", "ccr_retrieval.h")).read()
+    declared = set(re.findall(r"\b(ccr_[a-z0-9_]+)\s*\(", header))
+    declared -= {"ccr_index", "ccr_search_stats"}
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} not exported by libccr_hip.so"
+    assert lib.ccr_version() >= 100
+    assert lib.ccr_last_error() is not None
+
+
+def test_library_is_in_tree_and_has_no_torch_dependency():
+    from ccrec_amd import _lib
+    assert _lib.LIB_PATH.startswith(PKG)
+    import subprocess
+    out = subprocess.run(["ldd", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "libamdhip64" in out and "torch" not in out and "c10" not in out
+
+
+@pytest.mark.skipif(has_gpu(), reason="checks the no-GPU behaviour")
+def test_product_path_fails_loudly_without_gpu():
+    from ccrec_amd import _lib, ops
+    from ccrec_amd.ms_marco_eval import ranking, cos_sim
+    os.environ["CCREC_SIM_TYPE"] = "dot"
+    with pytest.raises(_lib.CcrError, match="no CPU fallback"):
+        ranking({"p": 0}, {"q": 0}, lambda rows: torch.zeros(len(rows), 8), 4)
+    with pytest.raises(_lib.CcrError):
+        cos_sim(torch.zeros(2, 8), torch.zeros(3, 8))
+    with pytest.raises(_lib.CcrError):
+        ops.require_gpu()
+
+
+def test_product_package_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "oracle/_" not in src, f
+
+
+def test_env_defaults_follow_reference_names():
+    import ccrec_amd
+    names = [n for n, _, _ in ccrec_amd.env_defaults]
+    for n in ["CCREC_EMBEDDING_TYPE", "CCREC_MAX_LENGTH", "CCREC_SIM_TYPE", "CCREC_BBPR_INV_TEMPERATURE", "CCREC_NON_BLOCKING"]:
+        assert n in names and n in os.environ
+    old = os.environ["CCREC_SIM_TYPE"]
+    os.environ["CCREC_SIM_TYPE"] = "euclid"
+    try:
+        with pytest.raises(AssertionError):
+            ccrec_amd.init_env_defaults()
+    finally:
+        os.environ["CCREC_SIM_TYPE"] = old
+
+
+def test_shard_bounds_partition():
+    from ccrec_amd.dist import shard_bounds
+    for n, w in [(10, 3), (2681468, 8), (7, 8), (256, 2)]:
+        b = [shard_bounds(n, w, r) for r in range(w)]
+        assert b[0][0] == 0 and b[-1][1] == n
+        assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+        assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
+
+
+def test_round_robin_negatives():
+    from ccrec_amd.bbpr_loss import pick_round_robin_negatives
+    table = {0: [5, 6, 7], 1: [9]}
+    assert pick_round_robin_negatives(table, [0, 1, 0, 0, 0]) == [5, 9, 6, 7, 5]
+    assert table == {0: [6, 7, 5], 1: [9]}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, nq, k, out_dir):
+    import torch.distributed as dist
+    sys.path[:0] = [ROOT, PKG]
+    from ccrec_amd.dist import shard_bounds, sharded_search
+    from oracle import oracle as orc
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(3)
+    Db = orc.pack_bf16((torch.randn(n, 64, generator=g) / 8).numpy())
+    Qb = orc.pack_bf16((torch.randn(nq, 64, generator=g) / 8).numpy())
+    Db[n // 2 + 1] = Db[1]          # cross-shard exact tie: the lower global id must win
+    lo, hi = shard_bounds(n, world, rank)
+
+    class Shard:  # CPU stand-in for a CorpusIndex: the oracle scores the local rows
+        n_rows = hi - lo
+
+    def search_fn(q, kk):
+        ids, sc = orc.canonical_search(Qb, Db[lo:hi], kk)
+        return torch.from_numpy(sc), torch.from_numpy(ids + lo)
+
+    def merge_fn(gs, gi):
+        s, i = orc.merge_topk(gs.numpy(), gi.numpy())
+        return torch.from_numpy(s), torch.from_numpy(i)
+
+    s, i = sharded_search(Shard(), None, k, merge_fn=merge_fn, search_fn=search_fn)
+    ref_i, ref_s = orc.canonical_search(Qb, Db, k)
+    ok = np.array_equal(i.numpy(), ref_i) and np.array_equal(s.numpy(), ref_s)
+    open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if ok else "MISMATCH")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,k", [(1000, 50), (9, 8)])   # second case: a shard smaller than k (padding path)
+def test_sharded_search_gloo_world2(tmp_path, n, k):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, n, 6, k, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert open(tmp_path / f"rank{r}.txt").read() == "ok"

@@ -1,0 +1,230 @@
+"""GPU parity proper: the HIP search path (through the C ABI) vs the CPU oracle and the golden vectors.
+Integer/index work is compared bit-exact; scores are canonical fp32 values and compared bit-exact too."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_rank_close, canonicalise
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+DENSE, FUSED = 1, 2
+
+
+def _bf16(bits):
+    return torch.from_numpy(bits.view(np.int16)).view(torch.bfloat16).cuda()
+
+
+def _bits(t):
+    return t.view(torch.int16).cpu().numpy().view(np.uint16)
+
+
+def _rand_bits(n, d, seed, scale=None):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, d, generator=g) * (scale if scale is not None else d ** -0.5)
+    return orc.pack_bf16(x.numpy())
+
+
+def _check_exact(index, Qb, Db, k, flags, block=None):
+    s, i = index.search(_bf16(Qb), k, flags)
+    ref_i, ref_s = orc.canonical_search(Qb, Db, k, block)
+    got_i, got_s = i.cpu().numpy() - index.offset, s.cpu().numpy()
+    assert np.array_equal(got_i, ref_i), f"ids differ in {np.sum(got_i != ref_i)} places"
+    assert np.array_equal(got_s.view(np.uint32), ref_s.view(np.uint32))
+    return index.last_stats()
+
+
+# ----------------------------------------------------------------------------------------- golden, via ranking()
+def _table_func(table):
+    return lambda rows: table[torch.as_tensor(rows, dtype=torch.long)]
+
+
+def _ranking_via_api(g, sim, block=None):
+    from ccrec_amd.ms_marco_eval import ranking
+    os.environ["CCREC_SIM_TYPE"] = sim
+    Eq, Ed = torch.from_numpy(g["Eq"]), torch.from_numpy(g["Ed"])
+    nq, nd = Eq.shape[0], Ed.shape[0]
+    table = torch.cat([Eq, Ed], 0)
+    queries = {f"q{i}": i for i in range(nq)}
+    corpus = {f"p{j}": nq + j for j in range(nd)}
+    block_dict = None if block is None else {f"q{i}": [f"p{j}" for j in block[i]] for i in range(nq)}
+    prof = ranking(corpus, queries, _table_func(table), int(g["batch_size"]), block_dict)
+    L = min(1001, nd)
+    ids = np.array([[int(p[1:]) for p in prof[f"q{i}"]] for i in range(nq)], np.int64)
+    sc = np.array([list(prof[f"q{i}"].values()) for i in range(nq)], np.float32)
+    assert ids.shape == (nq, L)
+    return ids, sc
+
+
+@pytest.mark.parametrize("name,sim,trunc,tol", [
+    ("g1_ranking_dot.npz", "dot", False, 2e-6), ("g4_ranking_trunc.npz", "dot", True, 2e-6),
+    ("g2_ranking_cos.npz", "cos", False, 1e-3)])
+def test_ranking_api_vs_reference_golden(golden_dir, name, sim, trunc, tol):
+    g = np.load(os.path.join(golden_dir, name))
+    ids, sc = _ranking_via_api(g, sim)
+    assert_rank_close(ids, sc, g["ids"], g["scores"], tol=tol, truncated=trunc)     # vs the reference's output
+    ref_i, ref_s = orc.canonical_ranking(g["Eq"], g["Ed"], sim)                      # vs the oracle: bit-exact
+    assert np.array_equal(ids, ref_i) and np.array_equal(sc.view(np.uint32), ref_s.view(np.uint32))
+
+
+def test_ranking_api_block_dict(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g3_ranking_block.npz"))
+    ptr, idx = g["block_ptr"], g["block_idx"]
+    block = [idx[ptr[i]:ptr[i + 1]].tolist() for i in range(len(ptr) - 1)]
+    ids, sc = _ranking_via_api(g, "dot", block)
+    ref_i, ref_s = orc.canonical_ranking(g["Eq"], g["Ed"], "dot", block=block)
+    assert np.array_equal(ids, ref_i) and np.array_equal(sc.view(np.uint32), ref_s.view(np.uint32))
+    ri, rs = canonicalise(g["ids"], g["scores"])
+    assert_rank_close(ids, sc, ri, rs, tol=2e-6)
+    from ccrec_amd.ms_marco_eval import ranking
+    with pytest.raises(AssertionError, match="block id not found"):
+        ranking({"p0": 0, "p1": 1}, {"q0": 0}, _table_func(torch.from_numpy(g["Ed"][:2])), 8, {"q0": ["nope"]})
+
+
+def test_exact_arithmetic_ties_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g5_ranking_exact_ties.npz"))
+    ids, sc = _ranking_via_api(g, "dot")
+    ri, rs = canonicalise(g["ids"], g["scores"])
+    assert np.array_equal(ids, ri) and np.array_equal(sc.view(np.uint32), rs.view(np.uint32))
+
+
+def test_sim_type_keyerror():
+    from ccrec_amd.ms_marco_eval import ranking
+    old = os.environ.pop("CCREC_SIM_TYPE", None)
+    try:
+        with pytest.raises(KeyError):
+            ranking({"p": 0}, {"q": 0}, _table_func(torch.zeros(1, 8)), 4)
+    finally:
+        if old is not None:
+            os.environ["CCREC_SIM_TYPE"] = old
+
+
+# ----------------------------------------------------------------------------------------- score kernels
+def test_canonical_and_mfma_scores():
+    from ccrec_amd import ops
+    Db, Qb = _rand_bits(700, 768, 1), _rand_bits(37, 768, 2)
+    index = ops.CorpusIndex(_bf16(Db))
+    can = index.debug_scores(_bf16(Qb), canonical=True).cpu().numpy()
+    ref = orc.canonical_scores(Qb, Db)
+    assert np.array_equal(can.view(np.uint32), ref.view(np.uint32))
+    mf = index.debug_scores(_bf16(Qb), canonical=False).cpu().numpy()
+    # MFMA fp32 accumulation: bounded by gamma * ||q|| * ||d|| (the filter margin); report the measured error
+    qn, dn = orc.row_norms_bf16(Qb), orc.row_norms_bf16(Db)
+    bound = 768 * 2.0 ** -23 * qn[:, None] * dn[None, :]
+    err = np.abs(mf.astype(np.float64) - ref)
+    print("max |mfma - canonical| =", err.max(), " worst fraction of the margin =", (err / bound).max())
+    assert (err <= bound).all()
+    # exact-integer operands (asymmetric): the MFMA product must be exact -> catches any layout transposition
+    rs = np.random.RandomState(3)
+    Di = orc.pack_bf16(rs.randint(-8, 9, size=(515, 128)).astype(np.float32))
+    Qi = orc.pack_bf16(rs.randint(-8, 9, size=(261, 128)).astype(np.float32))
+    ix2 = ops.CorpusIndex(_bf16(Di))
+    mf2 = ix2.debug_scores(_bf16(Qi), canonical=False).cpu().numpy()
+    assert np.array_equal(mf2, orc.canonical_scores(Qi, Di))
+
+
+# ----------------------------------------------------------------------------------------- search paths
+@pytest.mark.parametrize("n,nq,d,k", [(300, 7, 768, 300), (1000, 3, 64, 1), (5000, 70, 768, 100), (2049, 257, 1024, 1001),
+                                      (777, 1, 8, 10), (1500, 5, 776, 50)])
+def test_dense_path_exact(n, nq, d, k):
+    from ccrec_amd import ops
+    Db, Qb = _rand_bits(n, d, n), _rand_bits(nq, d, nq + 1)
+    st = _check_exact(ops.CorpusIndex(_bf16(Db)), Qb, Db, k, DENSE)
+    assert st["path"] == 0
+
+
+@pytest.mark.parametrize("n,nq,d,k", [(20000, 300, 768, 100), (16384, 64, 768, 10), (30001, 513, 1024, 257),
+                                      (40000, 33, 768, 1001), (9000, 1, 128, 5)])
+def test_fused_path_exact(n, nq, d, k):
+    from ccrec_amd import ops
+    Db, Qb = _rand_bits(n, d, n), _rand_bits(nq, d, nq + 1)
+    st = _check_exact(ops.CorpusIndex(_bf16(Db), global_row_offset=12345), Qb, Db, k, FUSED)
+    assert st["path"] == 1, st
+    print(st)
+
+
+def test_planner_default_is_fused_at_scale_and_exact():
+    from ccrec_amd import ops
+    n, nq, d, k = 300_000, 64, 768, 100
+    Db, Qb = _rand_bits(n, d, 77), _rand_bits(nq, d, 78)
+    st = _check_exact(ops.CorpusIndex(_bf16(Db)), Qb, Db, k, 0)
+    assert st["path"] == 1 and st["n_fallback"] == 0, st
+    print(st)
+
+
+def test_mass_ties_and_duplicates_fall_back_exactly():
+    """Exact-arithmetic corpus where thousands of rows tie at the top: the fused path must flag the
+    queries (candidate overflow / margin set too large) and the dense fallback must give the canonical order."""
+    from ccrec_amd import ops
+    rs = np.random.RandomState(5)
+    n, d = 12000, 128
+    D = rs.randint(-4, 5, size=(n, d)).astype(np.float32) / 4
+    D[2000:9000] = D[17]                    # 7001 identical rows
+    Q = rs.randint(-4, 5, size=(5, d)).astype(np.float32) / 4
+    Q[0] = D[17]                             # its top-k is inside the tie
+    Db, Qb = orc.pack_bf16(D), orc.pack_bf16(Q)
+    st = _check_exact(ops.CorpusIndex(_bf16(Db)), Qb, Db, 100, FUSED)
+    assert st["path"] == 1 and st["n_fallback"] >= 1, st
+
+
+def test_adversarial_sorted_corpus():
+    """Scores increase with the row index, so the sampled threshold is loose for late rows."""
+    from ccrec_amd import ops
+    n, d = 50000, 64
+    g = torch.Generator().manual_seed(9)
+    base = torch.randn(d, generator=g)
+    D = (torch.linspace(-1, 1, n)[:, None] * base[None, :] + 0.01 * torch.randn(n, d, generator=g)).numpy()
+    Q = (base[None, :] * torch.tensor([[1.0], [-1.0], [0.5]])).numpy()
+    Db, Qb = orc.pack_bf16(D), orc.pack_bf16(Q)
+    st = _check_exact(ops.CorpusIndex(_bf16(Db)), Qb, Db, 64, FUSED)
+    print(st)
+
+
+def test_empty_and_invalid():
+    from ccrec_amd import ops, _lib
+    Db = _rand_bits(100, 64, 1)
+    index = ops.CorpusIndex(_bf16(Db))
+    s, i = index.search(torch.empty(0, 64, dtype=torch.bfloat16, device="cuda"), 5)
+    assert s.shape == (0, 5) and i.shape == (0, 5)
+    with pytest.raises(_lib.CcrError):
+        index.search(_bf16(_rand_bits(2, 64, 2)), 101)      # k > n_rows
+    with pytest.raises(_lib.CcrError):
+        ops.CorpusIndex(torch.zeros(4, 12, dtype=torch.bfloat16, device="cuda"))   # dim % 8 != 0
+
+
+def test_merge_and_sharded_search_equal_single():
+    from ccrec_amd import ops
+    n, nq, d, k = 30000, 50, 768, 100
+    Db, Qb = _rand_bits(n, d, 31), _rand_bits(nq, d, 32)
+    D, Q = _bf16(Db), _bf16(Qb)
+    s1, i1 = ops.CorpusIndex(D).search(Q, k)
+    from ccrec_amd.dist import shard_bounds
+    parts = []
+    for r in range(3):
+        lo, hi = shard_bounds(n, 3, r)
+        parts.append(ops.CorpusIndex(D[lo:hi].contiguous(), global_row_offset=lo).search(Q, k))
+    gs, gi = torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts])
+    ms, mi = ops.merge_topk(gs, gi)
+    assert torch.equal(mi, i1) and torch.equal(ms.view(torch.int32), s1.view(torch.int32))
+    os_, oi = orc.merge_topk(gs.cpu().numpy(), gi.cpu().numpy())
+    assert np.array_equal(mi.cpu().numpy(), oi) and np.array_equal(ms.cpu().numpy(), os_)
+
+
+def test_assign_topk_golden(golden_dir):
+    from ccrec_amd.rime_util import _assign_topk
+    g = np.load(os.path.join(golden_dir, "g8_assign_topk.npz"))
+    k = int(g["k"])
+    csr = _assign_topk((g["U"], g["V"]), k)
+    assert csr.shape == (50, 4000) and np.array_equal(csr.indptr, g["indptr"]) and np.all(csr.data == 1)
+    ids = csr.indices.reshape(50, k)
+    ref_i, ref_s = orc.canonical_search(orc.pack_bf16(g["U"]), orc.pack_bf16(g["V"]), k)
+    assert np.array_equal(ids, ref_i)
+    ref_sc = np.take_along_axis(g["U"].astype(np.float64) @ g["V"].astype(np.float64).T, g["indices"], 1).astype(np.float32)
+    assert_rank_close(ids, ref_s, g["indices"], ref_sc, tol=2e-6, truncated=True)
+
+    class FakeMatMul:  # MatMulExpression duck type: .left [U,d], .right [d,I]  (score_array.py:320-323)
+        left, right = g["U"], g["V"].T
+    assert np.array_equal(_assign_topk(FakeMatMul(), k).indices, csr.indices)
