@@ -127,7 +127,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
 
         stage(0);
         for (int64_t step = 0; step < total; ++step) {
-            __syncthreads();  // stage `step` landed (vmcnt(0) + barrier); everyone is done with the other buffer
+            // Stage `step` must have LANDED in LDS for every wave before anyone reads it: an LDS-DMA is
+            // tracked by the issuing wave's vmcnt only, and hipcc does not add that wait to
+            // __syncthreads() here (seen in the .s: lgkmcnt(0) + s_barrier only) -> explicit drain.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // + barrier: everyone is also done reading the other buffer
             if (step + 1 < total) stage(step + 1);
             const char *buf = smem + (step & 1) * STAGE_BYTES;
 #pragma unroll
