@@ -115,6 +115,7 @@ struct ccr_index {
     uint32_t *dmax_bits;  // device: bits of the max row norm
     int num_cu;
     int device;
+    hipEvent_t ev[7];     // phase boundaries of the last search
     ccr_search_stats stats;
 };
 
@@ -139,6 +140,7 @@ extern "C" int ccr_index_create(const uint16_t *D_bf16, int64_t n_rows, int dim,
     hipDeviceProp_t prop;
     CCR_HIP_CHECK(hipGetDeviceProperties(&prop, ix->device));
     ix->num_cu = prop.multiProcessorCount;
+    for (int i = 0; i < 7; ++i) CCR_HIP_CHECK(hipEventCreate(&ix->ev[i]));
     CCR_HIP_CHECK(hipMalloc((void **)&ix->dmax_bits, 256));
     CCR_HIP_CHECK(hipMemsetAsync(ix->dmax_bits, 0, 256, s));
     int rc = launch_row_norms_bf16(D_bf16, n_rows, dim, nullptr, ix->dmax_bits, s);
@@ -151,6 +153,8 @@ extern "C" int ccr_index_create(const uint16_t *D_bf16, int64_t n_rows, int dim,
 extern "C" int ccr_index_destroy(ccr_index *ix) {
     if (!ix) return CCR_OK;
     if (ix->dmax_bits) (void)hipFree(ix->dmax_bits);
+    for (int i = 0; i < 7; ++i)
+        if (ix->ev[i]) (void)hipEventDestroy(ix->ev[i]);
     delete ix;
     return CCR_OK;
 }
@@ -205,9 +209,16 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
     char *ws = (char *)workspace;
     float *dense_scratch = (float *)(ws + p.off_dense);
 
+    CCR_HIP_CHECK(hipEventRecord(ix->ev[0], s));
     if (!p.fused) {
         ix->stats.path = 0;
-        return dense_for_list(ix, Q_bf16, nullptr, 0, n_q, k, dense_scratch, p.dense_rows_per_chunk, out_scores, out_ids, s);
+        int rc0 = dense_for_list(ix, Q_bf16, nullptr, 0, n_q, k, dense_scratch, p.dense_rows_per_chunk, out_scores, out_ids, s);
+        if (rc0 != CCR_OK) return rc0;
+        CCR_HIP_CHECK(hipEventRecord(ix->ev[6], s));
+        CCR_HIP_CHECK(hipStreamSynchronize(s));
+        CCR_HIP_CHECK(hipEventElapsedTime(&ix->stats.ms_total, ix->ev[0], ix->ev[6]));
+        ix->stats.ms_fallback = ix->stats.ms_total;
+        return CCR_OK;
     }
 
     float *qnorm = (float *)(ws + p.off_qnorm);
@@ -241,8 +252,10 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
     gs.tile_stride = p.sample_stride;
     gs.ranges = (int)round_up(std::min<int64_t>(p.ranges, std::max<int64_t>(NUM_XCD, p.sample_tiles / 4)), NUM_XCD);
     gs.gmax = gmax;
+    CCR_HIP_CHECK(hipEventRecord(ix->ev[1], s));
     rc = launch_gemm_gmax(gs, p.grid, s);
     if (rc != CCR_OK) return rc;
+    CCR_HIP_CHECK(hipEventRecord(ix->ev[2], s));
     rc = launch_threshold(gmax, (int64_t)p.sample_tiles * GROUPS_PER_TILE, n_q, p.nq_pad, k, qnorm, ix->dmax_bits, ix->dim,
                           thr, delta, s);
     if (rc != CCR_OK) return rc;
@@ -256,8 +269,10 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
     gm.cand = cand;
     gm.cnt = cnt;
     gm.cap = p.cap;
+    CCR_HIP_CHECK(hipEventRecord(ix->ev[3], s));
     rc = launch_gemm_filter(gm, p.grid, s);
     if (rc != CCR_OK) return rc;
+    CCR_HIP_CHECK(hipEventRecord(ix->ev[4], s));
 
     rc = launch_select_rescore(cand, cnt, p.ranges, n_q, p.nq_pad, p.cap, k, p.rescore_cap, delta, Q_bf16, ix->D, ix->dim,
                                ix->offset, out_scores, out_ids, flag_count, flag_list, stat_cand, s);
@@ -268,8 +283,19 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
         uint32_t nflag, pad;
         unsigned long long ncand;
     } host;
+    CCR_HIP_CHECK(hipEventRecord(ix->ev[5], s));
     CCR_HIP_CHECK(hipMemcpyAsync(&host, flag_count, sizeof(host), hipMemcpyDeviceToHost, s));
     CCR_HIP_CHECK(hipStreamSynchronize(s));
+    {
+        float a = 0, b = 0;
+        CCR_HIP_CHECK(hipEventElapsedTime(&ix->stats.ms_sample, ix->ev[1], ix->ev[2]));
+        CCR_HIP_CHECK(hipEventElapsedTime(&a, ix->ev[0], ix->ev[1]));
+        CCR_HIP_CHECK(hipEventElapsedTime(&b, ix->ev[2], ix->ev[3]));
+        ix->stats.ms_threshold = a + b;
+        CCR_HIP_CHECK(hipEventElapsedTime(&ix->stats.ms_main, ix->ev[3], ix->ev[4]));
+        CCR_HIP_CHECK(hipEventElapsedTime(&ix->stats.ms_select, ix->ev[4], ix->ev[5]));
+        CCR_HIP_CHECK(hipEventElapsedTime(&ix->stats.ms_total, ix->ev[0], ix->ev[5]));
+    }
     ix->stats.path = 1;
     ix->stats.n_fallback = (int32_t)host.nflag;
     ix->stats.sample_tiles = p.sample_tiles;
@@ -280,7 +306,10 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
         rc = dense_for_list(ix, Q_bf16, flag_list, 0, (int)host.nflag, k, dense_scratch, p.dense_rows_per_chunk, out_scores,
                             out_ids, s);
         if (rc != CCR_OK) return rc;
+        CCR_HIP_CHECK(hipEventRecord(ix->ev[6], s));
         CCR_HIP_CHECK(hipStreamSynchronize(s));
+        CCR_HIP_CHECK(hipEventElapsedTime(&ix->stats.ms_fallback, ix->ev[5], ix->ev[6]));
+        ix->stats.ms_total += ix->stats.ms_fallback;
     }
     return CCR_OK;
 }

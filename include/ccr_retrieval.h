@@ -53,6 +53,13 @@ typedef struct ccr_search_stats {
     int32_t cap;               /* candidate slots per (range, query) */
     int32_t reserved;
     int64_t n_candidates;      /* total stage-1 survivors over all queries */
+    /* device time of each phase of the last search, from HIP events on the search stream (ms) */
+    float ms_sample;           /* sample pass GEMM (group maxima) */
+    float ms_threshold;        /* query norms + threshold select */
+    float ms_main;             /* main pass GEMM + filter (the dominant kernel) */
+    float ms_select;           /* stage-2 select + canonical re-score */
+    float ms_fallback;         /* dense fallback for flagged queries (0 if none) */
+    float ms_total;
 } ccr_search_stats;
 
 const char *ccr_last_error(void);

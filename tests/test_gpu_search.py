@@ -228,3 +228,21 @@ def test_assign_topk_golden(golden_dir):
     class FakeMatMul:  # MatMulExpression duck type: .left [U,d], .right [d,I]  (score_array.py:320-323)
         left, right = g["U"], g["V"].T
     assert np.array_equal(_assign_topk(FakeMatMul(), k).indices, csr.indices)
+
+
+def test_many_query_blocks_multi_item_workgroups():
+    """3,452 queries = 14 query blocks: every workgroup walks several (range, query-block) items.
+    All queries are compared against the exact dense GPU path, a subset against the CPU oracle."""
+    from ccrec_amd import ops
+    n, nq, d, k = 60_000, 3452, 768, 100
+    Db, Qb = _rand_bits(n, d, 91), _rand_bits(nq, d, 92)
+    index = ops.CorpusIndex(_bf16(Db))
+    s, i = index.search(_bf16(Qb), k, FUSED)
+    st = index.last_stats()
+    print(st)
+    assert st["path"] == 1 and st["n_fallback"] == 0, st
+    s2, i2 = index.search(_bf16(Qb), k, DENSE)
+    assert torch.equal(i, i2) and torch.equal(s.view(torch.int32), s2.view(torch.int32))
+    sub = np.r_[0:8, 1700:1708, 3444:3452]
+    ref_i, ref_s = orc.canonical_search(Qb[sub], Db, k)
+    assert np.array_equal(i.cpu().numpy()[sub], ref_i) and np.array_equal(s.cpu().numpy()[sub], ref_s)
