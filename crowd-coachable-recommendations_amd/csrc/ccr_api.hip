@@ -1,5 +1,6 @@
 // ccr_api.hip -- host side of the C ABI: index object, planner, ccr_search orchestration.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -269,10 +270,37 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
     gm.cand = cand;
     gm.cnt = cnt;
     gm.cap = p.cap;
+    unsigned long long *stamps = nullptr;   // CCR_GEMM_DBG=16: in-kernel cycle stamps of the main pass (diagnostic build)
+    const char *dbg_env = getenv("CCR_GEMM_DBG");
+    const bool want_stamps = dbg_env && atoi(dbg_env) == 16;
+    if (want_stamps) {
+        CCR_HIP_CHECK(hipMalloc((void **)&stamps, (size_t)p.grid * 64 * 8));
+        CCR_HIP_CHECK(hipMemsetAsync(stamps, 0, (size_t)p.grid * 64 * 8, s));
+        gm.store = reinterpret_cast<float *>(stamps);
+    }
     CCR_HIP_CHECK(hipEventRecord(ix->ev[3], s));
     rc = launch_gemm_filter(gm, p.grid, s);
     if (rc != CCR_OK) return rc;
     CCR_HIP_CHECK(hipEventRecord(ix->ev[4], s));
+    if (want_stamps) {
+        std::vector<unsigned long long> h((size_t)p.grid * 64);
+        CCR_HIP_CHECK(hipMemcpyAsync(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost, s));
+        CCR_HIP_CHECK(hipStreamSynchronize(s));
+        static const char *names[6] = {"barrierB+loop", "epilogue", "dma_wait", "lds_reads", "barrierA", "mfma+issue"};
+        for (int grp = 0; grp < 2; ++grp) {
+            double sum[8] = {0};
+            int n = 0;
+            for (int b = 0; b < p.grid; ++b)
+                for (int w = grp * 4; w < grp * 4 + 4; ++w, ++n)
+                    for (int i = 0; i < 8; ++i) sum[i] += (double)h[((size_t)b * 8 + w) * 8 + i];
+            double tot = 0;
+            for (int i = 0; i < 6; ++i) tot += sum[i];
+            fprintf(stderr, "[ccr stamps] waves %d-%d: total %.0f cycles/wave;", grp * 4, grp * 4 + 3, tot / n);
+            for (int i = 0; i < 6; ++i) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * sum[i] / tot);
+            fprintf(stderr, "\n");
+        }
+        (void)hipFree(stamps);
+    }
 
     rc = launch_select_rescore(cand, cnt, p.ranges, n_q, p.nq_pad, p.cap, k, p.rescore_cap, delta, Q_bf16, ix->D, ix->dim,
                                ix->offset, out_scores, out_ids, flag_count, flag_list, stat_cand, s);

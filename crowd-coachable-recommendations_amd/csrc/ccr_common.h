@@ -83,6 +83,7 @@ struct GemmArgs {
     float *gmax;          // [n_vt * 16][nq_pad]
     // EPI_STORE (debug)
     float *store;         // [n_q][n_rows]
+    int dbg;              // timing-only ablations (CCR_GEMM_DBG; results are WRONG when non-zero)
 };
 
 Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu);

@@ -20,6 +20,8 @@
 // 16-byte chunk index XOR-swizzled with (row>>1)&7 on the SOURCE address and on the fragment read
 // (conflict-free ds_read_b128, cdna guide T2 / rule 21).
 #include "ccr_common.h"
+#include <stdlib.h>
+
 #include "ccr_topk_device.h"
 
 namespace ccr {
@@ -38,7 +40,7 @@ __device__ __forceinline__ void glds16(const void *gsrc, char *lds_wave_base) {
 }
 
 template <int EPI>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_v1(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t *lds_cnt = reinterpret_cast<uint32_t *>(smem + 2 * STAGE_BYTES);  // [TILE_Q]
 
@@ -219,6 +221,348 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
     }
 }
 
+
+// =============================================================================================
+// v2: ping-pong schedule.  K is walked in 32-element sub-stages through a ring of four 32-KiB LDS
+// buffers (3 sub-stages of LDS-DMA in flight, counted vmcnt, raw s_barrier).  The two waves that
+// share a SIMD (wave w and w+4) run one barrier interval apart: while one executes its 16 MFMAs
+// the other reads its next operands from LDS, issues the next sub-stage's DMA and runs the top-k
+// filter of a finished tile (VALU beside the partner's MFMAs).
+//   per wave and sub-stage u:   [mem(u): filter of a finished tile | wait own DMA of u+1 | 12 ds_read_b128 of u]
+//                               barrier  [16 x v_mfma_f32_32x32x16_bf16 with the DMA of u+3 issued among them]  barrier
+// Publication: a wave confirms (vmcnt) its own DMA of sub-stage u one phase pair before anyone
+// reads u, and a barrier instance lies between (see DESIGN.md "LDS ring protocol").
+constexpr int SUB_K = 32;
+constexpr int SUB_BYTES = (TILE_DOCS + TILE_Q) * SUB_K * 2;  // 32768
+constexpr int SUB_Q_REGION = TILE_DOCS * SUB_K * 2;           // 16384
+constexpr int RING = 4;
+
+#define CCR_BARRIER() asm volatile("s_barrier" ::: "memory")
+#define CCR_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define CCR_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+__device__ __forceinline__ uint32_t lds_inc_rtn(uint32_t *p) {
+    // hand-issued so that hipcc does not drain the LDS-DMA queue (vmcnt(0)) in front of an LDS atomic
+    const uint32_t addr = (uint32_t)(size_t)((__attribute__((address_space(3))) uint32_t *)p);
+    uint32_t r;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(addr), "v"(1u) : "memory");
+    return r;
+}
+
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#define CCR_STAMP(idx)                                   \
+    if constexpr ((DBG & 16) != 0) {                     \
+        __builtin_amdgcn_sched_barrier(0);               \
+        const unsigned long long _t = stamp();           \
+        __builtin_amdgcn_sched_barrier(0);               \
+        seg[idx] += _t - tprev;                          \
+        tprev = _t;                                      \
+    }
+
+template <int EPI, bool STAGGER, int DBG>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_v2(const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t *lds_cnt = reinterpret_cast<uint32_t *>(smem + RING * SUB_BYTES);  // [TILE_Q]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wd = wv >> 2;
+    const int wq = wv & 3;
+    const int l31 = lane & 31;
+    const int h = lane >> 5;
+    const bool g1 = STAGGER && (wv >= 4);  // the trailing half of the ping-pong (wave-uniform)
+    const int KS2 = a.dim / SUB_K;
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // DBG 16: cycles per segment of the inner loop
+    unsigned long long tprev = 0;
+    if constexpr ((DBG & 16) != 0) tprev = stamp();
+
+    const int srow = wv * 16 + (lane >> 2);                 // + i*128
+    const int schunk = (lane & 3) ^ ((srow >> 2) & 3);
+    const int swz = (lane >> 2) & 3;
+    int cofs[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) cofs[ks] = (((2 * ks + h) ^ swz) << 4);
+    const int a_base = (wd * 128 + l31) * 64;                  // + dt*2048
+    const int b_base = SUB_Q_REGION + (wq * 64 + l31) * 64;    // + qt*2048
+
+    const int xcd = blockIdx.x & (NUM_XCD - 1);
+    const int jx = blockIdx.x >> 3;
+    const int per_x = gridDim.x >> 3;
+    const int rl_x = (a.ranges - xcd + NUM_XCD - 1) / NUM_XCD;
+    const int count_x = rl_x * a.qblocks;
+
+    for (int item = jx; item < count_x; item += per_x) {
+        const int rl = item / a.qblocks;
+        const int qb = item - rl * a.qblocks;
+        const int r = xcd + NUM_XCD * rl;
+        const int64_t ntile = (a.n_vt - r + a.ranges - 1) / a.ranges;
+        if (ntile <= 0) continue;
+        const int q0 = qb * TILE_Q;
+
+        float thr[2] = {0.f, 0.f};
+        if (EPI == EPI_FILTER) {
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const int q = q0 + wq * 64 + qt * 32 + l31;
+                thr[qt] = (q < a.n_q) ? a.thr[q] : __builtin_nanf("");
+            }
+            if (tid < TILE_Q) lds_cnt[tid] = 0;
+        }
+        const uint16_t *qsrc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int qrow = q0 + i * 128 + srow;
+            if (qrow > a.n_q - 1) qrow = a.n_q - 1;
+            qsrc[i] = a.Q + (int64_t)qrow * a.dim + schunk * 8;
+        }
+
+        // make hipcc wait for the threshold loads HERE, before any LDS-DMA is in flight: its own wait
+        // at the first use inside the tile epilogue would be vmcnt(0) and drain the DMA ring
+        asm volatile("" : "+v"(thr[0]), "+v"(thr[1]));
+
+        f32x16 acc[4][2];
+        const int64_t U = ntile * KS2;
+
+        // ---- DMA issue stream (runs 3 sub-stages ahead of the consumer)
+        int64_t iu = 0, it = 0;
+        int iks = 0;
+        // one 1-KiB piece (piece 0,1: corpus rows, 2,3: query rows) of sub-stage `iu`; piece 3 advances the stream
+        auto issue_piece = [&](int piece) {
+            char *buf = smem + (int)(iu & (RING - 1)) * SUB_BYTES;
+            const int k0 = iks * SUB_K;
+            if constexpr (!(DBG & 4)) {
+                if (piece < 2) {
+                    const int64_t row0 = (DBG & 1) ? 0 : (r + it * a.ranges) * a.tile_stride * TILE_DOCS;
+                    int64_t drow = row0 + piece * 128 + srow;
+                    if (drow > a.n_rows - 1) drow = a.n_rows - 1;
+                    glds16(a.D + drow * a.dim + k0 + schunk * 8, buf + (piece * 512 + wv * 64) * 16);
+                } else {
+                    glds16(qsrc[piece - 2] + ((DBG & 2) ? 0 : k0), buf + SUB_Q_REGION + ((piece - 2) * 512 + wv * 64) * 16);
+                }
+            }
+            if (piece == 3) {
+                ++iu;
+                if (++iks == KS2) {
+                    iks = 0;
+                    ++it;
+                }
+            }
+        };
+        auto issue = [&]() {
+#pragma unroll
+            for (int piece = 0; piece < 4; ++piece) issue_piece(piece);
+        };
+
+        // ---- epilogue of a finished 256x256 tile (accumulators still live)
+        auto epilogue = [&](int64_t vt) {
+            const int64_t row_base = vt * a.tile_stride * TILE_DOCS + wd * 128 + 4 * h;
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const int ql = wq * 64 + qt * 32 + l31;
+                float mdt[4];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    float m = acc[dt][qt][0];
+#pragma unroll
+                    for (int e = 1; e < 16; ++e) m = fmaxf(m, acc[dt][qt][e]);
+                    mdt[dt] = m;
+                }
+                if (EPI == EPI_GMAX) {
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+                        a.gmax[(vt * GROUPS_PER_TILE + wd * 8 + dt * 2 + h) * a.nq_pad + q0 + ql] = mdt[dt];
+                } else if (EPI == EPI_FILTER) {
+                    const float mall = fmaxf(fmaxf(mdt[0], mdt[1]), fmaxf(mdt[2], mdt[3]));
+                    if (__ballot(mall >= thr[qt]) != 0ull) {
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt) {
+                            if (__ballot(mdt[dt] >= thr[qt]) == 0ull) continue;
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) {
+                                const float v = acc[dt][qt][e];
+                                if (v >= thr[qt]) {
+                                    const int64_t doc = row_base + dt * 32 + (e & 3) + 8 * (e >> 2);
+                                    if (doc < a.n_rows) {
+                                        const uint32_t slot = lds_inc_rtn(&lds_cnt[ql]);
+                                        if (slot < (uint32_t)a.cap)
+                                            a.cand[((int64_t)r * a.nq_pad + q0 + ql) * a.cap + slot] =
+                                                make_uint2(__float_as_uint(v), (uint32_t)doc);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                } else {  // EPI_STORE
+                    const int q = q0 + ql;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int64_t doc = row_base + dt * 32 + (e & 3) + 8 * (e >> 2);
+                            if (q < a.n_q && doc < a.n_rows) a.store[(int64_t)q * a.n_rows + doc] = acc[dt][qt][e];
+                        }
+                }
+            }
+        };
+
+        // ---- prologue: up to 3 sub-stages in flight, sub-stage 0 confirmed and published
+        const int npro = U < 3 ? (int)U : 3;
+        for (int i = 0; i < npro; ++i) issue();
+        if (npro == 3)
+            CCR_WAIT_VM(8);
+        else if (npro == 2)
+            CCR_WAIT_VM(4);
+        else
+            CCR_WAIT_VM(0);
+        CCR_WAIT_LGKM0();  // the lds_cnt zeroing stores
+        CCR_BARRIER();
+        if (g1) CCR_BARRIER();
+
+        int cks = 0;
+        int64_t ct = 0;
+        bool pending = false;
+        int64_t pending_vt = 0;
+        for (int64_t u = 0; u < U; ++u) {
+            // ================= mem phase
+            CCR_STAMP(0)  // barrier B wait (+ loop overhead)
+            if (pending) {
+                epilogue(pending_vt);
+                pending = false;
+            }
+            CCR_STAMP(1)  // tile epilogue
+            if (u + 1 < U) {  // confirm OWN DMA of sub-stage u+1 (published by the barrier below)
+                if (u + 2 < U)
+                    CCR_WAIT_VM(4);
+                else
+                    CCR_WAIT_VM(0);
+            }
+            CCR_STAMP(2)  // DMA wait
+            const char *buf = smem + (int)(u & (RING - 1)) * SUB_BYTES;
+            bf16x8 af[2][4], bfr[2][2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    af[ks][dt] = *reinterpret_cast<const bf16x8 *>(buf + a_base + dt * 2048 + cofs[ks]);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+                    bfr[ks][qt] = *reinterpret_cast<const bf16x8 *>(buf + b_base + qt * 2048 + cofs[ks]);
+            }
+            CCR_STAMP(3)  // LDS operand reads (the stamp drains them)
+            CCR_BARRIER();  // the LDS read latency overlaps the barrier; hipcc waits (lgkmcnt) per MFMA operand
+            CCR_STAMP(4)  // barrier A wait
+            // ================= mfma phase
+            if constexpr ((DBG & 8) != 0) {  // no matrix work: keep the operands alive, skip the MFMAs
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) asm volatile("" ::"v"(af[ks][dt]));
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt) asm volatile("" ::"v"(bfr[ks][qt]));
+                }
+                if (cks == 0) {
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) acc[dt][qt][e] = -1e30f;
+                }
+            } else {
+            // 16 MFMAs in four quads; one DMA piece of sub-stage u+3 rides behind each quad (MFMA issue is
+            // in order and paced at 32 cycles, so a VMEM issue between quads costs the matrix pipe nothing
+            // unless the memory pipe back-pressures for longer than a quad).  The DMA goes into the buffer of
+            // u-1: legal after barrier A_u (the partner group's reads of u-1 were retired before its barrier
+            // B_{u-1}, which is that same barrier instance).
+            const bool more = (u + 3 < U);
+            __builtin_amdgcn_s_setprio(1);
+            if (cks == 0) {
+                const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt)
+                        acc[dt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][dt], bfr[0][qt], z, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) issue_piece(0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int dt = 2; dt < 4; ++dt)
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt)
+                        acc[dt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][dt], bfr[0][qt], z, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt)
+                        acc[dt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][dt], bfr[0][qt], acc[dt][qt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) issue_piece(0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int dt = 2; dt < 4; ++dt)
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt)
+                        acc[dt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][dt], bfr[0][qt], acc[dt][qt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) issue_piece(1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+                    acc[dt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][dt], bfr[1][qt], acc[dt][qt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) issue_piece(2);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int dt = 2; dt < 4; ++dt)
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+                    acc[dt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][dt], bfr[1][qt], acc[dt][qt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) issue_piece(3);
+            __builtin_amdgcn_s_setprio(0);
+            }
+            if constexpr ((DBG & 8) != 0) {
+                if (u + 3 < U) issue();
+            }
+            CCR_STAMP(5)  // MFMA phase incl. DMA issue
+            if (++cks == KS2) {
+                cks = 0;
+                pending = true;
+                pending_vt = r + ct * a.ranges;
+                ++ct;
+            }
+            CCR_BARRIER();
+        }
+        if (pending) epilogue(pending_vt);
+        if (STAGGER && !g1) CCR_BARRIER();  // every wave executes the same number of barriers
+        if constexpr ((DBG & 16) != 0) tprev = stamp();
+
+        __syncthreads();
+        if (EPI == EPI_FILTER) {
+            if (tid < TILE_Q) a.cnt[(int64_t)r * a.nq_pad + q0 + tid] = lds_cnt[tid];
+            __syncthreads();
+        }
+        if constexpr ((DBG & 16) != 0) tprev = stamp();
+    }
+    if constexpr ((DBG & 16) != 0) {
+        if (lane == 0 && a.store) {
+            unsigned long long *o = reinterpret_cast<unsigned long long *>(a.store) + ((size_t)blockIdx.x * 8 + wv) * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = seg[i];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // bf16 row norms (fp32 accumulate; used only for error margins, inflated by the caller)
 __global__ __launch_bounds__(256) void row_norms_bf16_kernel(const uint16_t *__restrict__ X, int64_t rows, int dim,
@@ -381,19 +725,56 @@ __global__ __launch_bounds__(256) void select_rescore_kernel(const uint2 *__rest
 }
 
 // ---------------------------------------------------------------------------------------------
-static size_t gemm_lds_bytes() { return 2 * (size_t)STAGE_BYTES + TILE_Q * sizeof(uint32_t); }
+static int gemm_variant() {
+    // CCR_GEMM_VARIANT: 1 = v1 (two 64-KiB stages, one barrier per K step), 2 = v2 ring without
+    // stagger, 3 = v2 ping-pong (default)
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("CCR_GEMM_VARIANT");
+        v = e ? atoi(e) : 3;
+        if (v < 1 || v > 3) v = 3;
+    }
+    return v;
+}
+
+template <class K>
+static int launch_kernel(K kernel, size_t lds, const GemmArgs &a, int grid, hipStream_t s, bool &configured) {
+    if (!configured) {
+        CCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)lds));
+        configured = true;
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(GEMM_THREADS), lds, s, a);
+    CCR_LAUNCH_CHECK();
+    return CCR_OK;
+}
 
 template <int EPI>
 static int launch_gemm(const GemmArgs &a, int grid, hipStream_t s) {
-    static bool configured = false;
-    if (!configured) {
-        CCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_topk_kernel<EPI>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes()));
-        configured = true;
+    static bool c1 = false, c2 = false, c3 = false, cd = false;
+    static int dbg = -1;
+    if (dbg < 0) {
+        const char *e = getenv("CCR_GEMM_DBG");  // timing-only ablations of the main pass (WRONG results)
+        dbg = e ? atoi(e) : 0;
     }
-    hipLaunchKernelGGL(gemm_topk_kernel<EPI>, dim3(grid), dim3(GEMM_THREADS), gemm_lds_bytes(), s, a);
-    CCR_LAUNCH_CHECK();
-    return CCR_OK;
+    const size_t lds1 = 2 * (size_t)STAGE_BYTES + TILE_Q * sizeof(uint32_t);
+    const size_t lds2 = RING * (size_t)SUB_BYTES + TILE_Q * sizeof(uint32_t);
+    if (EPI == EPI_FILTER && dbg != 0) {
+        switch (dbg) {
+            case 1: return launch_kernel(&gemm_topk_v2<EPI_FILTER, true, 1>, lds2, a, grid, s, cd);
+            case 2: return launch_kernel(&gemm_topk_v2<EPI_FILTER, true, 2>, lds2, a, grid, s, cd);
+            case 3: return launch_kernel(&gemm_topk_v2<EPI_FILTER, true, 3>, lds2, a, grid, s, cd);
+            case 4: return launch_kernel(&gemm_topk_v2<EPI_FILTER, true, 4>, lds2, a, grid, s, cd);
+            case 8: return launch_kernel(&gemm_topk_v2<EPI_FILTER, true, 8>, lds2, a, grid, s, cd);
+            case 16: return launch_kernel(&gemm_topk_v2<EPI_FILTER, true, 16>, lds2, a, grid, s, cd);
+            default: return launch_kernel(&gemm_topk_v2<EPI_FILTER, true, 12>, lds2, a, grid, s, cd);
+        }
+    }
+    switch (gemm_variant()) {
+        case 1: return launch_kernel(&gemm_topk_v1<EPI>, lds1, a, grid, s, c1);
+        case 2: return launch_kernel(&gemm_topk_v2<EPI, false, 0>, lds2, a, grid, s, c2);
+        default: return launch_kernel(&gemm_topk_v2<EPI, true, 0>, lds2, a, grid, s, c3);
+    }
 }
 
 int launch_gemm_filter(const GemmArgs &a, int grid, hipStream_t s) { return launch_gemm<EPI_FILTER>(a, grid, s); }
