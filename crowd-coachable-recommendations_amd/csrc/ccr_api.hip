@@ -81,14 +81,15 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu) {
         p.ranges = (int)R;
         const double ratio = (double)p.tiles / (double)sample;
         const double expect = (double)k * ratio * 1.3 + 64.0;  // survivors per query
-        int64_t cap = (int64_t)(4.0 * expect / (double)R) + 32;
-        cap = round_up(std::min<int64_t>(std::max<int64_t>(cap, 32), 8192), 8);
+        // candidates go to 4 sub-lists per (range, query): one per (wave row, lane half) of the GEMM tile
+        int64_t cap = (int64_t)(4.0 * expect / (double)(R * 4)) + 16;
+        cap = round_up(std::min<int64_t>(std::max<int64_t>(cap, 16), 8192), 4);
         p.cap = (int)cap;
         p.off_qnorm = take((size_t)p.nq_pad * 4);
         p.off_thr = take((size_t)p.nq_pad * 4 * 2);  // thr then delta
         p.off_gmax = take((size_t)p.sample_tiles * GROUPS_PER_TILE * p.nq_pad * 4);
-        p.off_cnt = take((size_t)p.ranges * p.nq_pad * 4);
-        p.off_cand = take((size_t)p.ranges * p.nq_pad * p.cap * 8);
+        p.off_cnt = take((size_t)p.ranges * p.nq_pad * 4 * 4);
+        p.off_cand = take((size_t)p.ranges * p.nq_pad * 4 * p.cap * 8);
         p.off_flag = take(64 + (size_t)n_q * 4);
         p.dense_rows_per_chunk = FALLBACK_ROWS;
         p.off_dense = take((size_t)FALLBACK_ROWS * n_rows * 4);
@@ -233,7 +234,7 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
     uint32_t *flag_list = (uint32_t *)(ws + p.off_flag + 64);
 
     CCR_HIP_CHECK(hipMemsetAsync(flag_count, 0, 64, s));
-    CCR_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)p.ranges * p.nq_pad * 4, s));  // ranges with no tiles write nothing
+    CCR_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)p.ranges * p.nq_pad * 4 * 4, s));  // ranges with no tiles write nothing
     int rc = launch_row_norms_bf16(Q_bf16, n_q, ix->dim, qnorm, nullptr, s);
     if (rc != CCR_OK) return rc;
 
@@ -302,7 +303,7 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
         (void)hipFree(stamps);
     }
 
-    rc = launch_select_rescore(cand, cnt, p.ranges, n_q, p.nq_pad, p.cap, k, p.rescore_cap, delta, Q_bf16, ix->D, ix->dim,
+    rc = launch_select_rescore(cand, cnt, p.ranges * 4, n_q, p.nq_pad, p.cap, k, p.rescore_cap, delta, Q_bf16, ix->D, ix->dim,
                                ix->offset, out_scores, out_ids, flag_count, flag_list, stat_cand, s);
     if (rc != CCR_OK) return rc;
 

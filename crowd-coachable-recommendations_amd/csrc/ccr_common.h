@@ -54,7 +54,7 @@ struct Plan {
     int sample_tiles;     // tiles scored by the threshold pass
     int64_t sample_stride;
     int ranges;           // corpus ranges of the main pass (multiple of NUM_XCD)
-    int cap;              // candidate slots per (range, query)
+    int cap;              // candidate slots per sub-list
     int grid;             // persistent workgroups (multiple of NUM_XCD)
     int rescore_cap;      // max candidates re-scored per query (power of two)
     // workspace layout (byte offsets)
@@ -76,8 +76,8 @@ struct GemmArgs {
     int ranges;           // item (r, qb) covers virtual tiles r, r + ranges, ...
     // EPI_FILTER
     const float *thr;     // [nq_pad]
-    uint2 *cand;          // [ranges][nq_pad][cap] {score bits, local row}
-    uint32_t *cnt;        // [ranges][nq_pad]
+    uint2 *cand;          // [ranges][nq_pad][4][cap] {score bits, local row}; 4 = (wave row, lane half)
+    uint32_t *cnt;        // [ranges][nq_pad][4]
     int cap;
     // EPI_GMAX
     float *gmax;          // [n_vt * 16][nq_pad]

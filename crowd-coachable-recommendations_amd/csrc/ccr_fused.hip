@@ -31,207 +31,29 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum { EPI_FILTER = 0, EPI_GMAX = 1, EPI_STORE = 2 };
 
-constexpr int STAGE_BYTES = (TILE_DOCS + TILE_Q) * TILE_K * 2;  // 65536
-constexpr int Q_REGION = TILE_DOCS * TILE_K * 2;                 // 32768
 
 __device__ __forceinline__ void glds16(const void *gsrc, char *lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-template <int EPI>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_v1(const GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint32_t *lds_cnt = reinterpret_cast<uint32_t *>(smem + 2 * STAGE_BYTES);  // [TILE_Q]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wd = wv >> 2;  // doc half
-    const int wq = wv & 3;   // query quarter
-    const int l31 = lane & 31;
-    const int h = lane >> 5;
-    const int KS = a.dim / TILE_K;
-
-    // ---- staging roles: 8 x 16-byte chunks per thread per stage (4 doc rows, 4 query rows)
-    const int srow = wv * 8 + (lane >> 3);                       // + i*64
-    const int schunk = (lane & 7) ^ ((srow >> 1) & 7);           // logical chunk fetched into physical slot lane&7
-    // ---- fragment read offsets (bytes inside a stage buffer)
-    const int swz = (lane >> 1) & 7;
-    int cofs[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) cofs[ks] = (((2 * ks + h) ^ swz) << 4);
-    const int a_base = (wd * 128 + l31) * 128;             // + dt*32*128
-    const int b_base = Q_REGION + (wq * 64 + l31) * 128;   // + qt*32*128
-
-    // ---- work items of this workgroup (XCD-aware: blocks b and b+8 share an XCD / L2)
-    const int xcd = blockIdx.x & (NUM_XCD - 1);
-    const int jx = blockIdx.x >> 3;
-    const int per_x = gridDim.x >> 3;
-    const int rl_x = (a.ranges - xcd + NUM_XCD - 1) / NUM_XCD;  // ranges r with r % 8 == xcd
-    const int count_x = rl_x * a.qblocks;
-
-    for (int item = jx; item < count_x; item += per_x) {
-        const int rl = item / a.qblocks;
-        const int qb = item - rl * a.qblocks;
-        const int r = xcd + NUM_XCD * rl;
-        const int64_t ntile = (a.n_vt - r + a.ranges - 1) / a.ranges;  // virtual tiles r, r+R, ...
-        if (ntile <= 0) continue;
-        const int q0 = qb * TILE_Q;
-
-        // per-lane thresholds for the two query columns this lane owns
-        float thr[2];
-        if (EPI == EPI_FILTER) {
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                const int q = q0 + wq * 64 + qt * 32 + l31;
-                thr[qt] = (q < a.n_q) ? a.thr[q] : __builtin_nanf("");
-            }
-            if (tid < TILE_Q) lds_cnt[tid] = 0;
-        }
-
-        // query source pointers are fixed for the item
-        const uint16_t *qsrc[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int qrow = q0 + i * 64 + srow;
-            if (qrow > a.n_q - 1) qrow = a.n_q - 1;
-            qsrc[i] = a.Q + (int64_t)qrow * a.dim + schunk * 8;
-        }
-
-        f32x16 acc[4][2];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[dt][qt][e] = 0.f;
-
-        const int64_t total = ntile * KS;
-
-        auto stage = [&](int64_t step) {
-            const int64_t t = step / KS;
-            const int ks = (int)(step - t * KS);
-            const int64_t tile = (r + t * a.ranges) * a.tile_stride;
-            const int64_t row0 = tile * TILE_DOCS;
-            char *buf = smem + (step & 1) * STAGE_BYTES;
-            const int k0 = ks * TILE_K;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int64_t drow = row0 + i * 64 + srow;
-                if (drow > a.n_rows - 1) drow = a.n_rows - 1;
-                const uint16_t *src = a.D + drow * a.dim + k0 + schunk * 8;
-                glds16(src, buf + (i * 512 + wv * 64) * 16);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) glds16(qsrc[i] + k0, buf + Q_REGION + (i * 512 + wv * 64) * 16);
-        };
-
-        stage(0);
-        for (int64_t step = 0; step < total; ++step) {
-            // Stage `step` must have LANDED in LDS for every wave before anyone reads it: an LDS-DMA is
-            // tracked by the issuing wave's vmcnt only, and hipcc does not add that wait to
-            // __syncthreads() here (seen in the .s: lgkmcnt(0) + s_barrier only) -> explicit drain.
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();  // + barrier: everyone is also done reading the other buffer
-            if (step + 1 < total) stage(step + 1);
-            const char *buf = smem + (step & 1) * STAGE_BYTES;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                bf16x8 af[4], bfr[2];
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-                    af[dt] = *reinterpret_cast<const bf16x8 *>(buf + a_base + dt * 4096 + cofs[ks]);
-#pragma unroll
-                for (int qt = 0; qt < 2; ++qt)
-                    bfr[qt] = *reinterpret_cast<const bf16x8 *>(buf + b_base + qt * 4096 + cofs[ks]);
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                    for (int qt = 0; qt < 2; ++qt)
-                        acc[dt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[dt], bfr[qt], acc[dt][qt], 0, 0, 0);
-            }
-
-            const int64_t t = step / KS;
-            if (step - t * KS != KS - 1) continue;
-
-            // ------------------------------------------------------------ epilogue of one 256x256 tile
-            const int64_t vt = r + t * a.ranges;
-            const int64_t row_base = vt * a.tile_stride * TILE_DOCS + wd * 128 + 4 * h;  // + dt*32 + (e&3) + 8*(e>>2)
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                const int ql = wq * 64 + qt * 32 + l31;
-                float mdt[4];
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    float m = acc[dt][qt][0];
-#pragma unroll
-                    for (int e = 1; e < 16; ++e) m = fmaxf(m, acc[dt][qt][e]);
-                    mdt[dt] = m;
-                }
-                if (EPI == EPI_GMAX) {
-#pragma unroll
-                    for (int dt = 0; dt < 4; ++dt)
-                        a.gmax[(vt * GROUPS_PER_TILE + wd * 8 + dt * 2 + h) * a.nq_pad + q0 + ql] = mdt[dt];
-                } else if (EPI == EPI_FILTER) {
-                    const float mall = fmaxf(fmaxf(mdt[0], mdt[1]), fmaxf(mdt[2], mdt[3]));
-                    if (__ballot(mall >= thr[qt]) != 0ull) {
-#pragma unroll
-                        for (int dt = 0; dt < 4; ++dt) {
-                            if (__ballot(mdt[dt] >= thr[qt]) == 0ull) continue;
-#pragma unroll
-                            for (int e = 0; e < 16; ++e) {
-                                const float v = acc[dt][qt][e];
-                                if (v >= thr[qt]) {
-                                    const int64_t doc = row_base + dt * 32 + (e & 3) + 8 * (e >> 2);
-                                    if (doc < a.n_rows) {
-                                        const uint32_t slot = atomicAdd(&lds_cnt[ql], 1u);
-                                        if (slot < (uint32_t)a.cap)
-                                            a.cand[((int64_t)r * a.nq_pad + q0 + ql) * a.cap + slot] =
-                                                make_uint2(__float_as_uint(v), (uint32_t)doc);
-                                    }
-                                }
-                            }
-                        }
-                    }
-                } else {  // EPI_STORE
-                    const int q = q0 + ql;
-#pragma unroll
-                    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            const int64_t doc = row_base + dt * 32 + (e & 3) + 8 * (e >> 2);
-                            if (q < a.n_q && doc < a.n_rows) a.store[(int64_t)q * a.n_rows + doc] = acc[dt][qt][e];
-                        }
-                }
-            }
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[dt][qt][e] = 0.f;
-        }
-
-        __syncthreads();  // all appends of the item done; LDS stage buffers free for the next item
-        if (EPI == EPI_FILTER) {
-            if (tid < TILE_Q) a.cnt[(int64_t)r * a.nq_pad + q0 + tid] = lds_cnt[tid];
-            __syncthreads();
-        }
-    }
-}
 
 
 // =============================================================================================
-// v2: ping-pong schedule.  K is walked in 32-element sub-stages through a ring of four 32-KiB LDS
-// buffers (3 sub-stages of LDS-DMA in flight, counted vmcnt, raw s_barrier).  The two waves that
-// share a SIMD (wave w and w+4) run one barrier interval apart: while one executes its 16 MFMAs
-// the other reads its next operands from LDS, issues the next sub-stage's DMA and runs the top-k
-// filter of a finished tile (VALU beside the partner's MFMAs).
-//   per wave and sub-stage u:   [mem(u): filter of a finished tile | wait own DMA of u+1 | 12 ds_read_b128 of u]
-//                               barrier  [16 x v_mfma_f32_32x32x16_bf16 with the DMA of u+3 issued among them]  barrier
-// Publication: a wave confirms (vmcnt) its own DMA of sub-stage u one phase pair before anyone
-// reads u, and a barrier instance lies between (see DESIGN.md "LDS ring protocol").
+// GEMM + top-k filter kernel.  Ping-pong schedule: K is walked in 32-element sub-stages through a
+// ring of four 32-KiB LDS buffers (up to 3 sub-stages of LDS-DMA in flight, counted vmcnt, raw
+// s_barrier).  The two waves that share a SIMD (wave w and w+4) run one barrier interval apart:
+// while one executes its 16 MFMAs, the other reads its next operands from LDS, issues the next
+// sub-stage's DMA and runs the top-k filter of a finished tile (VALU beside the partner's MFMAs).
+//   per wave and sub-stage u:
+//     mem(u):  [filter of a finished tile] wait OWN DMA of u+1 | 12 ds_read_b128 of u | DMA of u+3 | lgkmcnt(0)
+//     barrier A_u | 16 x v_mfma_f32_32x32x16_bf16 | barrier B_u
+// LDS ring protocol (why this is race free):
+//   RAW  a wave confirms (vmcnt) its own DMA of sub-stage u in mem(u-1), i.e. before its barrier
+//        A_{u-1}; every reader of u starts mem(u) after a later barrier instance.
+//   WAR  DMA of u+3 overwrites the buffer of u-1.  It is issued in mem(u); every wave's reads of
+//        u-1 were retired (lgkmcnt(0)) before its barrier A_{u-1}, and for both groups that
+//        barrier instance precedes every mem(u).
 constexpr int SUB_K = 32;
 constexpr int SUB_BYTES = (TILE_DOCS + TILE_Q) * SUB_K * 2;  // 32768
 constexpr int SUB_Q_REGION = TILE_DOCS * SUB_K * 2;           // 16384
@@ -240,14 +62,6 @@ constexpr int RING = 4;
 #define CCR_BARRIER() asm volatile("s_barrier" ::: "memory")
 #define CCR_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define CCR_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-
-__device__ __forceinline__ uint32_t lds_inc_rtn(uint32_t *p) {
-    // hand-issued so that hipcc does not drain the LDS-DMA queue (vmcnt(0)) in front of an LDS atomic
-    const uint32_t addr = (uint32_t)(size_t)((__attribute__((address_space(3))) uint32_t *)p);
-    uint32_t r;
-    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(addr), "v"(1u) : "memory");
-    return r;
-}
 
 __device__ __forceinline__ unsigned long long stamp() {
     unsigned long long t;
@@ -263,33 +77,37 @@ __device__ __forceinline__ unsigned long long stamp() {
         tprev = _t;                                      \
     }
 
+// DBG (compile-time, diagnostic instantiations only; results are WRONG when non-zero):
+//   1 corpus rows always tile 0, 2 query slice always 0, 4 no DMA, 8 no MFMA, 16 cycle stamps
 template <int EPI, bool STAGGER, int DBG>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_v2(const GemmArgs a) {
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint32_t *lds_cnt = reinterpret_cast<uint32_t *>(smem + RING * SUB_BYTES);  // [TILE_Q]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wd = wv >> 2;
-    const int wq = wv & 3;
+    const int wd = wv >> 2;   // doc half of the tile
+    const int wq = wv & 3;    // query quarter of the tile
     const int l31 = lane & 31;
     const int h = lane >> 5;
     const bool g1 = STAGGER && (wv >= 4);  // the trailing half of the ping-pong (wave-uniform)
     const int KS2 = a.dim / SUB_K;
-    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // DBG 16: cycles per segment of the inner loop
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // DBG 16: cycles per segment of the inner loop
     unsigned long long tprev = 0;
     if constexpr ((DBG & 16) != 0) tprev = stamp();
 
-    const int srow = wv * 16 + (lane >> 2);                 // + i*128
+    // DMA role: 4 x 1-KiB pieces per sub-stage (16 rows x 64 B each); LDS image is lane-linear, the
+    // 16-byte chunk swizzle (chunk ^ (row>>2)&3) is applied on the SOURCE address and on the read
+    const int srow = wv * 16 + (lane >> 2);  // + piece*128
     const int schunk = (lane & 3) ^ ((srow >> 2) & 3);
     const int swz = (lane >> 2) & 3;
     int cofs[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) cofs[ks] = (((2 * ks + h) ^ swz) << 4);
-    const int a_base = (wd * 128 + l31) * 64;                  // + dt*2048
-    const int b_base = SUB_Q_REGION + (wq * 64 + l31) * 64;    // + qt*2048
+    const int a_base = (wd * 128 + l31) * 64;                // + dt*2048
+    const int b_base = SUB_Q_REGION + (wq * 64 + l31) * 64;  // + qt*2048
 
+    // work items (range r, query block qb); blocks b and b+8 share an XCD (its L2)
     const int xcd = blockIdx.x & (NUM_XCD - 1);
     const int jx = blockIdx.x >> 3;
     const int per_x = gridDim.x >> 3;
@@ -304,14 +122,21 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_v2(const GemmArgs a
         if (ntile <= 0) continue;
         const int q0 = qb * TILE_Q;
 
+        // Each lane owns ONE (query, lane-half, wave-row) candidate sub-list per query column, so the
+        // append counter is a plain register: no atomics anywhere in the filter.
         float thr[2] = {0.f, 0.f};
+        uint32_t ncand[2] = {0u, 0u};
+        uint2 *clist[2] = {nullptr, nullptr};
         if (EPI == EPI_FILTER) {
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
                 const int q = q0 + wq * 64 + qt * 32 + l31;
                 thr[qt] = (q < a.n_q) ? a.thr[q] : __builtin_nanf("");
+                clist[qt] = a.cand + (((int64_t)r * a.nq_pad + q) * 4 + wd * 2 + h) * a.cap;
             }
-            if (tid < TILE_Q) lds_cnt[tid] = 0;
+            // make hipcc wait for the threshold loads HERE, before any LDS-DMA is in flight: its own
+            // wait at the first use inside the tile epilogue would be vmcnt(0) and drain the DMA ring
+            asm volatile("" : "+v"(thr[0]), "+v"(thr[1]));
         }
         const uint16_t *qsrc[2];
 #pragma unroll
@@ -321,84 +146,89 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_v2(const GemmArgs a
             qsrc[i] = a.Q + (int64_t)qrow * a.dim + schunk * 8;
         }
 
-        // make hipcc wait for the threshold loads HERE, before any LDS-DMA is in flight: its own wait
-        // at the first use inside the tile epilogue would be vmcnt(0) and drain the DMA ring
-        asm volatile("" : "+v"(thr[0]), "+v"(thr[1]));
-
         f32x16 acc[4][2];
         const int64_t U = ntile * KS2;
 
-        // ---- DMA issue stream (runs 3 sub-stages ahead of the consumer)
+        // ---- DMA issue stream (runs up to 3 sub-stages ahead of the consumer).  Per-thread source pointers
+        // are recomputed once per tile; a sub-stage adds only the K offset.
         int64_t iu = 0, it = 0;
         int iks = 0;
-        // one 1-KiB piece (piece 0,1: corpus rows, 2,3: query rows) of sub-stage `iu`; piece 3 advances the stream
-        auto issue_piece = [&](int piece) {
+        const uint16_t *dsrc[2];
+        auto tile_ptrs = [&]() {
+            const int64_t row0 = (DBG & 1) ? 0 : (r + it * a.ranges) * a.tile_stride * TILE_DOCS;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int64_t drow = row0 + i * 128 + srow;
+                if (drow > a.n_rows - 1) drow = a.n_rows - 1;
+                dsrc[i] = a.D + drow * a.dim + schunk * 8;
+            }
+        };
+        tile_ptrs();
+        auto issue = [&]() {
             char *buf = smem + (int)(iu & (RING - 1)) * SUB_BYTES;
             const int k0 = iks * SUB_K;
             if constexpr (!(DBG & 4)) {
-                if (piece < 2) {
-                    const int64_t row0 = (DBG & 1) ? 0 : (r + it * a.ranges) * a.tile_stride * TILE_DOCS;
-                    int64_t drow = row0 + piece * 128 + srow;
-                    if (drow > a.n_rows - 1) drow = a.n_rows - 1;
-                    glds16(a.D + drow * a.dim + k0 + schunk * 8, buf + (piece * 512 + wv * 64) * 16);
-                } else {
-                    glds16(qsrc[piece - 2] + ((DBG & 2) ? 0 : k0), buf + SUB_Q_REGION + ((piece - 2) * 512 + wv * 64) * 16);
-                }
-            }
-            if (piece == 3) {
-                ++iu;
-                if (++iks == KS2) {
-                    iks = 0;
-                    ++it;
-                }
-            }
-        };
-        auto issue = [&]() {
 #pragma unroll
-            for (int piece = 0; piece < 4; ++piece) issue_piece(piece);
+                for (int i = 0; i < 2; ++i) glds16(dsrc[i] + k0, buf + (i * 512 + wv * 64) * 16);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    glds16(qsrc[i] + ((DBG & 2) ? 0 : k0), buf + SUB_Q_REGION + (i * 512 + wv * 64) * 16);
+            }
+            ++iu;
+            if (++iks == KS2) {
+                iks = 0;
+                ++it;
+                tile_ptrs();
+            }
         };
 
         // ---- epilogue of a finished 256x256 tile (accumulators still live)
+        // C layout of v_mfma_f32_32x32x16: lane -> query column (lane & 31); register e -> corpus row
+        // (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) of the 32-row MFMA tile.
         auto epilogue = [&](int64_t vt) {
             const int64_t row_base = vt * a.tile_stride * TILE_DOCS + wd * 128 + 4 * h;
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
-                const int ql = wq * 64 + qt * 32 + l31;
-                float mdt[4];
+                float sub[4][4], mdt[4];
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
-                    float m = acc[dt][qt][0];
 #pragma unroll
-                    for (int e = 1; e < 16; ++e) m = fmaxf(m, acc[dt][qt][e]);
-                    mdt[dt] = m;
+                    for (int g = 0; g < 4; ++g)
+                        sub[dt][g] = fmaxf(fmaxf(acc[dt][qt][4 * g], acc[dt][qt][4 * g + 1]),
+                                           fmaxf(acc[dt][qt][4 * g + 2], acc[dt][qt][4 * g + 3]));
+                    mdt[dt] = fmaxf(fmaxf(sub[dt][0], sub[dt][1]), fmaxf(sub[dt][2], sub[dt][3]));
                 }
                 if (EPI == EPI_GMAX) {
+                    const int ql = wq * 64 + qt * 32 + l31;
 #pragma unroll
                     for (int dt = 0; dt < 4; ++dt)
                         a.gmax[(vt * GROUPS_PER_TILE + wd * 8 + dt * 2 + h) * a.nq_pad + q0 + ql] = mdt[dt];
                 } else if (EPI == EPI_FILTER) {
+                    const float t = thr[qt];
                     const float mall = fmaxf(fmaxf(mdt[0], mdt[1]), fmaxf(mdt[2], mdt[3]));
-                    if (__ballot(mall >= thr[qt]) != 0ull) {
+                    if (__ballot(mall >= t) != 0ull) {
 #pragma unroll
                         for (int dt = 0; dt < 4; ++dt) {
-                            if (__ballot(mdt[dt] >= thr[qt]) == 0ull) continue;
+                            if (__ballot(mdt[dt] >= t) == 0ull) continue;
 #pragma unroll
-                            for (int e = 0; e < 16; ++e) {
-                                const float v = acc[dt][qt][e];
-                                if (v >= thr[qt]) {
-                                    const int64_t doc = row_base + dt * 32 + (e & 3) + 8 * (e >> 2);
-                                    if (doc < a.n_rows) {
-                                        const uint32_t slot = lds_inc_rtn(&lds_cnt[ql]);
-                                        if (slot < (uint32_t)a.cap)
-                                            a.cand[((int64_t)r * a.nq_pad + q0 + ql) * a.cap + slot] =
-                                                make_uint2(__float_as_uint(v), (uint32_t)doc);
+                            for (int g = 0; g < 4; ++g) {
+                                if (sub[dt][g] >= t) {  // rare, divergent: <= 4 rows to test
+#pragma unroll
+                                    for (int e2 = 0; e2 < 4; ++e2) {
+                                        const float v = acc[dt][qt][4 * g + e2];
+                                        const int64_t doc = row_base + dt * 32 + 8 * g + e2;
+                                        if (v >= t && doc < a.n_rows) {
+                                            if (ncand[qt] < (uint32_t)a.cap)
+                                                clist[qt][ncand[qt]] = make_uint2(__float_as_uint(v), (uint32_t)doc);
+                                            ++ncand[qt];
+                                        }
                                     }
                                 }
                             }
                         }
                     }
                 } else {  // EPI_STORE
-                    const int q = q0 + ql;
+                    const int q = q0 + wq * 64 + qt * 32 + l31;
 #pragma unroll
                     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -419,7 +249,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_v2(const GemmArgs a
             CCR_WAIT_VM(4);
         else
             CCR_WAIT_VM(0);
-        CCR_WAIT_LGKM0();  // the lds_cnt zeroing stores
         CCR_BARRIER();
         if (g1) CCR_BARRIER();
 
@@ -427,6 +256,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_v2(const GemmArgs a
         int64_t ct = 0;
         bool pending = false;
         int64_t pending_vt = 0;
+        if constexpr ((DBG & 16) != 0) tprev = stamp();
         for (int64_t u = 0; u < U; ++u) {
             // ================= mem phase
             CCR_STAMP(0)  // barrier B wait (+ loop overhead)
@@ -453,8 +283,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_v2(const GemmArgs a
                 for (int qt = 0; qt < 2; ++qt)
                     bfr[ks][qt] = *reinterpret_cast<const bf16x8 *>(buf + b_base + qt * 2048 + cofs[ks]);
             }
-            CCR_STAMP(3)  // LDS operand reads (the stamp drains them)
-            CCR_BARRIER();  // the LDS read latency overlaps the barrier; hipcc waits (lgkmcnt) per MFMA operand
+            if (u + 3 < U) issue();  // into the buffer of sub-stage u-1 (see the WAR note above)
+            CCR_WAIT_LGKM0();        // operands in registers BEFORE the barrier; free behind the DMA issue
+            CCR_STAMP(3)  // LDS reads + DMA issue
+            CCR_BARRIER();
             CCR_STAMP(4)  // barrier A wait
             // ================= mfma phase
             if constexpr ((DBG & 8) != 0) {  // no matrix work: keep the operands alive, skip the MFMAs
@@ -474,67 +306,29 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_v2(const GemmArgs a
                             for (int e = 0; e < 16; ++e) acc[dt][qt][e] = -1e30f;
                 }
             } else {
-            // 16 MFMAs in four quads; one DMA piece of sub-stage u+3 rides behind each quad (MFMA issue is
-            // in order and paced at 32 cycles, so a VMEM issue between quads costs the matrix pipe nothing
-            // unless the memory pipe back-pressures for longer than a quad).  The DMA goes into the buffer of
-            // u-1: legal after barrier A_u (the partner group's reads of u-1 were retired before its barrier
-            // B_{u-1}, which is that same barrier instance).
-            const bool more = (u + 3 < U);
-            __builtin_amdgcn_s_setprio(1);
-            if (cks == 0) {
-                const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                // no s_setprio(1) here: the partner wave's mem phase carries VALU work (filter, addresses) that a
+                // raised MFMA wave would starve (MI355X_MICROARCH 'Two waves per SIMD', item 2)
+                if (cks == 0) {  // first sub-stage of a tile: C = 0 (no accumulator clearing pass)
+                    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
+                    for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-                    for (int qt = 0; qt < 2; ++qt)
-                        acc[dt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][dt], bfr[0][qt], z, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) issue_piece(0);
-                __builtin_amdgcn_sched_barrier(0);
+                        for (int qt = 0; qt < 2; ++qt)
+                            acc[dt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][dt], bfr[0][qt], z, 0, 0, 0);
+                } else {
 #pragma unroll
-                for (int dt = 2; dt < 4; ++dt)
+                    for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-                    for (int qt = 0; qt < 2; ++qt)
-                        acc[dt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][dt], bfr[0][qt], z, 0, 0, 0);
-            } else {
+                        for (int qt = 0; qt < 2; ++qt)
+                            acc[dt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][dt], bfr[0][qt], acc[dt][qt], 0, 0, 0);
+                }
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
+                for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
                     for (int qt = 0; qt < 2; ++qt)
-                        acc[dt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][dt], bfr[0][qt], acc[dt][qt], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) issue_piece(0);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int dt = 2; dt < 4; ++dt)
-#pragma unroll
-                    for (int qt = 0; qt < 2; ++qt)
-                        acc[dt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][dt], bfr[0][qt], acc[dt][qt], 0, 0, 0);
+                        acc[dt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][dt], bfr[1][qt], acc[dt][qt], 0, 0, 0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) issue_piece(1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int qt = 0; qt < 2; ++qt)
-                    acc[dt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][dt], bfr[1][qt], acc[dt][qt], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) issue_piece(2);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int dt = 2; dt < 4; ++dt)
-#pragma unroll
-                for (int qt = 0; qt < 2; ++qt)
-                    acc[dt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][dt], bfr[1][qt], acc[dt][qt], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) issue_piece(3);
-            __builtin_amdgcn_s_setprio(0);
-            }
-            if constexpr ((DBG & 8) != 0) {
-                if (u + 3 < U) issue();
-            }
-            CCR_STAMP(5)  // MFMA phase incl. DMA issue
+            CCR_STAMP(5)  // MFMA phase
             if (++cks == KS2) {
                 cks = 0;
                 pending = true;
@@ -545,14 +339,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_v2(const GemmArgs a
         }
         if (pending) epilogue(pending_vt);
         if (STAGGER && !g1) CCR_BARRIER();  // every wave executes the same number of barriers
-        if constexpr ((DBG & 16) != 0) tprev = stamp();
 
-        __syncthreads();
         if (EPI == EPI_FILTER) {
-            if (tid < TILE_Q) a.cnt[(int64_t)r * a.nq_pad + q0 + tid] = lds_cnt[tid];
-            __syncthreads();
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+                a.cnt[((int64_t)r * a.nq_pad + q0 + wq * 64 + qt * 32 + l31) * 4 + wd * 2 + h] = ncand[qt];
         }
-        if constexpr ((DBG & 16) != 0) tprev = stamp();
+        __syncthreads();  // LDS ring free for the next item
     }
     if constexpr ((DBG & 16) != 0) {
         if (lane == 0 && a.store) {
@@ -649,8 +442,8 @@ __global__ __launch_bounds__(256) void select_rescore_kernel(const uint2 *__rest
     }
     __syncthreads();
     uint32_t my = 0;
-    for (int r = tid; r < ranges; r += blockDim.x) {
-        uint32_t c = cnt[(int64_t)r * nq_pad + q];
+    for (int r = tid; r < ranges; r += blockDim.x) {   // `ranges` counts SUB-LISTS here: 4 per (range, query)
+        uint32_t c = cnt[((int64_t)(r >> 2) * nq_pad + q) * 4 + (r & 3)];
         if (c > (uint32_t)cap) {
             s_flag = 1;  // overflow: some survivors were dropped
             c = (uint32_t)cap;
@@ -666,8 +459,8 @@ __global__ __launch_bounds__(256) void select_rescore_kernel(const uint2 *__rest
     bool bad = (s_flag != 0) || (s_total < (uint32_t)k);
 
     const int64_t slots = (int64_t)ranges * cap;
-    const uint2 *base = cand + (int64_t)q * cap;  // + r * nq_pad * cap
-    const int64_t rstride = (int64_t)nq_pad * cap;
+    // sub-list j = (range j>>2, wave-row/lane-half j&3) lives at (((j>>2) * nq_pad + q) * 4 + (j&3)) * cap
+    auto at = [&](int j, int sl) -> uint2 { return cand[(((int64_t)(j >> 2) * nq_pad + q) * 4 + (j & 3)) * cap + sl]; };
     uint32_t kth = 0;
     int need_eq = 0;
     if (!bad) {
@@ -679,7 +472,7 @@ __global__ __launch_bounds__(256) void select_rescore_kernel(const uint2 *__rest
                     skip = true;
                     return 0u;
                 }
-                return f32_orderable(__uint_as_float(base[r * rstride + s].x));
+                return f32_orderable(__uint_as_float(at(r, s).x));
             },
             slots, k, s_hist, s_ctl, kth, need_eq);
         const float cut = orderable_to_f32(kth) - delta[q];
@@ -688,7 +481,7 @@ __global__ __launch_bounds__(256) void select_rescore_kernel(const uint2 *__rest
             const int r = (int)(i / cap);
             const int s = (int)(i - (int64_t)r * cap);
             if ((uint32_t)s >= s_cnt[r]) continue;
-            const uint2 e = base[r * rstride + s];
+            const uint2 e = at(r, s);
             if (__uint_as_float(e.x) >= cut) {
                 const uint32_t p = atomicAdd(&s_ncoll, 1u);
                 if (p < (uint32_t)rescore_cap) s_keys[p] = (unsigned long long)e.y;  // local row for now
@@ -725,18 +518,6 @@ __global__ __launch_bounds__(256) void select_rescore_kernel(const uint2 *__rest
 }
 
 // ---------------------------------------------------------------------------------------------
-static int gemm_variant() {
-    // CCR_GEMM_VARIANT: 1 = v1 (two 64-KiB stages, one barrier per K step), 2 = v2 ring without
-    // stagger, 3 = v2 ping-pong (default)
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("CCR_GEMM_VARIANT");
-        v = e ? atoi(e) : 3;
-        if (v < 1 || v > 3) v = 3;
-    }
-    return v;
-}
-
 template <class K>
 static int launch_kernel(K kernel, size_t lds, const GemmArgs &a, int grid, hipStream_t s, bool &configured) {
     if (!configured) {
@@ -751,30 +532,28 @@ static int launch_kernel(K kernel, size_t lds, const GemmArgs &a, int grid, hipS
 
 template <int EPI>
 static int launch_gemm(const GemmArgs &a, int grid, hipStream_t s) {
-    static bool c1 = false, c2 = false, c3 = false, cd = false;
-    static int dbg = -1;
+    static bool c0 = false, c1 = false, cd = false;
+    static int dbg = -1, stagger = 1;
     if (dbg < 0) {
-        const char *e = getenv("CCR_GEMM_DBG");  // timing-only ablations of the main pass (WRONG results)
+        const char *e = getenv("CCR_GEMM_DBG");      // timing-only ablations of the main pass (WRONG results)
         dbg = e ? atoi(e) : 0;
+        const char *st = getenv("CCR_GEMM_STAGGER");  // 0: both wave groups in phase (A/B of the ping-pong)
+        stagger = st ? atoi(st) : 1;
     }
-    const size_t lds1 = 2 * (size_t)STAGE_BYTES + TILE_Q * sizeof(uint32_t);
-    const size_t lds2 = RING * (size_t)SUB_BYTES + TILE_Q * sizeof(uint32_t);
+    const size_t lds = RING * (size_t)SUB_BYTES;
     if (EPI == EPI_FILTER && dbg != 0) {
         switch (dbg) {
-            case 1: return launch_kernel(&gemm_topk_v2<EPI_FILTER, true, 1>, lds2, a, grid, s, cd);
-            case 2: return launch_kernel(&gemm_topk_v2<EPI_FILTER, true, 2>, lds2, a, grid, s, cd);
-            case 3: return launch_kernel(&gemm_topk_v2<EPI_FILTER, true, 3>, lds2, a, grid, s, cd);
-            case 4: return launch_kernel(&gemm_topk_v2<EPI_FILTER, true, 4>, lds2, a, grid, s, cd);
-            case 8: return launch_kernel(&gemm_topk_v2<EPI_FILTER, true, 8>, lds2, a, grid, s, cd);
-            case 16: return launch_kernel(&gemm_topk_v2<EPI_FILTER, true, 16>, lds2, a, grid, s, cd);
-            default: return launch_kernel(&gemm_topk_v2<EPI_FILTER, true, 12>, lds2, a, grid, s, cd);
+            case 1: return launch_kernel(&gemm_topk_kernel<EPI_FILTER, true, 1>, lds, a, grid, s, cd);
+            case 2: return launch_kernel(&gemm_topk_kernel<EPI_FILTER, true, 2>, lds, a, grid, s, cd);
+            case 3: return launch_kernel(&gemm_topk_kernel<EPI_FILTER, true, 3>, lds, a, grid, s, cd);
+            case 4: return launch_kernel(&gemm_topk_kernel<EPI_FILTER, true, 4>, lds, a, grid, s, cd);
+            case 8: return launch_kernel(&gemm_topk_kernel<EPI_FILTER, true, 8>, lds, a, grid, s, cd);
+            case 16: return launch_kernel(&gemm_topk_kernel<EPI_FILTER, true, 16>, lds, a, grid, s, cd);
+            default: return launch_kernel(&gemm_topk_kernel<EPI_FILTER, true, 12>, lds, a, grid, s, cd);
         }
     }
-    switch (gemm_variant()) {
-        case 1: return launch_kernel(&gemm_topk_v1<EPI>, lds1, a, grid, s, c1);
-        case 2: return launch_kernel(&gemm_topk_v2<EPI, false, 0>, lds2, a, grid, s, c2);
-        default: return launch_kernel(&gemm_topk_v2<EPI, true, 0>, lds2, a, grid, s, c3);
-    }
+    if (!stagger) return launch_kernel(&gemm_topk_kernel<EPI, false, 0>, lds, a, grid, s, c0);
+    return launch_kernel(&gemm_topk_kernel<EPI, true, 0>, lds, a, grid, s, c1);
 }
 
 int launch_gemm_filter(const GemmArgs &a, int grid, hipStream_t s) { return launch_gemm<EPI_FILTER>(a, grid, s); }
