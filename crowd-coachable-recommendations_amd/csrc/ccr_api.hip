@@ -29,15 +29,34 @@ int launch_threshold(const float *gmax, int64_t n_groups, int n_q, int nq_pad, i
                      const uint32_t *dmax_bits, int dim, float *thr, float *delta, hipStream_t s);
 size_t select_lds_bytes(int dim, int ranges, int rescore_cap);
 int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, int n_q, int nq_pad, int cap, int k,
-                          int rescore_cap, const float *delta, const uint16_t *Q, const uint16_t *D, int dim,
-                          int64_t id_offset, float *out_scores, int64_t *out_ids, uint32_t *flag_count,
-                          uint32_t *flag_list, unsigned long long *stat_cand, hipStream_t s);
+                          int rescore_cap, int groups, int64_t n_rows, const float *delta, const uint16_t *Q,
+                          const uint16_t *D, int dim, int64_t id_offset, float *out_scores, int64_t *out_ids,
+                          uint32_t *flag_count, uint32_t *flag_list, unsigned long long *stat_cand, hipStream_t s);
+int launch_gemm_filter_group(const GemmArgs &a, int grid, hipStream_t s);
 int launch_dense_scores(const uint16_t *D, int64_t n_rows, int dim, const uint16_t *Q, const uint32_t *qlist,
                         int q_begin, int nq_chunk, float *out, hipStream_t s);
 int launch_dense_select(const float *scores, int64_t n_rows, int k, const uint32_t *qlist, int q_begin, int nq_chunk,
                         int64_t id_offset, float *out_scores, int64_t *out_ids, hipStream_t s);
 
 // ------------------------------------------------------------------ planner
+// Query-block groups per XCD set: the smallest divisor of qblocks among {1,2,4,8} that keeps one XCD's
+// query rows (qblocks / groups blocks of 256 rows) within ~3 MiB of its 4-MiB L2.
+static int pick_qgroups(int qblocks, int dim) {
+    const char *e = getenv("CCR_QGROUPS");
+    if (e) {
+        const int v = atoi(e);
+        if ((v == 1 || v == 2 || v == 4 || v == 8) && qblocks % v == 0) return v;
+    }
+    const size_t block_bytes = (size_t)TILE_Q * dim * 2;
+    int best = 1;
+    for (int gq = 1; gq <= NUM_XCD; gq *= 2) {
+        if (qblocks % gq) continue;
+        best = gq;
+        if ((size_t)(qblocks / gq) * block_bytes <= (size_t)3 << 20) break;
+    }
+    return best;
+}
+
 static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
 constexpr size_t DENSE_SCRATCH_TARGET = (size_t)1 << 30;  // ~1 GiB of score rows per dense chunk
@@ -51,7 +70,14 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu) {
     p.tiles = (n_rows + TILE_DOCS - 1) / TILE_DOCS;
     p.full_tiles = n_rows / TILE_DOCS;
     p.grid = std::max(NUM_XCD, num_cu / NUM_XCD * NUM_XCD);
-    p.rescore_cap = std::min(8192, std::max(256, 2 * pow2_ceil(k)));
+    // small k: candidate records are 16-row MFMA fragments (cheap GEMM epilogue), all 16 rows of the kept
+    // fragments are re-scored; large k: one record per corpus row
+    // (opt-in until the 16x re-score is restructured: CCR_GROUP_RECORDS=1; see DESIGN.md "filter records")
+    {
+        const char *e = getenv("CCR_GROUP_RECORDS");
+        p.group_records = (e && atoi(e) == 1 && k <= 256) ? 1 : 0;
+    }
+    p.rescore_cap = p.group_records ? 16 * std::max(128, 2 * pow2_ceil(k)) : std::min(8192, std::max(256, 2 * pow2_ceil(k)));
 
     // sample pass: group maxima of 16 rows; need comfortably more groups than k
     const int64_t min_sample = (2 * (int64_t)k + GROUPS_PER_TILE - 1) / GROUPS_PER_TILE;
@@ -247,6 +273,7 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
     g.n_q = n_q;
     g.nq_pad = p.nq_pad;
     g.qblocks = p.qblocks;
+    g.qgroups = pick_qgroups(p.qblocks, ix->dim);
 
     // sample pass -> group maxima -> thresholds
     GemmArgs gs = g;
@@ -280,14 +307,14 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
         gm.store = reinterpret_cast<float *>(stamps);
     }
     CCR_HIP_CHECK(hipEventRecord(ix->ev[3], s));
-    rc = launch_gemm_filter(gm, p.grid, s);
+    rc = p.group_records ? launch_gemm_filter_group(gm, p.grid, s) : launch_gemm_filter(gm, p.grid, s);
     if (rc != CCR_OK) return rc;
     CCR_HIP_CHECK(hipEventRecord(ix->ev[4], s));
     if (want_stamps) {
         std::vector<unsigned long long> h((size_t)p.grid * 64);
         CCR_HIP_CHECK(hipMemcpyAsync(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost, s));
         CCR_HIP_CHECK(hipStreamSynchronize(s));
-        static const char *names[6] = {"barrierB+loop", "epilogue", "dma_wait", "lds_reads", "barrierA", "mfma+issue"};
+        static const char *names[7] = {"barrierB+loop", "epi_hits", "dma_wait", "lds_reads+dma_issue", "barrierA", "mfma", "epi_trees"};
         for (int grp = 0; grp < 2; ++grp) {
             double sum[8] = {0};
             int n = 0;
@@ -295,15 +322,16 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
                 for (int w = grp * 4; w < grp * 4 + 4; ++w, ++n)
                     for (int i = 0; i < 8; ++i) sum[i] += (double)h[((size_t)b * 8 + w) * 8 + i];
             double tot = 0;
-            for (int i = 0; i < 6; ++i) tot += sum[i];
+            for (int i = 0; i < 7; ++i) tot += sum[i];
             fprintf(stderr, "[ccr stamps] waves %d-%d: total %.0f cycles/wave;", grp * 4, grp * 4 + 3, tot / n);
-            for (int i = 0; i < 6; ++i) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * sum[i] / tot);
+            for (int i = 0; i < 7; ++i) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * sum[i] / tot);
             fprintf(stderr, "\n");
         }
         (void)hipFree(stamps);
     }
 
-    rc = launch_select_rescore(cand, cnt, p.ranges * 4, n_q, p.nq_pad, p.cap, k, p.rescore_cap, delta, Q_bf16, ix->D, ix->dim,
+    rc = launch_select_rescore(cand, cnt, p.ranges * 4, n_q, p.nq_pad, p.cap, k, p.rescore_cap, p.group_records, ix->n_rows, delta,
+                               Q_bf16, ix->D, ix->dim,
                                ix->offset, out_scores, out_ids, flag_count, flag_list, stat_cand, s);
     if (rc != CCR_OK) return rc;
 
@@ -359,6 +387,7 @@ extern "C" int ccr_debug_mfma_scores(const ccr_index *ix, const uint16_t *Q_bf16
     g.n_vt = (ix->n_rows + TILE_DOCS - 1) / TILE_DOCS;
     g.tile_stride = 1;
     g.ranges = (int)round_up(std::min<int64_t>(64, g.n_vt), NUM_XCD);
+    g.qgroups = 1;
     g.store = out;
     const int grid = std::max(NUM_XCD, ix->num_cu / NUM_XCD * NUM_XCD);
     return launch_gemm_store(g, grid, (hipStream_t)stream);

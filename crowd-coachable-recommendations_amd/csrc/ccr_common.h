@@ -56,7 +56,8 @@ struct Plan {
     int ranges;           // corpus ranges of the main pass (multiple of NUM_XCD)
     int cap;              // candidate slots per sub-list
     int grid;             // persistent workgroups (multiple of NUM_XCD)
-    int rescore_cap;      // max candidates re-scored per query (power of two)
+    int rescore_cap;      // max rows re-scored per query (power of two)
+    int group_records;    // 1: candidate records are 16-row MFMA fragments (k <= 256)
     // workspace layout (byte offsets)
     size_t off_qnorm, off_thr, off_gmax, off_cnt, off_cand, off_flag, off_dense, total;
     int64_t dense_rows_per_chunk;  // queries per dense chunk
@@ -74,6 +75,7 @@ struct GemmArgs {
     int64_t n_vt;         // virtual tiles; real tile = vt * tile_stride
     int64_t tile_stride;
     int ranges;           // item (r, qb) covers virtual tiles r, r + ranges, ...
+    int qgroups;          // query-block groups spread over the XCDs (1, 2, 4 or 8; divides qblocks)
     // EPI_FILTER
     const float *thr;     // [nq_pad]
     uint2 *cand;          // [ranges][nq_pad][4][cap] {score bits, local row}; 4 = (wave row, lane half)

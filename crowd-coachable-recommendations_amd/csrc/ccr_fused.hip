@@ -29,7 +29,10 @@ namespace ccr {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { EPI_FILTER = 0, EPI_GMAX = 1, EPI_STORE = 2 };
+enum { EPI_FILTER = 0, EPI_GMAX = 1, EPI_STORE = 2, EPI_FILTER_GROUP = 3 };
+// EPI_FILTER       : candidate record = one corpus row        {MFMA score, row}
+// EPI_FILTER_GROUP : candidate record = one 16-row MFMA fragment {fragment max, first row}; the select
+//                    stage re-scores all 16 rows of the fragments it keeps (small k only)
 
 
 __device__ __forceinline__ void glds16(const void *gsrc, char *lds_wave_base) {
@@ -107,17 +110,23 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
     const int a_base = (wd * 128 + l31) * 64;                // + dt*2048
     const int b_base = SUB_Q_REGION + (wq * 64 + l31) * 64;  // + qt*2048
 
-    // work items (range r, query block qb); blocks b and b+8 share an XCD (its L2)
+    // Work items (range r, query block qb).  Blocks b and b+8 share an XCD (its 4-MiB L2), so XCD x takes
+    // query-block group x % qgroups (its query rows stay L2-resident) and the ranges r = x / qgroups
+    // (mod 8 / qgroups); co-resident workgroups walk the same corpus tiles for different query blocks.
     const int xcd = blockIdx.x & (NUM_XCD - 1);
     const int jx = blockIdx.x >> 3;
     const int per_x = gridDim.x >> 3;
-    const int rl_x = (a.ranges - xcd + NUM_XCD - 1) / NUM_XCD;
-    const int count_x = rl_x * a.qblocks;
+    const int qg = xcd % a.qgroups;
+    const int rc = xcd / a.qgroups;
+    const int nrc = NUM_XCD / a.qgroups;           // range classes
+    const int qb_per = a.qblocks / a.qgroups;      // query blocks of this XCD (qgroups divides qblocks)
+    const int rl_x = (a.ranges - rc + nrc - 1) / nrc;
+    const int count_x = rl_x * qb_per;
 
     for (int item = jx; item < count_x; item += per_x) {
-        const int rl = item / a.qblocks;
-        const int qb = item - rl * a.qblocks;
-        const int r = xcd + NUM_XCD * rl;
+        const int rl = item / qb_per;
+        const int qb = qg * qb_per + (item - rl * qb_per);
+        const int r = rc + nrc * rl;
         const int64_t ntile = (a.n_vt - r + a.ranges - 1) / a.ranges;
         if (ntile <= 0) continue;
         const int q0 = qb * TILE_Q;
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
         float thr[2] = {0.f, 0.f};
         uint32_t ncand[2] = {0u, 0u};
         uint2 *clist[2] = {nullptr, nullptr};
-        if (EPI == EPI_FILTER) {
+        if (EPI == EPI_FILTER || EPI == EPI_FILTER_GROUP) {
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
                 const int q = q0 + wq * 64 + qt * 32 + l31;
@@ -198,11 +207,30 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
                                            fmaxf(acc[dt][qt][4 * g + 2], acc[dt][qt][4 * g + 3]));
                     mdt[dt] = fmaxf(fmaxf(sub[dt][0], sub[dt][1]), fmaxf(sub[dt][2], sub[dt][3]));
                 }
+                if constexpr ((DBG & 16) != 0) {
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) asm volatile("" : "+v"(mdt[dt]));
+                    CCR_STAMP(6)  // max trees (the hit path is charged to segment 1)
+                }
                 if (EPI == EPI_GMAX) {
                     const int ql = wq * 64 + qt * 32 + l31;
 #pragma unroll
                     for (int dt = 0; dt < 4; ++dt)
                         a.gmax[(vt * GROUPS_PER_TILE + wd * 8 + dt * 2 + h) * a.nq_pad + q0 + ql] = mdt[dt];
+                } else if (EPI == EPI_FILTER_GROUP) {
+                    const float t = thr[qt];
+                    const float mall = fmaxf(fmaxf(mdt[0], mdt[1]), fmaxf(mdt[2], mdt[3]));
+                    if (__ballot(mall >= t) != 0ull) {
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt) {
+                            const int64_t first = row_base + dt * 32;
+                            if (mdt[dt] >= t && first < a.n_rows) {  // rare, divergent
+                                if (ncand[qt] < (uint32_t)a.cap)
+                                    clist[qt][ncand[qt]] = make_uint2(__float_as_uint(mdt[dt]), (uint32_t)first);
+                                ++ncand[qt];
+                            }
+                        }
+                    }
                 } else if (EPI == EPI_FILTER) {
                     const float t = thr[qt];
                     const float mall = fmaxf(fmaxf(mdt[0], mdt[1]), fmaxf(mdt[2], mdt[3]));
@@ -340,7 +368,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
         if (pending) epilogue(pending_vt);
         if (STAGGER && !g1) CCR_BARRIER();  // every wave executes the same number of barriers
 
-        if (EPI == EPI_FILTER) {
+        if (EPI == EPI_FILTER || EPI == EPI_FILTER_GROUP) {
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt)
                 a.cnt[((int64_t)r * a.nq_pad + q0 + wq * 64 + qt * 32 + l31) * 4 + wd * 2 + h] = ncand[qt];
@@ -414,8 +442,9 @@ __global__ __launch_bounds__(256) void threshold_kernel(const float *__restrict_
 
 // Stage-2: per query, candidates -> exact canonical top-k.  grid = n_q, block = 256.
 // dyn LDS: [dim bf16 query row][ranges uint32 counts][rescore_cap u64 keys]
+template <bool GROUPS>
 __global__ __launch_bounds__(256) void select_rescore_kernel(const uint2 *__restrict__ cand, const uint32_t *__restrict__ cnt,
-                                                            int ranges, int nq_pad, int cap, int k, int rescore_cap,
+                                                            int ranges, int nq_pad, int cap, int k, int rescore_cap, int64_t n_rows,
                                                             const float *__restrict__ delta,
                                                             const uint16_t *__restrict__ Q, const uint16_t *__restrict__ D,
                                                             int dim, int64_t id_offset, float *__restrict__ out_scores,
@@ -432,6 +461,7 @@ __global__ __launch_bounds__(256) void select_rescore_kernel(const uint2 *__rest
     __shared__ int s_flag;
     __shared__ uint32_t s_total;
     __shared__ uint32_t s_ncoll;
+    __shared__ uint32_t s_grp[GROUPS ? 512 : 1];  // first rows of the kept fragments (rescore_cap / 16 <= 512)
 
     const int tid = threadIdx.x;
     const int q = blockIdx.x;
@@ -484,11 +514,11 @@ __global__ __launch_bounds__(256) void select_rescore_kernel(const uint2 *__rest
             const uint2 e = at(r, s);
             if (__uint_as_float(e.x) >= cut) {
                 const uint32_t p = atomicAdd(&s_ncoll, 1u);
-                if (p < (uint32_t)rescore_cap) s_keys[p] = (unsigned long long)e.y;  // local row for now
+                if (p < (uint32_t)(GROUPS ? rescore_cap / 16 : rescore_cap)) s_keys[p] = (unsigned long long)e.y;  // local row for now
             }
         }
         __syncthreads();
-        if (s_ncoll > (uint32_t)rescore_cap) bad = true;  // mass ties around the cut
+        if (s_ncoll > (uint32_t)(GROUPS ? rescore_cap / 16 : rescore_cap)) bad = true;  // mass ties around the cut
     }
     if (bad) {
         if (tid == 0) {
@@ -497,17 +527,28 @@ __global__ __launch_bounds__(256) void select_rescore_kernel(const uint2 *__rest
         }
         return;
     }
-    const int ncoll = (int)s_ncoll;
+    int ncoll = (int)s_ncoll;
+    if (GROUPS) {
+        // kept records are 16-row MFMA fragments: fragment g -> rows base + (e & 3) + 8 * (e >> 2), e = 0..15
+        for (int g = tid; g < ncoll; g += blockDim.x) s_grp[g] = (uint32_t)s_keys[g];
+        __syncthreads();
+        ncoll *= 16;
+    }
     const int np2 = pow2_ceil(ncoll);
-    // canonical re-score
+    // canonical re-score (each thread reads and rewrites only its own key slots)
     for (int i = tid; i < np2; i += blockDim.x) {
+        unsigned long long key = 0ull;
         if (i < ncoll) {
-            const uint32_t row = (uint32_t)s_keys[i];
-            const float sc = canonical_dot(s_q, D + (int64_t)row * dim, dim);
-            s_keys[i] = make_key(sc, row);
-        } else {
-            s_keys[i] = 0ull;
+            uint32_t row;
+            if (GROUPS) {
+                const int e = i & 15;
+                row = s_grp[i >> 4] + (uint32_t)((e & 3) + 8 * (e >> 2));
+            } else {
+                row = (uint32_t)s_keys[i];
+            }
+            if (!GROUPS || (int64_t)row < n_rows) key = make_key(canonical_dot(s_q, D + (int64_t)row * dim, dim), row);
         }
+        s_keys[i] = key;
     }
     block_bitonic_sort_desc(s_keys, np2);
     for (int i = tid; i < k; i += blockDim.x) {
@@ -541,15 +582,15 @@ static int launch_gemm(const GemmArgs &a, int grid, hipStream_t s) {
         stagger = st ? atoi(st) : 1;
     }
     const size_t lds = RING * (size_t)SUB_BYTES;
-    if (EPI == EPI_FILTER && dbg != 0) {
+    if ((EPI == EPI_FILTER || EPI == EPI_FILTER_GROUP) && dbg != 0) {
         switch (dbg) {
-            case 1: return launch_kernel(&gemm_topk_kernel<EPI_FILTER, true, 1>, lds, a, grid, s, cd);
-            case 2: return launch_kernel(&gemm_topk_kernel<EPI_FILTER, true, 2>, lds, a, grid, s, cd);
-            case 3: return launch_kernel(&gemm_topk_kernel<EPI_FILTER, true, 3>, lds, a, grid, s, cd);
-            case 4: return launch_kernel(&gemm_topk_kernel<EPI_FILTER, true, 4>, lds, a, grid, s, cd);
-            case 8: return launch_kernel(&gemm_topk_kernel<EPI_FILTER, true, 8>, lds, a, grid, s, cd);
-            case 16: return launch_kernel(&gemm_topk_kernel<EPI_FILTER, true, 16>, lds, a, grid, s, cd);
-            default: return launch_kernel(&gemm_topk_kernel<EPI_FILTER, true, 12>, lds, a, grid, s, cd);
+            case 1: return launch_kernel(&gemm_topk_kernel<EPI, true, 1>, lds, a, grid, s, cd);
+            case 2: return launch_kernel(&gemm_topk_kernel<EPI, true, 2>, lds, a, grid, s, cd);
+            case 3: return launch_kernel(&gemm_topk_kernel<EPI, true, 3>, lds, a, grid, s, cd);
+            case 4: return launch_kernel(&gemm_topk_kernel<EPI, true, 4>, lds, a, grid, s, cd);
+            case 8: return launch_kernel(&gemm_topk_kernel<EPI, true, 8>, lds, a, grid, s, cd);
+            case 16: return launch_kernel(&gemm_topk_kernel<EPI, true, 16>, lds, a, grid, s, cd);
+            default: return launch_kernel(&gemm_topk_kernel<EPI, true, 12>, lds, a, grid, s, cd);
         }
     }
     if (!stagger) return launch_kernel(&gemm_topk_kernel<EPI, false, 0>, lds, a, grid, s, c0);
@@ -557,6 +598,7 @@ static int launch_gemm(const GemmArgs &a, int grid, hipStream_t s) {
 }
 
 int launch_gemm_filter(const GemmArgs &a, int grid, hipStream_t s) { return launch_gemm<EPI_FILTER>(a, grid, s); }
+int launch_gemm_filter_group(const GemmArgs &a, int grid, hipStream_t s) { return launch_gemm<EPI_FILTER_GROUP>(a, grid, s); }
 int launch_gemm_gmax(const GemmArgs &a, int grid, hipStream_t s) { return launch_gemm<EPI_GMAX>(a, grid, s); }
 int launch_gemm_store(const GemmArgs &a, int grid, hipStream_t s) { return launch_gemm<EPI_STORE>(a, grid, s); }
 
@@ -582,18 +624,23 @@ size_t select_lds_bytes(int dim, int ranges, int rescore_cap) {
 }
 
 int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, int n_q, int nq_pad, int cap, int k,
-                          int rescore_cap, const float *delta, const uint16_t *Q, const uint16_t *D, int dim,
-                          int64_t id_offset, float *out_scores, int64_t *out_ids, uint32_t *flag_count,
-                          uint32_t *flag_list, unsigned long long *stat_cand, hipStream_t s) {
+                          int rescore_cap, int groups, int64_t n_rows, const float *delta, const uint16_t *Q,
+                          const uint16_t *D, int dim, int64_t id_offset, float *out_scores, int64_t *out_ids,
+                          uint32_t *flag_count, uint32_t *flag_list, unsigned long long *stat_cand, hipStream_t s) {
     const size_t lds = select_lds_bytes(dim, ranges, rescore_cap);
-    static size_t configured = 0;
-    if (lds > 48 * 1024 && lds > configured) {
-        CCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&select_rescore_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = lds;
+    static size_t configured[2] = {0, 0};
+    const void *fn = groups ? reinterpret_cast<const void *>(&select_rescore_kernel<true>)
+                            : reinterpret_cast<const void *>(&select_rescore_kernel<false>);
+    if (lds > 48 * 1024 && lds > configured[groups ? 1 : 0]) {
+        CCR_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured[groups ? 1 : 0] = lds;
     }
-    hipLaunchKernelGGL(select_rescore_kernel, dim3(n_q), dim3(256), lds, s, cand, cnt, ranges, nq_pad, cap, k, rescore_cap,
-                       delta, Q, D, dim, id_offset, out_scores, out_ids, flag_count, flag_list, stat_cand);
+    if (groups)
+        hipLaunchKernelGGL(select_rescore_kernel<true>, dim3(n_q), dim3(256), lds, s, cand, cnt, ranges, nq_pad, cap, k,
+                           rescore_cap, n_rows, delta, Q, D, dim, id_offset, out_scores, out_ids, flag_count, flag_list, stat_cand);
+    else
+        hipLaunchKernelGGL(select_rescore_kernel<false>, dim3(n_q), dim3(256), lds, s, cand, cnt, ranges, nq_pad, cap, k,
+                           rescore_cap, n_rows, delta, Q, D, dim, id_offset, out_scores, out_ids, flag_count, flag_list, stat_cand);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
 }

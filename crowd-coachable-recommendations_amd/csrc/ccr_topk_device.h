@@ -101,4 +101,5 @@ __device__ __forceinline__ float canonical_dot(const uint16_t *__restrict__ q, c
     return (float)acc;
 }
 
+
 }  // namespace ccr
