@@ -14,7 +14,7 @@ SEARCH_DEFAULT, SEARCH_FORCE_DENSE, SEARCH_FORCE_FUSED = 0, 1, 2
 EXPORTS = [
     "ccr_last_error", "ccr_version", "ccr_pack_bf16", "ccr_meanpool_pack_bf16", "ccr_index_create", "ccr_index_destroy",
     "ccr_index_rows", "ccr_index_dim", "ccr_search_workspace_bytes", "ccr_search", "ccr_search_last_stats",
-    "ccr_merge_topk", "ccr_apply_block", "ccr_inbatch_ce_fwd", "ccr_inbatch_ce_bwd", "ccr_debug_mfma_scores",
+    "ccr_merge_topk", "ccr_apply_block", "ccr_inbatch_ce_workspace_bytes", "ccr_inbatch_ce_fwd", "ccr_inbatch_ce_bwd", "ccr_debug_mfma_scores",
     "ccr_debug_canonical_scores",
 ]
 
@@ -60,8 +60,10 @@ def load():
     lib.ccr_search_last_stats.argtypes = [vp, ctypes.POINTER(SearchStats)]
     lib.ccr_merge_topk.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
     lib.ccr_apply_block.argtypes = [vp, vp, i32, i32, vp, vp, i64, vp, vp, i32, vp]
-    lib.ccr_inbatch_ce_fwd.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp, vp]
-    lib.ccr_inbatch_ce_bwd.argtypes = [vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp, vp]
+    lib.ccr_inbatch_ce_workspace_bytes.argtypes = [i32, i32]
+    lib.ccr_inbatch_ce_workspace_bytes.restype = sz
+    lib.ccr_inbatch_ce_fwd.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp, vp, sz, vp]
+    lib.ccr_inbatch_ce_bwd.argtypes = [vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp, vp, sz, vp]
     lib.ccr_debug_mfma_scores.argtypes = [vp, vp, i32, vp, vp]
     lib.ccr_debug_canonical_scores.argtypes = [vp, vp, i32, vp, vp]
     for name in EXPORTS:

@@ -165,10 +165,11 @@ class _InBatchCE(torch.autograd.Function):
         B, dim = qb.shape
         loss = torch.empty(1, dtype=torch.float32, device=q.device)
         lse = torch.empty(B, dtype=torch.float32, device=q.device)
+        ws = torch.empty(int(lib.ccr_inbatch_ce_workspace_bytes(B, dim)), dtype=torch.uint8, device=q.device)
         with _on(qb):
             _lib.check(lib.ccr_inbatch_ce_fwd(_ptr(qb), _ptr(pb), _ptr(nb), B, dim, float(inv_temperature), _ptr(loss),
-                                              _ptr(lse), _stream(qb)), "ccr_inbatch_ce_fwd")
-        ctx.save_for_backward(qb, pb, nb, lse)
+                                              _ptr(lse), _ptr(ws), ws.numel(), _stream(qb)), "ccr_inbatch_ce_fwd")
+        ctx.save_for_backward(qb, pb, nb, lse, ws)
         ctx.inv_t = float(inv_temperature)
         ctx.dtypes = (q.dtype, p.dtype, n.dtype)
         return loss[0]
@@ -176,12 +177,13 @@ class _InBatchCE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         lib = require_gpu()
-        qb, pb, nb, lse = ctx.saved_tensors
+        qb, pb, nb, lse, ws = ctx.saved_tensors
         B, dim = qb.shape
         dq, dp, dn = (torch.empty(B, dim, dtype=torch.float32, device=qb.device) for _ in range(3))
         with _on(qb):
             _lib.check(lib.ccr_inbatch_ce_bwd(_ptr(qb), _ptr(pb), _ptr(nb), _ptr(lse), B, dim, ctx.inv_t, float(grad_out),
-                                              _ptr(dq), _ptr(dp), _ptr(dn), _stream(qb)), "ccr_inbatch_ce_bwd")
+                                              _ptr(dq), _ptr(dp), _ptr(dn), _ptr(ws), ws.numel(), _stream(qb)),
+                       "ccr_inbatch_ce_bwd")
         return dq.to(ctx.dtypes[0]), dp.to(ctx.dtypes[1]), dn.to(ctx.dtypes[2]), None
 
 

@@ -138,11 +138,15 @@ int ccr_apply_block(const float *in_scores, const int64_t *in_ids, int n_q, int 
  *   Qe, Pe, Ne [B][dim] bf16; logits = [Qe Pe^T | Qe Ne^T] * inv_temperature (fp32 accumulate)
  *   fwd: loss (1 float, mean CE with labels arange(B)), lse [B] (saved for bwd)
  *   bwd: dQ, dP, dN [B][dim] fp32 = grad_out * dloss/d(.)
+ *   workspace: ccr_inbatch_ce_workspace_bytes(B, dim) bytes of device memory (split partials + the
+ *   [2B][B] fp32 gradient-of-logits matrix); dim % 16 == 0.
  */
+size_t ccr_inbatch_ce_workspace_bytes(int B, int dim);
 int ccr_inbatch_ce_fwd(const uint16_t *Qe, const uint16_t *Pe, const uint16_t *Ne, int B, int dim,
-                       float inv_temperature, float *loss, float *lse, void *stream);
+                       float inv_temperature, float *loss, float *lse, void *workspace, size_t ws_bytes, void *stream);
 int ccr_inbatch_ce_bwd(const uint16_t *Qe, const uint16_t *Pe, const uint16_t *Ne, const float *lse, int B, int dim,
-                       float inv_temperature, float grad_out, float *dQ, float *dP, float *dN, void *stream);
+                       float inv_temperature, float grad_out, float *dQ, float *dP, float *dN, void *workspace,
+                       size_t ws_bytes, void *stream);
 
 /*
  * Test/diagnostic entry points (not part of the drop-in surface).

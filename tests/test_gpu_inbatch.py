@@ -1,0 +1,54 @@
+"""GPU parity of the in-batch-negative contrastive loss (bbpr.py:205-212) vs the oracle and the golden
+vectors produced by the reference's own training_and_validation_step."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(x):
+    return torch.from_numpy(np.asarray(x, np.float32)).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("tag,B,sim", [("b8_dot", 8, "dot"), ("b32_dot", 32, "dot"), ("b8_cos", 8, "cos"), ("b32_cos", 32, "cos")])
+def test_loss_and_grads_vs_reference_golden(golden_dir, tag, B, sim):
+    from ccrec_amd.bbpr_loss import multiple_nrl_loss
+    g = np.load(os.path.join(golden_dir, "g7_contrastive.npz"))
+    E = torch.from_numpy(g[f"{tag}_E"]).cuda().requires_grad_(True)
+    loss = multiple_nrl_loss(E[:B], E[B:2 * B], E[2 * B:], inv_temperature=20.0, sim_type=sim)
+    loss.backward()
+    # bf16 operands (the reference ran fp32): logits differ by ~inv_T * 2^-9 * |q||k|
+    assert abs(float(loss) - float(g[f"{tag}_loss"])) < 3e-2 * max(1.0, abs(float(g[f"{tag}_loss"])))
+    ref = g[f"{tag}_grad"]
+    got = E.grad.cpu().numpy()
+    assert np.abs(got - ref).max() < 6e-2 * np.abs(ref).max()
+    # against the oracle on the SAME bf16-rounded operands: tight
+    Eb = E.detach()
+    if sim == "cos":
+        Eb = torch.nn.functional.normalize(Eb, p=2, dim=1)
+    Eb = Eb.to(torch.bfloat16).float().cpu().numpy()
+    l2, dQ, dP, dN = orc.inbatch_ce(Eb[:B], Eb[B:2 * B], Eb[2 * B:], 20.0, "dot")
+    assert abs(float(loss) - l2) < 2e-5 * max(1.0, abs(l2))
+
+
+@pytest.mark.parametrize("B,dim", [(1024, 768), (100, 64), (33, 1024), (1, 16)])
+def test_fwd_bwd_vs_oracle(B, dim):
+    from ccrec_amd import ops
+    g = torch.Generator().manual_seed(B)
+    q, p, n = (_bf(torch.randn(B, dim, generator=g) / dim ** 0.5) for _ in range(3))
+    qc, pc, nc = (t.cuda().float().requires_grad_(True) for t in (q, p, n))
+    inv_t = 20.0
+    loss = ops.inbatch_ce(qc, pc, nc, inv_t)
+    (loss * 3.0).backward()           # grad_out != 1
+    l2, dQ, dP, dN = orc.inbatch_ce(q.float().numpy(), p.float().numpy(), n.float().numpy(), inv_t, "dot")
+    assert abs(float(loss) - l2) < 2e-5 * max(1.0, abs(l2))
+    for got, ref in ((qc.grad, dQ), (pc.grad, dP), (nc.grad, dN)):
+        np.testing.assert_allclose(got.cpu().numpy(), 3.0 * ref, rtol=2e-4, atol=3e-6 * max(1e-6, np.abs(ref).max()) * 100)
+    # deterministic: same bits on a second run
+    loss2 = ops.inbatch_ce(qc.detach(), pc.detach(), nc.detach(), inv_t)
+    assert float(loss2) == float(loss)
