@@ -128,9 +128,12 @@ def main():
 
     state = {}
 
+    max_norm = torch.zeros(1, dtype=torch.float32, device=dev)
+
     def step():
-        ops.pack_bf16(corpus_f32, out=shard)
-        index = ops.CorpusIndex(shard, global_row_offset=lo)
+        max_norm.zero_()
+        ops.pack_bf16(corpus_f32, out=shard, max_norm=max_norm)     # pack + max packed-row norm in one pass
+        index = ops.CorpusIndex(shard, global_row_offset=lo, max_norm=max_norm)
         ops.pack_bf16(queries_f32, out=qpack)
         s, i = index.search(qpack, k_local)
         if world > 1:
@@ -170,7 +173,7 @@ def main():
     # untimed extras: pack-kernel HBM rate
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    ops.pack_bf16(corpus_f32, out=shard)
+    ops.pack_bf16(corpus_f32, out=shard, max_norm=max_norm)
     e1.record()
     torch.cuda.synchronize()
     pack_ms = e0.elapsed_time(e1)

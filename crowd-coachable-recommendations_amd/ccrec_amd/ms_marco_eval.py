@@ -23,7 +23,7 @@ KEEP = 1001  # ms_marco_eval.py:230
 
 
 def generate_embeddings(data_indices, data_dic, embedding_func, batch_size, embedding_size=768, name=None, pack=None,
-                        device=None):
+                        device=None, max_norm=None):
     """scripts/ms_marco_eval.py:123-152.  Same batching, progress lines and return value (a [num, dim]
     tensor), but the result stays on the GPU.  pack=None -> fp32; pack="dot"/"cos" -> bf16 shard packed
     batch by batch (cos = L2-normalised first)."""
@@ -49,7 +49,7 @@ def generate_embeddings(data_indices, data_dic, embedding_func, batch_size, embe
             if pack is None:
                 out[lo:lo + emb.shape[0]] = emb
             else:
-                ops.pack_bf16(emb, normalize=(pack == "cos"), out=out[lo:lo + emb.shape[0]])
+                ops.pack_bf16(emb, normalize=(pack == "cos"), out=out[lo:lo + emb.shape[0]], max_norm=max_norm)
     torch.cuda.synchronize()
     print(f"Processed total {num} t={time.time() - tic:.1f}s")
     if out is None:
@@ -78,9 +78,9 @@ class Retriever:
 
     corpus_ids: list of passage ids in corpus row order; corpus_bf16: packed shard [N, dim]."""
 
-    def __init__(self, corpus_ids, corpus_bf16, global_row_offset=0):
+    def __init__(self, corpus_ids, corpus_bf16, global_row_offset=0, max_norm=None):
         self.corpus_ids = list(corpus_ids)
-        self.index = ops.CorpusIndex(corpus_bf16, global_row_offset)
+        self.index = ops.CorpusIndex(corpus_bf16, global_row_offset, max_norm=max_norm)
         self._pos = None
 
     def _positions(self):
@@ -134,6 +134,7 @@ def ranking(corpus, queries, embedding_func, batch_size, block_dict=None):
     queries_ids, corpus_ids = list(queries.keys()), list(corpus.keys())
     sim = "cos" if os.environ["CCREC_SIM_TYPE"] == "cos" else "dot"
     queries_embeddings = generate_embeddings(queries_ids, queries, embedding_func, batch_size, pack=sim)
-    passage_embeddings = generate_embeddings(corpus_ids, corpus, embedding_func, batch_size, pack=sim)
-    retriever = Retriever(corpus_ids, passage_embeddings)
+    max_norm = torch.zeros(1, dtype=torch.float32, device="cuda")   # accumulated by the pack kernel, batch by batch
+    passage_embeddings = generate_embeddings(corpus_ids, corpus, embedding_func, batch_size, pack=sim, max_norm=max_norm)
+    retriever = Retriever(corpus_ids, passage_embeddings, max_norm=max_norm)
     return retriever.ranking_profile(queries_ids, queries_embeddings, block_dict)

@@ -28,9 +28,11 @@ def _on(t):
     return torch.cuda.device(t.device)
 
 
-def pack_bf16(x, normalize=False, out=None, return_norms=False):
+def pack_bf16(x, normalize=False, out=None, return_norms=False, max_norm=None):
     """fp32 [rows, dim] (cuda) -> bf16 [rows, dim]; normalize=True applies x / max(||x||, 1e-12) first
-    (the cos_sim rule, ms_marco_eval.py:160-161).  `out` may be a slice of a preallocated shard."""
+    (the cos_sim rule, ms_marco_eval.py:160-161).  `out` may be a slice of a preallocated shard.
+    max_norm: optional 1-element fp32 cuda tensor (zero-initialised by the caller) that accumulates an upper
+    bound of the largest packed-row norm over all batches; hand it to CorpusIndex(max_norm=...)."""
     lib = require_gpu()
     assert x.is_cuda and x.dim() == 2, "pack_bf16 expects a 2-d cuda tensor"
     x = x.contiguous()
@@ -41,9 +43,11 @@ def pack_bf16(x, normalize=False, out=None, return_norms=False):
         out = torch.empty(rows, dim, dtype=torch.bfloat16, device=x.device)
     assert out.is_contiguous() and out.dtype == torch.bfloat16 and tuple(out.shape) == (rows, dim)
     norms = torch.empty(rows, dtype=torch.float32, device=x.device) if return_norms else None
+    if max_norm is not None:
+        assert max_norm.is_cuda and max_norm.dtype == torch.float32 and max_norm.numel() == 1
     with _on(x):
-        _lib.check(lib.ccr_pack_bf16(_ptr(x), _ptr(out), _ptr(norms), rows, dim, int(bool(normalize)), _stream(x)),
-                   "ccr_pack_bf16")
+        _lib.check(lib.ccr_pack_bf16_ex(_ptr(x), _ptr(out), _ptr(norms), _ptr(max_norm), rows, dim, int(bool(normalize)),
+                                        _stream(x)), "ccr_pack_bf16")
     return (out, norms) if return_norms else out
 
 
@@ -71,7 +75,7 @@ class CorpusIndex:
     global_row_offset: id of row 0 in the whole corpus (row-sharded multi-GPU search).
     """
 
-    def __init__(self, corpus_bf16, global_row_offset=0):
+    def __init__(self, corpus_bf16, global_row_offset=0, max_norm=None):
         self._lib = require_gpu()
         assert corpus_bf16.is_cuda and corpus_bf16.dtype == torch.bfloat16 and corpus_bf16.dim() == 2
         self.corpus = corpus_bf16.contiguous()
@@ -80,8 +84,14 @@ class CorpusIndex:
         self._h = ctypes.c_void_p()
         self._ws = None
         with _on(self.corpus):
-            _lib.check(self._lib.ccr_index_create(_ptr(self.corpus), self.n_rows, self.dim, self.offset,
-                                                  _stream(self.corpus), ctypes.byref(self._h)), "ccr_index_create")
+            if max_norm is None:
+                _lib.check(self._lib.ccr_index_create(_ptr(self.corpus), self.n_rows, self.dim, self.offset,
+                                                      _stream(self.corpus), ctypes.byref(self._h)), "ccr_index_create")
+            else:  # bound from ccr_pack_bf16_ex: no extra pass over the shard, no synchronisation
+                assert max_norm.is_cuda and max_norm.dtype == torch.float32 and max_norm.numel() == 1
+                _lib.check(self._lib.ccr_index_create_with_norm(_ptr(self.corpus), self.n_rows, self.dim, self.offset,
+                                                                _ptr(max_norm), _stream(self.corpus),
+                                                                ctypes.byref(self._h)), "ccr_index_create_with_norm")
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None

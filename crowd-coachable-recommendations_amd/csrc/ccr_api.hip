@@ -150,8 +150,8 @@ struct ccr_index {
 extern "C" const char *ccr_last_error(void) { return g_err; }
 extern "C" int ccr_version(void) { return 100; }
 
-extern "C" int ccr_index_create(const uint16_t *D_bf16, int64_t n_rows, int dim, int64_t global_row_offset, void *stream,
-                                ccr_index **out) {
+static int index_create_impl(const uint16_t *D_bf16, int64_t n_rows, int dim, int64_t global_row_offset, const float *max_norm,
+                             void *stream, ccr_index **out) {
     CCR_REQUIRE(D_bf16 && out, "ccr_index_create: null pointer");
     CCR_REQUIRE(n_rows >= 1 && n_rows < ((int64_t)1 << 32), "ccr_index_create: n_rows=%lld out of range [1, 2^32)",
                 (long long)n_rows);
@@ -165,17 +165,30 @@ extern "C" int ccr_index_create(const uint16_t *D_bf16, int64_t n_rows, int dim,
     ix->dim = dim;
     ix->offset = global_row_offset;
     CCR_HIP_CHECK(hipGetDevice(&ix->device));
-    hipDeviceProp_t prop;
-    CCR_HIP_CHECK(hipGetDeviceProperties(&prop, ix->device));
-    ix->num_cu = prop.multiProcessorCount;
+    CCR_HIP_CHECK(hipDeviceGetAttribute(&ix->num_cu, hipDeviceAttributeMultiprocessorCount, ix->device));
     for (int i = 0; i < 7; ++i) CCR_HIP_CHECK(hipEventCreate(&ix->ev[i]));
     CCR_HIP_CHECK(hipMalloc((void **)&ix->dmax_bits, 256));
-    CCR_HIP_CHECK(hipMemsetAsync(ix->dmax_bits, 0, 256, s));
-    int rc = launch_row_norms_bf16(D_bf16, n_rows, dim, nullptr, ix->dmax_bits, s);
-    if (rc != CCR_OK) return rc;
-    CCR_HIP_CHECK(hipStreamSynchronize(s));
+    if (max_norm) {
+        CCR_HIP_CHECK(hipMemcpyAsync(ix->dmax_bits, max_norm, 4, hipMemcpyDeviceToDevice, s));
+    } else {
+        CCR_HIP_CHECK(hipMemsetAsync(ix->dmax_bits, 0, 256, s));
+        int rc = launch_row_norms_bf16(D_bf16, n_rows, dim, nullptr, ix->dmax_bits, s);
+        if (rc != CCR_OK) return rc;
+        CCR_HIP_CHECK(hipStreamSynchronize(s));
+    }
     *out = ix;
     return CCR_OK;
+}
+
+extern "C" int ccr_index_create(const uint16_t *D_bf16, int64_t n_rows, int dim, int64_t global_row_offset, void *stream,
+                                ccr_index **out) {
+    return index_create_impl(D_bf16, n_rows, dim, global_row_offset, nullptr, stream, out);
+}
+
+extern "C" int ccr_index_create_with_norm(const uint16_t *D_bf16, int64_t n_rows, int dim, int64_t global_row_offset,
+                                          const float *max_norm, void *stream, ccr_index **out) {
+    CCR_REQUIRE(max_norm, "ccr_index_create_with_norm: null max_norm");
+    return index_create_impl(D_bf16, n_rows, dim, global_row_offset, max_norm, stream, out);
 }
 
 extern "C" int ccr_index_destroy(ccr_index *ix) {

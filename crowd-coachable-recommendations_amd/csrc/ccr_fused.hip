@@ -414,29 +414,56 @@ __global__ __launch_bounds__(256) void row_norms_bf16_kernel(const uint16_t *__r
     if (max_bits && lane == 0) atomicMax(max_bits, __float_as_uint(wmax));  // non-negative floats order as uints
 }
 
-// thr[q] = (k-th largest group maximum) - delta[q];  grid = n_q, block = 256.
-__global__ __launch_bounds__(256) void threshold_kernel(const float *__restrict__ gmax, int64_t n_groups, int nq_pad,
+// thr[q] = (k-th largest group maximum) - delta[q].
+// One workgroup = 16 queries x 16 group phases: a gmax row is read as 64-byte segments (query-contiguous
+// layout), every query has its own 256-bin LDS histogram (no same-address atomics), 4 MSB-first passes.
+// grid = nq_pad / 16, block = 256.
+__global__ __launch_bounds__(256) void threshold_kernel(const float *__restrict__ gmax, int64_t n_groups, int n_q, int nq_pad,
                                                        int k, const float *__restrict__ qnorm,
                                                        const uint32_t *__restrict__ dmax_bits, float gamma,
                                                        float *__restrict__ thr, float *__restrict__ delta) {
-    __shared__ uint32_t s_hist[256];
-    __shared__ uint32_t s_ctl[4];
-    const int q = blockIdx.x;
-    uint32_t kth;
-    int need_eq;
-    block_radix_select(
-        [&](int64_t i, bool &skip) -> uint32_t {
-            (void)skip;
-            return f32_orderable(gmax[i * nq_pad + q]);
-        },
-        n_groups, k, s_hist, s_ctl, kth, need_eq);
-    if (threadIdx.x == 0) {
-        const float tau = orderable_to_f32(kth);
-        const float dmax = __uint_as_float(*dmax_bits);
-        // |mfma - exact| <= gamma * ||q|| * ||d|| for both the threshold docs and the candidate
-        const float dl = 2.f * gamma * (qnorm[q] * 1.001f) * (dmax * 1.001f) + 1e-30f;
-        delta[q] = dl;
-        thr[q] = tau - dl;
+    __shared__ uint32_t s_hist[16][256];
+    __shared__ uint32_t s_prefix[16], s_remaining[16];
+    const int tid = threadIdx.x;
+    const int ql = tid & 15, ph = tid >> 4;
+    const int q = blockIdx.x * 16 + ql;
+    if (tid < 16) {
+        s_prefix[tid] = 0;
+        s_remaining[tid] = (uint32_t)k;
+    }
+    uint32_t mask = 0;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int b = tid; b < 16 * 256; b += 256) (&s_hist[0][0])[b] = 0;
+        __syncthreads();
+        const uint32_t prefix = s_prefix[ql];
+        for (int64_t i = ph; i < n_groups; i += 16) {
+            const uint32_t o = f32_orderable(gmax[i * nq_pad + q]);
+            if ((o & mask) == prefix) atomicAdd(&s_hist[ql][(o >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 16) {
+            int remaining = (int)s_remaining[tid], cum = 0, d = 255;
+            for (; d > 0; --d) {
+                const int hcount = (int)s_hist[tid][d];
+                if (cum + hcount >= remaining) break;
+                cum += hcount;
+            }
+            s_prefix[tid] |= (uint32_t)d << shift;
+            s_remaining[tid] = (uint32_t)(remaining - cum);
+        }
+        mask |= 0xffu << shift;
+        __syncthreads();
+    }
+    if (tid < 16) {
+        const int qq = blockIdx.x * 16 + tid;
+        if (qq < n_q) {
+            const float tau = orderable_to_f32(s_prefix[tid]);
+            const float dmax = __uint_as_float(*dmax_bits);
+            // |mfma - exact| <= gamma * ||q|| * ||d|| for both the threshold rows and the candidate
+            const float dl = 2.f * gamma * (qnorm[qq] * 1.001f) * (dmax * 1.001f) + 1e-30f;
+            delta[qq] = dl;
+            thr[qq] = tau - dl;
+        }
     }
 }
 
@@ -613,7 +640,7 @@ int launch_row_norms_bf16(const uint16_t *X, int64_t rows, int dim, float *norms
 
 int launch_threshold(const float *gmax, int64_t n_groups, int n_q, int nq_pad, int k, const float *qnorm,
                      const uint32_t *dmax_bits, int dim, float *thr, float *delta, hipStream_t s) {
-    hipLaunchKernelGGL(threshold_kernel, dim3(n_q), dim3(256), 0, s, gmax, n_groups, nq_pad, k, qnorm, dmax_bits,
+    hipLaunchKernelGGL(threshold_kernel, dim3(nq_pad / 16), dim3(256), 0, s, gmax, n_groups, n_q, nq_pad, k, qnorm, dmax_bits,
                        mfma_gamma(dim), thr, delta);
     CCR_LAUNCH_CHECK();
     return CCR_OK;

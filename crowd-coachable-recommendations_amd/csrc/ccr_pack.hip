@@ -40,6 +40,40 @@ __global__ void pack_bf16_tail_kernel(const float *__restrict__ src, __bf16 *__r
     if (i < n) dst[i] = (__bf16)src[i];
 }
 
+
+// ---------------------------------------------------------------- pack + max row norm of the PACKED rows
+// One wave per row, 8 consecutive floats per lane per step (two 16-B loads -> one 16-B store), fp32 sum of
+// squares of the bf16-ROUNDED values, wave reduce, one atomicMax per wave on the bit pattern
+// (non-negative floats order as unsigned).  The index uses the maximum only inside error margins.
+__global__ __launch_bounds__(256) void pack_rows_maxnorm_kernel(const float *__restrict__ src, __bf16 *__restrict__ dst,
+                                                               int64_t rows, int dim, uint32_t *__restrict__ max_bits) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int n8 = dim >> 3;
+    float wmax = 0.f;
+    for (int64_t r = wave; r < rows; r += nwaves) {
+        const float4 *x = reinterpret_cast<const float4 *>(src + r * dim);
+        bf16x8 *y = reinterpret_cast<bf16x8 *>(dst + r * dim);
+        float ss = 0.f;
+        for (int c = lane; c < n8; c += 64) {
+            const float4 a = x[2 * c], b = x[2 * c + 1];
+            const bf16x4 lo = cvt4(a), hi = cvt4(b);
+            const bf16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            y[c] = v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = (float)v[e];
+                ss = fmaf(f, f, ss);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+        wmax = fmaxf(wmax, sqrtf(ss));
+    }
+    if (lane == 0) atomicMax(max_bits, __float_as_uint(wmax));
+}
+
 // ---------------------------------------------------------------- row-wise: norms / normalise + pack
 // One wave per row.  Lane l owns float4 chunks c with c % 64 == l; per-lane fp64 partial sum in
 // increasing index, then the butterfly p += shfl_xor(p, off) for off = 32..1 (every lane ends
@@ -61,7 +95,7 @@ __device__ __forceinline__ double wave_sumsq(const float *__restrict__ x, int di
 
 __global__ __launch_bounds__(256) void pack_rows_kernel(const float *__restrict__ src, __bf16 *__restrict__ dst,
                                                        float *__restrict__ norms, int64_t rows, int dim,
-                                                       int normalize) {
+                                                       int normalize, uint32_t *__restrict__ max_bits) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -83,6 +117,8 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float *__restrict_
             }
             y[c] = cvt4(v);
         }
+        // upper bound of the packed row's norm: bf16 rounding moves each element by at most 2^-8 relative
+        if (max_bits && lane == 0) atomicMax(max_bits, __float_as_uint((float)((normalize ? nrm / den : nrm) * 1.004)));
     }
 }
 
@@ -182,15 +218,25 @@ __global__ __launch_bounds__(256) void meanpool_pack_kernel(const T *__restrict_
 
 using namespace ccr;
 
-extern "C" int ccr_pack_bf16(const float *src, uint16_t *dst, float *norms, int64_t rows, int dim, int normalize,
-                             void *stream) {
+extern "C" int ccr_pack_bf16_ex(const float *src, uint16_t *dst, float *norms, float *max_norm, int64_t rows, int dim,
+                                int normalize, void *stream) {
     CCR_REQUIRE(src && dst, "ccr_pack_bf16: null pointer");
     CCR_REQUIRE(rows >= 0 && dim > 0, "ccr_pack_bf16: bad shape rows=%lld dim=%d", (long long)rows, dim);
     if (rows == 0) return CCR_OK;
     hipStream_t s = (hipStream_t)stream;
+    uint32_t *max_bits = reinterpret_cast<uint32_t *>(max_norm);
     if (!normalize && !norms) {
-        const int64_t n = rows * dim;
         CCR_REQUIRE(((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0), "ccr_pack_bf16: buffers must be 16-byte aligned");
+        if (max_bits) {
+            CCR_REQUIRE(dim % 8 == 0, "ccr_pack_bf16: max_norm needs dim %% 8 == 0 (dim=%d)", dim);
+            int64_t blocks = (rows + 3) / 4;
+            if (blocks > 256 * 8) blocks = 256 * 8;
+            hipLaunchKernelGGL(pack_rows_maxnorm_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src,
+                               reinterpret_cast<__bf16 *>(dst), rows, dim, max_bits);
+            CCR_LAUNCH_CHECK();
+            return CCR_OK;
+        }
+        const int64_t n = rows * dim;
         const int64_t n8 = n / 8;
         if (n8 > 0) {
             int64_t blocks = (n8 + 255) / 256;
@@ -211,9 +257,14 @@ extern "C" int ccr_pack_bf16(const float *src, uint16_t *dst, float *norms, int6
     int64_t blocks = (rows + 3) / 4;
     if (blocks > 256 * 8) blocks = 256 * 8;
     hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, reinterpret_cast<__bf16 *>(dst),
-                       norms, rows, dim, normalize);
+                       norms, rows, dim, normalize, max_bits);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
+}
+
+extern "C" int ccr_pack_bf16(const float *src, uint16_t *dst, float *norms, int64_t rows, int dim, int normalize,
+                             void *stream) {
+    return ccr_pack_bf16_ex(src, dst, norms, nullptr, rows, dim, normalize, stream);
 }
 
 extern "C" int ccr_meanpool_pack_bf16(const void *hidden, int hidden_dtype, const int64_t *mask, uint16_t *dst_bf16,

@@ -75,6 +75,11 @@ int ccr_version(void);
  * dim % 4 == 0.  normalize: y = x / max(||x||, 1e-12), fixed reduction order (oracle/ccr_oracle.c).
  */
 int ccr_pack_bf16(const float *src, uint16_t *dst, float *norms, int64_t rows, int dim, int normalize, void *stream);
+/* Same, plus max_norm (device float, may be NULL): an upper bound of the largest L2 norm of the PACKED rows is
+ * max-accumulated into it (zero it before the first batch; several batches may share it).  Passing it on to
+ * ccr_index_create_with_norm saves the index build's own pass over the shard. */
+int ccr_pack_bf16_ex(const float *src, uint16_t *dst, float *norms, float *max_norm, int64_t rows, int dim, int normalize,
+                     void *stream);
 
 /*
  * Fused masked mean pooling (+ optional normalise) + pack of the encoder's last hidden state.
@@ -93,6 +98,10 @@ int ccr_meanpool_pack_bf16(const void *hidden, int hidden_dtype, const int64_t *
  */
 int ccr_index_create(const uint16_t *D_bf16, int64_t n_rows, int dim, int64_t global_row_offset, void *stream,
                      ccr_index **out);
+/* As ccr_index_create, but the caller supplies (device pointer) an upper bound of the shard's largest row norm
+ * (from ccr_pack_bf16_ex): no pass over the corpus, no stream synchronisation. */
+int ccr_index_create_with_norm(const uint16_t *D_bf16, int64_t n_rows, int dim, int64_t global_row_offset,
+                               const float *max_norm, void *stream, ccr_index **out);
 int ccr_index_destroy(ccr_index *index);
 int64_t ccr_index_rows(const ccr_index *index);
 int ccr_index_dim(const ccr_index *index);
