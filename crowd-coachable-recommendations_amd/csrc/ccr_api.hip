@@ -33,6 +33,8 @@ int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, in
                           const uint16_t *D, int dim, int64_t id_offset, float *out_scores, int64_t *out_ids,
                           uint32_t *flag_count, uint32_t *flag_list, unsigned long long *stat_cand, hipStream_t s);
 int launch_gemm_filter_group(const GemmArgs &a, int grid, hipStream_t s);
+int launch_threshold_update(const uint2 *cand, const uint32_t *cnt, int nsub, int n_q, int nq_pad, int cap, int k,
+                            const float *delta, float *thr, hipStream_t s);
 int launch_dense_scores(const uint16_t *D, int64_t n_rows, int dim, const uint16_t *Q, const uint32_t *qlist,
                         int q_begin, int nq_chunk, float *out, hipStream_t s);
 int launch_dense_select(const float *scores, int64_t n_rows, int k, const uint32_t *qlist, int q_begin, int nq_chunk,
@@ -100,11 +102,41 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu) {
     if (p.fused) {
         p.sample_tiles = (int)sample;
         p.sample_stride = std::max<int64_t>(1, p.full_tiles / sample);
-        // main-pass ranges: ~6 work items per workgroup, each at least 8 tiles, multiple of 8 (XCDs)
-        int64_t R = round_up(std::max<int64_t>(NUM_XCD, (int64_t)p.grid * 6 / p.qblocks), NUM_XCD);
-        R = std::min<int64_t>(R, round_up(std::max<int64_t>(1, p.tiles / 8), NUM_XCD));
-        R = std::min<int64_t>(R, 1024);
+        // Main-pass ranges.  Work items are (range, query block); an XCD set of per_x workgroups walks
+        // (R / nrc) * qb_per equal items, so R is chosen (multiple of 8, near 6 items per workgroup, each item at
+        // least 8 tiles) to make that count as close below a multiple of per_x as possible -- NQ: R = 128 gives
+        // exactly 7 items per workgroup where R = 112 left the last round 1/8 full.
+        p.qgroups = pick_qgroups(p.qblocks, dim);
+        const int nrc = NUM_XCD / p.qgroups, qb_per = p.qblocks / p.qgroups, per_x = p.grid / NUM_XCD;
+        const int64_t r_hi = std::min<int64_t>(1024 / 4, round_up(std::max<int64_t>(1, p.tiles / 8), NUM_XCD));
+        const int64_t target = std::min<int64_t>(r_hi, round_up(std::max<int64_t>(NUM_XCD, (int64_t)p.grid * 6 / p.qblocks), NUM_XCD));
+        int64_t R = target;
+        double best = -1.0;
+        for (int64_t cand_r = std::max<int64_t>(NUM_XCD, target / 2 / NUM_XCD * NUM_XCD); cand_r <= std::min(r_hi, target * 2);
+             cand_r += NUM_XCD) {
+            const int64_t items = cand_r / nrc * qb_per;
+            const int64_t rounds = (items + per_x - 1) / per_x;
+            const double eff = (double)items / (double)(rounds * per_x) - 1e-4 * std::abs((double)(cand_r - target)) / (double)target;
+            if (eff > best) {
+                best = eff;
+                R = cand_r;
+            }
+        }
         p.ranges = (int)R;
+        // Phase A: the first ranges (one round of items at most), after which thresholds are re-tightened from
+        // the candidates found so far; the remaining ranges keep the balanced count.  CCR_PROGRESSIVE=0 disables.
+        p.ranges_a = 0;
+        {
+            const char *e = getenv("CCR_PROGRESSIVE");
+            const bool on = !(e && atoi(e) == 0);
+            int64_t ra = (int64_t)per_x * nrc / qb_per / NUM_XCD * NUM_XCD;   // largest multiple of 8 with items <= per_x
+            ra = std::min<int64_t>(ra, R / 4 / NUM_XCD * NUM_XCD);
+            if (on && ra >= NUM_XCD && R + ra <= 1024 / 4 && (double)p.tiles / (double)(R + ra) >= 8.0) {
+                p.ranges_a = (int)ra;
+                p.ranges = (int)(R + ra);
+                R = p.ranges;
+            }
+        }
         const double ratio = (double)p.tiles / (double)sample;
         const double expect = (double)k * ratio * 1.3 + 64.0;  // survivors per query
         // candidates go to 4 sub-lists per (range, query): one per (wave row, lane half) of the GEMM tile
@@ -286,7 +318,7 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
     g.n_q = n_q;
     g.nq_pad = p.nq_pad;
     g.qblocks = p.qblocks;
-    g.qgroups = pick_qgroups(p.qblocks, ix->dim);
+    g.qgroups = p.qgroups;
 
     // sample pass -> group maxima -> thresholds
     GemmArgs gs = g;
@@ -294,6 +326,8 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
     gs.tile_stride = p.sample_stride;
     gs.ranges = (int)round_up(std::min<int64_t>(p.ranges, std::max<int64_t>(NUM_XCD, p.sample_tiles / 4)), NUM_XCD);
     gs.gmax = gmax;
+    gs.range_begin = 0;
+    gs.range_end = gs.ranges;
     CCR_HIP_CHECK(hipEventRecord(ix->ev[1], s));
     rc = launch_gemm_gmax(gs, p.grid, s);
     if (rc != CCR_OK) return rc;
@@ -320,8 +354,18 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
         gm.store = reinterpret_cast<float *>(stamps);
     }
     CCR_HIP_CHECK(hipEventRecord(ix->ev[3], s));
+    gm.range_begin = 0;
+    gm.range_end = p.ranges_a > 0 ? p.ranges_a : p.ranges;
     rc = p.group_records ? launch_gemm_filter_group(gm, p.grid, s) : launch_gemm_filter(gm, p.grid, s);
     if (rc != CCR_OK) return rc;
+    if (p.ranges_a > 0) {
+        rc = launch_threshold_update(cand, cnt, p.ranges_a * 4, n_q, p.nq_pad, p.cap, k, delta, thr, s);
+        if (rc != CCR_OK) return rc;
+        gm.range_begin = p.ranges_a;
+        gm.range_end = p.ranges;
+        rc = p.group_records ? launch_gemm_filter_group(gm, p.grid, s) : launch_gemm_filter(gm, p.grid, s);
+        if (rc != CCR_OK) return rc;
+    }
     CCR_HIP_CHECK(hipEventRecord(ix->ev[4], s));
     if (want_stamps) {
         std::vector<unsigned long long> h((size_t)p.grid * 64);
@@ -401,6 +445,8 @@ extern "C" int ccr_debug_mfma_scores(const ccr_index *ix, const uint16_t *Q_bf16
     g.tile_stride = 1;
     g.ranges = (int)round_up(std::min<int64_t>(64, g.n_vt), NUM_XCD);
     g.qgroups = 1;
+    g.range_begin = 0;
+    g.range_end = g.ranges;
     g.store = out;
     const int grid = std::max(NUM_XCD, ix->num_cu / NUM_XCD * NUM_XCD);
     return launch_gemm_store(g, grid, (hipStream_t)stream);

@@ -54,6 +54,8 @@ struct Plan {
     int sample_tiles;     // tiles scored by the threshold pass
     int64_t sample_stride;
     int ranges;           // corpus ranges of the main pass (multiple of NUM_XCD)
+    int ranges_a;         // ranges scored by phase A (0 = single phase); thresholds are re-tightened after it
+    int qgroups;          // query-block groups over the XCDs
     int cap;              // candidate slots per sub-list
     int grid;             // persistent workgroups (multiple of NUM_XCD)
     int rescore_cap;      // max rows re-scored per query (power of two)
@@ -76,6 +78,7 @@ struct GemmArgs {
     int64_t tile_stride;
     int ranges;           // item (r, qb) covers virtual tiles r, r + ranges, ...
     int qgroups;          // query-block groups spread over the XCDs (1, 2, 4 or 8; divides qblocks)
+    int range_begin, range_end;  // this launch covers ranges [range_begin, range_end), both multiples of 8
     // EPI_FILTER
     const float *thr;     // [nq_pad]
     uint2 *cand;          // [ranges][nq_pad][4][cap] {score bits, local row}; 4 = (wave row, lane half)

@@ -120,12 +120,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
     const int rc = xcd / a.qgroups;
     const int nrc = NUM_XCD / a.qgroups;           // range classes
     const int qb_per = a.qblocks / a.qgroups;      // query blocks of this XCD (qgroups divides qblocks)
-    const int rl_x = (a.ranges - rc + nrc - 1) / nrc;
+    const int rl0 = a.range_begin / nrc;
+    const int rl_x = (a.range_end - a.range_begin) / nrc;
     const int count_x = rl_x * qb_per;
 
     for (int item = jx; item < count_x; item += per_x) {
-        const int rl = item / qb_per;
-        const int qb = qg * qb_per + (item - rl * qb_per);
+        const int rl = rl0 + item / qb_per;
+        const int qb = qg * qb_per + item % qb_per;
         const int r = rc + nrc * rl;
         const int64_t ntile = (a.n_vt - r + a.ranges - 1) / a.ranges;
         if (ntile <= 0) continue;
@@ -467,6 +468,50 @@ __global__ __launch_bounds__(256) void threshold_kernel(const float *__restrict_
     }
 }
 
+// Progressive thresholds: after phase A of the main pass (ranges [0, ranges_a)), the k-th largest candidate
+// score found so far is a tighter valid lower bound of the k-th largest score (the candidates are real rows
+// with their real MFMA scores, whether or not a sub-list overflowed).  thr[q] = max(thr[q], kth - delta[q]).
+// grid = n_q, block = 256.
+__global__ __launch_bounds__(256) void threshold_update_kernel(const uint2 *__restrict__ cand, const uint32_t *__restrict__ cnt,
+                                                              int nsub, int nq_pad, int cap, int k,
+                                                              const float *__restrict__ delta, float *__restrict__ thr) {
+    __shared__ uint32_t s_hist[256];
+    __shared__ uint32_t s_ctl[4];
+    __shared__ uint32_t s_cnt[1024];
+    __shared__ uint32_t s_total;
+    const int tid = threadIdx.x;
+    const int q = blockIdx.x;
+    if (tid == 0) s_total = 0;
+    __syncthreads();
+    uint32_t my = 0;
+    for (int j = tid; j < nsub; j += blockDim.x) {
+        uint32_t c = cnt[((int64_t)(j >> 2) * nq_pad + q) * 4 + (j & 3)];
+        if (c > (uint32_t)cap) c = (uint32_t)cap;
+        s_cnt[j] = c;
+        my += c;
+    }
+    if (my) atomicAdd(&s_total, my);
+    __syncthreads();
+    if (s_total < (uint32_t)k) return;  // not enough rows seen yet: keep the sample threshold
+    uint32_t kth;
+    int need_eq;
+    block_radix_select(
+        [&](int64_t i, bool &skip) -> uint32_t {
+            const int j = (int)(i / cap);
+            const int sl = (int)(i - (int64_t)j * cap);
+            if ((uint32_t)sl >= s_cnt[j]) {
+                skip = true;
+                return 0u;
+            }
+            return f32_orderable(__uint_as_float(cand[(((int64_t)(j >> 2) * nq_pad + q) * 4 + (j & 3)) * cap + sl].x));
+        },
+        (int64_t)nsub * cap, k, s_hist, s_ctl, kth, need_eq);
+    if (tid == 0) {
+        const float t1 = orderable_to_f32(kth) - delta[q];
+        if (t1 > thr[q]) thr[q] = t1;
+    }
+}
+
 // Stage-2: per query, candidates -> exact canonical top-k.  grid = n_q, block = 256.
 // dyn LDS: [dim bf16 query row][ranges uint32 counts][rescore_cap u64 keys]
 template <bool GROUPS>
@@ -642,6 +687,17 @@ int launch_threshold(const float *gmax, int64_t n_groups, int n_q, int nq_pad, i
                      const uint32_t *dmax_bits, int dim, float *thr, float *delta, hipStream_t s) {
     hipLaunchKernelGGL(threshold_kernel, dim3(nq_pad / 16), dim3(256), 0, s, gmax, n_groups, n_q, nq_pad, k, qnorm, dmax_bits,
                        mfma_gamma(dim), thr, delta);
+    CCR_LAUNCH_CHECK();
+    return CCR_OK;
+}
+
+int launch_threshold_update(const uint2 *cand, const uint32_t *cnt, int nsub, int n_q, int nq_pad, int cap, int k,
+                            const float *delta, float *thr, hipStream_t s) {
+    if (nsub > 1024) {
+        set_error("threshold_update: %d sub-lists exceed 1024", nsub);
+        return CCR_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(threshold_update_kernel, dim3(n_q), dim3(256), 0, s, cand, cnt, nsub, nq_pad, cap, k, delta, thr);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
 }
