@@ -360,8 +360,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
             CCR_STAMP(5)  // MFMA phase
             if (++cks == KS2) {
                 cks = 0;
-                pending = true;
-                pending_vt = r + ct * a.ranges;
+                // Tile finished.  The leading group filters it at the start of its next mem phase; the trailing
+                // group (one barrier interval behind) filters it right here, so that BOTH filters fall into the
+                // same interval instead of stalling the partner twice per tile.
+                if (g1) {
+                    epilogue(r + ct * a.ranges);
+                } else {
+                    pending = true;
+                    pending_vt = r + ct * a.ranges;
+                }
                 ++ct;
             }
             CCR_BARRIER();
