@@ -12,13 +12,12 @@
 //                              the candidates, keep everything within delta_q of it, re-score those
 //                              canonically (fp64 ordered) and sort by (score desc, id asc).
 //
-// GEMM geometry (gfx950): 256 docs x 256 queries per workgroup tile, K step 64, 512 threads =
-// 8 waves as 2 (doc halves) x 4 (query quarters); each wave owns 128 docs x 64 queries =
-// 4 x 2 tiles of v_mfma_f32_32x32x16_bf16 (docs on the accumulator rows/registers, queries on
-// the lanes, so a lane compares its 16 registers against ONE per-lane threshold).
-// Staging: global_load_lds_dwordx4 into a double-buffered LDS image (2 x 64 KiB), rows of 128 B,
-// 16-byte chunk index XOR-swizzled with (row>>1)&7 on the SOURCE address and on the fragment read
-// (conflict-free ds_read_b128, cdna guide T2 / rule 21).
+// GEMM geometry (gfx950): 256 docs x 256 queries per workgroup tile, 512 threads = 8 waves as
+// 2 (doc halves) x 4 (query quarters); each wave owns 128 docs x 64 queries = 4 x 2 tiles of
+// v_mfma_f32_32x32x16_bf16 (docs on the accumulator rows/registers, queries on the lanes, so a lane
+// compares its 16 registers against ONE per-lane threshold).  Staging: global_load_lds_dwordx4 into a
+// ring of four 32-KiB sub-stages (32 K elements = 64-B rows), 16-byte chunk index XOR-swizzled with
+// (row>>2)&3 on the SOURCE address and on the fragment read (conflict-free ds_read_b128).
 #include "ccr_common.h"
 #include <stdlib.h>
 
@@ -519,6 +518,8 @@ __global__ __launch_bounds__(256) void threshold_update_kernel(const uint2 *__re
     }
 }
 
+constexpr int SELECT_COMPACT = 4096;  // candidates gathered into LDS per query before the radix select
+
 // Stage-2: per query, candidates -> exact canonical top-k.  grid = n_q, block = 256.
 // dyn LDS: [dim bf16 query row][ranges uint32 counts][rescore_cap u64 keys]
 template <bool GROUPS>
@@ -535,6 +536,8 @@ __global__ __launch_bounds__(256) void select_rescore_kernel(const uint2 *__rest
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(sm + (((size_t)dim * 2 + 15) & ~(size_t)15));
     unsigned long long *s_keys =
         reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(s_cnt) + (((size_t)ranges * 4 + 15) & ~(size_t)15));
+    uint2 *s_comp = reinterpret_cast<uint2 *>(s_keys + rescore_cap);   // [SELECT_COMPACT] gathered candidates
+    __shared__ uint32_t s_fill;
     __shared__ uint32_t s_hist[256];
     __shared__ uint32_t s_ctl[4];
     __shared__ int s_flag;
@@ -548,6 +551,7 @@ __global__ __launch_bounds__(256) void select_rescore_kernel(const uint2 *__rest
         s_flag = 0;
         s_total = 0;
         s_ncoll = 0;
+        s_fill = 0;
     }
     __syncthreads();
     uint32_t my = 0;
@@ -570,34 +574,62 @@ __global__ __launch_bounds__(256) void select_rescore_kernel(const uint2 *__rest
     const int64_t slots = (int64_t)ranges * cap;
     // sub-list j = (range j>>2, wave-row/lane-half j&3) lives at (((j>>2) * nq_pad + q) * 4 + (j&3)) * cap
     auto at = [&](int j, int sl) -> uint2 { return cand[(((int64_t)(j >> 2) * nq_pad + q) * 4 + (j & 3)) * cap + sl]; };
+    const int coll_cap = GROUPS ? rescore_cap / 16 : rescore_cap;
     uint32_t kth = 0;
     int need_eq = 0;
-    if (!bad) {
+    if (!bad && s_total <= (uint32_t)SELECT_COMPACT) {
+        // The sub-lists are ~4 % full: gather them once into LDS (order is irrelevant), then select there.
+        for (int j = tid; j < ranges; j += blockDim.x) {
+            const uint32_t c = s_cnt[j];
+            if (c) {
+                const uint32_t b0 = atomicAdd(&s_fill, c);
+                for (uint32_t sl = 0; sl < c; ++sl) s_comp[b0 + sl] = at(j, (int)sl);
+            }
+        }
+        __syncthreads();
+        const int M = (int)s_total;
+        block_radix_select(
+            [&](int64_t i, bool &skip) -> uint32_t {
+                (void)skip;
+                return f32_orderable(__uint_as_float(s_comp[i].x));
+            },
+            M, k, s_hist, s_ctl, kth, need_eq);
+        const float cut = orderable_to_f32(kth) - delta[q];
+        for (int i = tid; i < M; i += blockDim.x) {
+            const uint2 e = s_comp[i];
+            if (__uint_as_float(e.x) >= cut) {
+                const uint32_t p = atomicAdd(&s_ncoll, 1u);
+                if (p < (uint32_t)coll_cap) s_keys[p] = (unsigned long long)e.y;  // local row for now
+            }
+        }
+        __syncthreads();
+        if (s_ncoll > (uint32_t)coll_cap) bad = true;  // mass ties around the cut
+    } else if (!bad) {
         block_radix_select(
             [&](int64_t i, bool &skip) -> uint32_t {
                 const int r = (int)(i / cap);
-                const int s = (int)(i - (int64_t)r * cap);
-                if ((uint32_t)s >= s_cnt[r]) {
+                const int sl = (int)(i - (int64_t)r * cap);
+                if ((uint32_t)sl >= s_cnt[r]) {
                     skip = true;
                     return 0u;
                 }
-                return f32_orderable(__uint_as_float(at(r, s).x));
+                return f32_orderable(__uint_as_float(at(r, sl).x));
             },
             slots, k, s_hist, s_ctl, kth, need_eq);
         const float cut = orderable_to_f32(kth) - delta[q];
         // collect everything within the margin of the k-th MFMA score
         for (int64_t i = tid; i < slots; i += blockDim.x) {
             const int r = (int)(i / cap);
-            const int s = (int)(i - (int64_t)r * cap);
-            if ((uint32_t)s >= s_cnt[r]) continue;
-            const uint2 e = at(r, s);
+            const int sl = (int)(i - (int64_t)r * cap);
+            if ((uint32_t)sl >= s_cnt[r]) continue;
+            const uint2 e = at(r, sl);
             if (__uint_as_float(e.x) >= cut) {
                 const uint32_t p = atomicAdd(&s_ncoll, 1u);
-                if (p < (uint32_t)(GROUPS ? rescore_cap / 16 : rescore_cap)) s_keys[p] = (unsigned long long)e.y;  // local row for now
+                if (p < (uint32_t)coll_cap) s_keys[p] = (unsigned long long)e.y;  // local row for now
             }
         }
         __syncthreads();
-        if (s_ncoll > (uint32_t)(GROUPS ? rescore_cap / 16 : rescore_cap)) bad = true;  // mass ties around the cut
+        if (s_ncoll > (uint32_t)coll_cap) bad = true;  // mass ties around the cut
     }
     if (bad) {
         if (tid == 0) {
@@ -710,7 +742,8 @@ int launch_threshold_update(const uint2 *cand, const uint32_t *cnt, int nsub, in
 }
 
 size_t select_lds_bytes(int dim, int ranges, int rescore_cap) {
-    return (((size_t)dim * 2 + 15) & ~(size_t)15) + (((size_t)ranges * 4 + 15) & ~(size_t)15) + (size_t)rescore_cap * 8;
+    return (((size_t)dim * 2 + 15) & ~(size_t)15) + (((size_t)ranges * 4 + 15) & ~(size_t)15) + (size_t)rescore_cap * 8 +
+           (size_t)SELECT_COMPACT * 8;
 }
 
 int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, int n_q, int nq_pad, int cap, int k,
