@@ -28,18 +28,25 @@ def short(n):
     return n.split("(")[0][:60]
 
 
+STEPS = int(os.environ.get("PMC_BENCH_STEPS", "2"))   # bench steps in the profiled run (warmup + timed)
 out = {}
 for k, ctrs in acc.items():
     if "ccr::" not in k:
         continue
-    out[short(k)] = {c: sum(v) / len(v) for c, v in ctrs.items()}
-    out[short(k)]["dispatches"] = max(len(v) for v in ctrs.values())
-main = out.get("void gemm_topk_kernel<0>", {})
-summary = {"kernels": out}
+    # per bench step: the main pass is two launches (phase A + phase B) of the same kernel, so sum and divide
+    out[short(k)] = {c: sum(v) / STEPS for c, v in ctrs.items()}
+    out[short(k)]["dispatches_per_step"] = max(len(v) for v in ctrs.values()) / STEPS
+main = next((v for k, v in out.items() if k.startswith("void gemm_topk_kernel<0")), {})
+summary = {"note": "counter totals per bench step (all launches of a kernel summed)", "kernels": out}
 if "FETCH_SIZE" in main:
     rd = main["FETCH_SIZE"] * 1024 * 2          # gfx950: x2 for wide coalesced streaming reads
     wr = main.get("WRITE_SIZE", 0.0) * 1024
     summary["main_pass_hbm_read_bytes_per_launch"] = rd
     summary["main_pass_hbm_write_bytes_per_launch"] = wr
     summary["main_pass_hbm_bytes_per_launch"] = rd + wr
+    if "TCC_HIT_sum" in main:
+        summary["main_pass_l2_hit_rate"] = main["TCC_HIT_sum"] / (main["TCC_HIT_sum"] + main["TCC_MISS_sum"])
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in main and "GRBM_GUI_ACTIVE" in main:
+        # MFMA busy cycles are summed over 1024 SIMDs, GRBM_GUI_ACTIVE over 8 XCDs
+        summary["main_pass_mfma_busy_frac"] = (main["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (main["GRBM_GUI_ACTIVE"] / 8.0)
 print(json.dumps(summary, indent=1))
