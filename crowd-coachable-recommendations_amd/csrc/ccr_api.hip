@@ -28,12 +28,14 @@ int launch_row_norms_bf16(const uint16_t *X, int64_t rows, int dim, float *norms
 int launch_threshold(const float *gmax, int64_t n_groups, int n_q, int nq_pad, int k, const float *qnorm,
                      const uint32_t *dmax_bits, int dim, float *thr, float *delta, hipStream_t s);
 size_t select_lds_bytes(int dim, int ranges, int rescore_cap);
-int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, int n_q, int nq_pad, int cap, int k,
+int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, int sp, int n_q, int nq_pad, int cap, int k,
                           int rescore_cap, int groups, int64_t n_rows, const float *delta, const uint16_t *Q,
                           const uint16_t *D, int dim, int64_t id_offset, float *out_scores, int64_t *out_ids,
                           uint32_t *flag_count, uint32_t *flag_list, unsigned long long *stat_cand, hipStream_t s);
 int launch_gemm_filter_group(const GemmArgs &a, int grid, hipStream_t s);
-int launch_threshold_update(const uint2 *cand, const uint32_t *cnt, int nsub, int n_q, int nq_pad, int cap, int k,
+int launch_gemm16_filter(const GemmArgs &a, int grid, hipStream_t s);
+int launch_gemm16_store(const GemmArgs &a, int grid, hipStream_t s);
+int launch_threshold_update(const uint2 *cand, const uint32_t *cnt, int nsub, int sp, int n_q, int nq_pad, int cap, int k,
                             const float *delta, float *thr, hipStream_t s);
 int launch_dense_scores(const uint16_t *D, int64_t n_rows, int dim, const uint16_t *Q, const uint32_t *qlist,
                         int q_begin, int nq_chunk, float *out, hipStream_t s);
@@ -62,7 +64,10 @@ static int pick_qgroups(int qblocks, int dim) {
 static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
 constexpr size_t DENSE_SCRATCH_TARGET = (size_t)1 << 30;  // ~1 GiB of score rows per dense chunk
-constexpr int FALLBACK_ROWS = 16;                         // score rows reserved for flagged queries
+constexpr int FALLBACK_ROWS = 16;
+#ifndef CCR_MFMA16_DEFAULT
+#define CCR_MFMA16_DEFAULT 0
+#endif                         // score rows reserved for flagged queries
 
 Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu) {
     Plan p;
@@ -78,6 +83,11 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu) {
     {
         const char *e = getenv("CCR_GROUP_RECORDS");
         p.group_records = (e && atoi(e) == 1 && k <= 256) ? 1 : 0;
+    }
+    {
+        const char *e = getenv("CCR_MFMA16");   // main pass on v_mfma_f32_16x16x32_bf16 (row records only)
+        p.mfma16 = (e ? atoi(e) : CCR_MFMA16_DEFAULT) && !p.group_records ? 1 : 0;
+        p.sublists = p.mfma16 ? 8 : 4;
     }
     p.rescore_cap = p.group_records ? 16 * std::max(128, 2 * pow2_ceil(k)) : std::min(8192, std::max(256, 2 * pow2_ceil(k)));
 
@@ -108,7 +118,7 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu) {
         // exactly 7 items per workgroup where R = 112 left the last round 1/8 full.
         p.qgroups = pick_qgroups(p.qblocks, dim);
         const int nrc = NUM_XCD / p.qgroups, qb_per = p.qblocks / p.qgroups, per_x = p.grid / NUM_XCD;
-        const int64_t r_hi = std::min<int64_t>(1024 / 4, round_up(std::max<int64_t>(1, p.tiles / 8), NUM_XCD));
+        const int64_t r_hi = std::min<int64_t>(1024 / p.sublists, round_up(std::max<int64_t>(1, p.tiles / 8), NUM_XCD));
         const int64_t target = std::min<int64_t>(r_hi, round_up(std::max<int64_t>(NUM_XCD, (int64_t)p.grid * 6 / p.qblocks), NUM_XCD));
         int64_t R = target;
         double best = -1.0;
@@ -131,7 +141,7 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu) {
             const bool on = !(e && atoi(e) == 0);
             int64_t ra = (int64_t)per_x * nrc / qb_per / NUM_XCD * NUM_XCD;   // largest multiple of 8 with items <= per_x
             ra = std::min<int64_t>(ra, R / 4 / NUM_XCD * NUM_XCD);
-            if (on && ra >= NUM_XCD && R + ra <= 1024 / 4 && (double)p.tiles / (double)(R + ra) >= 8.0) {
+            if (on && ra >= NUM_XCD && R + ra <= 1024 / p.sublists && (double)p.tiles / (double)(R + ra) >= 8.0) {
                 p.ranges_a = (int)ra;
                 p.ranges = (int)(R + ra);
                 R = p.ranges;
@@ -140,14 +150,14 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu) {
         const double ratio = (double)p.tiles / (double)sample;
         const double expect = (double)k * ratio * 1.3 + 64.0;  // survivors per query
         // candidates go to 4 sub-lists per (range, query): one per (wave row, lane half) of the GEMM tile
-        int64_t cap = (int64_t)(4.0 * expect / (double)(R * 4)) + 16;
+        int64_t cap = (int64_t)(4.0 * expect / (double)(R * p.sublists)) + 16;
         cap = round_up(std::min<int64_t>(std::max<int64_t>(cap, 16), 8192), 4);
         p.cap = (int)cap;
         p.off_qnorm = take((size_t)p.nq_pad * 4);
         p.off_thr = take((size_t)p.nq_pad * 4 * 2);  // thr then delta
         p.off_gmax = take((size_t)p.sample_tiles * GROUPS_PER_TILE * p.nq_pad * 4);
-        p.off_cnt = take((size_t)p.ranges * p.nq_pad * 4 * 4);
-        p.off_cand = take((size_t)p.ranges * p.nq_pad * 4 * p.cap * 8);
+        p.off_cnt = take((size_t)p.ranges * p.nq_pad * p.sublists * 4);
+        p.off_cand = take((size_t)p.ranges * p.nq_pad * p.sublists * p.cap * 8);
         p.off_flag = take(64 + (size_t)n_q * 4);
         p.dense_rows_per_chunk = FALLBACK_ROWS;
         p.off_dense = take((size_t)FALLBACK_ROWS * n_rows * 4);
@@ -305,7 +315,7 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
     uint32_t *flag_list = (uint32_t *)(ws + p.off_flag + 64);
 
     CCR_HIP_CHECK(hipMemsetAsync(flag_count, 0, 64, s));
-    CCR_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)p.ranges * p.nq_pad * 4 * 4, s));  // ranges with no tiles write nothing
+    CCR_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)p.ranges * p.nq_pad * p.sublists * 4, s));  // ranges with no tiles write nothing
     int rc = launch_row_norms_bf16(Q_bf16, n_q, ix->dim, qnorm, nullptr, s);
     if (rc != CCR_OK) return rc;
 
@@ -356,14 +366,18 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
     CCR_HIP_CHECK(hipEventRecord(ix->ev[3], s));
     gm.range_begin = 0;
     gm.range_end = p.ranges_a > 0 ? p.ranges_a : p.ranges;
-    rc = p.group_records ? launch_gemm_filter_group(gm, p.grid, s) : launch_gemm_filter(gm, p.grid, s);
+    auto main_pass = [&](const GemmArgs &ga) {
+        if (p.mfma16) return launch_gemm16_filter(ga, p.grid, s);
+        return p.group_records ? launch_gemm_filter_group(ga, p.grid, s) : launch_gemm_filter(ga, p.grid, s);
+    };
+    rc = main_pass(gm);
     if (rc != CCR_OK) return rc;
     if (p.ranges_a > 0) {
-        rc = launch_threshold_update(cand, cnt, p.ranges_a * 4, n_q, p.nq_pad, p.cap, k, delta, thr, s);
+        rc = launch_threshold_update(cand, cnt, p.ranges_a * p.sublists, p.sublists, n_q, p.nq_pad, p.cap, k, delta, thr, s);
         if (rc != CCR_OK) return rc;
         gm.range_begin = p.ranges_a;
         gm.range_end = p.ranges;
-        rc = p.group_records ? launch_gemm_filter_group(gm, p.grid, s) : launch_gemm_filter(gm, p.grid, s);
+        rc = main_pass(gm);
         if (rc != CCR_OK) return rc;
     }
     CCR_HIP_CHECK(hipEventRecord(ix->ev[4], s));
@@ -387,7 +401,7 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
         (void)hipFree(stamps);
     }
 
-    rc = launch_select_rescore(cand, cnt, p.ranges * 4, n_q, p.nq_pad, p.cap, k, p.rescore_cap, p.group_records, ix->n_rows, delta,
+    rc = launch_select_rescore(cand, cnt, p.ranges * p.sublists, p.sublists, n_q, p.nq_pad, p.cap, k, p.rescore_cap, p.group_records, ix->n_rows, delta,
                                Q_bf16, ix->D, ix->dim,
                                ix->offset, out_scores, out_ids, flag_count, flag_list, stat_cand, s);
     if (rc != CCR_OK) return rc;
@@ -449,6 +463,8 @@ extern "C" int ccr_debug_mfma_scores(const ccr_index *ix, const uint16_t *Q_bf16
     g.range_end = g.ranges;
     g.store = out;
     const int grid = std::max(NUM_XCD, ix->num_cu / NUM_XCD * NUM_XCD);
+    const char *e16 = getenv("CCR_MFMA16");
+    if (e16 ? atoi(e16) : CCR_MFMA16_DEFAULT) return launch_gemm16_store(g, grid, (hipStream_t)stream);
     return launch_gemm_store(g, grid, (hipStream_t)stream);
 }
 

@@ -60,6 +60,8 @@ struct Plan {
     int grid;             // persistent workgroups (multiple of NUM_XCD)
     int rescore_cap;      // max rows re-scored per query (power of two)
     int group_records;    // 1: candidate records are 16-row MFMA fragments (k <= 256)
+    int mfma16;           // 1: main pass on the 16x16x32 MFMA kernel
+    int sublists;         // candidate sub-lists per (range, query): 4 (32x32x16 kernel) or 8 (16x16x32 kernel)
     // workspace layout (byte offsets)
     size_t off_qnorm, off_thr, off_gmax, off_cnt, off_cand, off_flag, off_dense, total;
     int64_t dense_rows_per_chunk;  // queries per dense chunk
