@@ -659,7 +659,19 @@ __global__ __launch_bounds__(256) void threshold_kernel(const float *__restrict_
         for (int b = tid; b < 16 * 256; b += 256) (&s_hist[0][0])[b] = 0;
         __syncthreads();
         const uint32_t prefix = s_prefix[ql];
-        for (int64_t i = ph; i < n_groups; i += 16) {
+        // 4 independent loads in flight per thread (the loop is latency-bound otherwise)
+        int64_t i = ph;
+        for (; i + 48 < n_groups; i += 64) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = gmax[(i + 16 * j) * nq_pad + q];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t o = f32_orderable(v[j]);
+                if ((o & mask) == prefix) atomicAdd(&s_hist[ql][(o >> shift) & 255u], 1u);
+            }
+        }
+        for (; i < n_groups; i += 16) {
             const uint32_t o = f32_orderable(gmax[i * nq_pad + q]);
             if ((o & mask) == prefix) atomicAdd(&s_hist[ql][(o >> shift) & 255u], 1u);
         }

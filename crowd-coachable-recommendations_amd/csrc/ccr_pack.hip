@@ -52,24 +52,35 @@ __global__ __launch_bounds__(256) void pack_rows_maxnorm_kernel(const float *__r
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const int n8 = dim >> 3;
     float wmax = 0.f;
-    for (int64_t r = wave; r < rows; r += nwaves) {
-        const float4 *x = reinterpret_cast<const float4 *>(src + r * dim);
-        bf16x8 *y = reinterpret_cast<bf16x8 *>(dst + r * dim);
-        float ss = 0.f;
+    // two rows per iteration: twice the bytes in flight per wave (the kernel is a pure HBM stream)
+    for (int64_t r = 2 * wave; r < rows; r += 2 * nwaves) {
+        const bool two = (r + 1 < rows);
+        const float4 *x0 = reinterpret_cast<const float4 *>(src + r * dim);
+        const float4 *x1 = reinterpret_cast<const float4 *>(src + (two ? r + 1 : r) * dim);
+        bf16x8 *y0 = reinterpret_cast<bf16x8 *>(dst + r * dim);
+        bf16x8 *y1 = reinterpret_cast<bf16x8 *>(dst + (r + 1) * dim);
+        float ss0 = 0.f, ss1 = 0.f;
         for (int c = lane; c < n8; c += 64) {
-            const float4 a = x[2 * c], b = x[2 * c + 1];
-            const bf16x4 lo = cvt4(a), hi = cvt4(b);
-            const bf16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            y[c] = v;
+            const float4 a0 = x0[2 * c], b0 = x0[2 * c + 1];
+            const float4 a1 = x1[2 * c], b1 = x1[2 * c + 1];
+            const bf16x4 lo0 = cvt4(a0), hi0 = cvt4(b0), lo1 = cvt4(a1), hi1 = cvt4(b1);
+            const bf16x8 v0 = __builtin_shufflevector(lo0, hi0, 0, 1, 2, 3, 4, 5, 6, 7);
+            const bf16x8 v1 = __builtin_shufflevector(lo1, hi1, 0, 1, 2, 3, 4, 5, 6, 7);
+            y0[c] = v0;
+            if (two) y1[c] = v1;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float f = (float)v[e];
-                ss = fmaf(f, f, ss);
+                const float f0 = (float)v0[e], f1 = (float)v1[e];
+                ss0 = fmaf(f0, f0, ss0);
+                ss1 = fmaf(f1, f1, ss1);
             }
         }
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
-        wmax = fmaxf(wmax, sqrtf(ss));
+        for (int off = 32; off >= 1; off >>= 1) {
+            ss0 += __shfl_xor(ss0, off, 64);
+            ss1 += __shfl_xor(ss1, off, 64);
+        }
+        wmax = fmaxf(wmax, sqrtf(fmaxf(ss0, ss1)));
     }
     if (lane == 0) atomicMax(max_bits, __float_as_uint(wmax));
 }
@@ -229,7 +240,7 @@ extern "C" int ccr_pack_bf16_ex(const float *src, uint16_t *dst, float *norms, f
         CCR_REQUIRE(((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0), "ccr_pack_bf16: buffers must be 16-byte aligned");
         if (max_bits) {
             CCR_REQUIRE(dim % 8 == 0, "ccr_pack_bf16: max_norm needs dim %% 8 == 0 (dim=%d)", dim);
-            int64_t blocks = (rows + 3) / 4;
+            int64_t blocks = (rows + 7) / 8;
             if (blocks > 256 * 8) blocks = 256 * 8;
             hipLaunchKernelGGL(pack_rows_maxnorm_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src,
                                reinterpret_cast<__bf16 *>(dst), rows, dim, max_bits);
