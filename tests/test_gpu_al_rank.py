@@ -1,0 +1,81 @@
+"""End-to-end rank step (al_0_rank.py:69-127) with a local random-init BertModel (no network): text ->
+tokens -> encoder -> fused mean-pool -> bf16 pack -> fused search; checked against the oracle on the
+SAME encoder outputs, plus the ranking_profile.pt cache/resume behaviour."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+class ToyTokenizer:
+    """Whitespace tokenizer with the HF call signature used by the reference (padding=True, truncation, max_length)."""
+
+    def __call__(self, texts, truncation=True, padding=True, max_length=32, return_tensors="pt"):
+        ids = [[1] + [2 + (hash(w) % 500) for w in t.split()][: max_length - 2] + [3] for t in texts]
+        L = max(len(r) for r in ids)
+        input_ids = torch.zeros(len(ids), L, dtype=torch.long)
+        mask = torch.zeros(len(ids), L, dtype=torch.long)
+        for r, row in enumerate(ids):
+            input_ids[r, : len(row)] = torch.tensor(row)
+            mask[r, : len(row)] = 1
+        return {"input_ids": input_ids, "attention_mask": mask}
+
+
+def _tower():
+    from transformers import BertConfig, BertModel
+    from ccrec_amd.item_tower import NaiveItemTower
+    torch.manual_seed(0)
+    cfg = BertConfig(vocab_size=512, hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+                     max_position_embeddings=64)
+    return NaiveItemTower(BertModel(cfg).eval(), torch.nn.LayerNorm(64, elementwise_affine=False))
+
+
+def test_generate_ranking_profile_end_to_end(tmp_path):
+    from ccrec_amd.al_rank import cached_ranking_profile, generate_ranking_profile
+    os.environ["CCREC_SIM_TYPE"] = "dot"
+    os.environ["CCREC_EMBEDDING_TYPE"] = "mean_pooling"
+    os.environ["CCREC_MAX_LENGTH"] = "32"
+    rs = np.random.RandomState(0)
+    words = [f"w{i}" for i in range(200)]
+    corpus = {f"p{j}": " ".join(rs.choice(words, rs.randint(3, 20))) for j in range(700)}
+    queries = {f"q{i}": " ".join(rs.choice(words, rs.randint(2, 8))) for i in range(9)}
+    tower, tok = _tower(), ToyTokenizer()
+    prof = generate_ranking_profile(tower, "unused", corpus, queries, tokenizer=tok)
+    assert list(prof) == list(queries) and all(len(v) == 700 for v in prof.values())
+
+    # oracle on the same encoder outputs (fp32 mean pooling from torch, then the canonical path)
+    with torch.no_grad():
+        def emb(texts):
+            t = tok(list(texts), max_length=32)
+            h = tower.cls_model(**{k: v.cuda() for k, v in t.items()}).last_hidden_state.float().cpu().numpy()
+            return orc.meanpool(h, t["attention_mask"].numpy())
+        Eq, Ed = emb(queries.values()), emb(corpus.values())
+    ref_i, ref_s = orc.canonical_ranking(Eq, Ed, "dot")
+    got_i = np.array([[int(p[1:]) for p in prof[q]] for q in queries])
+    got_s = np.array([list(prof[q].values()) for q in queries], np.float32)
+    assert np.array_equal(got_i, ref_i) and np.array_equal(got_s.view(np.uint32), ref_s.view(np.uint32))
+
+    # cache / resume: second call must not rebuild the model (al_0_rank.py:115-118)
+    path = str(tmp_path / "ranking_profile.pt")
+    calls = []
+
+    class Wrap:
+        item_tower = tower
+
+    def make():
+        calls.append(1)
+        return Wrap()
+
+    p1 = cached_ranking_profile(path, make, "unused", corpus, queries, tokenizer=tok)
+    p2 = cached_ranking_profile(path, make, "unused", corpus, queries, tokenizer=tok)
+    assert len(calls) == 1 and list(p1["q0"]) == list(p2["q0"]) and os.path.isfile(path)
+    # under autocast the encoder runs in reduced precision: same shape, scores close to the fp32 run
+    for q in queries:
+        assert len(p1[q]) == 700
+        s32, s16 = np.array(list(prof[q].values())[:5]), np.array(list(p1[q].values())[:5])
+        np.testing.assert_allclose(s16, s32, rtol=0.05, atol=0.05)
