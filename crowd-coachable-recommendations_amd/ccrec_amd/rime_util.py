@@ -32,6 +32,11 @@ def _factors(S):
 
 
 def _assign_topk(S, k, tie_breaker=1e-10, device="cpu", batch_size=None):
+    if hasattr(S, "topk") and hasattr(S, "user") and hasattr(S, "item"):   # bbpr_transform.LowRankScore
+        _, ids = S.topk(k)
+        indices = ids.cpu().numpy()
+        return sps.csr_matrix((np.ones(indices.size), np.ravel(indices), np.arange(0, indices.size + 1, indices.shape[1])),
+                              shape=S.shape)
     fac = _factors(S)
     if fac is None:
         raise NotImplementedError("ccrec_amd._assign_topk handles low-rank (left @ right) scores; "

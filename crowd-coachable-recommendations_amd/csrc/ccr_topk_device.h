@@ -87,6 +87,8 @@ __host__ __device__ __forceinline__ int pow2_ceil(int v) {
 // q: bf16 row in LDS (or global), d: bf16 row in global; dim % 8 == 0; both 16-byte aligned.
 __device__ __forceinline__ float canonical_dot(const uint16_t *__restrict__ q, const uint16_t *__restrict__ d, int dim) {
     double acc = 0.0;
+    // the loads of 4 steps are independent of the fp64 chain: unrolled so that they are in flight together
+#pragma unroll 4
     for (int c = 0; c < dim; c += 8) {
         const uint4 dv = *reinterpret_cast<const uint4 *>(d + c);
         const uint4 qv = *reinterpret_cast<const uint4 *>(q + c);

@@ -246,3 +246,20 @@ def test_many_query_blocks_multi_item_workgroups():
     sub = np.r_[0:8, 1700:1708, 3444:3452]
     ref_i, ref_s = orc.canonical_search(Qb[sub], Db, k)
     assert np.array_equal(i.cpu().numpy()[sub], ref_i) and np.array_equal(s.cpu().numpy()[sub], ref_s)
+
+
+def test_bbpr_transform_low_rank_score():
+    """BertBPR.transform twin (bbpr.py:526-550): lazy user x item score, top-k through the fused path."""
+    from ccrec_amd import ops
+    from ccrec_amd.bbpr_transform import transform
+    from ccrec_amd.rime_util import _assign_topk
+    allb = _rand_bits(3000, 768, 5)
+    rs = np.random.RandomState(1)
+    i_to_ptr, j_to_ptr = rs.permutation(3000)[:40], rs.permutation(3000)[:2500]
+    S = transform(_bf16(allb), i_to_ptr, j_to_ptr)
+    assert S.shape == (40, 2500) and S.T.shape == (2500, 40)
+    ref = orc.canonical_scores(allb[i_to_ptr], allb[j_to_ptr])
+    assert np.array_equal(S.numpy().view(np.uint32), ref.view(np.uint32))
+    csr = _assign_topk(S, 20)
+    ref_i, _ = orc.rank(ref, 20)
+    assert np.array_equal(csr.indices.reshape(40, 20), ref_i)
