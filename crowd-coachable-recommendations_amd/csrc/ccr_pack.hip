@@ -3,6 +3,8 @@
 // Pure HBM streaming kernels: 6 B per element (4 read + 2 written); the mean-pool variant reads
 // L * dim * sizeof(hidden) per row.  16 B per lane loads, 16 B per lane stores, one wave per row
 // where a row reduction is needed (fixed reduction order, mirrored by oracle/ccr_oracle.c).
+#include <stdlib.h>
+
 #include "ccr_common.h"
 
 namespace ccr {
@@ -10,6 +12,7 @@ namespace ccr {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4n __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ bf16x4 cvt4(float4 v) {
     bf16x4 r;
@@ -45,6 +48,7 @@ __global__ void pack_bf16_tail_kernel(const float *__restrict__ src, __bf16 *__r
 // One wave per row, 8 consecutive floats per lane per step (two 16-B loads -> one 16-B store), fp32 sum of
 // squares of the bf16-ROUNDED values, wave reduce, one atomicMax per wave on the bit pattern
 // (non-negative floats order as unsigned).  The index uses the maximum only inside error margins.
+template <int ROWS>
 __global__ __launch_bounds__(256) void pack_rows_maxnorm_kernel(const float *__restrict__ src, __bf16 *__restrict__ dst,
                                                                int64_t rows, int dim, uint32_t *__restrict__ max_bits) {
     const int lane = threadIdx.x & 63;
@@ -52,35 +56,40 @@ __global__ __launch_bounds__(256) void pack_rows_maxnorm_kernel(const float *__r
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const int n8 = dim >> 3;
     float wmax = 0.f;
-    // two rows per iteration: twice the bytes in flight per wave (the kernel is a pure HBM stream)
-    for (int64_t r = 2 * wave; r < rows; r += 2 * nwaves) {
-        const bool two = (r + 1 < rows);
-        const float4 *x0 = reinterpret_cast<const float4 *>(src + r * dim);
-        const float4 *x1 = reinterpret_cast<const float4 *>(src + (two ? r + 1 : r) * dim);
-        bf16x8 *y0 = reinterpret_cast<bf16x8 *>(dst + r * dim);
-        bf16x8 *y1 = reinterpret_cast<bf16x8 *>(dst + (r + 1) * dim);
-        float ss0 = 0.f, ss1 = 0.f;
-        for (int c = lane; c < n8; c += 64) {
-            const float4 a0 = x0[2 * c], b0 = x0[2 * c + 1];
-            const float4 a1 = x1[2 * c], b1 = x1[2 * c + 1];
-            const bf16x4 lo0 = cvt4(a0), hi0 = cvt4(b0), lo1 = cvt4(a1), hi1 = cvt4(b1);
-            const bf16x8 v0 = __builtin_shufflevector(lo0, hi0, 0, 1, 2, 3, 4, 5, 6, 7);
-            const bf16x8 v1 = __builtin_shufflevector(lo1, hi1, 0, 1, 2, 3, 4, 5, 6, 7);
-            y0[c] = v0;
-            if (two) y1[c] = v1;
+    // ROWS rows per iteration: 2*ROWS 16-byte loads in flight per lane (pure HBM stream, read once -> nontemporal)
+    for (int64_t r = ROWS * wave; r < rows; r += ROWS * nwaves) {
+        float ss[ROWS];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float f0 = (float)v0[e], f1 = (float)v1[e];
-                ss0 = fmaf(f0, f0, ss0);
-                ss1 = fmaf(f1, f1, ss1);
+        for (int j = 0; j < ROWS; ++j) ss[j] = 0.f;
+        for (int c = lane; c < n8; c += 64) {
+            f32x4n a[ROWS], b[ROWS];
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) {
+                const int64_t rr = (r + j < rows) ? r + j : rows - 1;
+                const f32x4n *x = reinterpret_cast<const f32x4n *>(src + rr * dim);
+                a[j] = __builtin_nontemporal_load(x + 2 * c);
+                b[j] = __builtin_nontemporal_load(x + 2 * c + 1);
+            }
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) {
+                const bf16x4 lo = cvt4(make_float4(a[j][0], a[j][1], a[j][2], a[j][3]));
+                const bf16x4 hi = cvt4(make_float4(b[j][0], b[j][1], b[j][2], b[j][3]));
+                const bf16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                if (r + j < rows) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8 *>(dst + (r + j) * dim) + c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = (float)v[e];
+                    ss[j] = fmaf(f, f, ss[j]);
+                }
             }
         }
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            ss0 += __shfl_xor(ss0, off, 64);
-            ss1 += __shfl_xor(ss1, off, 64);
+        for (int j = 0; j < ROWS; ++j) {
+            float t = ss[j];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
+            wmax = fmaxf(wmax, sqrtf(t));
         }
-        wmax = fmaxf(wmax, sqrtf(fmaxf(ss0, ss1)));
     }
     if (lane == 0) atomicMax(max_bits, __float_as_uint(wmax));
 }
@@ -240,9 +249,21 @@ extern "C" int ccr_pack_bf16_ex(const float *src, uint16_t *dst, float *norms, f
         CCR_REQUIRE(((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0), "ccr_pack_bf16: buffers must be 16-byte aligned");
         if (max_bits) {
             CCR_REQUIRE(dim % 8 == 0, "ccr_pack_bf16: max_norm needs dim %% 8 == 0 (dim=%d)", dim);
-            int64_t blocks = (rows + 7) / 8;
+            static int rows_per = -1;
+            if (rows_per < 0) {
+                const char *e = getenv("CCR_PACK_ROWS");
+                rows_per = e ? atoi(e) : 2;
+            }
+            int64_t blocks = (rows + 4 * rows_per - 1) / (4 * rows_per);
             if (blocks > 256 * 8) blocks = 256 * 8;
-            hipLaunchKernelGGL(pack_rows_maxnorm_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src,
+            if (rows_per == 1)
+                hipLaunchKernelGGL(pack_rows_maxnorm_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, src,
+                                   reinterpret_cast<__bf16 *>(dst), rows, dim, max_bits);
+            else if (rows_per == 2)
+                hipLaunchKernelGGL(pack_rows_maxnorm_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, src,
+                                   reinterpret_cast<__bf16 *>(dst), rows, dim, max_bits);
+            else
+            hipLaunchKernelGGL(pack_rows_maxnorm_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, src,
                                reinterpret_cast<__bf16 *>(dst), rows, dim, max_bits);
             CCR_LAUNCH_CHECK();
             return CCR_OK;
