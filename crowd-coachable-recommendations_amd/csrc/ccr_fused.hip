@@ -97,6 +97,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
     unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // DBG 16: cycles per segment of the inner loop
     unsigned long long tprev = 0;
     if constexpr ((DBG & 16) != 0) tprev = stamp();
+    if constexpr ((DBG & 4) != 0) {  // no-DMA ablation: zero operands (scores 0 stay below the thresholds)
+        for (int i = tid; i < RING * SUB_BYTES / 16; i += GEMM_THREADS) reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+    }
 
     // DMA role: 4 x 1-KiB pieces per sub-stage (16 rows x 64 B each); LDS image is lane-linear, the
     // 16-byte chunk swizzle (chunk ^ (row>>2)&3) is applied on the SOURCE address and on the read
@@ -176,7 +180,24 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
         auto issue = [&]() {
             char *buf = smem + (int)(iu & (RING - 1)) * SUB_BYTES;
             const int k0 = iks * SUB_K;
-            if constexpr (!(DBG & 4)) {
+            if constexpr ((DBG & 32) != 0) {
+                // timing-only: same bytes per sub-stage, but every 1-KiB piece reads 8 rows x 128 B (whole cache
+                // lines) instead of 16 rows x 64 B; rows alternate between the tile halves by sub-stage parity
+                const int r8 = wv * 8 + (lane >> 3) + (iks & 1) * 128;
+                const int col = (lane & 7) * 8 + (iks >> 1) * 64;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    int64_t drow = (r + it * a.ranges) * a.tile_stride * TILE_DOCS + i * 64 + r8;
+                    if (drow > a.n_rows - 1) drow = a.n_rows - 1;
+                    glds16(a.D + drow * a.dim + col, buf + (i * 512 + wv * 64) * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    int qrow = q0 + i * 64 + r8;
+                    if (qrow > a.n_q - 1) qrow = a.n_q - 1;
+                    glds16(a.Q + (int64_t)qrow * a.dim + col, buf + SUB_Q_REGION + (i * 512 + wv * 64) * 16);
+                }
+            } else if constexpr (!(DBG & 4)) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) glds16(dsrc[i] + k0, buf + (i * 512 + wv * 64) * 16);
 #pragma unroll
@@ -929,6 +950,8 @@ static int launch_gemm(const GemmArgs &a, int grid, hipStream_t s) {
             case 4: return launch_kernel(&gemm_topk_kernel<EPI, true, 4>, lds, a, grid, s, cd);
             case 8: return launch_kernel(&gemm_topk_kernel<EPI, true, 8>, lds, a, grid, s, cd);
             case 16: return launch_kernel(&gemm_topk_kernel<EPI, true, 16>, lds, a, grid, s, cd);
+            case 32: return launch_kernel(&gemm_topk_kernel<EPI, true, 32>, lds, a, grid, s, cd);
+            case 40: return launch_kernel(&gemm_topk_kernel<EPI, true, 40>, lds, a, grid, s, cd);
             default: return launch_kernel(&gemm_topk_kernel<EPI, true, 12>, lds, a, grid, s, cd);
         }
     }
