@@ -139,9 +139,10 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu) {
         {
             const char *e = getenv("CCR_PROGRESSIVE");
             const bool on = !(e && atoi(e) == 0);
-            int64_t ra = (int64_t)per_x * nrc / qb_per / NUM_XCD * NUM_XCD;   // largest multiple of 8 with items <= per_x
-            ra = std::min<int64_t>(ra, R / 4 / NUM_XCD * NUM_XCD);
-            if (on && ra >= NUM_XCD && R + ra <= 1024 / p.sublists && (double)p.tiles / (double)(R + ra) >= 8.0) {
+            // largest range count (multiple of the range classes) whose items fit one round: items = ra / nrc * qb_per
+            int64_t ra = (int64_t)per_x * nrc / qb_per / nrc * nrc;
+            ra = std::min<int64_t>(ra, R / 4 / nrc * nrc);
+            if (on && ra >= nrc && R + ra <= 1024 / p.sublists && (double)p.tiles / (double)(R + ra) >= 8.0) {
                 p.ranges_a = (int)ra;
                 p.ranges = (int)(R + ra);
                 R = p.ranges;
