@@ -78,3 +78,34 @@ def test_top1000_fused_equals_dense_at_1m():
     s2, i2 = index.search(Q, k, 1)
     assert torch.equal(i, i2) and torch.equal(s.view(torch.int32), s2.view(torch.int32))
     assert int(i.min()) >= 5_000_000_000
+
+
+def test_prime_pantry_shaped_ranking_with_brand_blocks():
+    """configs[0] shape: queries == corpus (9,862 items), block_dict = all items of the query's brand
+    (1,960 Zipf-sized brands, self included), ranking() keeps 1001 entries.  Through the drop-in API."""
+    from ccrec_amd.ms_marco_eval import ranking
+    import os
+    os.environ["CCREC_SIM_TYPE"] = "dot"
+    n, d = 9862, 768
+    g = torch.Generator().manual_seed(3)
+    E = torch.randn(n, d, generator=g) / d ** 0.5
+    rs = np.random.RandomState(5)
+    brand = np.minimum((rs.zipf(1.3, size=n) - 1), 1959)          # a few very large brands, many tiny ones
+    members = {b: np.nonzero(brand == b)[0].tolist() for b in np.unique(brand)}
+    ids = [f"B{j:05d}" for j in range(n)]
+    corpus = {ids[j]: j for j in range(n)}
+    nq = 600                                                        # the API path is per-query python: keep it short
+    queries = {ids[j]: j for j in range(nq)}
+    block_dict = {ids[j]: [ids[m] for m in members[brand[j]]] for j in range(nq)}
+    longest = max(len(v) for v in block_dict.values())
+    assert longest > 100
+    prof = ranking(corpus, queries, lambda rows: E[torch.as_tensor(rows, dtype=torch.long)], 2048, block_dict)
+    assert len(prof) == nq and all(len(v) == 1001 for v in prof.values())
+    sub = list(range(0, nq, 37))
+    Eb = orc.pack_bf16(E.numpy())
+    ref_i, ref_s = orc.canonical_search(Eb[sub], Eb, 1001, block=[members[brand[j]] for j in sub])
+    for c, j in enumerate(sub):
+        got = prof[ids[j]]
+        assert [int(p[1:]) for p in got] == ref_i[c].tolist()
+        assert np.array_equal(np.array(list(got.values()), np.float32).view(np.uint32), ref_s[c].view(np.uint32))
+        assert ids[j] not in list(got)[: 1001 - longest]            # the query's own item is blocked (self-block)
