@@ -193,6 +193,8 @@ struct ccr_index {
 extern "C" const char *ccr_last_error(void) { return g_err; }
 extern "C" int ccr_version(void) { return 100; }
 
+extern "C" int ccr_index_destroy(ccr_index *ix);
+
 static int index_create_impl(const uint16_t *D_bf16, int64_t n_rows, int dim, int64_t global_row_offset, const float *max_norm,
                              void *stream, ccr_index **out) {
     CCR_REQUIRE(D_bf16 && out, "ccr_index_create: null pointer");
@@ -207,17 +209,26 @@ static int index_create_impl(const uint16_t *D_bf16, int64_t n_rows, int dim, in
     ix->n_rows = n_rows;
     ix->dim = dim;
     ix->offset = global_row_offset;
-    CCR_HIP_CHECK(hipGetDevice(&ix->device));
-    CCR_HIP_CHECK(hipDeviceGetAttribute(&ix->num_cu, hipDeviceAttributeMultiprocessorCount, ix->device));
-    for (int i = 0; i < 7; ++i) CCR_HIP_CHECK(hipEventCreate(&ix->ev[i]));
-    CCR_HIP_CHECK(hipMalloc((void **)&ix->dmax_bits, 256));
-    if (max_norm) {
-        CCR_HIP_CHECK(hipMemcpyAsync(ix->dmax_bits, max_norm, 4, hipMemcpyDeviceToDevice, s));
-    } else {
-        CCR_HIP_CHECK(hipMemsetAsync(ix->dmax_bits, 0, 256, s));
-        int rc = launch_row_norms_bf16(D_bf16, n_rows, dim, nullptr, ix->dmax_bits, s);
-        if (rc != CCR_OK) return rc;
-        CCR_HIP_CHECK(hipStreamSynchronize(s));
+    // on any failure below the partially built index is released before returning
+    auto build = [&]() -> int {
+        CCR_HIP_CHECK(hipGetDevice(&ix->device));
+        CCR_HIP_CHECK(hipDeviceGetAttribute(&ix->num_cu, hipDeviceAttributeMultiprocessorCount, ix->device));
+        for (int i = 0; i < 7; ++i) CCR_HIP_CHECK(hipEventCreate(&ix->ev[i]));
+        CCR_HIP_CHECK(hipMalloc((void **)&ix->dmax_bits, 256));
+        if (max_norm) {
+            CCR_HIP_CHECK(hipMemcpyAsync(ix->dmax_bits, max_norm, 4, hipMemcpyDeviceToDevice, s));
+        } else {
+            CCR_HIP_CHECK(hipMemsetAsync(ix->dmax_bits, 0, 256, s));
+            int rc = launch_row_norms_bf16(D_bf16, n_rows, dim, nullptr, ix->dmax_bits, s);
+            if (rc != CCR_OK) return rc;
+            CCR_HIP_CHECK(hipStreamSynchronize(s));
+        }
+        return CCR_OK;
+    };
+    const int rc = build();
+    if (rc != CCR_OK) {
+        ccr_index_destroy(ix);
+        return rc;
     }
     *out = ix;
     return CCR_OK;

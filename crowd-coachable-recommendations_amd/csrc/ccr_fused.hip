@@ -952,6 +952,7 @@ static int launch_gemm(const GemmArgs &a, int grid, hipStream_t s) {
             case 16: return launch_kernel(&gemm_topk_kernel<EPI, true, 16>, lds, a, grid, s, cd);
             case 32: return launch_kernel(&gemm_topk_kernel<EPI, true, 32>, lds, a, grid, s, cd);
             case 40: return launch_kernel(&gemm_topk_kernel<EPI, true, 40>, lds, a, grid, s, cd);
+            case 11: return launch_kernel(&gemm_topk_kernel<EPI, true, 11>, lds, a, grid, s, cd);
             default: return launch_kernel(&gemm_topk_kernel<EPI, true, 12>, lds, a, grid, s, cd);
         }
     }
