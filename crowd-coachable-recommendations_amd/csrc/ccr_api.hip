@@ -115,39 +115,46 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu) {
         // Main-pass ranges.  Work items are (range, query block); an XCD set of per_x workgroups walks
         // (R / nrc) * qb_per equal items, so R is chosen (multiple of 8, near 6 items per workgroup, each item at
         // least 8 tiles) to make that count as close below a multiple of per_x as possible -- NQ: R = 128 gives
-        // exactly 7 items per workgroup where R = 112 left the last round 1/8 full.
+        // exactly 7 items per workgroup where R = 112 left the last round 1/8 full.  The choice is made by
+        // simulating the static item assignment (also covers the tile granularity of short ranges on small shards).
         p.qgroups = pick_qgroups(p.qblocks, dim);
         const int nrc = NUM_XCD / p.qgroups, qb_per = p.qblocks / p.qgroups, per_x = p.grid / NUM_XCD;
         const int64_t r_hi = std::min<int64_t>(1024 / p.sublists, round_up(std::max<int64_t>(1, p.tiles / 8), NUM_XCD));
         const int64_t target = std::min<int64_t>(r_hi, round_up(std::max<int64_t>(NUM_XCD, (int64_t)p.grid * 6 / p.qblocks), NUM_XCD));
-        int64_t R = target;
-        double best = -1.0;
-        for (int64_t cand_r = std::max<int64_t>(NUM_XCD, target / 2 / NUM_XCD * NUM_XCD); cand_r <= std::min(r_hi, target * 2);
-             cand_r += NUM_XCD) {
-            const int64_t items = cand_r / nrc * qb_per;
-            const int64_t rounds = (items + per_x - 1) / per_x;
-            const double eff = (double)items / (double)(rounds * per_x) - 1e-4 * std::abs((double)(cand_r - target)) / (double)target;
-            if (eff > best) {
-                best = eff;
-                R = cand_r;
+        // makespan (in tiles, + 0.15 tile of pipeline fill per item) of one launch over ranges [rb, re) of R: the
+        // busiest XCD set is range class 0; its per_x workgroups take items round-robin, range r owns
+        // ceil((tiles - r) / R) tiles
+        auto makespan = [&](int64_t rb, int64_t re, int64_t Rt) -> double {
+            std::vector<double> load((size_t)per_x, 0.0);
+            int64_t i = 0;
+            for (int64_t r = rb; r < re; r += nrc)
+                for (int qi = 0; qi < qb_per; ++qi, ++i) {
+                    const int64_t nt = (p.tiles - r + Rt - 1) / Rt;
+                    if (nt > 0) load[(size_t)(i % per_x)] += (double)nt + 0.15;
+                }
+            return *std::max_element(load.begin(), load.end());
+        };
+        // Phase A (progressive thresholds): the first ranges, at most one round of items; CCR_PROGRESSIVE=0 disables.
+        const char *pe = getenv("CCR_PROGRESSIVE");
+        const bool prog_on = !(pe && atoi(pe) == 0);
+        int64_t R = target, RA = 0;
+        double best = 1e300;
+        for (int64_t rbody = std::max<int64_t>(NUM_XCD, target / 2 / NUM_XCD * NUM_XCD); rbody <= std::min(r_hi, target * 2);
+             rbody += NUM_XCD) {
+            int64_t ra = (int64_t)per_x * nrc / qb_per / nrc * nrc;   // items = ra / nrc * qb_per <= per_x
+            ra = std::min<int64_t>(ra, rbody / 4 / nrc * nrc);
+            if (!(prog_on && ra >= nrc && rbody + ra <= 1024 / p.sublists && (double)p.tiles / (double)(rbody + ra) >= 8.0)) ra = 0;
+            const int64_t Rt = rbody + ra;
+            const double cost = (ra ? makespan(0, ra, Rt) : 0.0) + makespan(ra, Rt, Rt) +
+                                1e-3 * std::abs((double)(rbody - target));   // ties: stay near 6 items per workgroup
+            if (cost < best) {
+                best = cost;
+                R = Rt;
+                RA = ra;
             }
         }
         p.ranges = (int)R;
-        // Phase A: the first ranges (one round of items at most), after which thresholds are re-tightened from
-        // the candidates found so far; the remaining ranges keep the balanced count.  CCR_PROGRESSIVE=0 disables.
-        p.ranges_a = 0;
-        {
-            const char *e = getenv("CCR_PROGRESSIVE");
-            const bool on = !(e && atoi(e) == 0);
-            // largest range count (multiple of the range classes) whose items fit one round: items = ra / nrc * qb_per
-            int64_t ra = (int64_t)per_x * nrc / qb_per / nrc * nrc;
-            ra = std::min<int64_t>(ra, R / 4 / nrc * nrc);
-            if (on && ra >= nrc && R + ra <= 1024 / p.sublists && (double)p.tiles / (double)(R + ra) >= 8.0) {
-                p.ranges_a = (int)ra;
-                p.ranges = (int)(R + ra);
-                R = p.ranges;
-            }
-        }
+        p.ranges_a = (int)RA;
         const double ratio = (double)p.tiles / (double)sample;
         const double expect = (double)k * ratio * 1.3 + 64.0;  // survivors per query
         // candidates go to 4 sub-lists per (range, query): one per (wave row, lane half) of the GEMM tile
