@@ -128,7 +128,7 @@ def test_canonical_and_mfma_scores():
 
 # ----------------------------------------------------------------------------------------- search paths
 @pytest.mark.parametrize("n,nq,d,k", [(300, 7, 768, 300), (1000, 3, 64, 1), (5000, 70, 768, 100), (2049, 257, 1024, 1001),
-                                      (777, 1, 8, 10), (1500, 5, 776, 50)])
+                                      (777, 1, 8, 10), (1500, 5, 776, 50), (9000, 3, 64, 4096)])
 def test_dense_path_exact(n, nq, d, k):
     from ccrec_amd import ops
     Db, Qb = _rand_bits(n, d, n), _rand_bits(nq, d, nq + 1)
@@ -137,7 +137,8 @@ def test_dense_path_exact(n, nq, d, k):
 
 
 @pytest.mark.parametrize("n,nq,d,k", [(20000, 300, 768, 100), (16384, 64, 768, 10), (30001, 513, 1024, 257),
-                                      (40000, 33, 768, 1001), (9000, 1, 128, 5)])
+                                      (40000, 33, 768, 1001), (9000, 1, 128, 5), (70000, 20, 64, 10),
+                                      (50000, 10, 2048, 20), (140000, 6, 64, 4096)])
 def test_fused_path_exact(n, nq, d, k):
     from ccrec_amd import ops
     Db, Qb = _rand_bits(n, d, n), _rand_bits(nq, d, nq + 1)
