@@ -158,6 +158,16 @@ int ccr_inbatch_ce_bwd(const uint16_t *Qe, const uint16_t *Pe, const uint16_t *N
                        size_t ws_bytes, void *stream);
 
 /*
+ * Reciprocal rank / hit counts of every query at several cut-offs, from the id tensor of ccr_search.
+ * Replaces: EvaluateRetrieval.evaluate_custom(qrels, ranking_profile, [1,5,10,100], metric="mrr")
+ * (scripts/al_0_rank.py:130-133) and its python-dict traversal; the caller averages over queries.
+ *   ids [n_q][k] int64 (rank order); qrel_ptr [n_q+1], qrel_idx ascending per query (relevant ids, score > 0);
+ *   k_values [n_k] int32 (n_k <= 16); out_rr [n_q][n_k] fp32; out_hits [n_q][n_k] int32.
+ */
+int ccr_rank_metrics(const int64_t *ids, int n_q, int k, const int64_t *qrel_ptr, const int64_t *qrel_idx,
+                     const int32_t *k_values, int n_k, float *out_rr, int32_t *out_hits, void *stream);
+
+/*
  * Test/diagnostic entry points (not part of the drop-in surface).
  *   ccr_debug_mfma_scores: the raw MFMA (bf16 x bf16 -> fp32) score matrix [n_q][n_rows] the filter sees.
  *   ccr_debug_canonical_scores: the canonical fp64-ordered scores [n_q][n_rows].

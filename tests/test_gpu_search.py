@@ -264,3 +264,23 @@ def test_bbpr_transform_low_rank_score():
     csr = _assign_topk(S, 20)
     ref_i, _ = orc.rank(ref, 20)
     assert np.array_equal(csr.indices.reshape(40, 20), ref_i)
+
+
+def test_rank_metrics_and_profile_tensors():
+    """MRR@k / Recall@k on device vs the oracle's restatement of BEIR's mrr; ranking_profile <-> tensors."""
+    from ccrec_amd.evaluation import profile_to_tensors, rank_metrics, tensors_to_profile
+    rs = np.random.RandomState(4)
+    nq, k, n = 57, 100, 5000
+    ids = np.stack([rs.permutation(n)[:k] for _ in range(nq)]).astype(np.int64)
+    qrels = [set(rs.randint(0, n, size=rs.randint(0, 4)).tolist()) | ({int(ids[q, rs.randint(0, k)])} if q % 3 else set())
+             for q in range(nq)]
+    got = rank_metrics(torch.from_numpy(ids).cuda(), qrels, (1, 5, 10, 100))
+    for kk in (1, 5, 10, 100):
+        assert got[f"MRR@{kk}"] == orc.mrr(ids, qrels, kk)
+        rec = [len(set(ids[q, :kk].tolist()) & qrels[q]) / len(qrels[q]) for q in range(nq) if qrels[q]]
+        assert abs(got[f"Recall@{kk}"] - round(float(np.mean(rec)), 5)) < 2e-5
+    corpus_ids = [f"p{j}" for j in range(n)]
+    prof = {f"q{q}": {corpus_ids[j]: float(-r) for r, j in enumerate(ids[q])} for q in range(nq)}
+    qids, ti, ts = profile_to_tensors(prof, corpus_ids)
+    assert np.array_equal(ti.numpy(), ids)
+    assert tensors_to_profile(qids, corpus_ids, ti, ts) == prof
