@@ -3,7 +3,7 @@
 Mirrors (reference file:line):
   ms_marco_eval.generate_embeddings / cos_sim / ranking   scripts/ms_marco_eval.py:123-162,189-235
   item_tower.ItemTowerBase / NaiveItemTower               src/ccrec/models/item_tower.py:8-151
-  data_parallel.DataParallel.cache_replicas               src/ccrec/util/data_parallel.py:8-20
+  replica_cache.DataParallel.cache_replicas               src/ccrec/util/data_parallel.py:8-20
   rime_util._assign_topk                                  src/rime_lite/util/__init__.py:117-155
   bbpr_loss.multiple_nrl_loss                             src/ccrec/models/bbpr.py:187-214
 Config: the CCREC_* environment variables of src/ccrec/__init__.py:8-25 (same names, defaults, options).

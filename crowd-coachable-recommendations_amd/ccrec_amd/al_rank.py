@@ -12,7 +12,7 @@ import warnings
 
 import torch
 
-from .data_parallel import DataParallel
+from .replica_cache import DataParallel
 from .ms_marco_eval import ranking
 
 

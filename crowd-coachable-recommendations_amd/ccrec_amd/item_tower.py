@@ -1,34 +1,67 @@
-"""Encoder wrapper mirror of src/ccrec/models/item_tower.py: the HF encoder stays PyTorch-ROCm, the
-pooling + pack that follows it is the fused HIP kernel.
+"""Item-tower surface of the reference (src/ccrec/models/item_tower.py) over the fused pooling kernel.
 
-  ItemTowerBase   item_tower.py:8-96    (text -> inputs -> cls -> embedding; tokenizer_kw defaults :17-22)
-  NaiveItemTower  item_tower.py:99-151  (output_step cls|mu|mean -> CLS row, mean_layer_norm -> LayerNorm(CLS),
-                                         mean_pooling -> masked mean over tokens, un-normalised :137-147)
-Extra (not in the reference): output_step="mean_pooling_bf16" / forward_packed() return the packed bf16
-rows the retrieval index consumes, so fp32 [B,768] never round-trips through HBM twice.
+Kept from the reference, because callers depend on it:
+  * class names ItemTowerBase / NaiveItemTower and their constructor arguments (:13, :102);
+  * forward(cls=None, text=None, input_step="inputs", output_step="embedding", **inputs) (:34-44, :107-114) with
+    the output steps cls | mu | mean (CLS row), mean_layer_norm (LayerNorm of the CLS row), mean_pooling (masked
+    token mean, un-normalised, :137-147), "embedding" = os.environ["CCREC_EMBEDDING_TYPE"], NotImplementedError else;
+  * to_map_fn(input_step, output_step, data_parallel=False, sample_param=0) -> no_grad batch function (:46-89);
+  * tokenizer_kw defaults: truncation, padding="max_length", max_length=CCREC_MAX_LENGTH (200), return_tensors="pt".
+New here: the mean pooling runs in ccr_meanpool_pack_bf16 (one pass over the hidden states), and the extra output
+steps "mean_pooling_bf16" / "mean_pooling_bf16_cos" hand back the packed bf16 rows the retrieval index consumes.
+The HF encoder itself stays PyTorch-ROCm.
 """
-import collections
+import collections.abc
 import os
 import warnings
 
 import torch
 
 from . import ops
-from .data_parallel import DataParallel
+from .replica_cache import DataParallel
+
+_CLS_STEPS = ("cls", "mu", "mean")
+_POOL_STEPS = {"mean_pooling": (False, False), "mean_pooling_bf16": (True, False), "mean_pooling_bf16_cos": (True, True)}
+
+
+def _tokenizer_defaults():
+    return dict(truncation=True, padding="max_length", max_length=int(os.environ.get("CCREC_MAX_LENGTH", 200)),
+                return_tensors="pt")
+
+
+class _BatchMapper:
+    """The callable to_map_fn returns: batch (dict | tensor | list of str) -> {output_step: ndarray}."""
+
+    def __init__(self, tower, runner, input_step, output_step, to_device):
+        self.tower, self.runner = tower, runner
+        self.input_step, self.output_step, self.to_device = input_step, output_step, to_device
+
+    def _as_inputs(self, batch):
+        if not isinstance(batch, collections.abc.Mapping):
+            if self.input_step not in ("cls", "text"):
+                return NotImplemented
+            batch = {self.input_step: batch}
+        if self.input_step == "text":
+            batch = self.tower.tokenizer(batch["text"], **self.tower.tokenizer_kw)
+        if self.to_device:
+            batch = {name: value.cuda() for name, value in batch.items()}
+        return batch
+
+    @torch.no_grad()
+    def __call__(self, batch):
+        step = "inputs" if self.input_step == "text" else self.input_step
+        out = self.runner(**self._as_inputs(batch), input_step=step, output_step=self.output_step)
+        return {self.output_step: out.float().cpu().numpy()}
 
 
 class ItemTowerBase(torch.nn.Module):
+    """text -> inputs -> cls -> embedding; a tokenizer is needed for the text entry points."""
+
     def __init__(self, *module_list, tokenizer=None, tokenizer_kw={}):
         super().__init__()
         self.module_list = module_list
         self.tokenizer = tokenizer
-        _default_tokenizer_kw = {
-            "truncation": True,
-            "padding": "max_length",
-            "max_length": int(os.environ.get("CCREC_MAX_LENGTH", 200)),
-            "return_tensors": "pt",
-        }
-        self.tokenizer_kw = {**_default_tokenizer_kw, **tokenizer_kw}
+        self.tokenizer_kw = {**_tokenizer_defaults(), **tokenizer_kw}
 
     @property
     def device(self):
@@ -38,78 +71,53 @@ class ItemTowerBase(torch.nn.Module):
         return self.tokenizer(text, **self.tokenizer_kw)
 
     def forward(self, cls=None, text=None, input_step="inputs", output_step="embedding", **inputs):
-        raise NotImplementedError(f"{self.__class__.__name__} does not support {input_step}->{output_step} forward")
+        raise NotImplementedError(f"{type(self).__name__} does not support {input_step}->{output_step} forward")
 
     def to_map_fn(self, input_step, output_step, data_parallel=False, sample_param=0):
-        """item_tower.py:46-89: a no_grad function mapping a batch dict to {output_step: ndarray}."""
-        assert self.tokenizer is not None or input_step != "text", "map_fn with text input requires tokenizer attribute"
+        """Puts the tower in eval mode (and on the GPUs when data_parallel) as a side effect, like the reference."""
+        if input_step == "text" and self.tokenizer is None:
+            raise AssertionError("map_fn with text input requires tokenizer attribute")
         self.eval()
         if hasattr(self, "set_sample_param"):
             self.set_sample_param(sample_param)
-
-        def wrap_dict(x):
-            if isinstance(x, collections.abc.Mapping):
-                return x
-            if input_step == "cls":
-                return {"cls": x}
-            if input_step == "text":
-                return {"text": x}
-            return NotImplemented
-
-        if input_step == "text":
-            step = "inputs"
-            tokenizer, tokenizer_kw = self.tokenizer, self.tokenizer_kw
-            wrap_text = lambda x: tokenizer(x["text"], **tokenizer_kw)  # noqa: E731
-        else:
-            step = input_step
-            wrap_text = lambda x: x  # noqa: E731
-
-        model = self
-        if data_parallel:
-            model = DataParallel(self.cuda()).cache_replicas()
-            wrap_device = lambda x: {k: v.cuda() for k, v in x.items()}  # noqa: E731
-        else:
-            wrap_device = lambda x: x  # noqa: E731
-
-        return torch.no_grad()(
-            lambda x: {output_step: model(**wrap_device(wrap_text(wrap_dict(x))), input_step=step,
-                                          output_step=output_step).float().cpu().numpy()})
+        runner = DataParallel(self.cuda()).cache_replicas() if data_parallel else self
+        return _BatchMapper(self, runner, input_step, output_step, to_device=bool(data_parallel))
 
 
 class NaiveItemTower(ItemTowerBase):
-    """standard_layer_norm on top of the CLS token, or masked mean pooling."""
+    """HF encoder + (CLS | LayerNorm(CLS) | masked mean pooling)."""
 
     def __init__(self, cls_model, standard_layer_norm, **kw):
         super().__init__(cls_model, standard_layer_norm, **kw)
         self.cls_model = cls_model
         self.standard_layer_norm = standard_layer_norm
 
+    def _encode(self, inputs):
+        on_model = {name: value.to(self.cls_model.device) for name, value in inputs.items()}
+        return self.cls_model(**on_model).last_hidden_state
+
     def forward(self, cls=None, text=None, input_step="inputs", output_step="embedding", **inputs):
         if input_step == "text":
-            inputs = self.text_to_inputs(text=text)
-            input_step = "inputs"
-
+            inputs, input_step = self.text_to_inputs(text=text), "inputs"
+        hidden = None
         if input_step == "inputs":
-            inputs = {k: v.to(self.cls_model.device) for k, v in inputs.items()}
-            last_hidden_state = self.cls_model(**inputs).last_hidden_state
-            cls = last_hidden_state[:, 0]
-        else:  # cls
+            hidden = self._encode(inputs)
+            cls = hidden[:, 0]
+        else:
             cls = cls.to(self.device)
 
         if output_step == "embedding":
             output_step = os.environ["CCREC_EMBEDDING_TYPE"]
             warnings.warn(f"{self.__class__} inferring output_step from CCREC_EMBEDDING_TYPE as {output_step}")
 
-        if output_step in ["cls", "mu", "mean"]:
+        if output_step in _CLS_STEPS:
             return cls
-        elif output_step == "mean_layer_norm":
+        if output_step == "mean_layer_norm":
             return self.standard_layer_norm(cls)
-        elif output_step in ("mean_pooling", "mean_pooling_bf16", "mean_pooling_bf16_cos"):
-            assert input_step != "cls", "cannot create mean pooling from cls"
-            mask = inputs["attention_mask"]
-            want_bf16 = output_step != "mean_pooling"
-            pooled, packed = ops.meanpool_pack(last_hidden_state, mask, normalize=output_step.endswith("_cos"),
-                                               want_f32=not want_bf16, want_bf16=want_bf16)
-            return packed if want_bf16 else pooled  # unnormalized fp32, as item_tower.py:147
-
-        raise NotImplementedError(f"{self.__class__.__name__} does not support {input_step}->{output_step} forward")
+        if output_step in _POOL_STEPS:
+            assert hidden is not None, "cannot create mean pooling from cls"
+            packed, cosine = _POOL_STEPS[output_step]
+            pooled_f32, pooled_bf16 = ops.meanpool_pack(hidden, inputs["attention_mask"], normalize=cosine,
+                                                        want_f32=not packed, want_bf16=packed)
+            return pooled_bf16 if packed else pooled_f32
+        raise NotImplementedError(f"{type(self).__name__} does not support {input_step}->{output_step} forward")
