@@ -10,27 +10,38 @@ Config: the CCREC_* environment variables of src/ccrec/__init__.py:8-25 (same na
 """
 import os
 import warnings
+from typing import NamedTuple, Optional, Tuple
 
-env_defaults = [
-    ("CCREC_EMBEDDING_TYPE", "mean_layer_norm", ["cls", "mu", "mean", "mean_pooling", "mean_layer_norm"]),
-    ("CCREC_MAX_LENGTH", "256", None),
-    ("CCREC_SIM_TYPE", "cos", ["cos", "dot"]),
-    ("CCREC_TRAIN_MAIN", "bmt_main", ["bmt_main", "bbpr_main"]),
-    ("CCREC_TRAINING_PRECISION", "32", ["32", "bf16"]),
-    ("CCREC_BBPR_INV_TEMPERATURE", "20", None),
-    ("CCREC_DISPLAY_LENGTH", "250", None),
-    ("CCREC_NON_BLOCKING", "1", ["0", "1"]),
-]
+
+class _EnvVar(NamedTuple):
+    name: str
+    default: str
+    choices: Optional[Tuple[str, ...]]   # None = free-form value
+
+
+# same variable names, defaults and allowed values as the reference's import-time configuration
+# (src/ccrec/__init__.py:8-25); only the entries that reach this path are kept
+_ENV = (
+    _EnvVar("CCREC_EMBEDDING_TYPE", "mean_layer_norm", ("cls", "mu", "mean", "mean_pooling", "mean_layer_norm")),
+    _EnvVar("CCREC_MAX_LENGTH", "256", None),
+    _EnvVar("CCREC_SIM_TYPE", "cos", ("cos", "dot")),
+    _EnvVar("CCREC_TRAIN_MAIN", "bmt_main", ("bmt_main", "bbpr_main")),
+    _EnvVar("CCREC_TRAINING_PRECISION", "32", ("32", "bf16")),
+    _EnvVar("CCREC_BBPR_INV_TEMPERATURE", "20", None),
+    _EnvVar("CCREC_DISPLAY_LENGTH", "250", None),
+    _EnvVar("CCREC_NON_BLOCKING", "1", ("0", "1")),
+)
+env_defaults = [(v.name, v.default, list(v.choices) if v.choices else None) for v in _ENV]   # reference-shaped view
 
 
 def init_env_defaults(verbose=False):
-    """Same names / defaults / validation as ccrec/__init__.py:28-48 (the options assert included)."""
-    for name, default, options in env_defaults:
-        val = os.environ.setdefault(name, default)
-        if options is not None:
-            assert val in options, f"{name}={val} not in {options}"
+    """Fill in missing CCREC_* variables and validate the present ones (AssertionError on a value outside the
+    allowed set, like the reference's import-time check, src/ccrec/__init__.py:28-48)."""
+    for var in _ENV:
+        value = os.environ.setdefault(var.name, var.default)
+        assert var.choices is None or value in var.choices, f"{var.name}={value} not in {list(var.choices)}"
         if verbose:
-            print(f"{name}={val}; options: {options}")
+            print(f"{var.name}={value}")
     if os.environ["CCREC_SIM_TYPE"] == "dot" and float(os.environ["CCREC_BBPR_INV_TEMPERATURE"]) >= 20:
         warnings.warn("dot similarity works best with small inv_temperature")
 
