@@ -18,28 +18,12 @@
 // compares its 16 registers against ONE per-lane threshold).  Staging: global_load_lds_dwordx4 into a
 // ring of four 32-KiB sub-stages (32 K elements = 64-B rows), 16-byte chunk index XOR-swizzled with
 // (row>>2)&3 on the SOURCE address and on the fragment read (conflict-free ds_read_b128).
-#include "ccr_common.h"
 #include <stdlib.h>
 
+#include "ccr_gemm_common.h"
 #include "ccr_topk_device.h"
 
 namespace ccr {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-enum { EPI_FILTER = 0, EPI_GMAX = 1, EPI_STORE = 2, EPI_FILTER_GROUP = 3 };
-// EPI_FILTER       : candidate record = one corpus row        {MFMA score, row}
-// EPI_FILTER_GROUP : candidate record = one 16-row MFMA fragment {fragment max, first row}; the select
-//                    stage re-scores all 16 rows of the fragments it keeps (small k only)
-
-
-__device__ __forceinline__ void glds16(const void *gsrc, char *lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
-                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
-}
-
-
 
 // =============================================================================================
 // GEMM + top-k filter kernel.  Ping-pong schedule: K is walked in 32-element sub-stages through a
@@ -56,14 +40,6 @@ __device__ __forceinline__ void glds16(const void *gsrc, char *lds_wave_base) {
 //   WAR  DMA of u+3 overwrites the buffer of u-1.  It is issued in mem(u); every wave's reads of
 //        u-1 were retired (lgkmcnt(0)) before its barrier A_{u-1}, and for both groups that
 //        barrier instance precedes every mem(u).
-constexpr int SUB_K = 32;
-constexpr int SUB_BYTES = (TILE_DOCS + TILE_Q) * SUB_K * 2;  // 32768
-constexpr int SUB_Q_REGION = TILE_DOCS * SUB_K * 2;           // 16384
-constexpr int RING = 4;
-
-#define CCR_BARRIER() asm volatile("s_barrier" ::: "memory")
-#define CCR_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-#define CCR_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 __device__ __forceinline__ unsigned long long stamp() {
     unsigned long long t;
