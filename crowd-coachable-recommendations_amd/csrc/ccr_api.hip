@@ -93,7 +93,12 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu) {
 
     // sample pass: group maxima of 16 rows; need comfortably more groups than k
     const int64_t min_sample = (2 * (int64_t)k + GROUPS_PER_TILE - 1) / GROUPS_PER_TILE;
-    int64_t sample = std::max<int64_t>({(p.tiles + 31) / 32, min_sample, 4});
+    int64_t sample_div = 32;   // fraction of the tiles scored by the threshold pass (CCR_SAMPLE_DIV overrides)
+    {
+        const char *e = getenv("CCR_SAMPLE_DIV");
+        if (e && atoi(e) >= 4 && atoi(e) <= 256) sample_div = atoi(e);
+    }
+    int64_t sample = std::max<int64_t>({(p.tiles + sample_div - 1) / sample_div, min_sample, 4});
     bool fused = (dim % TILE_K == 0) && dim >= TILE_K && (sample * 4 <= p.full_tiles) && k <= MAX_K;
     if ((flags & CCR_SEARCH_FORCE_FUSED) && (dim % TILE_K == 0) && p.full_tiles >= 1) {
         // honour the request where at all possible: the sample may be the whole corpus
