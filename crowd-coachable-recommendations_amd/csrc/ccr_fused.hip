@@ -895,13 +895,11 @@ __global__ __launch_bounds__(256) void select_rescore_kernel(const uint2 *__rest
 }
 
 // ---------------------------------------------------------------------------------------------
+// The dynamic-LDS opt-in (> 64 KiB) is a per-device function attribute: set it on every launch (a cheap
+// host-side call) instead of caching a per-process flag that would be wrong for a second device.
 template <class K>
-static int launch_kernel(K kernel, size_t lds, const GemmArgs &a, int grid, hipStream_t s, bool &configured) {
-    if (!configured) {
-        CCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)lds));
-        configured = true;
-    }
+static int launch_kernel(K kernel, size_t lds, const GemmArgs &a, int grid, hipStream_t s, bool &) {
+    CCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(GEMM_THREADS), lds, s, a);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
@@ -987,13 +985,9 @@ int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, in
                           const uint16_t *D, int dim, int64_t id_offset, float *out_scores, int64_t *out_ids,
                           uint32_t *flag_count, uint32_t *flag_list, unsigned long long *stat_cand, hipStream_t s) {
     const size_t lds = select_lds_bytes(dim, ranges, rescore_cap);
-    static size_t configured[2] = {0, 0};
     const void *fn = groups ? reinterpret_cast<const void *>(&select_rescore_kernel<true>)
                             : reinterpret_cast<const void *>(&select_rescore_kernel<false>);
-    if (lds > 48 * 1024 && lds > configured[groups ? 1 : 0]) {
-        CCR_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured[groups ? 1 : 0] = lds;
-    }
+    if (lds > 48 * 1024) CCR_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (groups)
         hipLaunchKernelGGL(select_rescore_kernel<true>, dim3(n_q), dim3(256), lds, s, cand, cnt, ranges, sp, nq_pad, cap, k,
                            rescore_cap, n_rows, delta, Q, D, dim, id_offset, out_scores, out_ids, flag_count, flag_list, stat_cand);
