@@ -27,9 +27,9 @@ int launch_gemm_store(const GemmArgs &a, int grid, hipStream_t s);
 int launch_row_norms_bf16(const uint16_t *X, int64_t rows, int dim, float *norms, uint32_t *max_bits, hipStream_t s);
 int launch_threshold(const float *gmax, int64_t n_groups, int n_q, int nq_pad, int k, const float *qnorm,
                      const uint32_t *dmax_bits, int dim, float *thr, float *delta, hipStream_t s);
-size_t select_lds_bytes(int dim, int ranges, int rescore_cap);
+int select_compact_entries(int dim, int ranges, int rescore_cap, int64_t want);
 int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, int sp, int n_q, int nq_pad, int cap, int k,
-                          int rescore_cap, int groups, int64_t n_rows, const float *delta, const uint16_t *Q,
+                          int rescore_cap, int compact, int groups, int64_t n_rows, const float *delta, const uint16_t *Q,
                           const uint16_t *D, int dim, int64_t id_offset, float *out_scores, int64_t *out_ids,
                           uint32_t *flag_count, uint32_t *flag_list, unsigned long long *stat_cand, hipStream_t s);
 int launch_gemm_filter_group(const GemmArgs &a, int grid, hipStream_t s);
@@ -166,6 +166,9 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu) {
         int64_t cap = (int64_t)(4.0 * expect / (double)(R * p.sublists)) + 16;
         cap = round_up(std::min<int64_t>(std::max<int64_t>(cap, 16), 8192), 4);
         p.cap = (int)cap;
+        // survivors per query reaching the select stage: ~12 k after the progressive re-tightening, `expect` without it
+        p.select_compact = select_compact_entries(dim, p.ranges * p.sublists, p.rescore_cap,
+                                                  (int64_t)((RA ? 16.0 * k + 512.0 : expect) * 1.25));
         p.off_qnorm = take((size_t)p.nq_pad * 4);
         p.off_thr = take((size_t)p.nq_pad * 4 * 2);  // thr then delta
         p.off_gmax = take((size_t)p.sample_tiles * GROUPS_PER_TILE * p.nq_pad * 4);
@@ -425,7 +428,7 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
         (void)hipFree(stamps);
     }
 
-    rc = launch_select_rescore(cand, cnt, p.ranges * p.sublists, p.sublists, n_q, p.nq_pad, p.cap, k, p.rescore_cap, p.group_records, ix->n_rows, delta,
+    rc = launch_select_rescore(cand, cnt, p.ranges * p.sublists, p.sublists, n_q, p.nq_pad, p.cap, k, p.rescore_cap, p.select_compact, p.group_records, ix->n_rows, delta,
                                Q_bf16, ix->D, ix->dim,
                                ix->offset, out_scores, out_ids, flag_count, flag_list, stat_cand, s);
     if (rc != CCR_OK) return rc;

@@ -673,15 +673,41 @@ __global__ __launch_bounds__(256) void threshold_kernel(const float *__restrict_
             if ((o & mask) == prefix) atomicAdd(&s_hist[ql][(o >> shift) & 255u], 1u);
         }
         __syncthreads();
-        if (tid < 16) {
-            int remaining = (int)s_remaining[tid], cum = 0, d = 255;
-            for (; d > 0; --d) {
-                const int hcount = (int)s_hist[tid][d];
-                if (cum + hcount >= remaining) break;
-                cum += hcount;
+        {   // digit pick: 16 lanes per query (16 bins each), shuffle suffix-scan instead of a 256-step serial walk
+            const int qi = tid >> 4, part = tid & 15;
+            const uint32_t remaining = s_remaining[qi];
+            uint32_t hb[16];
+            uint32_t own = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                hb[j] = s_hist[qi][16 * part + j];
+                own += hb[j];
             }
-            s_prefix[tid] |= (uint32_t)d << shift;
-            s_remaining[tid] = (uint32_t)(remaining - cum);
+            uint32_t incl = own;
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                const uint32_t t = __shfl_down(incl, off, 16);
+                if (part + off < 16) incl += t;
+            }
+            const uint32_t above = incl - own;
+            const uint32_t total = __shfl(incl, 0, 16);
+            __syncthreads();   // every lane has read s_remaining before the crossing lane rewrites it
+            if (above < remaining && remaining <= incl) {
+                uint32_t cum = above;
+                int d = 16 * part;
+#pragma unroll
+                for (int j = 15; j >= 1; --j) {
+                    if (cum + hb[j] >= remaining) {
+                        d = 16 * part + j;
+                        break;
+                    }
+                    cum += hb[j];
+                }
+                s_prefix[qi] |= (uint32_t)d << shift;
+                s_remaining[qi] = remaining - cum;
+            } else if (part == 0 && total < remaining) {   // fewer groups than k (cannot happen: the planner samples >= 2k)
+                s_remaining[qi] = remaining - (total - hb[0]);
+            }
         }
         mask |= 0xffu << shift;
         __syncthreads();
@@ -699,6 +725,8 @@ __global__ __launch_bounds__(256) void threshold_kernel(const float *__restrict_
     }
 }
 
+constexpr int UPDATE_COMPACT = 4096;  // scores gathered into LDS by threshold_update_kernel
+
 // Progressive thresholds: after phase A of the main pass (ranges [0, ranges_a)), the k-th largest candidate
 // score found so far is a tighter valid lower bound of the k-th largest score (the candidates are real rows
 // with their real MFMA scores, whether or not a sub-list overflowed).  thr[q] = max(thr[q], kth - delta[q]).
@@ -709,64 +737,94 @@ __global__ __launch_bounds__(256) void threshold_update_kernel(const uint2 *__re
     __shared__ uint32_t s_hist[256];
     __shared__ uint32_t s_ctl[4];
     __shared__ uint32_t s_cnt[1024];
-    __shared__ uint32_t s_total;
+    __shared__ uint32_t s_total, s_maxc, s_fill;
+    __shared__ uint32_t s_val[UPDATE_COMPACT];   // orderable scores of the candidates found so far
     const int tid = threadIdx.x;
     const int q = blockIdx.x;
-    if (tid == 0) s_total = 0;
+    if (tid == 0) {
+        s_total = 0;
+        s_maxc = 0;
+        s_fill = 0;
+    }
     __syncthreads();
-    uint32_t my = 0;
+    uint32_t my = 0, mymax = 0;
     for (int j = tid; j < nsub; j += blockDim.x) {
         uint32_t c = cnt[((int64_t)(j / sp) * nq_pad + q) * sp + (j % sp)];
         if (c > (uint32_t)cap) c = (uint32_t)cap;
         s_cnt[j] = c;
         my += c;
+        mymax = c > mymax ? c : mymax;
     }
-    if (my) atomicAdd(&s_total, my);
+    if (my) {
+        atomicAdd(&s_total, my);
+        atomicMax(&s_maxc, mymax);
+    }
     __syncthreads();
     if (s_total < (uint32_t)k) return;  // not enough rows seen yet: keep the sample threshold
+    auto sub_base = [&](int j) -> int64_t { return (((int64_t)(j / sp) * nq_pad + q) * sp + (j % sp)) * cap; };
     uint32_t kth;
     int need_eq;
-    block_radix_select(
-        [&](int64_t i, bool &skip) -> uint32_t {
-            const int j = (int)(i / cap);
-            const int sl = (int)(i - (int64_t)j * cap);
-            if ((uint32_t)sl >= s_cnt[j]) {
-                skip = true;
-                return 0u;
+    if (s_total <= (uint32_t)UPDATE_COMPACT) {
+        // the sub-lists are sparse: one sweep over (sub-list, slot < longest list) with independent loads gathers the
+        // scores into LDS, the four radix passes then never touch global memory
+        const int maxc = (int)s_maxc;
+        const int M = (int)s_total;
+        for (int i = tid; i < nsub * maxc; i += blockDim.x) {
+            const int j = i / maxc, sl = i - j * maxc;
+            if ((uint32_t)sl < s_cnt[j]) {
+                const uint32_t o = f32_orderable(__uint_as_float(cand[sub_base(j) + sl].x));
+                s_val[atomicAdd(&s_fill, 1u)] = o;
             }
-            return f32_orderable(__uint_as_float(cand[(((int64_t)(j / sp) * nq_pad + q) * sp + (j % sp)) * cap + sl].x));
-        },
-        (int64_t)nsub * cap, k, s_hist, s_ctl, kth, need_eq);
+        }
+        __syncthreads();
+        block_radix_select(
+            [&](int64_t i, bool &skip) -> uint32_t {
+                (void)skip;
+                return s_val[i];
+            },
+            (int64_t)M, k, s_hist, s_ctl, kth, need_eq);
+    } else {
+        block_radix_select(
+            [&](int64_t i, bool &skip) -> uint32_t {
+                const int j = (int)(i / cap);
+                const int sl = (int)(i - (int64_t)j * cap);
+                if ((uint32_t)sl >= s_cnt[j]) {
+                    skip = true;
+                    return 0u;
+                }
+                return f32_orderable(__uint_as_float(cand[sub_base(j) + sl].x));
+            },
+            (int64_t)nsub * cap, k, s_hist, s_ctl, kth, need_eq);
+    }
     if (tid == 0) {
         const float t1 = orderable_to_f32(kth) - delta[q];
         if (t1 > thr[q]) thr[q] = t1;
     }
 }
 
-constexpr int SELECT_COMPACT = 4096;  // candidates gathered into LDS per query before the radix select
-
-// Stage-2: per query, candidates -> exact canonical top-k.  grid = n_q, block = 256.
-// dyn LDS: [dim bf16 query row][ranges uint32 counts][rescore_cap u64 keys]
-template <bool GROUPS>
-__global__ __launch_bounds__(256) void select_rescore_kernel(const uint2 *__restrict__ cand, const uint32_t *__restrict__ cnt,
-                                                            int ranges, int sp, int nq_pad, int cap, int k, int rescore_cap, int64_t n_rows,
-                                                            const float *__restrict__ delta,
+// Stage-2: per query, candidates -> exact canonical top-k.  grid = n_q, block = THREADS (256; 1024 for large k).
+// dyn LDS: [dim bf16 query row][sub-list counts][sub-list offsets][rescore_cap u64 keys][compact x 8-byte candidates]
+template <bool GROUPS, int THREADS>
+__global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__restrict__ cand, const uint32_t *__restrict__ cnt,
+                                                            int ranges, int sp, int nq_pad, int cap, int k, int rescore_cap, int compact,
+                                                            int64_t n_rows, const float *__restrict__ delta,
                                                             const uint16_t *__restrict__ Q, const uint16_t *__restrict__ D,
                                                             int dim, int64_t id_offset, float *__restrict__ out_scores,
                                                             int64_t *__restrict__ out_ids, uint32_t *__restrict__ flag_count,
                                                             uint32_t *__restrict__ flag_list,
                                                             unsigned long long *__restrict__ stat_cand) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
+    const size_t cnt_bytes = ((size_t)(ranges + 1) * 4 + 15) & ~(size_t)15;
     uint16_t *s_q = reinterpret_cast<uint16_t *>(sm);
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(sm + (((size_t)dim * 2 + 15) & ~(size_t)15));
-    unsigned long long *s_keys =
-        reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(s_cnt) + (((size_t)ranges * 4 + 15) & ~(size_t)15));
-    uint2 *s_comp = reinterpret_cast<uint2 *>(s_keys + rescore_cap);   // [SELECT_COMPACT] gathered candidates
-    __shared__ uint32_t s_fill;
+    uint32_t *s_off = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(s_cnt) + cnt_bytes);
+    unsigned long long *s_keys = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(s_off) + cnt_bytes);
+    uint2 *s_comp = reinterpret_cast<uint2 *>(s_keys + rescore_cap);   // [compact] gathered candidates
     __shared__ uint32_t s_hist[256];
     __shared__ uint32_t s_ctl[4];
+    __shared__ uint32_t s_wsum[THREADS / 64];
     __shared__ int s_flag;
-    __shared__ uint32_t s_total;
+    __shared__ uint32_t s_total, s_maxc;
     __shared__ uint32_t s_ncoll;
     __shared__ uint32_t s_grp[GROUPS ? 512 : 1];  // first rows of the kept fragments (rescore_cap / 16 <= 512)
 
@@ -776,39 +834,107 @@ __global__ __launch_bounds__(256) void select_rescore_kernel(const uint2 *__rest
         s_flag = 0;
         s_total = 0;
         s_ncoll = 0;
-        s_fill = 0;
+        s_maxc = 0;
     }
     __syncthreads();
-    uint32_t my = 0;
-    for (int r = tid; r < ranges; r += blockDim.x) {   // `ranges` counts SUB-LISTS here: 4 per (range, query)
-        uint32_t c = cnt[((int64_t)(r / sp) * nq_pad + q) * sp + (r % sp)];
+    // `ranges` counts SUB-LISTS here (sp per (range, query)); thread t owns the contiguous sub-lists [t*per, t*per+per)
+    // so that the exclusive scan of the counts below is a plain block scan of per-thread sums
+    const int per = (ranges + THREADS - 1) / THREADS;
+    uint32_t my = 0, mymax = 0;
+    for (int j = tid * per; j < min(ranges, tid * per + per); ++j) {
+        uint32_t c = cnt[((int64_t)(j / sp) * nq_pad + q) * sp + (j % sp)];
         if (c > (uint32_t)cap) {
             s_flag = 1;  // overflow: some survivors were dropped
             c = (uint32_t)cap;
         }
-        s_cnt[r] = c;
+        s_cnt[j] = c;
         my += c;
+        mymax = c > mymax ? c : mymax;
     }
-    if (my) atomicAdd(&s_total, my);
-    for (int c = tid; c < dim / 8; c += blockDim.x)
-        reinterpret_cast<uint4 *>(s_q)[c] = reinterpret_cast<const uint4 *>(Q + (int64_t)q * dim)[c];
-    __syncthreads();
+    {   // block exclusive scan of `my` -> s_off[]
+        const int lane = tid & 63, wid = tid >> 6;
+        uint32_t incl = my;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) s_wsum[wid] = incl;
+        if (my) atomicMax(&s_maxc, mymax);
+        for (int c = tid; c < dim / 8; c += THREADS)
+            reinterpret_cast<uint4 *>(s_q)[c] = reinterpret_cast<const uint4 *>(Q + (int64_t)q * dim)[c];
+        __syncthreads();
+        uint32_t base = incl - my;
+        for (int w = 0; w < wid; ++w) base += s_wsum[w];
+        for (int j = tid * per; j < min(ranges, tid * per + per); ++j) {
+            s_off[j] = base;
+            base += s_cnt[j];
+        }
+        if (tid == THREADS - 1) s_total = base;
+        __syncthreads();
+    }
     if (tid == 0 && stat_cand) atomicAdd(stat_cand, (unsigned long long)s_total);
     bool bad = (s_flag != 0) || (s_total < (uint32_t)k);
 
     const int64_t slots = (int64_t)ranges * cap;
-    // sub-list j = (range j>>2, wave-row/lane-half j&3) lives at (((j>>2) * nq_pad + q) * 4 + (j&3)) * cap
+    // sub-list j = (range j / sp, wave-row / lane part j % sp) lives at (((j / sp) * nq_pad + q) * sp + (j % sp)) * cap
     auto at = [&](int j, int sl) -> uint2 { return cand[(((int64_t)(j / sp) * nq_pad + q) * sp + (j % sp)) * cap + sl]; };
     const int coll_cap = GROUPS ? rescore_cap / 16 : rescore_cap;
     uint32_t kth = 0;
     int need_eq = 0;
-    if (!bad && s_total <= (uint32_t)SELECT_COMPACT) {
-        // The sub-lists are ~4 % full: gather them once into LDS (order is irrelevant), then select there.
-        for (int j = tid; j < ranges; j += blockDim.x) {
-            const uint32_t c = s_cnt[j];
-            if (c) {
-                const uint32_t b0 = atomicAdd(&s_fill, c);
-                for (uint32_t sl = 0; sl < c; ++sl) s_comp[b0 + sl] = at(j, (int)sl);
+    if (!bad && s_total <= (uint32_t)compact) {
+        // The sub-lists are sparse: one sweep over (sub-list, slot < longest list) gathers them into LDS at their
+        // scanned offsets (independent loads, no atomics); the select then never touches global memory.
+        // (1) every thread takes the first 8 records of each of its sub-lists with four unconditional 16-byte loads
+        //     (cap >= 16, so the read stays inside the sub-list), all in flight together;
+        // (2) only lists longer than that are swept: (sub-list, slot 8 + s), s < W = pow2 >= longest - 8.
+        constexpr int MAXPER = 4;   // ranges <= 1024 sub-lists, THREADS >= 256
+        {
+            uint4 v[MAXPER][4];
+#pragma unroll
+            for (int t = 0; t < MAXPER; ++t) {
+                const int j = tid * per + t;
+                if (t < per && j < ranges) {
+                    const uint4 *src = reinterpret_cast<const uint4 *>(cand + (((int64_t)(j / sp) * nq_pad + q) * sp + (j % sp)) * cap);
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) v[t][w] = src[w];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < MAXPER; ++t) {
+                const int j = tid * per + t;
+                if (t < per && j < ranges) {
+                    const uint32_t c = s_cnt[j], o = s_off[j];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        if (2u * w < c) s_comp[o + 2 * w] = make_uint2(v[t][w].x, v[t][w].y);
+                        if (2u * w + 1 < c) s_comp[o + 2 * w + 1] = make_uint2(v[t][w].z, v[t][w].w);
+                    }
+                }
+            }
+        }
+        const int maxc = (int)s_maxc;
+        if (maxc > 8) {
+            int lw = 0;
+            while ((1 << lw) < maxc - 8) ++lw;
+            const int sweep = ranges << lw;
+            constexpr int BATCH = 8;   // loads issued back to back before the first LDS store
+            for (int i0 = tid; i0 < sweep; i0 += THREADS * BATCH) {
+                uint2 e[BATCH];
+                int dst[BATCH];
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u) {
+                    const int i = i0 + u * THREADS;
+                    const int j = i >> lw, sl = 8 + (i & ((1 << lw) - 1));
+                    dst[u] = -1;
+                    if (i < sweep && (uint32_t)sl < s_cnt[j]) {
+                        dst[u] = (int)s_off[j] + sl;
+                        e[u] = at(j, sl);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u)
+                    if (dst[u] >= 0) s_comp[dst[u]] = e[u];
             }
         }
         __syncthreads();
@@ -820,7 +946,7 @@ __global__ __launch_bounds__(256) void select_rescore_kernel(const uint2 *__rest
             },
             M, k, s_hist, s_ctl, kth, need_eq);
         const float cut = orderable_to_f32(kth) - delta[q];
-        for (int i = tid; i < M; i += blockDim.x) {
+        for (int i = tid; i < M; i += THREADS) {
             const uint2 e = s_comp[i];
             if (__uint_as_float(e.x) >= cut) {
                 const uint32_t p = atomicAdd(&s_ncoll, 1u);
@@ -843,7 +969,7 @@ __global__ __launch_bounds__(256) void select_rescore_kernel(const uint2 *__rest
             slots, k, s_hist, s_ctl, kth, need_eq);
         const float cut = orderable_to_f32(kth) - delta[q];
         // collect everything within the margin of the k-th MFMA score
-        for (int64_t i = tid; i < slots; i += blockDim.x) {
+        for (int64_t i = tid; i < slots; i += THREADS) {
             const int r = (int)(i / cap);
             const int sl = (int)(i - (int64_t)r * cap);
             if ((uint32_t)sl >= s_cnt[r]) continue;
@@ -975,27 +1101,38 @@ int launch_threshold_update(const uint2 *cand, const uint32_t *cnt, int nsub, in
     return CCR_OK;
 }
 
-size_t select_lds_bytes(int dim, int ranges, int rescore_cap) {
-    return (((size_t)dim * 2 + 15) & ~(size_t)15) + (((size_t)ranges * 4 + 15) & ~(size_t)15) + (size_t)rescore_cap * 8 +
-           (size_t)SELECT_COMPACT * 8;
+constexpr size_t SELECT_LDS_BUDGET = 150 * 1024;   // dynamic LDS the select kernel may ask for (160 KiB per CU)
+
+static size_t select_fixed_lds(int dim, int ranges, int rescore_cap) {
+    const size_t cnt_bytes = ((size_t)(ranges + 1) * 4 + 15) & ~(size_t)15;
+    return (((size_t)dim * 2 + 15) & ~(size_t)15) + 2 * cnt_bytes + (size_t)rescore_cap * 8;
+}
+
+// Candidates per query the select kernel can gather into LDS: `want` (the planner's expectation with head room),
+// at least 4096 where that fits, never more than the LDS budget allows.
+int select_compact_entries(int dim, int ranges, int rescore_cap, int64_t want) {
+    const size_t fixed = select_fixed_lds(dim, ranges, rescore_cap);
+    const int64_t fit = fixed + 2048 < SELECT_LDS_BUDGET ? (int64_t)((SELECT_LDS_BUDGET - fixed) / 8) : 256;
+    return (int)std::min<int64_t>(std::max<int64_t>(want, 4096), fit) / 256 * 256;
 }
 
 int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, int sp, int n_q, int nq_pad, int cap, int k,
-                          int rescore_cap, int groups, int64_t n_rows, const float *delta, const uint16_t *Q,
+                          int rescore_cap, int compact, int groups, int64_t n_rows, const float *delta, const uint16_t *Q,
                           const uint16_t *D, int dim, int64_t id_offset, float *out_scores, int64_t *out_ids,
                           uint32_t *flag_count, uint32_t *flag_list, unsigned long long *stat_cand, hipStream_t s) {
-    const size_t lds = select_lds_bytes(dim, ranges, rescore_cap);
-    const void *fn = groups ? reinterpret_cast<const void *>(&select_rescore_kernel<true>)
-                            : reinterpret_cast<const void *>(&select_rescore_kernel<false>);
-    if (lds > 48 * 1024) CCR_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (groups)
-        hipLaunchKernelGGL(select_rescore_kernel<true>, dim3(n_q), dim3(256), lds, s, cand, cnt, ranges, sp, nq_pad, cap, k,
-                           rescore_cap, n_rows, delta, Q, D, dim, id_offset, out_scores, out_ids, flag_count, flag_list, stat_cand);
-    else
-        hipLaunchKernelGGL(select_rescore_kernel<false>, dim3(n_q), dim3(256), lds, s, cand, cnt, ranges, sp, nq_pad, cap, k,
-                           rescore_cap, n_rows, delta, Q, D, dim, id_offset, out_scores, out_ids, flag_count, flag_list, stat_cand);
-    CCR_LAUNCH_CHECK();
-    return CCR_OK;
+    const size_t lds = select_fixed_lds(dim, ranges, rescore_cap) + (size_t)compact * 8;
+    const bool wide = !groups && (rescore_cap > 512 || compact > 8192);   // 1024 threads: one re-scored row per thread at large k
+    auto go = [&](auto kernel, int threads) -> int {
+        if (lds > 48 * 1024)
+            CCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kernel, dim3(n_q), dim3(threads), lds, s, cand, cnt, ranges, sp, nq_pad, cap, k, rescore_cap, compact,
+                           n_rows, delta, Q, D, dim, id_offset, out_scores, out_ids, flag_count, flag_list, stat_cand);
+        CCR_LAUNCH_CHECK();
+        return CCR_OK;
+    };
+    if (groups) return go(&select_rescore_kernel<true, 256>, 256);
+    if (wide) return go(&select_rescore_kernel<false, 1024>, 1024);
+    return go(&select_rescore_kernel<false, 256>, 256);
 }
 
 }  // namespace ccr

@@ -9,6 +9,42 @@
 
 namespace ccr {
 
+// Wave-parallel digit pick of one radix pass (called by lanes 0..63 of ONE wave): the largest digit d whose
+// suffix count hist[d] + ... + hist[255] reaches `remaining`; ctl[0] = d, ctl[1] = remaining - (count above d).
+// Lane l owns bins 4l..4l+3; a shuffle suffix-scan replaces the 256-step serial walk (d = 0 if never reached).
+__device__ __forceinline__ void radix_pick_digit(const uint32_t *hist, int lane, uint32_t remaining, uint32_t *ctl) {
+    uint32_t h[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h[j] = hist[4 * lane + j];
+    const uint32_t own = h[0] + h[1] + h[2] + h[3];
+    uint32_t incl = own;   // sum over lanes >= lane
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_down(incl, off, 64);
+        if (lane + off < 64) incl += t;
+    }
+    const uint32_t above = incl - own;
+    const bool cross = above < remaining && remaining <= incl;
+    if (cross) {
+        uint32_t cum = above;
+        int d = 4 * lane;   // falls through to the lane's lowest bin
+#pragma unroll
+        for (int j = 3; j >= 1; --j) {
+            if (cum + h[j] >= remaining) {
+                d = 4 * lane + j;
+                break;
+            }
+            cum += h[j];
+        }
+        ctl[0] = (uint32_t)d;
+        ctl[1] = remaining - cum;
+    }
+    if (lane == 0 && incl < remaining) {  // fewer items than requested (contract violation): same answer as the serial walk
+        ctl[0] = 0u;
+        ctl[1] = remaining - (incl - h[0]);
+    }
+}
+
 // All threads of the block must call.  get(i) -> uint32 orderable key of item i (0 <= i < M) or
 // skip == true to ignore the slot.  On return (uniform across the block):
 //   kth      = key of the k-th largest item
@@ -30,16 +66,7 @@ __device__ __forceinline__ void block_radix_select(Get get, int64_t M, int k, ui
             if (!skip && (o & mask) == prefix) atomicAdd(&s_hist[(o >> shift) & 255u], 1u);
         }
         __syncthreads();
-        if (tid == 0) {
-            int cum = 0, d = 255;
-            for (; d > 0; --d) {
-                int h = (int)s_hist[d];
-                if (cum + h >= remaining) break;
-                cum += h;
-            }
-            s_ctl[0] = (uint32_t)d;
-            s_ctl[1] = (uint32_t)(remaining - cum);
-        }
+        if (tid < 64) radix_pick_digit(s_hist, tid, (uint32_t)remaining, s_ctl);
         __syncthreads();
         prefix |= s_ctl[0] << shift;
         mask |= 0xffu << shift;
