@@ -117,7 +117,7 @@ def main():
             dist.init_process_group(args.dist_backend)
 
     from ccrec_amd import ops
-    from ccrec_amd.dist import shard_bounds, all_gather_topk
+    from ccrec_amd.dist import shard_bounds, TopkMessage
 
     lo, hi = shard_bounds(args.rows, world, rank)
     # every rank generates the same global stream and keeps its rows: identical corpus for every N
@@ -136,16 +136,22 @@ def main():
     state = {}
 
     max_norm = torch.zeros(1, dtype=torch.float32, device=dev)
+    # N > 1: the search writes its top-k straight into the packed exchange message (one all-gather per step)
+    message = None
+    if world > 1:
+        assert k_local == args.k, "shard smaller than k"
+        message = TopkMessage(args.queries, args.k, dev, world)
 
     def step():
         max_norm.zero_()
         ops.pack_bf16(corpus_f32, out=shard, max_norm=max_norm)     # pack + max packed-row norm in one pass
         index = ops.CorpusIndex(shard, global_row_offset=lo, max_norm=max_norm)
         ops.pack_bf16(queries_f32, out=qpack)
-        s, i = index.search(qpack, k_local)
         if world > 1:
-            gs, gi = all_gather_topk(s, i)
-            s, i = ops.merge_topk(gs, gi)
+            index.search(qpack, k_local, out=(message.scores, message.ids))
+            s, i = ops.merge_topk(*message.gather())
+        else:
+            s, i = index.search(qpack, k_local)
         state["index"], state["scores"], state["ids"] = index, s, i
 
     def fence():

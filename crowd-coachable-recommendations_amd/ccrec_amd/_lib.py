@@ -15,7 +15,7 @@ EXPORTS = [
     "ccr_last_error", "ccr_version", "ccr_pack_bf16", "ccr_pack_bf16_ex", "ccr_meanpool_pack_bf16", "ccr_index_create",
     "ccr_index_create_with_norm", "ccr_index_destroy",
     "ccr_index_rows", "ccr_index_dim", "ccr_search_workspace_bytes", "ccr_search", "ccr_search_last_stats",
-    "ccr_merge_topk", "ccr_apply_block", "ccr_inbatch_ce_workspace_bytes", "ccr_inbatch_ce_fwd", "ccr_inbatch_ce_bwd", "ccr_rank_metrics", "ccr_debug_mfma_scores",
+    "ccr_merge_topk", "ccr_merge_topk_strided", "ccr_apply_block", "ccr_inbatch_ce_workspace_bytes", "ccr_inbatch_ce_fwd", "ccr_inbatch_ce_bwd", "ccr_rank_metrics", "ccr_debug_mfma_scores",
     "ccr_debug_canonical_scores",
 ]
 
@@ -62,6 +62,7 @@ def load():
     lib.ccr_search.argtypes = [vp, vp, i32, i32, vp, vp, vp, sz, i32, vp]
     lib.ccr_search_last_stats.argtypes = [vp, ctypes.POINTER(SearchStats)]
     lib.ccr_merge_topk.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
+    lib.ccr_merge_topk_strided.argtypes = [vp, vp, i64, i64, i32, i32, i32, vp, vp, vp]
     lib.ccr_apply_block.argtypes = [vp, vp, i32, i32, vp, vp, i64, vp, vp, i32, vp]
     lib.ccr_inbatch_ce_workspace_bytes.argtypes = [i32, i32]
     lib.ccr_inbatch_ce_workspace_bytes.restype = sz

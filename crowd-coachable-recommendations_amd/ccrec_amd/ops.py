@@ -105,14 +105,20 @@ class CorpusIndex:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.corpus.device)
         return self._ws
 
-    def search(self, queries_bf16, k, flags=_lib.SEARCH_DEFAULT):
-        """-> (scores [n_q, k] fp32, ids [n_q, k] int64 global), canonical order."""
+    def search(self, queries_bf16, k, flags=_lib.SEARCH_DEFAULT, out=None):
+        """-> (scores [n_q, k] fp32, ids [n_q, k] int64 global), canonical order.
+        out=(scores, ids): contiguous [n_q, k] destinations (e.g. views of a packed all-gather message)."""
         q = queries_bf16
         assert q.is_cuda and q.dtype == torch.bfloat16 and q.dim() == 2 and q.shape[1] == self.dim
         q = q.contiguous()
         n_q = q.shape[0]
-        scores = torch.empty(n_q, k, dtype=torch.float32, device=q.device)
-        ids = torch.empty(n_q, k, dtype=torch.int64, device=q.device)
+        if out is None:
+            scores = torch.empty(n_q, k, dtype=torch.float32, device=q.device)
+            ids = torch.empty(n_q, k, dtype=torch.int64, device=q.device)
+        else:
+            scores, ids = out
+            assert scores.shape == (n_q, k) and ids.shape == (n_q, k) and scores.is_contiguous() and ids.is_contiguous()
+            assert scores.dtype == torch.float32 and ids.dtype == torch.int64 and scores.device == q.device == ids.device
         if n_q == 0:
             return scores, ids
         ws = self._workspace(n_q, k)
@@ -135,16 +141,25 @@ class CorpusIndex:
         return out
 
 
+def _rank_strided(t):
+    """[R, n_q, k] tensor whose [n_q, k] lists are dense; only the rank stride is free (a view of a gathered message)."""
+    return t.dim() == 3 and t.stride(2) == 1 and t.stride(1) == t.shape[2] and t.stride(0) >= t.shape[1] * t.shape[2]
+
+
 def merge_topk(scores, ids):
-    """[R, n_q, k] per-shard canonical lists -> global ([n_q, k], [n_q, k])."""
+    """[R, n_q, k] per-shard canonical lists -> global ([n_q, k], [n_q, k]).  Rank-strided views are merged in place."""
     lib = require_gpu()
     assert scores.is_cuda and scores.dtype == torch.float32 and ids.dtype == torch.int64 and scores.shape == ids.shape
-    scores, ids = scores.contiguous(), ids.contiguous()
+    if not _rank_strided(scores):
+        scores = scores.contiguous()
+    if not _rank_strided(ids):
+        ids = ids.contiguous()
     R, n_q, k = scores.shape
     os_ = torch.empty(n_q, k, dtype=torch.float32, device=scores.device)
     oi = torch.empty(n_q, k, dtype=torch.int64, device=scores.device)
     with _on(scores):
-        _lib.check(lib.ccr_merge_topk(_ptr(scores), _ptr(ids), R, n_q, k, _ptr(os_), _ptr(oi), _stream(scores)), "ccr_merge_topk")
+        _lib.check(lib.ccr_merge_topk_strided(_ptr(scores), _ptr(ids), scores.stride(0), ids.stride(0), R, n_q, k, _ptr(os_),
+                                              _ptr(oi), _stream(scores)), "ccr_merge_topk")
     return os_, oi
 
 

@@ -12,23 +12,24 @@ __device__ __forceinline__ bool precedes(float sa, int64_t ia, float sb, int64_t
 // order and ids are unique across shards, so the order is strict and ranks are a permutation).
 // grid = (ceil(R*k/256), n_q), block = 256.
 __global__ __launch_bounds__(256) void merge_topk_kernel(const float *__restrict__ scores, const int64_t *__restrict__ ids,
-                                                        int R, int n_q, int k, float *__restrict__ out_scores,
-                                                        int64_t *__restrict__ out_ids) {
+                                                        int64_t rs_scores, int64_t rs_ids, int R, int n_q, int k,
+                                                        float *__restrict__ out_scores, int64_t *__restrict__ out_ids) {
+    // list (r, q) starts at scores[r * rs_scores + q * k] / ids[r * rs_ids + q * k] (rank strides in elements)
     const int q = blockIdx.y;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= R * k) return;
     const int r = e / k, p = e - r * k;
-    const int64_t base = ((int64_t)r * n_q + q) * k;
-    const float s = scores[base + p];
-    const int64_t id = ids[base + p];
+    const float s = scores[r * rs_scores + (int64_t)q * k + p];
+    const int64_t id = ids[r * rs_ids + (int64_t)q * k + p];
     int rank = p;
     for (int o = 0; o < R && rank < k; ++o) {
         if (o == r) continue;
-        const int64_t ob = ((int64_t)o * n_q + q) * k;
+        const float *os = scores + o * rs_scores + (int64_t)q * k;
+        const int64_t *oi = ids + o * rs_ids + (int64_t)q * k;
         int lo = 0, hi = k;  // first position whose element does NOT precede (s, id)
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
-            if (precedes(scores[ob + mid], ids[ob + mid], s, id))
+            if (precedes(os[mid], oi[mid], s, id))
                 lo = mid + 1;
             else
                 hi = mid;
@@ -98,15 +99,24 @@ __global__ __launch_bounds__(256) void apply_block_kernel(const float *__restric
 
 using namespace ccr;
 
-extern "C" int ccr_merge_topk(const float *scores, const int64_t *ids, int R, int n_q, int k, float *out_scores,
-                              int64_t *out_ids, void *stream) {
+extern "C" int ccr_merge_topk_strided(const float *scores, const int64_t *ids, int64_t score_rank_stride, int64_t id_rank_stride,
+                                      int R, int n_q, int k, float *out_scores, int64_t *out_ids, void *stream) {
     CCR_REQUIRE(scores && ids && out_scores && out_ids, "ccr_merge_topk: null pointer");
     CCR_REQUIRE(R >= 1 && n_q >= 0 && k >= 1 && k <= MAX_K, "ccr_merge_topk: bad shape R=%d n_q=%d k=%d", R, n_q, k);
+    CCR_REQUIRE(score_rank_stride >= (int64_t)n_q * k && id_rank_stride >= (int64_t)n_q * k,
+                "ccr_merge_topk: rank strides %lld / %lld shorter than one [n_q, k] list", (long long)score_rank_stride,
+                (long long)id_rank_stride);
     if (n_q == 0) return CCR_OK;
     dim3 grid((unsigned)((R * k + 255) / 256), (unsigned)n_q);
-    hipLaunchKernelGGL(merge_topk_kernel, grid, dim3(256), 0, (hipStream_t)stream, scores, ids, R, n_q, k, out_scores, out_ids);
+    hipLaunchKernelGGL(merge_topk_kernel, grid, dim3(256), 0, (hipStream_t)stream, scores, ids, score_rank_stride, id_rank_stride, R,
+                       n_q, k, out_scores, out_ids);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
+}
+
+extern "C" int ccr_merge_topk(const float *scores, const int64_t *ids, int R, int n_q, int k, float *out_scores,
+                              int64_t *out_ids, void *stream) {
+    return ccr_merge_topk_strided(scores, ids, (int64_t)n_q * k, (int64_t)n_q * k, R, n_q, k, out_scores, out_ids, stream);
 }
 
 extern "C" int ccr_apply_block(const float *in_scores, const int64_t *in_ids, int n_q, int k_in, const int64_t *block_ptr,

@@ -128,6 +128,11 @@ int ccr_search_last_stats(const ccr_index *index, ccr_search_stats *stats /* hos
  */
 int ccr_merge_topk(const float *scores, const int64_t *ids, int R, int n_q, int k, float *out_scores,
                    int64_t *out_ids, void *stream);
+/* Same merge over rank-strided inputs: list (r, q) starts at scores + r * score_rank_stride + q * k and
+ * ids + r * id_rank_stride + q * k (strides in elements).  This is the layout ONE all-gather of a packed per-rank
+ * message {scores [n_q][k] fp32 | ids [n_q][k] int64} leaves behind: a single collective instead of two. */
+int ccr_merge_topk_strided(const float *scores, const int64_t *ids, int64_t score_rank_stride, int64_t id_rank_stride,
+                           int R, int n_q, int k, float *out_scores, int64_t *out_ids, void *stream);
 
 /*
  * Apply per-query blocked ids to an over-fetched result list.

@@ -214,6 +214,29 @@ def test_merge_and_sharded_search_equal_single():
     assert np.array_equal(mi.cpu().numpy(), oi) and np.array_equal(ms.cpu().numpy(), os_)
 
 
+def test_packed_message_strided_merge_equals_single():
+    """The one-collective exchange layout: every shard's search writes into a TopkMessage, the gathered buffer is
+    emulated by copying the three messages side by side, and the merge reads the rank-strided views in place."""
+    from ccrec_amd import ops
+    from ccrec_amd.dist import shard_bounds, TopkMessage
+    n, nq, d, k = 20000, 37, 768, 100          # nq * k * 4 is not a multiple of 16: exercises the id-block padding
+    Db, Qb = _rand_bits(n, d, 33), _rand_bits(nq, d, 34)
+    D, Q = _bf16(Db), _bf16(Qb)
+    s1, i1 = ops.CorpusIndex(D).search(Q, k)
+    world = 3
+    gathered = TopkMessage(nq, k, D.device, world)
+    for r in range(world):
+        lo, hi = shard_bounds(n, world, r)
+        m = TopkMessage(nq, k, D.device, 1)
+        so, io = ops.CorpusIndex(D[lo:hi].contiguous(), global_row_offset=lo).search(Q, k, out=(m.scores, m.ids))
+        assert so.data_ptr() == m.scores.data_ptr() and io.data_ptr() == m.ids.data_ptr()
+        gathered.recv.view(world, -1)[r].copy_(m.send)
+    gs, gi = gathered.all_scores, gathered.all_ids
+    assert not gs.is_contiguous() and gs.stride(0) * 4 == gathered.nbytes
+    ms, mi = ops.merge_topk(gs, gi)
+    assert torch.equal(mi, i1) and torch.equal(ms.view(torch.int32), s1.view(torch.int32))
+
+
 def test_assign_topk_golden(golden_dir):
     from ccrec_amd.rime_util import _assign_topk
     g = np.load(os.path.join(golden_dir, "g8_assign_topk.npz"))
