@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "ccr_common.h"
@@ -193,12 +194,49 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu) {
 
 using namespace ccr;
 
+// Per-device slab of 256-byte slots for the indices' small device state: building an index per active-learning
+// step must not cost a hipMalloc / hipFree pair (hipFree synchronises the device).
+namespace {
+constexpr int SLAB_SLOTS = 1024, SLAB_SLOT_BYTES = 256, MAX_DEVICES = 64;
+struct Slab {
+    char *base = nullptr;
+    std::vector<int> free_slots;
+};
+std::mutex g_slab_mutex;
+Slab g_slabs[MAX_DEVICES];
+
+int slab_take(int device, uint32_t **out) {
+    std::lock_guard<std::mutex> lock(g_slab_mutex);
+    CCR_REQUIRE(device >= 0 && device < MAX_DEVICES, "device ordinal %d out of range", device);
+    Slab &sl = g_slabs[device];
+    if (!sl.base) {
+        CCR_HIP_CHECK(hipMalloc((void **)&sl.base, (size_t)SLAB_SLOTS * SLAB_SLOT_BYTES));
+        for (int i = SLAB_SLOTS - 1; i >= 0; --i) sl.free_slots.push_back(i);
+    }
+    if (sl.free_slots.empty()) {
+        set_error("ccr_index_create: more than %d live indices on device %d", SLAB_SLOTS, device);
+        return CCR_ERR_INVALID;
+    }
+    *out = reinterpret_cast<uint32_t *>(sl.base + (size_t)sl.free_slots.back() * SLAB_SLOT_BYTES);
+    sl.free_slots.pop_back();
+    return CCR_OK;
+}
+
+void slab_give(int device, uint32_t *p) {
+    if (!p || device < 0 || device >= MAX_DEVICES) return;
+    std::lock_guard<std::mutex> lock(g_slab_mutex);
+    Slab &sl = g_slabs[device];
+    sl.free_slots.push_back((int)((reinterpret_cast<char *>(p) - sl.base) / SLAB_SLOT_BYTES));
+}
+}  // namespace
+
 struct ccr_index {
     const uint16_t *D;
     int64_t n_rows;
     int dim;
     int64_t offset;
-    uint32_t *dmax_bits;  // device: bits of the max row norm
+    uint32_t *dmax_bits;  // device: bits of the max row norm (a slot of the per-device slab below)
+    bool have_events;
     int num_cu;
     int device;
     hipEvent_t ev[7];     // phase boundaries of the last search
@@ -228,12 +266,14 @@ static int index_create_impl(const uint16_t *D_bf16, int64_t n_rows, int dim, in
     auto build = [&]() -> int {
         CCR_HIP_CHECK(hipGetDevice(&ix->device));
         CCR_HIP_CHECK(hipDeviceGetAttribute(&ix->num_cu, hipDeviceAttributeMultiprocessorCount, ix->device));
-        for (int i = 0; i < 7; ++i) CCR_HIP_CHECK(hipEventCreate(&ix->ev[i]));
-        CCR_HIP_CHECK(hipMalloc((void **)&ix->dmax_bits, 256));
+        {
+            const int rc = slab_take(ix->device, &ix->dmax_bits);
+            if (rc != CCR_OK) return rc;
+        }
         if (max_norm) {
             CCR_HIP_CHECK(hipMemcpyAsync(ix->dmax_bits, max_norm, 4, hipMemcpyDeviceToDevice, s));
         } else {
-            CCR_HIP_CHECK(hipMemsetAsync(ix->dmax_bits, 0, 256, s));
+            CCR_HIP_CHECK(hipMemsetAsync(ix->dmax_bits, 0, 4, s));
             int rc = launch_row_norms_bf16(D_bf16, n_rows, dim, nullptr, ix->dmax_bits, s);
             if (rc != CCR_OK) return rc;
             CCR_HIP_CHECK(hipStreamSynchronize(s));
@@ -262,9 +302,12 @@ extern "C" int ccr_index_create_with_norm(const uint16_t *D_bf16, int64_t n_rows
 
 extern "C" int ccr_index_destroy(ccr_index *ix) {
     if (!ix) return CCR_OK;
-    if (ix->dmax_bits) (void)hipFree(ix->dmax_bits);
-    for (int i = 0; i < 7; ++i)
-        if (ix->ev[i]) (void)hipEventDestroy(ix->ev[i]);
+    // a slot handed back may be rewritten by the next index's create on ITS stream; the caller destroys an index only
+    // after the work that uses it has completed (the same contract as for the borrowed corpus)
+    slab_give(ix->device, ix->dmax_bits);
+    if (ix->have_events)
+        for (int i = 0; i < 7; ++i)
+            if (ix->ev[i]) (void)hipEventDestroy(ix->ev[i]);
     delete ix;
     return CCR_OK;
 }
@@ -319,6 +362,10 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
     char *ws = (char *)workspace;
     float *dense_scratch = (float *)(ws + p.off_dense);
 
+    if (!ix->have_events) {   // phase-boundary events of the statistics, created on first use
+        for (int i = 0; i < 7; ++i) CCR_HIP_CHECK(hipEventCreate(&ix->ev[i]));
+        ix->have_events = true;
+    }
     CCR_HIP_CHECK(hipEventRecord(ix->ev[0], s));
     if (!p.fused) {
         ix->stats.path = 0;
