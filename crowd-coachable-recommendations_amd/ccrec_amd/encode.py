@@ -1,0 +1,158 @@
+"""Encoder-side fusion: length-sorted variable-length batches, pooled + packed straight into the
+resident bf16 shard, each rank encoding only its own corpus rows.
+
+What the reference does (and what this replaces):
+  * `tokenizer_kw` pads every text to max_length (src/ccrec/models/item_tower.py:27-33, CCREC_MAX_LENGTH 200), or
+    to the longest text of a corpus-order batch of 512 x n_gpus (scripts/al_0_rank.py:73-84): most encoder flops
+    go into padding tokens.  Here texts are tokenised once without padding, sorted by token count and cut into
+    batches under a token budget; a batch is padded only to its own longest text (rounded up to `pad_multiple`).
+  * the pooled fp32 batch is copied to the host and vstack-ed (scripts/ms_marco_eval.py:141-149).  Here
+    ccr_meanpool_pack_bf16_ex pools, optionally L2-normalises, rounds to bf16 and scatters every row to its
+    corpus position inside the shard, and accumulates the max row norm the index needs -- one kernel per batch.
+  * torch.nn.DataParallel splits every batch over the GPUs of one process (src/ccrec/util/data_parallel.py:8-20,
+    scripts/al_0_rank.py:92).  Here one process per GPU encodes the contiguous row block dist.shard_bounds gives it
+    and searches it as a shard (dist.sharded_search merges over RCCL).
+
+Masked mean pooling skips padding positions and sums the real tokens in order, so the pooled row is independent
+of the padded length whenever the encoder's hidden states for the real tokens are (BERT attention masks make them
+so up to the fp32 reduction order of its GEMMs/softmax: ~1e-6 relative).
+"""
+import math
+import os
+
+import numpy as np
+import torch
+
+from . import ops
+from .dist import shard_bounds
+
+
+def plan_batches(lengths, max_tokens=65536, max_batch=512, pad_multiple=8):
+    """lengths: token count per text.  -> list of (index array, padded length): texts sorted by length (stable),
+    cut so that batch_size * padded_length <= max_tokens and batch_size <= max_batch.  Every index appears once."""
+    lengths = np.asarray(lengths, dtype=np.int64)
+    assert lengths.ndim == 1 and (lengths.size == 0 or lengths.min() >= 1)
+    order = np.argsort(lengths, kind="stable")
+    batches, lo, n = [], 0, lengths.size
+    while lo < n:
+        hi = lo
+        padded = 0
+        while hi < n and hi - lo < max_batch:
+            cand = int(math.ceil(int(lengths[order[hi]]) / pad_multiple) * pad_multiple)   # ascending: the newest is the longest
+            if hi > lo and (hi - lo + 1) * cand > max_tokens:
+                break
+            padded = cand
+            hi += 1
+        batches.append((order[lo:hi], padded))
+        lo = hi
+    return batches
+
+
+def _tokenize_unpadded(tokenizer, texts, max_length):
+    """-> list of python int lists (input ids incl. special tokens), truncated to max_length, no padding."""
+    enc = tokenizer(list(texts), truncation=True, padding=False, max_length=max_length, return_tensors=None)
+    ids = enc["input_ids"]
+    if torch.is_tensor(ids):   # a tokenizer that always pads: strip by its attention mask
+        mask = enc["attention_mask"]
+        return [row[m.bool()].tolist() for row, m in zip(ids, mask)]
+    return [list(r) for r in ids]
+
+
+class LengthSortedEncoder:
+    """texts -> packed bf16 rows through `tower` (a NaiveItemTower: .cls_model is the HF encoder).
+
+    tokenizer: HF-style callable; pad id from tokenizer.pad_token_id (0 if absent).
+    max_tokens / max_batch: batch budget (padded tokens / texts); pad_multiple: padded lengths are rounded up to it.
+    """
+
+    def __init__(self, tower, tokenizer, max_length=None, max_tokens=65536, max_batch=512, pad_multiple=8):
+        self.tower, self.tokenizer = tower, tokenizer
+        self.max_length = int(max_length if max_length is not None else os.environ.get("CCREC_MAX_LENGTH", 200))
+        self.max_tokens, self.max_batch, self.pad_multiple = int(max_tokens), int(max_batch), int(pad_multiple)
+        self.pad_id = int(getattr(tokenizer, "pad_token_id", 0) or 0)
+        self.stats = {}
+
+    def _batch_tensors(self, token_lists, idx, padded, device):
+        rows = [token_lists[j] for j in idx]
+        lens = np.fromiter((len(r) for r in rows), dtype=np.int64, count=len(rows))
+        ids = np.full((len(rows), padded), self.pad_id, dtype=np.int64)
+        mask = np.zeros((len(rows), padded), dtype=np.int64)
+        r_of = np.repeat(np.arange(len(rows)), lens)
+        c_of = np.arange(int(lens.sum())) - np.repeat(np.cumsum(lens) - lens, lens)
+        ids[r_of, c_of] = np.concatenate([np.asarray(r, dtype=np.int64) for r in rows])
+        mask[r_of, c_of] = 1
+        return {"input_ids": torch.from_numpy(ids).to(device, non_blocking=True),
+                "attention_mask": torch.from_numpy(mask).to(device, non_blocking=True)}
+
+    @torch.no_grad()
+    def encode(self, texts, sim="dot", out=None, row_offset=0, max_norm=None, out_f32=None):
+        """Encode `texts` into rows [row_offset, row_offset + len(texts)) of `out` (bf16 [>=N, dim] cuda; allocated if
+        None).  sim "cos" L2-normalises before rounding.  max_norm: see ops.pack_bf16.  out_f32: optional fp32
+        [>=N, dim] tensor that also receives the un-rounded pooled rows (tests / the cls|mean_layer_norm consumers).
+        Returns the bf16 tensor."""
+        ops.require_gpu()
+        tower = self.tower
+        tower.eval()
+        device = tower.cls_model.device
+        token_lists = _tokenize_unpadded(self.tokenizer, texts, self.max_length)
+        lengths = [len(t) for t in token_lists]
+        batches = plan_batches(lengths, self.max_tokens, self.max_batch, self.pad_multiple) if lengths else []
+        n = len(token_lists)
+        real = int(sum(lengths))
+        padded_tokens = int(sum(len(idx) * pl for idx, pl in batches))
+        self.stats = {"texts": n, "batches": len(batches), "real_tokens": real, "padded_tokens": padded_tokens,
+                      "fixed_length_tokens": n * self.max_length}
+        for idx, padded in batches:
+            inputs = self._batch_tensors(token_lists, idx, padded, device)
+            hidden = tower.cls_model(**inputs).last_hidden_state
+            if out is None:
+                out = torch.empty(n + row_offset, hidden.shape[-1], dtype=torch.bfloat16, device=hidden.device)
+            rows = torch.as_tensor(np.asarray(idx, dtype=np.int64) + int(row_offset))
+            ops.meanpool_pack(hidden, inputs["attention_mask"], normalize=(sim == "cos"), want_f32=False, out_bf16=out,
+                              out_f32=out_f32, dst_rows=rows, max_norm=max_norm)
+        if out is None:   # no texts
+            out = torch.empty(row_offset, 0, dtype=torch.bfloat16, device=device)
+        return out
+
+
+def encode_local_shard(encoder, corpus_ids, corpus, sim, rank, world, max_norm=None):
+    """This rank's contiguous block of the corpus (dist.shard_bounds) -> (bf16 shard [hi-lo, dim], lo, hi)."""
+    lo, hi = shard_bounds(len(corpus_ids), world, rank)
+    shard = encoder.encode([corpus[c] for c in corpus_ids[lo:hi]], sim=sim, max_norm=max_norm)
+    return shard, lo, hi
+
+
+def ranking_sharded(corpus, queries, encoder, block_dict=None, rank=0, world=1, group=None, keep=None):
+    """Multi-GPU form of ms_marco_eval.ranking (scripts/ms_marco_eval.py:189-235): every rank encodes and indexes its
+    own corpus rows, all ranks encode the (small) query set, per-shard fused top-k, one all-gather, merge.
+    Returns the same rank-ordered {qid: {pid: score}} on every rank.  block_dict needs the single-shard Retriever
+    path (world == 1); with world > 1 blocked ids are applied after the merge."""
+    from .ms_marco_eval import KEEP, Retriever
+    from .dist import sharded_search
+    queries_ids, corpus_ids = list(queries.keys()), list(corpus.keys())
+    sim = "cos" if os.environ["CCREC_SIM_TYPE"] == "cos" else "dot"
+    keep = KEEP if keep is None else keep
+    q_bf16 = encoder.encode([queries[q] for q in queries_ids], sim=sim)
+    max_norm = torch.zeros(1, dtype=torch.float32, device=q_bf16.device)
+    shard, lo, hi = encode_local_shard(encoder, corpus_ids, corpus, sim, rank, world, max_norm=max_norm)
+    if world == 1:
+        return Retriever(corpus_ids, shard, max_norm=max_norm).ranking_profile(queries_ids, q_bf16, block_dict, keep)
+    index = ops.CorpusIndex(shard, global_row_offset=lo, max_norm=max_norm)
+    n = len(corpus_ids)
+    maxb = max((len(block_dict[q]) for q in queries_ids), default=0) if block_dict is not None else 0
+    k = min(n, keep + maxb)
+    scores, ids = sharded_search(index, q_bf16, k, group=group)
+    if block_dict is not None:
+        print("using block_dict")
+        pos = {pid: i for i, pid in enumerate(corpus_ids)}
+        lists = []
+        for qid in queries_ids:
+            rows = sorted({pos.get(pid, -1) for pid in block_dict[qid]})
+            assert -1 not in rows, "block id not found"
+            lists.append(rows)
+        ptr = torch.zeros(len(lists) + 1, dtype=torch.int64)
+        ptr[1:] = torch.cumsum(torch.tensor([len(b) for b in lists], dtype=torch.int64), 0)
+        idx = torch.tensor([j for b in lists for j in b], dtype=torch.int64)
+        scores, ids = ops.apply_block(scores, ids, ptr, idx, min(n, keep), n)
+    scores, ids = scores.cpu().tolist(), ids.cpu().tolist()
+    return {qid: dict(zip([corpus_ids[j] for j in row_i], row_s)) for qid, row_i, row_s in zip(queries_ids, ids, scores)}

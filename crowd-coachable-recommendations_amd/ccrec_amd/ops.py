@@ -51,20 +51,35 @@ def pack_bf16(x, normalize=False, out=None, return_norms=False, max_norm=None):
     return (out, norms) if return_norms else out
 
 
-def meanpool_pack(hidden, mask, normalize=False, want_f32=True, want_bf16=True):
+def meanpool_pack(hidden, mask, normalize=False, want_f32=True, want_bf16=True, out_bf16=None, out_f32=None, dst_rows=None,
+                  max_norm=None):
     """Fused masked mean pooling (item_tower.py:141-146) + bf16 pack of [B, L, dim] hidden states.
-    Returns (pooled_f32 or None, packed_bf16 or None)."""
+    Returns (pooled_f32 or None, packed_bf16 or None).
+
+    out_bf16 / out_f32: write into these [rows, dim] tensors (e.g. the resident shard) instead of fresh [B, dim] ones;
+    dst_rows: [B] int64 destination rows inside them (length-sorted batches scatter back to corpus order);
+    max_norm: 1-element fp32 cuda tensor accumulating a bound of the packed rows' norm (see pack_bf16)."""
     lib = require_gpu()
     assert hidden.is_cuda and hidden.dim() == 3 and hidden.dtype in _DTYPES
     hidden = hidden.contiguous()
     mask = mask.to(device=hidden.device, dtype=torch.int64).contiguous()
     B, L, dim = hidden.shape
     assert tuple(mask.shape) == (B, L)
-    f32 = torch.empty(B, dim, dtype=torch.float32, device=hidden.device) if want_f32 else None
-    b16 = torch.empty(B, dim, dtype=torch.bfloat16, device=hidden.device) if want_bf16 else None
+    f32 = out_f32 if out_f32 is not None else (torch.empty(B, dim, dtype=torch.float32, device=hidden.device) if want_f32 else None)
+    b16 = out_bf16 if out_bf16 is not None else (torch.empty(B, dim, dtype=torch.bfloat16, device=hidden.device) if want_bf16 else None)
+    for t, dt in ((f32, torch.float32), (b16, torch.bfloat16)):
+        if t is not None:
+            assert t.is_cuda and t.dtype == dt and t.dim() == 2 and t.shape[1] == dim and t.is_contiguous()
+            assert dst_rows is not None or t.shape[0] >= B
+    if dst_rows is not None:
+        dst_rows = dst_rows.to(device=hidden.device, dtype=torch.int64).contiguous()
+        assert dst_rows.numel() == B
+    if max_norm is not None:
+        assert max_norm.is_cuda and max_norm.dtype == torch.float32 and max_norm.numel() == 1
     with _on(hidden):
-        _lib.check(lib.ccr_meanpool_pack_bf16(_ptr(hidden), _DTYPES[hidden.dtype], _ptr(mask), _ptr(b16), _ptr(f32), B, L,
-                                              dim, int(bool(normalize)), _stream(hidden)), "ccr_meanpool_pack_bf16")
+        _lib.check(lib.ccr_meanpool_pack_bf16_ex(_ptr(hidden), _DTYPES[hidden.dtype], _ptr(mask), _ptr(b16), _ptr(f32),
+                                                 _ptr(dst_rows), _ptr(max_norm), B, L, dim, int(bool(normalize)),
+                                                 _stream(hidden)), "ccr_meanpool_pack_bf16")
     return f32, b16
 
 

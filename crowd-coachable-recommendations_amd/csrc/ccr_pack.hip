@@ -170,10 +170,13 @@ __global__ __launch_bounds__(256) void meanpool_pack_kernel(const T *__restrict_
                                                            const int64_t *__restrict__ mask,
                                                            __bf16 *__restrict__ dst_bf16,
                                                            float *__restrict__ dst_f32, int L, int dim,
-                                                           int normalize) {
+                                                           int normalize, const int64_t *__restrict__ dst_rows,
+                                                           uint32_t *__restrict__ max_bits) {
     __shared__ double red[4];
+    __shared__ float redf[4];
     __shared__ int s_cnt;
     const int b = blockIdx.x;
+    const int64_t ob = dst_rows ? dst_rows[b] : (int64_t)b;   // destination row (length-sorted batches scatter back)
     const int tid = threadIdx.x;
     const int nchunk = dim >> 2;
     const int64_t *m = mask + (int64_t)b * L;
@@ -219,9 +222,10 @@ __global__ __launch_bounds__(256) void meanpool_pack_kernel(const T *__restrict_
         den = nrm > 1e-12 ? nrm : 1e-12;
     }
     nown = 0;
+    float pss = 0.f;   // squared norm of the PACKED row (what the index's filter margin needs a bound of)
     for (int c = tid; c < nchunk && nown < 4; c += blockDim.x, ++nown) {
         float4 a = acc[nown];
-        if (dst_f32) reinterpret_cast<float4 *>(dst_f32 + (int64_t)b * dim)[c] = a;  // un-normalised pooled row
+        if (dst_f32) reinterpret_cast<float4 *>(dst_f32 + ob * dim)[c] = a;  // un-normalised pooled row
         if (dst_bf16) {
             if (normalize) {
                 a.x = (float)((double)a.x / den);
@@ -229,7 +233,24 @@ __global__ __launch_bounds__(256) void meanpool_pack_kernel(const T *__restrict_
                 a.z = (float)((double)a.z / den);
                 a.w = (float)((double)a.w / den);
             }
-            reinterpret_cast<bf16x4 *>(dst_bf16 + (int64_t)b * dim)[c] = cvt4(a);
+            const bf16x4 v = cvt4(a);
+            reinterpret_cast<bf16x4 *>(dst_bf16 + ob * dim)[c] = v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float f = (float)v[e];
+                pss = fmaf(f, f, pss);
+            }
+        }
+    }
+    if (max_bits && dst_bf16) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) pss += __shfl_xor(pss, off, 64);
+        if ((tid & 63) == 0) redf[tid >> 6] = pss;
+        __syncthreads();
+        if (tid == 0) {
+            float tot = 0.f;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += redf[w];
+            atomicMax(max_bits, __float_as_uint(sqrtf(tot) * 1.0001f));   // non-negative floats order as uints
         }
     }
 }
@@ -299,8 +320,9 @@ extern "C" int ccr_pack_bf16(const float *src, uint16_t *dst, float *norms, int6
     return ccr_pack_bf16_ex(src, dst, norms, nullptr, rows, dim, normalize, stream);
 }
 
-extern "C" int ccr_meanpool_pack_bf16(const void *hidden, int hidden_dtype, const int64_t *mask, uint16_t *dst_bf16,
-                                      float *dst_f32, int B, int L, int dim, int normalize, void *stream) {
+extern "C" int ccr_meanpool_pack_bf16_ex(const void *hidden, int hidden_dtype, const int64_t *mask, uint16_t *dst_bf16,
+                                         float *dst_f32, const int64_t *dst_rows, float *max_norm, int B, int L, int dim,
+                                         int normalize, void *stream) {
     CCR_REQUIRE(hidden && mask && (dst_bf16 || dst_f32), "ccr_meanpool_pack_bf16: null pointer");
     CCR_REQUIRE(B >= 0 && L > 0 && dim > 0 && dim % 4 == 0 && dim <= 4096,
                 "ccr_meanpool_pack_bf16: bad shape B=%d L=%d dim=%d (dim %% 4 == 0, dim <= 4096)", B, L, dim);
@@ -309,18 +331,19 @@ extern "C" int ccr_meanpool_pack_bf16(const void *hidden, int hidden_dtype, cons
     int threads = ((dim / 4 + 63) / 64) * 64;
     if (threads > 256) threads = 256;
     __bf16 *db = reinterpret_cast<__bf16 *>(dst_bf16);
+    uint32_t *mb = reinterpret_cast<uint32_t *>(max_norm);
     switch (hidden_dtype) {
         case CCR_DTYPE_F32:
             hipLaunchKernelGGL(meanpool_pack_kernel<float>, dim3(B), dim3(threads), 0, s, (const float *)hidden, mask, db,
-                               dst_f32, L, dim, normalize);
+                               dst_f32, L, dim, normalize, dst_rows, mb);
             break;
         case CCR_DTYPE_F16:
             hipLaunchKernelGGL(meanpool_pack_kernel<_Float16>, dim3(B), dim3(threads), 0, s, (const _Float16 *)hidden,
-                               mask, db, dst_f32, L, dim, normalize);
+                               mask, db, dst_f32, L, dim, normalize, dst_rows, mb);
             break;
         case CCR_DTYPE_BF16:
             hipLaunchKernelGGL(meanpool_pack_kernel<__bf16>, dim3(B), dim3(threads), 0, s, (const __bf16 *)hidden, mask,
-                               db, dst_f32, L, dim, normalize);
+                               db, dst_f32, L, dim, normalize, dst_rows, mb);
             break;
         default:
             set_error("ccr_meanpool_pack_bf16: unknown hidden_dtype %d", hidden_dtype);
@@ -328,4 +351,10 @@ extern "C" int ccr_meanpool_pack_bf16(const void *hidden, int hidden_dtype, cons
     }
     CCR_LAUNCH_CHECK();
     return CCR_OK;
+}
+
+extern "C" int ccr_meanpool_pack_bf16(const void *hidden, int hidden_dtype, const int64_t *mask, uint16_t *dst_bf16,
+                                      float *dst_f32, int B, int L, int dim, int normalize, void *stream) {
+    return ccr_meanpool_pack_bf16_ex(hidden, hidden_dtype, mask, dst_bf16, dst_f32, nullptr, nullptr, B, L, dim, normalize,
+                                     stream);
 }

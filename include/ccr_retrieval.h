@@ -89,6 +89,15 @@ int ccr_pack_bf16_ex(const float *src, uint16_t *dst, float *norms, float *max_n
  */
 int ccr_meanpool_pack_bf16(const void *hidden, int hidden_dtype, const int64_t *mask, uint16_t *dst_bf16,
                            float *dst_f32, int B, int L, int dim, int normalize, void *stream);
+/* Same for length-sorted (variable-length) encoder batches that write straight into the resident shard:
+ *   dst_rows [B] int64 or NULL: pooled row b goes to row dst_rows[b] of dst_bf16 / dst_f32 (NULL = row b);
+ *   max_norm (device float) or NULL: max-accumulates a bound of the packed rows' L2 norm, as ccr_pack_bf16_ex.
+ * The pooled value does not depend on L (masked positions are skipped, real tokens are summed in order), so a batch
+ * padded to its own longest text gives the same bits as the reference's fixed max_length padding (item_tower.py:29,
+ * tokenizer_kw) whenever the encoder's hidden states for the real tokens are the same. */
+int ccr_meanpool_pack_bf16_ex(const void *hidden, int hidden_dtype, const int64_t *mask, uint16_t *dst_bf16,
+                              float *dst_f32, const int64_t *dst_rows, float *max_norm, int B, int L, int dim,
+                              int normalize, void *stream);
 
 /*
  * Build a search index over a resident bf16 corpus shard (borrowed pointer, no copy).

@@ -134,3 +134,22 @@ def test_sharded_search_gloo_world2(tmp_path, n, k):
     mp.spawn(_worker, args=(2, port, n, 6, k, str(tmp_path)), nprocs=2, join=True)
     for r in range(2):
         assert open(tmp_path / f"rank{r}.txt").read() == "ok"
+
+
+def test_plan_batches_covers_every_text_once_under_the_budget():
+    """Host logic of the length-sorted encoder."""
+    from ccrec_amd.encode import plan_batches
+    rs = np.random.RandomState(0)
+    lengths = rs.randint(1, 200, 5000)
+    batches = plan_batches(lengths, max_tokens=4096, max_batch=64, pad_multiple=8)
+    seen = np.concatenate([idx for idx, _ in batches])
+    assert np.array_equal(np.sort(seen), np.arange(5000))
+    prev = 0
+    for idx, padded in batches:
+        assert 1 <= len(idx) <= 64 and padded % 8 == 0 and padded >= lengths[idx].max() > padded - 8
+        assert len(idx) * padded <= 4096 or len(idx) == 1
+        assert lengths[idx].min() >= prev          # ascending across batches
+        prev = lengths[idx].max()
+    padded_total = sum(len(i) * p for i, p in batches)
+    assert padded_total < 1.1 * lengths.sum() + 8 * 5000 and padded_total < 0.6 * 5000 * 200
+    assert plan_batches([], 4096) == [] and plan_batches([9000], 4096)[0][1] == 9000

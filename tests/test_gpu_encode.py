@@ -1,0 +1,181 @@
+"""length-sorted variable-length encode, pooled + packed straight into the shard
+(ccr_meanpool_pack_bf16_ex), per-rank corpus shards.  Parity: the scatter/max-norm kernel is bit-exact against
+the oracle's pooling; the length-sorted encoder equals the reference's fixed max_length padding
+(item_tower.py:27-33) up to the encoder's fp32 reduction-order noise; a 2-rank sharded ranking equals the
+single-process one exactly."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, PKG
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+class ToyTokenizer:
+    """Whitespace tokenizer; honours padding=False / "max_length" / True like the HF call the reference makes."""
+    pad_token_id = 0
+
+    def __call__(self, texts, truncation=True, padding=True, max_length=32, return_tensors="pt"):
+        ids = [[1] + [2 + (sum(map(ord, w)) * 7 % 500) for w in t.split()][: max_length - 2] + [3] for t in texts]
+        if padding is False:
+            return {"input_ids": ids, "attention_mask": [[1] * len(r) for r in ids]}
+        L = max_length if padding == "max_length" else max(len(r) for r in ids)
+        input_ids = torch.zeros(len(ids), L, dtype=torch.long)
+        mask = torch.zeros(len(ids), L, dtype=torch.long)
+        for r, row in enumerate(ids):
+            input_ids[r, : len(row)] = torch.tensor(row)
+            mask[r, : len(row)] = 1
+        return {"input_ids": input_ids, "attention_mask": mask}
+
+
+def _tower(seed=0):
+    from transformers import BertConfig, BertModel
+    from ccrec_amd.item_tower import NaiveItemTower
+    torch.manual_seed(seed)
+    cfg = BertConfig(vocab_size=512, hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+                     max_position_embeddings=64)
+    return NaiveItemTower(BertModel(cfg).eval(), torch.nn.LayerNorm(64, elementwise_affine=False)).cuda()
+
+
+def _texts(n, seed, lo=2, hi=28):
+    rs = np.random.RandomState(seed)
+    words = [f"w{i}" for i in range(300)]
+    return [" ".join(rs.choice(words, rs.randint(lo, hi))) for _ in range(n)]
+
+
+@pytest.mark.parametrize("normalize", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_meanpool_scatter_and_max_norm_bit_exact(normalize, dtype):
+    from ccrec_amd import ops
+    B, L, d, rows_total = 37, 24, 768, 100
+    g = torch.Generator().manual_seed(5)
+    hidden = (torch.randn(B, L, d, generator=g) * 0.3).to(dtype)
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    mask = (torch.arange(L)[None, :] < lens[:, None]).long()
+    mask[3] = 0
+    mask[3, 5] = 1                      # a non-prefix mask: position 5 only
+    rows = torch.randperm(rows_total, generator=g)[:B]
+    out = torch.zeros(rows_total, d, dtype=torch.bfloat16, device="cuda")
+    out32 = torch.zeros(rows_total, d, dtype=torch.float32, device="cuda")
+    mx = torch.zeros(1, dtype=torch.float32, device="cuda")
+    ops.meanpool_pack(hidden.cuda(), mask.cuda(), normalize=normalize, out_bf16=out, out_f32=out32, dst_rows=rows, max_norm=mx)
+    ref32 = orc.meanpool(hidden.float().numpy(), mask.numpy())
+    got16 = out.view(torch.int16).cpu().numpy().view(np.uint16)
+    assert np.array_equal(out32.cpu().numpy()[rows.numpy()].view(np.uint32), ref32.view(np.uint32))
+    if normalize:   # the kernel's fp64 norm reduction order is its own: compare values (as test_gpu_pack does)
+        refn = ref32 / np.maximum(np.linalg.norm(ref32.astype(np.float64), axis=1, keepdims=True), 1e-12)
+        np.testing.assert_allclose(orc.unpack_bf16(got16[rows.numpy()]), refn, atol=4e-3, rtol=8e-3)
+    else:
+        assert np.array_equal(got16[rows.numpy()], orc.pack_bf16(ref32))
+    untouched = np.setdiff1d(np.arange(rows_total), rows.numpy())
+    assert not got16[untouched].any() and not out32.cpu().numpy()[untouched].any()
+    ref16 = got16[rows.numpy()]
+    true_max = float(np.sqrt((orc.unpack_bf16(ref16).astype(np.float64) ** 2).sum(1)).max())
+    assert true_max <= float(mx.item()) <= true_max * 1.001
+
+
+def test_plan_and_encode_match_fixed_padding():
+    """Length-sorted batches vs the reference's tokenizer_kw (padding="max_length"): same pooled rows up to the fp32
+    noise of the encoder at a different padded length; far fewer padded tokens."""
+    from ccrec_amd.encode import LengthSortedEncoder
+    tower, tok = _tower(), ToyTokenizer()
+    texts = _texts(333, 1)
+    enc = LengthSortedEncoder(tower, tok, max_length=32, max_tokens=1024, max_batch=64)
+    out32 = torch.zeros(len(texts), 64, dtype=torch.float32, device="cuda")
+    mx = torch.zeros(1, dtype=torch.float32, device="cuda")
+    got = enc.encode(texts, sim="dot", out_f32=out32, max_norm=mx)
+    st = enc.stats
+    assert st["texts"] == 333 and st["real_tokens"] <= st["padded_tokens"] < 0.75 * st["fixed_length_tokens"]
+    assert st["batches"] > 333 // 64           # the token budget, not only max_batch, cut the batches
+    # reference path: fixed padding to max_length, corpus order, pooled by the same kernel
+    ref32, ref16 = [], []
+    with torch.no_grad():
+        for lo in range(0, len(texts), 50):
+            toks = tok(texts[lo:lo + 50], padding="max_length", max_length=32)
+            ref32.append(tower(**{k: v.cuda() for k, v in toks.items()}, output_step="mean_pooling"))
+            ref16.append(tower(**{k: v.cuda() for k, v in toks.items()}, output_step="mean_pooling_bf16"))
+    ref32, ref16 = torch.cat(ref32), torch.cat(ref16)
+    torch.testing.assert_close(out32, ref32, rtol=1e-4, atol=1e-5)        # tolerance: fp32 reduction order inside BERT
+    diff = (got.view(torch.int16).int() - ref16.view(torch.int16).int()).abs()
+    assert int(diff.max()) <= 1 and float((diff != 0).float().mean()) < 0.02   # bf16 rows: equal bits, rare 1-ulp flips
+    packed_norm = got.float().norm(dim=1).max().item()
+    assert packed_norm <= mx.item() <= packed_norm * 1.001
+
+
+def test_ranking_sharded_single_rank_equals_ranking_api():
+    from ccrec_amd.encode import LengthSortedEncoder, ranking_sharded
+    os.environ["CCREC_SIM_TYPE"] = "cos"
+    tower, tok = _tower(), ToyTokenizer()
+    corpus = {f"p{j}": t for j, t in enumerate(_texts(500, 2))}
+    queries = {f"q{i}": t for i, t in enumerate(_texts(7, 3, 2, 9))}
+    enc = LengthSortedEncoder(tower, tok, max_length=32, max_tokens=2048)
+    block = {q: [f"p{(7 * i + j) % 500}" for j in range(3)] for i, q in enumerate(queries)}
+    prof = ranking_sharded(corpus, queries, enc, block_dict=block, keep=50)
+    # the oracle on the encoder outputs the product packed (fp32 rows recovered by a second encode into out_f32 would
+    # not be bit-reproducible; the packed bf16 rows ARE the inputs of the search)
+    q16 = enc.encode(list(queries.values()), sim="cos")
+    d16 = enc.encode(list(corpus.values()), sim="cos")
+    Qb = q16.view(torch.int16).cpu().numpy().view(np.uint16)
+    Db = d16.view(torch.int16).cpu().numpy().view(np.uint16)
+    blocked = [[int(p[1:]) for p in block[q]] for q in queries]
+    ref_i, ref_s = orc.canonical_search(Qb, Db, 50, block=blocked)
+    got_i = np.array([[int(p[1:]) for p in prof[q]] for q in queries])
+    got_s = np.array([list(prof[q].values()) for q in queries], np.float32)
+    assert np.array_equal(got_i, ref_i) and np.array_equal(got_s.view(np.uint32), ref_s.view(np.uint32))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    sys.path[:0] = [ROOT, PKG]
+    os.environ["CCREC_SIM_TYPE"] = "dot"
+    from ccrec_amd.encode import LengthSortedEncoder, ranking_sharded
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    tower, tok = _tower(), ToyTokenizer()
+    corpus = {f"p{j}": t for j, t in enumerate(_texts(901, 4))}
+    queries = {f"q{i}": t for i, t in enumerate(_texts(5, 5, 2, 9))}
+    enc = LengthSortedEncoder(tower, tok, max_length=32, max_tokens=4096)
+    prof = ranking_sharded(corpus, queries, enc, rank=rank, world=world, keep=40)
+    torch.save(prof, os.path.join(out_dir, f"prof{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranking_sharded_two_ranks_equal_one(tmp_path):
+    """Two processes (gloo, both on this one GPU) each encode + index half of the corpus; the merged profile must equal
+    the single-process profile: the shard batches differ, so compare ids exactly and scores to the encoder noise."""
+    import torch.multiprocessing as mp
+    from ccrec_amd.encode import LengthSortedEncoder, ranking_sharded
+    port = _free_port()
+    mp.spawn(_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    p0, p1 = torch.load(tmp_path / "prof0.pt"), torch.load(tmp_path / "prof1.pt")
+    assert p0 == p1                                            # every rank holds the same merged result
+    os.environ["CCREC_SIM_TYPE"] = "dot"
+    tower, tok = _tower(), ToyTokenizer()
+    corpus = {f"p{j}": t for j, t in enumerate(_texts(901, 4))}
+    queries = {f"q{i}": t for i, t in enumerate(_texts(5, 5, 2, 9))}
+    single = ranking_sharded(corpus, queries, LengthSortedEncoder(tower, tok, max_length=32, max_tokens=4096), keep=40)
+    for q in queries:
+        a, b = single[q], p0[q]
+        assert len(a) == len(b) == 40
+        sa, sb = np.array(list(a.values())), np.array(list(b.values()))
+        np.testing.assert_allclose(sa, sb, rtol=1e-3, atol=1e-3)
+        # ids agree wherever neighbouring scores are separated by more than the encoder noise
+        ia, ib = list(a), list(b)
+        for r in range(40):
+            if ia[r] != ib[r]:
+                assert abs(sa[r] - sb[r]) < 1e-3 and ib[r] in ia[max(0, r - 3):r + 4]
