@@ -19,6 +19,9 @@ Fixtures:
   G7 multiple_nrl in-batch-negative loss + autograd grads
   G8 _assign_topk on a MatMulExpression
   G9 fp32->bf16 RNE bit patterns (torch, not the reference)
+  G10 request builder (scripts/al_0_rank.py '## creation' block, executed from the reference file in a prepared
+      namespace: the script itself is not importable -- it parses argv and loads datasets at import time)
+  G11 generate_train_data (scripts/al_oracle_agent.py, the function's own source executed the same way)
 """
 import contextlib
 import importlib.abc
@@ -256,14 +259,98 @@ def g_pack():
     np.savez_compressed(f"{OUT}/g9_pack_bf16.npz", x=x.numpy(), bits=bits)
 
 
+def _reference_lines(rel_path, first_marker, last_marker=None):
+    """Source text of a reference script between two marker lines (inclusive of the first; to EOF if no last)."""
+    lines = open(os.path.join(REF, rel_path)).read().split("\n")
+    lo = next(i for i, l in enumerate(lines) if l.startswith(first_marker))
+    hi = len(lines) if last_marker is None else next(i for i, l in enumerate(lines) if i > lo and l.startswith(last_marker))
+    return "\n".join(lines[lo:hi])
+
+
+def _toy_profiles(seed, n_docs=40, n_queries=9, depth=12):
+    rs = np.random.RandomState(seed)
+    alphabet = list("abcdefghij KLMNOP,:.;?$!()&[]#@%^*~\u00e9\u4e2d")
+    corpus = {str(100 + j): "".join(rs.choice(alphabet, rs.randint(5, 60))) for j in range(n_docs)}
+    queries = {str(j): "query " + "".join(rs.choice(alphabet, rs.randint(3, 20))) for j in range(n_queries)}
+    keys = list(corpus)
+
+    def profile(overlap_with=None):
+        prof = {}
+        for qid in queries:
+            order = [keys[i] for i in rs.permutation(n_docs)[:depth]]
+            if overlap_with is not None and rs.rand() < 0.7:     # BM25 often repeats the dense top-2
+                order[:2] = list(overlap_with[qid])[:2][::-1]
+            prof[qid] = {pid: float(depth - r) for r, pid in enumerate(order)}
+        return prof
+    dense = profile()
+    return corpus, queries, dense, profile(dense)
+
+
+def g_requests():
+    """G10: run the reference's own request-creation block on toy inputs, with and without landingImage."""
+    import json
+    import tempfile
+    import pandas as pd
+    import re as _re
+    src = _reference_lines("scripts/al_0_rank.py", "## creation")
+    cases = {}
+    for name, seed, step, with_img in (("plain", 0, 1, False), ("images", 1, 2, True)):
+        corpus, queries, dense, bm25 = _toy_profiles(seed)
+        qids = list(queries)
+        splits = [qids[0::3], qids[1::3], qids[2::3]]
+        with tempfile.TemporaryDirectory() as tmp:
+            os.environ["CCREC_DISPLAY_LENGTH"] = "25"
+            ns = dict(np=np, pd=pd, re=_re, os=os, torch=torch, corpus=corpus, queries=queries, ranking_profile=dense,
+                      ranking_profile_bm25=bm25, qids_split=splits, STEP=step, number_of_qid_split_batch=3,
+                      landingImage=({**{q: f"img_q{q}.jpg" for q in queries}, **{p: f"img_{p}.jpg" for p in corpus}}
+                                    if with_img else None),
+                      current_working_dir=tmp, N_REPEATS=2, REPEAT_SEED=7)
+            with contextlib.redirect_stdout(io.StringIO()):
+                exec(compile(src, "al_0_rank.py[creation]", "exec"), ns)
+            cases[name] = {
+                "inputs": {"corpus": corpus, "queries": queries, "ranking_profile": dense, "ranking_profile_bm25": bm25,
+                           "qids_split": splits, "STEP": step, "number_of_qid_split_batch": 3, "landingImage": ns["landingImage"],
+                           "N_REPEATS": 2, "REPEAT_SEED": 7, "CCREC_DISPLAY_LENGTH": 25},
+                "request_orig_csv": open(os.path.join(tmp, "request_orig.csv")).read(),
+                "request_perm_csv": open(os.path.join(tmp, "request_perm.csv")).read(),
+                "id_track": torch.load(os.path.join(tmp, "id_track.pt")),
+            }
+    json.dump(cases, open(os.path.join(OUT, "g10_requests.json"), "w"), ensure_ascii=True, indent=0)
+    print("g10_requests.json", {k: len(v["request_perm_csv"]) for k, v in cases.items()})
+
+
+def g_train_data():
+    """G11: the reference's generate_train_data (al_oracle_agent.py) on toy inputs; random.shuffle seeded."""
+    import json
+    import random
+    src = _reference_lines("scripts/al_oracle_agent.py", "def generate_train_data(", "def combine_train_data(")
+    ns = dict(np=np, random=random)
+    exec(compile(src, "al_oracle_agent.py[generate_train_data]", "exec"), ns)
+    cases = {}
+    for name, seed, with_keys in (("no_random_pad", 3, False), ("attention_check", 4, True)):
+        corpus, queries, dense, bm25 = _toy_profiles(seed)
+        rs = np.random.RandomState(seed)
+        qrels = {q: {list(dense[q])[int(rs.randint(0, 6))]: 1} for q in queries}
+        qids = list(queries)[::2] + list(queries)[1::2]
+        random.seed(1234 + seed)
+        out = ns["generate_train_data"](qids, qrels, dense, bm25, list(corpus) if with_keys else [], rng_seed=seed)
+        cases[name] = {"inputs": {"qids": qids, "qrels": qrels, "ranking_profile": dense, "ranking_profile_2": bm25,
+                                  "corpus_key_list": list(corpus) if with_keys else [], "rng_seed": seed,
+                                  "random_seed": 1234 + seed},
+                       "train_data": out}
+    json.dump(cases, open(os.path.join(OUT, "g11_train_data.json"), "w"), indent=0)
+    print("g11_train_data.json", {k: len(v["train_data"]) for k, v in cases.items()})
+
+
 def main():
+    """No arguments: every fixture.  `make_golden.py g10 g11`: only the named groups (g1 = all ranking fixtures)."""
     os.makedirs(OUT, exist_ok=True)
-    mod = _import_reference("dot")
-    g_ranking(mod)
-    g_item_tower()
-    g_contrastive()
-    g_assign_topk()
-    g_pack()
+    want = set(sys.argv[1:])
+    groups = [("g1", lambda: g_ranking(_import_reference("dot"))), ("g6", g_item_tower), ("g7", g_contrastive),
+              ("g8", g_assign_topk), ("g9", g_pack), ("g10", g_requests), ("g11", g_train_data)]
+    for name, fn in groups:
+        if not want or name in want:
+            fn()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
