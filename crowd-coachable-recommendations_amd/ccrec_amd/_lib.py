@@ -16,7 +16,8 @@ EXPORTS = [
     "ccr_index_create_with_norm", "ccr_index_destroy",
     "ccr_index_rows", "ccr_index_dim", "ccr_search_workspace_bytes", "ccr_search", "ccr_search_last_stats",
     "ccr_merge_topk", "ccr_merge_topk_strided", "ccr_apply_block", "ccr_inbatch_ce_workspace_bytes", "ccr_inbatch_ce_fwd", "ccr_inbatch_ce_bwd", "ccr_rank_metrics", "ccr_debug_mfma_scores",
-    "ccr_debug_canonical_scores",
+    "ccr_debug_canonical_scores", "ccr_bm25_index_create", "ccr_bm25_index_destroy", "ccr_bm25_search_workspace_bytes",
+    "ccr_bm25_search",
 ]
 
 
@@ -72,6 +73,11 @@ def load():
     lib.ccr_rank_metrics.argtypes = [vp, i32, i32, vp, vp, vp, i32, vp, vp, vp]
     lib.ccr_debug_mfma_scores.argtypes = [vp, vp, i32, vp, vp]
     lib.ccr_debug_canonical_scores.argtypes = [vp, vp, i32, vp, vp]
+    lib.ccr_bm25_index_create.argtypes = [vp, vp, vp, vp, i64, i64, ctypes.c_double, ctypes.POINTER(vp)]
+    lib.ccr_bm25_index_destroy.argtypes = [vp]
+    lib.ccr_bm25_search_workspace_bytes.argtypes = [vp, i32, i32]
+    lib.ccr_bm25_search_workspace_bytes.restype = sz
+    lib.ccr_bm25_search.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp, sz, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is ctypes.c_int and name not in ("ccr_version", "ccr_index_dim"):

@@ -1,0 +1,123 @@
+"""BM25 as a device-side sparse scorer: mirror of scripts/bm_25.py (class BM25) and of
+ranking_bm25 (scripts/ms_marco_eval.py:165-186), whose output -- {qid: {pid: score}} with 1001 entries -- is the
+`ranking_profile_bm25` the request builder consumes (al_request.build_requests).
+
+The reference fits a TfidfVectorizer on the host and scores one query at a time with scipy against all N documents,
+then sorts all N scores.  Here fit() builds the same vocabulary / counts / idf / length factors on the host (text
+analysis is host work), keeps the postings on the device, and transform_topk() scores whole query batches with
+ccr_bm25_search: fp64 accumulation in ascending term order, one rounding to fp32, exact top-k in the order
+(score desc, document index asc).
+"""
+import ctypes
+import re
+
+import numpy as np
+import torch
+
+from . import _lib
+from .ops import require_gpu
+
+_TOKEN = re.compile(r"(?u)\b\w\w+\b")   # scikit-learn's default token_pattern (what TfidfVectorizer() analyses with)
+KEEP = 1001                             # ms_marco_eval.py:183
+
+
+def analyse(text):
+    return _TOKEN.findall(text.lower())
+
+
+class BM25:
+    """fit(X) / transform(q) like scripts/bm_25.py; transform_topk(queries, k) is the batched device path."""
+
+    def __init__(self, b=0.75, k1=1.6):   # bm_25.py:12 (ranking_bm25 passes b=0.75, k1=1.2)
+        self.b, self.k1 = float(b), float(k1)
+        self._h = None
+
+    def fit(self, X):
+        """X: iterable of document strings."""
+        self._lib = require_gpu()
+        docs = [analyse(t) for t in X]
+        self.vocabulary_ = {w: i for i, w in enumerate(sorted({w for d in docs for w in d}))}
+        n, V = len(docs), len(self.vocabulary_)
+        assert n >= 1 and V >= 1, "empty corpus or empty vocabulary"
+        voc = self.vocabulary_
+        flat = np.fromiter((voc[w] for d in docs for w in d), dtype=np.int64)
+        owner = np.repeat(np.arange(n, dtype=np.int64), [len(d) for d in docs])
+        # (term, doc) pairs with counts: sort by term then doc, run-length encode
+        key = flat * n + owner
+        key.sort()
+        uniq, counts = np.unique(key, return_counts=True)
+        terms, rows = uniq // n, uniq % n
+        indptr = np.zeros(V + 1, np.int64)
+        np.add.at(indptr, terms + 1, 1)
+        self.indptr = np.cumsum(indptr)
+        length = np.bincount(owner, minlength=n).astype(np.float64)
+        self.avdl = float(length.mean())
+        self.idf = np.log(n / np.diff(self.indptr).astype(np.float64))          # idf_ - 1 with smooth_idf=False
+        doc_k = self.k1 * (1 - self.b + self.b * length / self.avdl)
+        self.n_docs = n
+        self._doc_ids = torch.from_numpy(rows.astype(np.int32)).cuda()
+        self._tf = torch.from_numpy(counts.astype(np.float32)).cuda()
+        self._doc_k = torch.from_numpy(doc_k).cuda()
+        self._h = ctypes.c_void_p()
+        _lib.check(self._lib.ccr_bm25_index_create(self.indptr.ctypes.data_as(ctypes.c_void_p), self._doc_ids.data_ptr(),
+                                                   self._tf.data_ptr(), self._doc_k.data_ptr(), V, n, self.k1,
+                                                   ctypes.byref(self._h)), "ccr_bm25_index_create")
+        return self
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.ccr_bm25_index_destroy(h)
+
+    def query_terms(self, q):
+        """Distinct in-vocabulary term ids of q, ascending (CountVectorizer.transform([q]).indices)."""
+        voc = self.vocabulary_
+        return np.asarray(sorted({voc[w] for w in analyse(q) if w in voc}), np.int32)
+
+    def transform_topk(self, queries, k):
+        """queries: list of strings -> (scores [n_q, k] fp32, document rows [n_q, k] int64) on the device."""
+        assert self._h, "fit() first"
+        k = min(int(k), self.n_docs)
+        terms = [self.query_terms(q) for q in queries]
+        n_q = len(terms)
+        q_ptr = np.zeros(n_q + 1, np.int64)
+        q_ptr[1:] = np.cumsum([len(t) for t in terms])
+        q_terms = np.concatenate(terms).astype(np.int32) if q_ptr[-1] else np.zeros(1, np.int32)
+        q_idf = np.ascontiguousarray(self.idf[q_terms[:q_ptr[-1]]], np.float64) if q_ptr[-1] else np.zeros(1, np.float64)
+        scores = torch.empty(n_q, k, dtype=torch.float32, device="cuda")
+        ids = torch.empty(n_q, k, dtype=torch.int64, device="cuda")
+        if n_q == 0:
+            return scores, ids
+        need = int(self._lib.ccr_bm25_search_workspace_bytes(self._h, n_q, int(max(len(t) for t in terms))))
+        ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+        vp = ctypes.c_void_p
+        _lib.check(self._lib.ccr_bm25_search(self._h, q_ptr.ctypes.data_as(vp), q_terms.ctypes.data_as(vp), q_idf.ctypes.data_as(vp),
+                                             n_q, k, scores.data_ptr(), ids.data_ptr(), ws.data_ptr(), ws.numel(),
+                                             vp(torch.cuda.current_stream().cuda_stream)), "ccr_bm25_search")
+        torch.cuda.current_stream().synchronize()   # the host arrays above must outlive the stream work
+        return scores, ids
+
+    def transform(self, q, X=None):
+        """bm_25.py:31-52: dense [n_docs] score vector of one query (small corpora / tests: reads back k = n_docs)."""
+        assert X is None, "re-caching another corpus: fit() a new BM25 instead"
+        s, i = self.transform_topk([q], self.n_docs)
+        out = np.zeros(self.n_docs, np.float32)
+        out[i[0].cpu().numpy()] = s[0].cpu().numpy()
+        return out
+
+
+def ranking_bm25(corpus, queries, b=0.75, k1=1.2, keep=KEEP, batch=4096):
+    """scripts/ms_marco_eval.py:165-186: {qid: {pid: score}} in rank order, min(1001, N) entries per query."""
+    print("Fitting BM-25 model")
+    model = BM25(b=b, k1=k1).fit(list(corpus.values()))
+    print("Retrieval with BM-25 model")
+    queries_ids, corpus_ids = list(queries.keys()), list(corpus.keys())
+    profile = {}
+    for lo in range(0, len(queries_ids), batch):
+        qids = queries_ids[lo:lo + batch]
+        print("processing query: {} | {}".format(lo, len(queries_ids)))
+        s, i = model.transform_topk([queries[q] for q in qids], keep)
+        s, i = s.cpu().tolist(), i.cpu().tolist()
+        for qid, row_i, row_s in zip(qids, i, s):
+            profile[qid] = dict(zip([corpus_ids[j] for j in row_i], row_s))
+    return profile

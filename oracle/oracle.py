@@ -285,3 +285,68 @@ def mrr(ids, qrels, kmax):
                 tot += 1.0 / (r + 1)
                 break
     return round(tot / max(1, len(qrels)), 5)
+
+
+# ----------------------------------------------------------------------------- BM25 (lexical leg of the candidate builder)
+_TOKEN = None
+
+
+def bm25_tokens(text):
+    """The analyser the reference's TfidfVectorizer() uses with default settings (scripts/bm_25.py:13; scikit-learn
+    1.x CountVectorizer: lowercase, token_pattern r"(?u)\\b\\w\\w+\\b", no stop words, unigrams)."""
+    global _TOKEN
+    if _TOKEN is None:
+        import re
+        _TOKEN = re.compile(r"(?u)\b\w\w+\b")
+    return _TOKEN.findall(text.lower())
+
+
+def bm25_fit(texts, b=0.75, k1=1.2):
+    """BM25.fit (scripts/bm_25.py:17-28): vocabulary = sorted distinct tokens (scikit-learn orders features
+    alphabetically), count matrix in term-major (CSC) form, idf_t - 1 = ln(n / df_t) (smooth_idf=False, bm_25.py:47),
+    len_d = counted tokens of d, avdl = mean, doc_k = k1 * (1 - b + b * len_d / avdl) in fp64 (bm_25.py:45)."""
+    docs = [bm25_tokens(t) for t in texts]
+    vocab = {w: i for i, w in enumerate(sorted({w for d in docs for w in d}))}
+    n, V = len(docs), len(vocab)
+    rows, cols, vals = [], [], []
+    for d, toks in enumerate(docs):
+        cnt = {}
+        for w in toks:
+            cnt[vocab[w]] = cnt.get(vocab[w], 0) + 1
+        for t, c in cnt.items():
+            rows.append(d)
+            cols.append(t)
+            vals.append(c)
+    rows, cols, vals = np.asarray(rows, np.int64), np.asarray(cols, np.int64), np.asarray(vals, np.float64)
+    order = np.lexsort((rows, cols))                       # term-major, documents ascending inside a term
+    rows, cols, vals = rows[order], cols[order], vals[order]
+    indptr = np.zeros(V + 1, np.int64)
+    np.add.at(indptr, cols + 1, 1)
+    indptr = np.cumsum(indptr)
+    df = np.diff(indptr).astype(np.float64)
+    length = np.zeros(n, np.float64)
+    np.add.at(length, rows, vals)
+    avdl = length.mean()
+    return {"vocab": vocab, "indptr": indptr, "doc_ids": rows.astype(np.int32), "tf": vals.astype(np.float32),
+            "idf": np.log(n / df), "doc_k": k1 * (1 - b + b * length / avdl), "n_docs": n, "k1": float(k1), "b": float(b)}
+
+
+def bm25_query_terms(model, text):
+    """Distinct in-vocabulary terms of the query, ascending term id (CountVectorizer.transform([q]).indices)."""
+    return np.asarray(sorted({model["vocab"][w] for w in bm25_tokens(text) if w in model["vocab"]}), np.int32)
+
+
+def bm25_scores(model, text):
+    """[n_docs] fp32 canonical BM25 scores of one query."""
+    terms = bm25_query_terms(model, text)
+    idf = np.ascontiguousarray(model["idf"][terms], np.float64)
+    out = np.empty(model["n_docs"], np.float32)
+    lib().orc_bm25_scores(_p(model["indptr"]), _p(model["doc_ids"]), _p(model["tf"]), _p(np.ascontiguousarray(model["doc_k"])),
+                          _i64(model["n_docs"]), _p(terms), _p(idf), _i64(len(terms)), ctypes.c_double(model["k1"]), _p(out))
+    return out
+
+
+def bm25_ranking(model, query_texts, k):
+    """ranking_bm25 (scripts/ms_marco_eval.py:165-186) with the canonical tie rule: (ids [nq,k], scores [nq,k])."""
+    sc = np.stack([bm25_scores(model, t) for t in query_texts])
+    return rank(sc, min(k, model["n_docs"]))

@@ -1,0 +1,86 @@
+"""BM25 sparse scorer.  CPU: the oracle restatement against fixtures produced by the reference's own
+bm_25.BM25 / ranking_bm25 (tools/make_golden.py g12).  GPU: ccr_bm25_search against the oracle, bit for bit."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+
+def _golden(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "g12_bm25.json")))
+    dense = np.load(os.path.join(golden_dir, "g12_bm25_scores.npz"))["dense"]
+    return g, dense
+
+
+def test_oracle_bm25_matches_reference_fixture(golden_dir):
+    g, dense = _golden(golden_dir)
+    model = orc.bm25_fit(list(g["corpus"].values()), b=g["b"], k1=g["k1"])
+    assert model["vocab"] == g["vocabulary"]                       # same analyser, same alphabetical feature order
+    assert abs(model["doc_k"].mean() - g["k1"]) < 1e-9              # mean of k1 * (1 - b + b * len / avdl) is k1
+    qtexts = list(g["queries"].values())
+    got = np.stack([orc.bm25_scores(model, t) for t in qtexts])
+    # the reference sums a query's terms in numpy's pairwise order (>= 8 terms), the oracle in ascending order:
+    # fp64 results agree to 1e-12, i.e. to the last bit of fp32 except on rare rounding boundaries
+    np.testing.assert_allclose(got, dense.astype(np.float32), rtol=2e-7, atol=0)
+    assert (got != dense.astype(np.float32)).mean() < 1e-3
+    oov = list(g["queries"]).index("q_oov")
+    assert not got[oov].any() and len(orc.bm25_query_terms(model, g["queries"]["q_rep"])) == 3
+    # ranking_bm25 profile: 1001 -> min(1001, N) entries, rank order, scores as the reference printed them
+    ids, sc = orc.bm25_ranking(model, qtexts, 1001)
+    cids = list(g["corpus"])
+    for r, qid in enumerate(g["queries"]):
+        ref = g["profile"][qid]
+        assert len(ref) == ids.shape[1] == len(cids)
+        ref_s = np.array(list(ref.values()), np.float32)
+        np.testing.assert_allclose(sc[r], ref_s, rtol=2e-7, atol=0)
+        # ids agree wherever the score is not tied with a neighbour (torch.sort leaves tie order unspecified)
+        ref_i = [cids.index(p) for p in ref]
+        uniq = np.flatnonzero(np.concatenate(([True], sc[r][1:] != sc[r][:-1])) & np.concatenate((sc[r][:-1] != sc[r][1:], [True])))
+        assert all(ids[r][j] == ref_i[j] for j in uniq)
+    d3, d7 = cids.index("d3"), cids.index("d7")                     # duplicate documents: the lower index ranks first
+    for r in range(ids.shape[0]):
+        row = list(ids[r])
+        a, b_ = row.index(d3), row.index(d7)
+        assert a < b_ and sc[r][a] == sc[r][b_] and all(d3 < ids[r][j] < d7 for j in range(a + 1, b_))
+
+
+@pytest.mark.gpu
+def test_hip_bm25_bit_exact_vs_oracle_and_profile(golden_dir):
+    from ccrec_amd.bm25 import BM25, ranking_bm25
+    g, dense = _golden(golden_dir)
+    texts, qtexts = list(g["corpus"].values()), list(g["queries"].values())
+    model = orc.bm25_fit(texts, b=g["b"], k1=g["k1"])
+    hip = BM25(b=g["b"], k1=g["k1"]).fit(texts)
+    assert hip.vocabulary_ == g["vocabulary"] and abs(hip.avdl - g["avdl"]) < 1e-12
+    ref_i, ref_s = orc.bm25_ranking(model, qtexts, 50)
+    s, i = hip.transform_topk(qtexts, 50)
+    assert np.array_equal(i.cpu().numpy(), ref_i) and np.array_equal(s.cpu().numpy().view(np.uint32), ref_s.view(np.uint32))
+    np.testing.assert_allclose(hip.transform(qtexts[0]), dense[0].astype(np.float32), rtol=2e-7)
+    prof = ranking_bm25(g["corpus"], g["queries"])
+    assert list(prof) == list(g["queries"])
+    for qid in g["queries"]:
+        np.testing.assert_allclose(list(prof[qid].values()), list(g["profile"][qid].values()), rtol=2e-7)
+        assert len(prof[qid]) == len(g["profile"][qid])
+
+
+@pytest.mark.gpu
+def test_hip_bm25_larger_corpus_many_batches():
+    """40k documents, 700 queries (several accumulator batches, long posting lists): ids and score bits vs the oracle."""
+    from ccrec_amd.bm25 import BM25
+    rs = np.random.RandomState(5)
+    words = np.array([f"t{i}" for i in range(3000)])
+    p = 1.0 / np.arange(1, 3001) ** 1.1
+    p /= p.sum()
+    texts = [" ".join(rs.choice(words, rs.randint(5, 60), p=p)) for _ in range(40000)]
+    qtexts = [" ".join(rs.choice(words, rs.randint(1, 12), p=p)) for _ in range(700)]
+    model = orc.bm25_fit(texts, 0.75, 1.2)
+    hip = BM25(0.75, 1.2).fit(texts)
+    s, i = hip.transform_topk(qtexts, 100)
+    sub = list(range(0, 700, 23))
+    ref_i, ref_s = orc.bm25_ranking(model, [qtexts[j] for j in sub], 100)
+    assert np.array_equal(i.cpu().numpy()[sub], ref_i)
+    assert np.array_equal(s.cpu().numpy()[sub].view(np.uint32), ref_s.view(np.uint32))

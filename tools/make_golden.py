@@ -22,6 +22,7 @@ Fixtures:
   G10 request builder (scripts/al_0_rank.py '## creation' block, executed from the reference file in a prepared
       namespace: the script itself is not importable -- it parses argv and loads datasets at import time)
   G11 generate_train_data (scripts/al_oracle_agent.py, the function's own source executed the same way)
+  G12 BM25: the reference's bm_25.BM25 (imported) and ranking_bm25 (function source executed) on a toy corpus
 """
 import contextlib
 import importlib.abc
@@ -342,12 +343,40 @@ def g_train_data():
     print("g11_train_data.json", {k: len(v["train_data"]) for k, v in cases.items()})
 
 
+def g_bm25():
+    """G12: dense BM25 score vectors from the reference's BM25.transform and the ranking_bm25 profile."""
+    import json
+    sys.path.insert(0, os.path.join(REF, "scripts"))
+    import bm_25
+    rs = np.random.RandomState(12)
+    words = [f"w{i}" for i in range(120)] + ["Alpha", "beta-gamma", "x", "42", "caf\u00e9", "a1", "THE", "the"]
+    zipf = 1.0 / np.arange(1, len(words) + 1)
+    zipf /= zipf.sum()
+    corpus = {f"d{j}": " ".join(rs.choice(words, rs.randint(1, 40), p=zipf)) for j in range(400)}
+    corpus["d7"] = corpus["d3"]                                  # duplicate document: exact score tie
+    queries = {f"q{i}": " ".join(rs.choice(words, rs.randint(1, 14), p=zipf)) for i in range(12)}
+    queries["q_oov"] = "zzzz qqqq"                               # no vocabulary term: all scores 0
+    queries["q_rep"] = "w0 w0 w0 w1 the THE"                     # repeated terms count once
+    model = bm_25.BM25(b=0.75, k1=1.2).fit(list(corpus.values()))
+    dense = np.stack([model.transform(q) for q in queries.values()])          # fp64 [nq, n_docs]
+    src = _reference_lines("scripts/ms_marco_eval.py", "def ranking_bm25(", "def ranking(")
+    ns = dict(BM25=bm_25.BM25, torch=torch)
+    exec(compile(src, "ms_marco_eval.py[ranking_bm25]", "exec"), ns)
+    with contextlib.redirect_stdout(io.StringIO()):
+        prof = ns["ranking_bm25"](corpus, queries)
+    json.dump({"corpus": corpus, "queries": queries, "b": 0.75, "k1": 1.2,
+               "vocabulary": {k: int(v) for k, v in model.vectorizer.vocabulary_.items()},
+               "avdl": float(model.avdl), "profile": prof}, open(os.path.join(OUT, "g12_bm25.json"), "w"), indent=0)
+    np.savez_compressed(os.path.join(OUT, "g12_bm25_scores.npz"), dense=dense)
+    print("g12_bm25", dense.shape, len(model.vectorizer.vocabulary_))
+
+
 def main():
     """No arguments: every fixture.  `make_golden.py g10 g11`: only the named groups (g1 = all ranking fixtures)."""
     os.makedirs(OUT, exist_ok=True)
     want = set(sys.argv[1:])
     groups = [("g1", lambda: g_ranking(_import_reference("dot"))), ("g6", g_item_tower), ("g7", g_contrastive),
-              ("g8", g_assign_topk), ("g9", g_pack), ("g10", g_requests), ("g11", g_train_data)]
+              ("g8", g_assign_topk), ("g9", g_pack), ("g10", g_requests), ("g11", g_train_data), ("g12", g_bm25)]
     for name, fn in groups:
         if not want or name in want:
             fn()
