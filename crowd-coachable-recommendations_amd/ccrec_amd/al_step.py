@@ -1,0 +1,45 @@
+"""One active-learning step, end to end, on the device path: the sequence scripts/al_0_rank.py runs at module level
+(:107-218) as a function -- rank (cached), report MRR, build the labelling request.
+
+    ranking_profile.pt  <- encode (length-sorted) + fused search      [encode.ranking_sharded / cached on disk]
+    MRR@{1,5,10,100}    <- ccr_rank_metrics on the id tensor           [evaluation.rank_metrics]
+    request_orig.csv, request_perm.csv, id_track.pt                    [al_request.build_requests]
+`ranking_profile_bm25` is an input of the reference (parse_al_args loads it from disk, al_commons.py:55-58);
+pass it in, or leave it None to compute it with bm25.ranking_bm25.
+"""
+import os
+
+import torch
+
+from . import evaluation
+from .al_request import build_requests
+from .bm25 import ranking_bm25
+from .encode import LengthSortedEncoder, ranking_sharded
+
+
+def run_rank_step(tower, tokenizer, corpus, queries, qrels, step_qids, step, results_dir, ranking_profile_bm25=None,
+                  block_dict=None, landing_image=None, n_repeats=3, repeat_seed=42, encoder_kw=None, autocast=True):
+    """-> {"ranking_profile", "mrr", "requests"}; files are written to results_dir/data_iteration_{step}/."""
+    work = os.path.join(results_dir, f"data_iteration_{step}")
+    os.makedirs(work, exist_ok=True)
+    path = os.path.join(work, "ranking_profile.pt")
+    if os.path.isfile(path):                                   # al_0_rank.py:115-118: resume from the saved profile
+        profile = torch.load(path)
+    else:
+        encoder = LengthSortedEncoder(tower, tokenizer, **(encoder_kw or {}))
+        with torch.autocast("cuda", enabled=bool(autocast)):
+            profile = ranking_sharded(corpus, queries, encoder, block_dict=block_dict)
+        torch.save(profile, path)
+    corpus_ids = list(corpus)
+    qids, ids, _ = evaluation.profile_to_tensors(profile, corpus_ids)
+    pos = {pid: i for i, pid in enumerate(corpus_ids)}
+    rel = [[pos[p] for p in qrels.get(q, {}) if p in pos] for q in qids]
+    kmax = ids.shape[1]
+    mrr = evaluation.rank_metrics(ids.cuda(), rel, tuple(k for k in (1, 5, 10, 100) if k <= kmax))
+    for name, value in mrr.items():
+        print(name, ":", value)
+    if ranking_profile_bm25 is None:
+        ranking_profile_bm25 = ranking_bm25(corpus, queries)
+    requests = build_requests(profile, ranking_profile_bm25, step_qids, corpus, queries, step, n_repeats=n_repeats,
+                              repeat_seed=repeat_seed, landing_image=landing_image, out_dir=work)
+    return {"ranking_profile": profile, "mrr": mrr, "requests": requests}
