@@ -802,6 +802,35 @@ __global__ __launch_bounds__(256) void threshold_update_kernel(const uint2 *__re
     }
 }
 
+// Visit every record (sub-list j, slot sl) with first <= sl < count[j]: the (sub-list, slot) rectangle is padded to a
+// power of two per sub-list, BATCH independent 8-byte loads are issued before the first record is consumed.
+template <int THREADS, int BATCH, class At, class Want, class Put>
+__device__ __forceinline__ void sweep_sublists(int tid, int n_lists, int first, int longest, const uint32_t *s_cnt, At at,
+                                               Want want, Put put) {
+    if (longest <= first) return;
+    int lw = 0;
+    while ((1 << lw) < longest - first) ++lw;
+    const int sweep = n_lists << lw;
+    for (int i0 = tid; i0 < sweep; i0 += THREADS * BATCH) {
+        uint2 e[BATCH];
+        int jj[BATCH], ss[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int i = i0 + u * THREADS;
+            const int j = i >> lw, sl = first + (i & ((1 << lw) - 1));
+            jj[u] = -1;
+            ss[u] = sl;
+            if (i < sweep && (uint32_t)sl < s_cnt[j] && want(j, sl)) {
+                jj[u] = j;
+                e[u] = at(j, sl);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u)
+            if (jj[u] >= 0) put(jj[u], ss[u], e[u]);
+    }
+}
+
 // Stage-2: per query, candidates -> exact canonical top-k.  grid = n_q, block = THREADS (256; 1024 for large k).
 // dyn LDS: [dim bf16 query row][sub-list counts][sub-list offsets][rescore_cap u64 keys][compact x 8-byte candidates]
 template <bool GROUPS, int THREADS>
@@ -824,7 +853,7 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
     __shared__ uint32_t s_ctl[4];
     __shared__ uint32_t s_wsum[THREADS / 64];
     __shared__ int s_flag;
-    __shared__ uint32_t s_total, s_maxc;
+    __shared__ uint32_t s_total, s_maxc, s_fill;
     __shared__ uint32_t s_ncoll;
     __shared__ uint32_t s_grp[GROUPS ? 512 : 1];  // first rows of the kept fragments (rescore_cap / 16 <= 512)
 
@@ -835,6 +864,7 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
         s_total = 0;
         s_ncoll = 0;
         s_maxc = 0;
+        s_fill = 0;
     }
     __syncthreads();
     // `ranges` counts SUB-LISTS here (sp per (range, query)); thread t owns the contiguous sub-lists [t*per, t*per+per)
@@ -876,12 +906,12 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
     if (tid == 0 && stat_cand) atomicAdd(stat_cand, (unsigned long long)s_total);
     bool bad = (s_flag != 0) || (s_total < (uint32_t)k);
 
-    const int64_t slots = (int64_t)ranges * cap;
     // sub-list j = (range j / sp, wave-row / lane part j % sp) lives at (((j / sp) * nq_pad + q) * sp + (j % sp)) * cap
     auto at = [&](int j, int sl) -> uint2 { return cand[(((int64_t)(j / sp) * nq_pad + q) * sp + (j % sp)) * cap + sl]; };
     const int coll_cap = GROUPS ? rescore_cap / 16 : rescore_cap;
     uint32_t kth = 0;
     int need_eq = 0;
+    int n_lds = 0;   // candidates resident in s_comp
     if (!bad && s_total <= (uint32_t)compact) {
         // The sub-lists are sparse: one sweep over (sub-list, slot < longest list) gathers them into LDS at their
         // scanned offsets (independent loads, no atomics); the select then never touches global memory.
@@ -913,32 +943,45 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
                 }
             }
         }
-        const int maxc = (int)s_maxc;
-        if (maxc > 8) {
-            int lw = 0;
-            while ((1 << lw) < maxc - 8) ++lw;
-            const int sweep = ranges << lw;
-            constexpr int BATCH = 8;   // loads issued back to back before the first LDS store
-            for (int i0 = tid; i0 < sweep; i0 += THREADS * BATCH) {
-                uint2 e[BATCH];
-                int dst[BATCH];
-#pragma unroll
-                for (int u = 0; u < BATCH; ++u) {
-                    const int i = i0 + u * THREADS;
-                    const int j = i >> lw, sl = 8 + (i & ((1 << lw) - 1));
-                    dst[u] = -1;
-                    if (i < sweep && (uint32_t)sl < s_cnt[j]) {
-                        dst[u] = (int)s_off[j] + sl;
-                        e[u] = at(j, sl);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < BATCH; ++u)
-                    if (dst[u] >= 0) s_comp[dst[u]] = e[u];
-            }
-        }
+        sweep_sublists<THREADS, 8>(tid, ranges, 8, (int)s_maxc, s_cnt, at, [](int, int) { return true; },
+                                   [&](int j, int sl, uint2 e) { s_comp[s_off[j] + sl] = e; });
         __syncthreads();
-        const int M = (int)s_total;
+        n_lds = (int)s_total;
+    } else if (!bad && compact < k) {
+        bad = true;   // the LDS budget cannot even hold k records (huge dim * k): exact dense path
+    } else if (!bad) {
+        // More candidates than the LDS holds: select on the PREFIX that fits (sub-list order) -- its k-th largest score is
+        // a valid lower bound of the query's k-th largest -- then sweep again and keep only the records above that bound
+        // (minus the margin); they fit with room to spare (about k * total / compact records).
+        sweep_sublists<THREADS, 8>(tid, ranges, 0, (int)s_maxc, s_cnt, at,
+                                   [&](int j, int sl) { return s_off[j] + (uint32_t)sl < (uint32_t)compact; },
+                                   [&](int j, int sl, uint2 e) { s_comp[s_off[j] + sl] = e; });
+        __syncthreads();
+        uint32_t kth0 = 0;
+        int eq0 = 0;
+        block_radix_select(
+            [&](int64_t i, bool &skip) -> uint32_t {
+                (void)skip;
+                return f32_orderable(__uint_as_float(s_comp[i].x));
+            },
+            compact, k, s_hist, s_ctl, kth0, eq0);
+        const float keep = orderable_to_f32(kth0) - delta[q];
+        __syncthreads();   // every thread is done with the prefix before it is overwritten
+        sweep_sublists<THREADS, 8>(tid, ranges, 0, (int)s_maxc, s_cnt, at, [](int, int) { return true; },
+                                   [&](int, int, uint2 e) {
+                                       if (__uint_as_float(e.x) >= keep) {
+                                           const uint32_t p = atomicAdd(&s_fill, 1u);
+                                           if (p < (uint32_t)compact) s_comp[p] = e;
+                                       }
+                                   });
+        __syncthreads();
+        if (s_fill > (uint32_t)compact)
+            bad = true;   // (near-)constant scores: the exact dense path takes the query
+        else
+            n_lds = (int)s_fill;
+    }
+    if (!bad) {
+        const int M = n_lds;
         block_radix_select(
             [&](int64_t i, bool &skip) -> uint32_t {
                 (void)skip;
@@ -948,32 +991,6 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
         const float cut = orderable_to_f32(kth) - delta[q];
         for (int i = tid; i < M; i += THREADS) {
             const uint2 e = s_comp[i];
-            if (__uint_as_float(e.x) >= cut) {
-                const uint32_t p = atomicAdd(&s_ncoll, 1u);
-                if (p < (uint32_t)coll_cap) s_keys[p] = (unsigned long long)e.y;  // local row for now
-            }
-        }
-        __syncthreads();
-        if (s_ncoll > (uint32_t)coll_cap) bad = true;  // mass ties around the cut
-    } else if (!bad) {
-        block_radix_select(
-            [&](int64_t i, bool &skip) -> uint32_t {
-                const int r = (int)(i / cap);
-                const int sl = (int)(i - (int64_t)r * cap);
-                if ((uint32_t)sl >= s_cnt[r]) {
-                    skip = true;
-                    return 0u;
-                }
-                return f32_orderable(__uint_as_float(at(r, sl).x));
-            },
-            slots, k, s_hist, s_ctl, kth, need_eq);
-        const float cut = orderable_to_f32(kth) - delta[q];
-        // collect everything within the margin of the k-th MFMA score
-        for (int64_t i = tid; i < slots; i += THREADS) {
-            const int r = (int)(i / cap);
-            const int sl = (int)(i - (int64_t)r * cap);
-            if ((uint32_t)sl >= s_cnt[r]) continue;
-            const uint2 e = at(r, sl);
             if (__uint_as_float(e.x) >= cut) {
                 const uint32_t p = atomicAdd(&s_ncoll, 1u);
                 if (p < (uint32_t)coll_cap) s_keys[p] = (unsigned long long)e.y;  // local row for now
@@ -997,20 +1014,75 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
         ncoll *= 16;
     }
     const int np2 = pow2_ceil(ncoll);
-    // canonical re-score (each thread reads and rewrites only its own key slots)
-    for (int i = tid; i < np2; i += blockDim.x) {
-        unsigned long long key = 0ull;
-        if (i < ncoll) {
-            uint32_t row;
-            if (GROUPS) {
-                const int e = i & 15;
-                row = s_grp[i >> 4] + (uint32_t)((e & 3) + 8 * (e >> 2));
-            } else {
-                row = (uint32_t)s_keys[i];
+    // Canonical re-score.  The candidate rows are scattered over the shard; a thread walking "its" row 16 bytes at a
+    // time makes every wave-load touch 64 different cache lines (measured 1.5 TB/s at k = 1000).  Instead the rows are
+    // staged through the (now free) candidate area of the LDS in K slices of SB bytes per row: lanes_per_row adjacent
+    // lanes fetch one row's slice (whole 64/128-byte segments, all loads of a slice in flight), then every thread runs
+    // the fp64 chain of its own row(s) over the slice from LDS.  Element order inside a row is unchanged.
+    const size_t stage_bytes = (size_t)compact * 8;
+    // (only in the 1024-thread large-k variant: at k <= 256 the ~100 rows per query are re-read from L2 / Infinity Cache
+    // quickly enough by the direct walk, and the slice barriers cost more than they save)
+    const int SB = (GROUPS || THREADS < 1024) ? 0 : ((size_t)ncoll * 144 <= stage_bytes ? 128 : ((size_t)ncoll * 80 <= stage_bytes ? 64 : 0));
+    if (SB != 0 && ncoll <= 2 * THREADS) {
+        char *stage = reinterpret_cast<char *>(s_comp);
+        const int stride = SB + 16;                 // +16: consecutive rows start 4 banks apart (conflict-free b128 reads)
+        const int lpr = SB / 16;                    // lanes per row and slice
+        const int row_bytes = dim * 2;
+        const char *Dbytes = reinterpret_cast<const char *>(D);
+        double acc[2] = {0.0, 0.0};
+        for (int k0 = 0; k0 < row_bytes; k0 += SB) {
+            __syncthreads();                        // the previous slice has been consumed (first pass: s_keys/s_comp settled)
+            for (int idx = tid; idx < ncoll * lpr; idx += THREADS) {
+                const int r = idx / lpr, c = idx - r * lpr;
+                if (k0 + c * 16 < row_bytes) {
+                    const uint32_t row = (uint32_t)s_keys[r];
+                    *reinterpret_cast<uint4 *>(stage + (size_t)r * stride + c * 16) =
+                        *reinterpret_cast<const uint4 *>(Dbytes + (int64_t)row * row_bytes + k0 + c * 16);
+                }
             }
-            if (!GROUPS || (int64_t)row < n_rows) key = make_key(canonical_dot(s_q, D + (int64_t)row * dim, dim), row);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int i = tid + j * THREADS;
+                if (i < ncoll) {
+                    double a = acc[j];
+                    for (int c = 0; c < lpr && k0 + c * 16 < row_bytes; ++c) {
+                        const uint4 dv = *reinterpret_cast<const uint4 *>(stage + (size_t)i * stride + c * 16);
+                        const uint4 qv = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(s_q) + k0 + c * 16);
+                        const uint32_t dw[4] = {dv.x, dv.y, dv.z, dv.w};
+                        const uint32_t qw[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            a = fma((double)__uint_as_float(qw[e] << 16), (double)__uint_as_float(dw[e] << 16), a);
+                            a = fma((double)__uint_as_float(qw[e] & 0xffff0000u), (double)__uint_as_float(dw[e] & 0xffff0000u), a);
+                        }
+                    }
+                    acc[j] = a;
+                }
+            }
         }
-        s_keys[i] = key;
+        __syncthreads();                            // every loader is done reading the row ids in s_keys
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = tid + j * THREADS;
+            if (i < np2) s_keys[i] = i < ncoll ? make_key((float)acc[j], (uint32_t)s_keys[i]) : 0ull;
+        }
+    } else {
+        // each thread reads and rewrites only its own key slots
+        for (int i = tid; i < np2; i += blockDim.x) {
+            unsigned long long key = 0ull;
+            if (i < ncoll) {
+                uint32_t row;
+                if (GROUPS) {
+                    const int e = i & 15;
+                    row = s_grp[i >> 4] + (uint32_t)((e & 3) + 8 * (e >> 2));
+                } else {
+                    row = (uint32_t)s_keys[i];
+                }
+                if (!GROUPS || (int64_t)row < n_rows) key = make_key(canonical_dot(s_q, D + (int64_t)row * dim, dim), row);
+            }
+            s_keys[i] = key;
+        }
     }
     block_bitonic_sort_desc(s_keys, np2);
     for (int i = tid; i < k; i += blockDim.x) {
