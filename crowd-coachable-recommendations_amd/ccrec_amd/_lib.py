@@ -15,7 +15,7 @@ EXPORTS = [
     "ccr_last_error", "ccr_version", "ccr_pack_bf16", "ccr_pack_bf16_ex", "ccr_meanpool_pack_bf16", "ccr_meanpool_pack_bf16_ex", "ccr_index_create",
     "ccr_index_create_with_norm", "ccr_index_destroy",
     "ccr_index_rows", "ccr_index_dim", "ccr_search_workspace_bytes", "ccr_search", "ccr_search_last_stats",
-    "ccr_merge_topk", "ccr_merge_topk_strided", "ccr_apply_block", "ccr_inbatch_ce_workspace_bytes", "ccr_inbatch_ce_fwd", "ccr_inbatch_ce_bwd", "ccr_rank_metrics", "ccr_debug_mfma_scores",
+    "ccr_merge_topk", "ccr_merge_topk_strided", "ccr_apply_block", "ccr_inbatch_ce_workspace_bytes", "ccr_inbatch_ce_fwd", "ccr_inbatch_ce_bwd", "ccr_inbatch_ce_bwd_dev", "ccr_rank_metrics", "ccr_debug_mfma_scores",
     "ccr_debug_canonical_scores", "ccr_bm25_index_create", "ccr_bm25_index_destroy", "ccr_bm25_search_workspace_bytes",
     "ccr_bm25_search",
 ]
@@ -70,6 +70,7 @@ def load():
     lib.ccr_inbatch_ce_workspace_bytes.restype = sz
     lib.ccr_inbatch_ce_fwd.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp, vp, sz, vp]
     lib.ccr_inbatch_ce_bwd.argtypes = [vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp, vp, sz, vp]
+    lib.ccr_inbatch_ce_bwd_dev.argtypes = [vp, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp, vp, sz, vp]
     lib.ccr_rank_metrics.argtypes = [vp, i32, i32, vp, vp, vp, i32, vp, vp, vp]
     lib.ccr_debug_mfma_scores.argtypes = [vp, vp, i32, vp, vp]
     lib.ccr_debug_canonical_scores.argtypes = [vp, vp, i32, vp, vp]

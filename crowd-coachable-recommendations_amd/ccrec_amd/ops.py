@@ -220,9 +220,10 @@ class _InBatchCE(torch.autograd.Function):
         qb, pb, nb, lse, ws = ctx.saved_tensors
         B, dim = qb.shape
         dq, dp, dn = (torch.empty(B, dim, dtype=torch.float32, device=qb.device) for _ in range(3))
+        g = grad_out.detach().to(device=qb.device, dtype=torch.float32).reshape(1).contiguous()   # stays on the device
         with _on(qb):
-            _lib.check(lib.ccr_inbatch_ce_bwd(_ptr(qb), _ptr(pb), _ptr(nb), _ptr(lse), B, dim, ctx.inv_t, float(grad_out),
-                                              _ptr(dq), _ptr(dp), _ptr(dn), _ptr(ws), ws.numel(), _stream(qb)),
+            _lib.check(lib.ccr_inbatch_ce_bwd_dev(_ptr(qb), _ptr(pb), _ptr(nb), _ptr(lse), B, dim, ctx.inv_t, _ptr(g),
+                                                  _ptr(dq), _ptr(dp), _ptr(dn), _ptr(ws), ws.numel(), _stream(qb)),
                        "ccr_inbatch_ce_bwd")
         return dq.to(ctx.dtypes[0]), dp.to(ctx.dtypes[1]), dn.to(ctx.dtypes[2]), None
 

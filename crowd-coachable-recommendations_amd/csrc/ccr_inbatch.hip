@@ -8,7 +8,8 @@
 // read straight from L2 in fragment layout, no LDS staging.
 //   fwd : per (query tile, key split) partial (max, sum, diagonal) -> fixed-order combine -> lse, loss
 //   bwd : G[j][i] = (softmax - onehot) * inv_T * grad_out / B  (fp32, recomputed logits, MFMA)
-//         dQ = G^T K,  dK = G Q   as fp32 tiled outer-product GEMMs (deterministic, no atomics)
+//         dQ = G^T K,  dK = G Q   on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 products of the fp32
+//         gradient matrix with the bf16 embeddings, fp32 accumulate; LDS-staged 64x64 tiles, deterministic, no atomics)
 #include "ccr_common.h"
 
 namespace ccr {
@@ -26,8 +27,9 @@ __global__ __launch_bounds__(64) void inbatch_logits_kernel(const uint16_t *__re
                                                            const uint16_t *__restrict__ N, int B, int dim, float inv_t,
                                                            int splits, float *__restrict__ pm, float *__restrict__ pl,
                                                            float *__restrict__ pd, const float *__restrict__ lse,
-                                                           float gscale, float *__restrict__ G) {
+                                                           float gscale, const float *__restrict__ gscale_dev, float *__restrict__ G) {
     const int lane = threadIdx.x;
+    if (MODE == 1 && gscale_dev) gscale *= gscale_dev[0];   // upstream gradient read on the device: no host round trip
     const int l31 = lane & 31, h = lane >> 5;
     const int i0 = blockIdx.x * 32;
     const int s = blockIdx.y;
@@ -45,7 +47,19 @@ __global__ __launch_bounds__(64) void inbatch_logits_kernel(const uint16_t *__re
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        for (int k0 = 0; k0 < dim; k0 += 16) {
+        // operands come straight from L2 in fragment layout: 8 K steps (16 loads) are issued before the first MFMA
+        int k0 = 0;
+        for (; k0 + 128 <= dim; k0 += 128) {
+            bf16x8 a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a[u] = *reinterpret_cast<const bf16x8 *>(krow + k0 + 16 * u);
+                b[u] = *reinterpret_cast<const bf16x8 *>(qrow + k0 + 16 * u);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u], b[u], acc, 0, 0, 0);
+        }
+        for (; k0 < dim; k0 += 16) {
             const bf16x8 a = *reinterpret_cast<const bf16x8 *>(krow + k0);
             const bf16x8 b = *reinterpret_cast<const bf16x8 *>(qrow + k0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
@@ -94,108 +108,198 @@ __global__ __launch_bounds__(64) void inbatch_logits_kernel(const uint16_t *__re
     }
 }
 
-// combine the split partials in a fixed order: lse[i], loss = sum_i (lse_i - logit_ii) / B
+// combine the split partials in a fixed order: lse[i], loss = sum_i (lse_i - logit_ii) / B.
+// grid = ceil(B / 256) blocks of 256 queries; every block writes its fp64 partial, the block that draws the last ticket
+// adds the partials in block order (deterministic) and writes the loss.  `ticket` is zeroed by the caller's memset.
 __global__ __launch_bounds__(256) void inbatch_reduce_kernel(const float *__restrict__ pm, const float *__restrict__ pl,
                                                             const float *__restrict__ pd, int B, int splits,
-                                                            float *__restrict__ lse, float *__restrict__ loss) {
-    __shared__ double s_sum[256];
+                                                            float *__restrict__ lse, float *__restrict__ loss,
+                                                            double *__restrict__ block_part, unsigned int *__restrict__ ticket) {
+    __shared__ double s_sum[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
     double part = 0.0;
-    for (int i = threadIdx.x; i < B; i += blockDim.x) {
-        float M = -INFINITY, dg = -INFINITY;
-        for (int s = 0; s < splits; ++s) {
-            M = fmaxf(M, pm[(int64_t)s * B + i]);
-            dg = fmaxf(dg, pd[(int64_t)s * B + i]);
-        }
-        float L = 0.f;
-        for (int s = 0; s < splits; ++s) {
-            const float ms = pm[(int64_t)s * B + i];
-            if (ms > -INFINITY) L += pl[(int64_t)s * B + i] * __expf(ms - M);
+    if (i < B) {
+        float M = -INFINITY, dg = -INFINITY, L = 0.f;
+        for (int s0 = 0; s0 < splits; s0 += 16) {   // 3 x 16 independent loads per round
+            float vm[16], vl[16], vd[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const bool in = s0 + u < splits;
+                const int64_t at = (int64_t)(in ? s0 + u : 0) * B + i;
+                vm[u] = in ? pm[at] : -INFINITY;
+                vl[u] = in ? pl[at] : 0.f;
+                vd[u] = in ? pd[at] : -INFINITY;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {   // online combine in split order
+                const float mn = fmaxf(M, vm[u]);
+                if (mn > -INFINITY) L = (M > -INFINITY ? L * __expf(M - mn) : 0.f) + (vm[u] > -INFINITY ? vl[u] * __expf(vm[u] - mn) : 0.f);
+                M = mn;
+                dg = fmaxf(dg, vd[u]);
+            }
         }
         const float v = M + __logf(L);
         lse[i] = v;
-        part += (double)(v - dg);
+        part = (double)(v - dg);
     }
-    s_sum[threadIdx.x] = part;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = part;
     __syncthreads();
-    for (int off = 128; off >= 1; off >>= 1) {
-        if ((int)threadIdx.x < off) s_sum[threadIdx.x] += s_sum[threadIdx.x + off];
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        // publish the partial (agent-scope release before the ticket), last arriver acquires and sums in block order
+        block_part[blockIdx.x] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == gridDim.x - 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            double tot = 0.0;
+            for (unsigned int b = 0; b < gridDim.x; ++b) tot += block_part[b];
+            loss[0] = (float)(tot / (double)B);
+        }
     }
-    if (threadIdx.x == 0) loss[0] = (float)(s_sum[0] / (double)B);
 }
 
-// C[M][Nc] (fp32) = sum_k A(k, m) * Bm(k, n);  A fp32: A_KMAJOR ? A[k*lda + m] : A[m*lda + k];
-// Bm rows are bf16 embedding rows selected by the mode: KEYS -> key_row(P, N, B, k), else Q + k*dim.
-// Output row m goes to C0 (m < split) or C1 (m >= split).  64x64 tile, 256 threads x (4x4), K chunk 16.
-template <bool A_KMAJOR, bool B_KEYS>
-__global__ __launch_bounds__(256) void inbatch_grad_gemm_kernel(const float *__restrict__ A, int lda, const uint16_t *__restrict__ X0,
+// C[M][Nc] (fp32) = sum_k A(k, m) * Bm(k, n) on v_mfma_f32_32x32x2_f32.
+//   A fp32: A_KMAJOR ? A[k*lda + m] : A[m*lda + k];  Bm rows are bf16 embedding rows selected by the mode:
+//   KEYS -> key_row(P, N, B, k), else Q + k*dim (widened to fp32 exactly).  Output row m goes to C0 (m < split) or C1.
+// Block = 4 waves, 64 x 64 output tile (32 x 32 per wave), K walked in chunks of 32 through two LDS buffers; the next
+// chunk's global loads are in flight while the current chunk's 16 MFMAs per wave run.  LDS rows are k-major with a
+// stride of 68 floats (16-byte aligned rows): the MFMA operand reads (32 consecutive floats per half wave) and both staging patterns
+// (m-fastest and k-fastest) are bank-conflict free.
+typedef float f32x16v __attribute__((ext_vector_type(16)));
+constexpr int GG_T = 64, GG_THREADS = 256, GG_KC = 32, GG_LD = 68;   // 64 x 64 block tile, 4 waves of 32 x 32, K chunk 32
+// VEC: 16-byte loads (needs lda % 4 == 0, M % 4 == 0, dim % 8 == 0, 16-byte aligned bases): 3 loads per thread and chunk
+// instead of 16 scalar ones.
+template <bool A_KMAJOR, bool B_KEYS, bool VEC>
+__global__ __launch_bounds__(GG_THREADS) void inbatch_grad_gemm_kernel(const float *__restrict__ A, int lda, const uint16_t *__restrict__ X0,
                                                                const uint16_t *__restrict__ X1, int B, int M, int K, int dim,
                                                                float *__restrict__ C0, float *__restrict__ C1, int split) {
-    __shared__ __attribute__((aligned(16))) float As[16][68];
-    __shared__ __attribute__((aligned(16))) float Bs[16][68];
+    __shared__ __attribute__((aligned(16))) float As[2][GG_KC][GG_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GG_KC][GG_LD];
     const int tid = threadIdx.x;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    const int tm = tid >> 4, tn = tid & 15;
-    float acc[4][4];
+    const int lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int m0 = blockIdx.y * GG_T, n0 = blockIdx.x * GG_T;
+    f32x16v acc;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+
+    // Raw load results are only touched AFTER the MFMAs of the current chunk and out-of-range elements are zeroed
+    // arithmetically there (addresses are clamped): behind a select LLVM sinks each load into the select's branch and
+    // waits for it separately, one dependent round trip per element.
+    constexpr int NA = VEC ? 2 : 8;
+    float4 va[VEC ? 2 : 1];
+    uint4 vb;
+    float ra[VEC ? 1 : 8];
+    uint32_t rb[VEC ? 1 : 8];
+    auto fetch = [&](int k0) {
+        if constexpr (VEC) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
-    for (int k0 = 0; k0 < K; k0 += 16) {
-        // stage A chunk [16 k][64 m] and B chunk [16 k][64 n]: 1024 elements each, 4 per thread
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int idx = r * 256 + tid;
-            int kk, mm;
-            if (A_KMAJOR) {
-                kk = idx >> 6;
-                mm = idx & 63;
-            } else {
-                mm = idx >> 4;
-                kk = idx & 15;
+            for (int r = 0; r < NA; ++r) {
+                const int v = r * GG_THREADS + tid;   // 512 float4 of the A chunk
+                const int kk = A_KMAJOR ? (v >> 4) : ((v & 7) * 4), mm = A_KMAJOR ? ((v & 15) * 4) : (v >> 3);
+                const int k = k0 + kk, mrow = m0 + mm;
+                // K and M are multiples of 4 here, so a 4-vector is entirely inside or entirely outside the matrix
+                const int kc = A_KMAJOR ? (k < K ? k : K - 1) : (k < K ? k : K - 4);
+                const int mc = A_KMAJOR ? (mrow < M ? mrow : M - 4) : (mrow < M ? mrow : M - 1);
+                va[r] = *reinterpret_cast<const float4 *>(A_KMAJOR ? A + (int64_t)kc * lda + mc : A + (int64_t)mc * lda + kc);
             }
-            const int k = k0 + kk, mrow = m0 + mm;
-            float v = 0.f;
-            if (k < K && mrow < M) v = A_KMAJOR ? A[(int64_t)k * lda + mrow] : A[(int64_t)mrow * lda + k];
-            As[kk][mm] = v;
-            const int kb = idx >> 6, nn = idx & 63;
-            const int kr = k0 + kb, ncol = n0 + nn;
-            float w = 0.f;
-            if (kr < K && ncol < dim) {
-                const uint16_t *row = B_KEYS ? key_row(X0, X1, B, kr, dim) : X0 + (int64_t)kr * dim;
-                w = bf16_bits_to_f32(row[ncol]);
+            const int kb = tid >> 3, n8 = (tid & 7) * 8;   // 256 x 16 bytes of the B chunk
+            const int kr = k0 + kb, ncol = n0 + n8;
+            const int krc = kr < K ? kr : K - 1, ncc = ncol + 7 < dim ? ncol : dim - 8;
+            const uint16_t *row = B_KEYS ? key_row(X0, X1, B, krc, dim) : X0 + (int64_t)krc * dim;
+            vb = *reinterpret_cast<const uint4 *>(row + ncc);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int idx = r * GG_THREADS + tid;
+                const int kk = A_KMAJOR ? (idx >> 6) : (idx & 31), mm = A_KMAJOR ? (idx & 63) : (idx >> 5);
+                const int k = k0 + kk, mrow = m0 + mm;
+                const int kc = k < K ? k : K - 1, mc = mrow < M ? mrow : M - 1;
+                ra[r] = A_KMAJOR ? A[(int64_t)kc * lda + mc] : A[(int64_t)mc * lda + kc];
+                const int kr = k0 + (idx >> 6), ncol = n0 + (idx & 63);
+                const int krc = kr < K ? kr : K - 1, ncc = ncol < dim ? ncol : dim - 1;
+                const uint16_t *row = B_KEYS ? key_row(X0, X1, B, krc, dim) : X0 + (int64_t)krc * dim;
+                rb[r] = row[ncc];
             }
-            Bs[kb][nn] = w;
         }
-        __syncthreads();
+    };
+    auto stash = [&](int buf, int k0) {
+        if constexpr (VEC) {
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            const float4 av = *reinterpret_cast<const float4 *>(&As[kk][4 * tm]);
-            const float4 bv = *reinterpret_cast<const float4 *>(&Bs[kk][4 * tn]);
-            const float a4[4] = {av.x, av.y, av.z, av.w}, b4[4] = {bv.x, bv.y, bv.z, bv.w};
+            for (int r = 0; r < NA; ++r) {
+                const int v = r * GG_THREADS + tid;
+                const int kk = A_KMAJOR ? (v >> 4) : ((v & 7) * 4), mm = A_KMAJOR ? ((v & 15) * 4) : (v >> 3);
+                const float e4[4] = {va[r].x, va[r].y, va[r].z, va[r].w};
+                if (A_KMAJOR) {   // 4 consecutive m of one k row; a row/vector is entirely in or out (M % 4 == 0)
+                    const float ok = (k0 + kk < K && m0 + mm < M) ? 1.f : 0.f;
+                    *reinterpret_cast<float4 *>(&As[buf][kk][mm]) = make_float4(e4[0] * ok, e4[1] * ok, e4[2] * ok, e4[3] * ok);
+                } else {          // 4 consecutive k of one m row
+                    const float ok = (k0 + kk < K && m0 + mm < M) ? 1.f : 0.f;
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+                    for (int j = 0; j < 4; ++j) As[buf][kk + j][mm] = e4[j] * ok;
+                }
+            }
+            const int kb = tid >> 3, n8 = (tid & 7) * 8;
+            const uint32_t ok = (k0 + kb < K && n0 + n8 < dim) ? 0xffffffffu : 0u;
+            const uint32_t w[4] = {vb.x, vb.y, vb.z, vb.w};
+            float f[8];
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = fmaf(a4[a], b4[b], acc[a][b]);
+            for (int e = 0; e < 4; ++e) {
+                f[2 * e] = __uint_as_float((w[e] << 16) & ok);
+                f[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u & ok);
+            }
+            *reinterpret_cast<float4 *>(&Bs[buf][kb][n8]) = make_float4(f[0], f[1], f[2], f[3]);
+            *reinterpret_cast<float4 *>(&Bs[buf][kb][n8 + 4]) = make_float4(f[4], f[5], f[6], f[7]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int idx = r * GG_THREADS + tid;
+                const int kk = A_KMAJOR ? (idx >> 6) : (idx & 31), mm = A_KMAJOR ? (idx & 63) : (idx >> 5);
+                As[buf][kk][mm] = ra[r] * ((k0 + kk < K && m0 + mm < M) ? 1.f : 0.f);
+                Bs[buf][idx >> 6][idx & 63] =
+                    __uint_as_float((rb[r] << 16) & ((k0 + (idx >> 6) < K && n0 + (idx & 63) < dim) ? 0xffffffffu : 0u));
+            }
         }
+    };
+    fetch(0);
+    stash(0, 0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += GG_KC) {
+        const bool more = k0 + GG_KC < K;
+        if (more) fetch(k0 + GG_KC);                   // global loads of the next chunk stay in flight over the MFMAs
+#pragma unroll
+        for (int ks = 0; ks < GG_KC / 2; ++ks) {
+            const float a = As[buf][2 * ks + h][wm * 32 + l31];
+            const float b = Bs[buf][2 * ks + h][wn * 32 + l31];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        if (more) stash(buf ^ 1, k0 + GG_KC);
         __syncthreads();
+        buf ^= 1;
     }
+    // C layout of v_mfma_f32_32x32x2: column = lane & 31, register e -> row (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+    const int ncol = n0 + wn * 32 + l31;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const int mrow = m0 + 4 * tm + a;
-        if (mrow >= M) continue;
-        float *crow = (mrow < split) ? C0 + (int64_t)mrow * dim : C1 + (int64_t)(mrow - split) * dim;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int ncol = n0 + 4 * tn + b;
-            if (ncol < dim) crow[ncol] = acc[a][b];
+    for (int e = 0; e < 16; ++e) {
+        const int mrow = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (mrow < M && ncol < dim) {
+            float *crow = (mrow < split) ? C0 + (int64_t)mrow * dim : C1 + (int64_t)(mrow - split) * dim;
+            crow[ncol] = acc[e];
         }
     }
 }
 
 static int pick_splits(int B) {
+    // one wave per (32-query tile, key split): aim at ~8 waves per CU, at most one split per 32-key tile and 64 splits
     const int qtiles = (B + 31) / 32, ktiles = (2 * B + 31) / 32;
-    int s = 512 / (qtiles > 0 ? qtiles : 1);
+    int s = 2048 / (qtiles > 0 ? qtiles : 1);
     if (s < 1) s = 1;
     if (s > ktiles) s = ktiles;
     if (s > 64) s = 64;
@@ -211,7 +315,8 @@ extern "C" size_t ccr_inbatch_ce_workspace_bytes(int B, int dim) {
     if (B <= 0) return 0;
     const size_t partial = (size_t)3 * 64 * B * sizeof(float);
     const size_t g = (size_t)2 * B * B * sizeof(float);
-    return ((partial + 255) / 256) * 256 + g + 256;
+    const size_t red = (size_t)((B + 255) / 256) * sizeof(double) + 256;   // block partials + ticket of the loss reduction
+    return ((partial + 255) / 256) * 256 + g + ((red + 255) / 256) * 256 + 256;
 }
 
 extern "C" int ccr_inbatch_ce_fwd(const uint16_t *Qe, const uint16_t *Pe, const uint16_t *Ne, int B, int dim,
@@ -227,16 +332,23 @@ extern "C" int ccr_inbatch_ce_fwd(const uint16_t *Qe, const uint16_t *Pe, const 
     float *pm = (float *)workspace, *pl = pm + (size_t)64 * B, *pd = pl + (size_t)64 * B;
     dim3 grid((B + 31) / 32, splits);
     hipLaunchKernelGGL(inbatch_logits_kernel<0>, grid, dim3(64), 0, s, Qe, Pe, Ne, B, dim, inv_temperature, splits, pm, pl, pd,
-                       (const float *)nullptr, 0.f, (float *)nullptr);
+                       (const float *)nullptr, 0.f, (const float *)nullptr, (float *)nullptr);
     CCR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(inbatch_reduce_kernel, dim3(1), dim3(256), 0, s, pm, pl, pd, B, splits, lse, loss);
+    const size_t partial = (((size_t)3 * 64 * B * sizeof(float) + 255) / 256) * 256;
+    char *red = (char *)workspace + partial + (size_t)2 * B * B * sizeof(float);
+    red += (256 - (uintptr_t)red % 256) % 256;
+    unsigned int *ticket = (unsigned int *)red;
+    double *block_part = (double *)(red + 64);
+    CCR_HIP_CHECK(hipMemsetAsync(ticket, 0, 64, s));
+    hipLaunchKernelGGL(inbatch_reduce_kernel, dim3((B + 255) / 256), dim3(256), 0, s, pm, pl, pd, B, splits, lse, loss, block_part,
+                       ticket);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
 }
 
-extern "C" int ccr_inbatch_ce_bwd(const uint16_t *Qe, const uint16_t *Pe, const uint16_t *Ne, const float *lse, int B, int dim,
-                                  float inv_temperature, float grad_out, float *dQ, float *dP, float *dN, void *workspace,
-                                  size_t ws_bytes, void *stream) {
+static int inbatch_bwd_impl(const uint16_t *Qe, const uint16_t *Pe, const uint16_t *Ne, const float *lse, int B, int dim,
+                            float inv_temperature, float grad_out, const float *grad_out_dev, float *dQ, float *dP, float *dN,
+                            void *workspace, size_t ws_bytes, void *stream) {
     CCR_REQUIRE(Qe && Pe && Ne && lse && dQ && dP && dN, "ccr_inbatch_ce_bwd: null pointer");
     CCR_REQUIRE(B >= 1 && dim >= 16 && dim % 16 == 0, "ccr_inbatch_ce_bwd: B=%d dim=%d (dim %% 16 == 0)", B, dim);
     if (!workspace || ws_bytes < ccr_inbatch_ce_workspace_bytes(B, dim)) {
@@ -249,15 +361,35 @@ extern "C" int ccr_inbatch_ce_bwd(const uint16_t *Qe, const uint16_t *Pe, const 
     const int splits = pick_splits(B);
     dim3 grid((B + 31) / 32, splits);
     hipLaunchKernelGGL(inbatch_logits_kernel<1>, grid, dim3(64), 0, s, Qe, Pe, Ne, B, dim, inv_temperature, splits,
-                       (float *)nullptr, (float *)nullptr, (float *)nullptr, lse, inv_temperature * grad_out / (float)B, G);
+                       (float *)nullptr, (float *)nullptr, (float *)nullptr, lse, inv_temperature * grad_out / (float)B, grad_out_dev, G);
     CCR_LAUNCH_CHECK();
     // dQ[i][:] = sum_j G[j][i] K[j][:]      (A k-major: A[k=j][m=i])
-    hipLaunchKernelGGL((inbatch_grad_gemm_kernel<true, true>), dim3((dim + 63) / 64, (B + 63) / 64), dim3(256), 0, s, G, B, Pe, Ne,
-                       B, B, 2 * B, dim, dQ, dQ, B);
-    CCR_LAUNCH_CHECK();
     // dK[j][:] = sum_i G[j][i] Q[i][:]      (A row-major [m=j][k=i]); rows < B -> dP, the rest -> dN
-    hipLaunchKernelGGL((inbatch_grad_gemm_kernel<false, false>), dim3((dim + 63) / 64, (2 * B + 63) / 64), dim3(256), 0, s, G, B,
-                       Qe, Qe, B, 2 * B, B, dim, dP, dN, B);
+    const bool vec = (B % 4 == 0) && B >= 4 && (dim % 8 == 0) && dim >= 8 && ((uintptr_t)Qe % 16 == 0) && ((uintptr_t)Pe % 16 == 0) &&
+                     ((uintptr_t)Ne % 16 == 0) && ((uintptr_t)G % 16 == 0);
+    const dim3 gq((dim + GG_T - 1) / GG_T, (B + GG_T - 1) / GG_T), gk((dim + GG_T - 1) / GG_T, (2 * B + GG_T - 1) / GG_T);
+    if (vec) {
+        hipLaunchKernelGGL((inbatch_grad_gemm_kernel<true, true, true>), gq, dim3(GG_THREADS), 0, s, G, B, Pe, Ne, B, B, 2 * B, dim, dQ, dQ, B);
+        CCR_LAUNCH_CHECK();
+        hipLaunchKernelGGL((inbatch_grad_gemm_kernel<false, false, true>), gk, dim3(GG_THREADS), 0, s, G, B, Qe, Qe, B, 2 * B, B, dim, dP, dN, B);
+    } else {
+        hipLaunchKernelGGL((inbatch_grad_gemm_kernel<true, true, false>), gq, dim3(GG_THREADS), 0, s, G, B, Pe, Ne, B, B, 2 * B, dim, dQ, dQ, B);
+        CCR_LAUNCH_CHECK();
+        hipLaunchKernelGGL((inbatch_grad_gemm_kernel<false, false, false>), gk, dim3(GG_THREADS), 0, s, G, B, Qe, Qe, B, 2 * B, B, dim, dP, dN, B);
+    }
     CCR_LAUNCH_CHECK();
     return CCR_OK;
+}
+
+extern "C" int ccr_inbatch_ce_bwd(const uint16_t *Qe, const uint16_t *Pe, const uint16_t *Ne, const float *lse, int B, int dim,
+                                  float inv_temperature, float grad_out, float *dQ, float *dP, float *dN, void *workspace,
+                                  size_t ws_bytes, void *stream) {
+    return inbatch_bwd_impl(Qe, Pe, Ne, lse, B, dim, inv_temperature, grad_out, nullptr, dQ, dP, dN, workspace, ws_bytes, stream);
+}
+
+extern "C" int ccr_inbatch_ce_bwd_dev(const uint16_t *Qe, const uint16_t *Pe, const uint16_t *Ne, const float *lse, int B, int dim,
+                                      float inv_temperature, const float *grad_out_dev, float *dQ, float *dP, float *dN,
+                                      void *workspace, size_t ws_bytes, void *stream) {
+    CCR_REQUIRE(grad_out_dev, "ccr_inbatch_ce_bwd_dev: null grad_out_dev");
+    return inbatch_bwd_impl(Qe, Pe, Ne, lse, B, dim, inv_temperature, 1.f, grad_out_dev, dQ, dP, dN, workspace, ws_bytes, stream);
 }

@@ -170,6 +170,11 @@ int ccr_inbatch_ce_fwd(const uint16_t *Qe, const uint16_t *Pe, const uint16_t *N
 int ccr_inbatch_ce_bwd(const uint16_t *Qe, const uint16_t *Pe, const uint16_t *Ne, const float *lse, int B, int dim,
                        float inv_temperature, float grad_out, float *dQ, float *dP, float *dN, void *workspace,
                        size_t ws_bytes, void *stream);
+/* Same with the upstream gradient read from device memory (a 1-element fp32 tensor, as autograd hands it over):
+ * no host read-back of the scalar, so the training step stays asynchronous. */
+int ccr_inbatch_ce_bwd_dev(const uint16_t *Qe, const uint16_t *Pe, const uint16_t *Ne, const float *lse, int B, int dim,
+                           float inv_temperature, const float *grad_out_dev, float *dQ, float *dP, float *dN,
+                           void *workspace, size_t ws_bytes, void *stream);
 
 /*
  * Reciprocal rank / hit counts of every query at several cut-offs, from the id tensor of ccr_search.
