@@ -174,35 +174,43 @@ __global__ __launch_bounds__(256) void meanpool_pack_kernel(const T *__restrict_
                                                            uint32_t *__restrict__ max_bits) {
     __shared__ double red[4];
     __shared__ float redf[4];
-    __shared__ int s_cnt;
     const int b = blockIdx.x;
     const int64_t ob = dst_rows ? dst_rows[b] : (int64_t)b;   // destination row (length-sorted batches scatter back)
     const int tid = threadIdx.x;
     const int nchunk = dim >> 2;
     const int64_t *m = mask + (int64_t)b * L;
-    if (tid == 0) {
-        long long c = 0;
-        for (int l = 0; l < L; ++l) c += m[l];
-        s_cnt = (int)c;
-    }
-    __syncthreads();
-    const float inv_is_div = (float)s_cnt;  // reference divides by the count (item_tower.py:145)
-    // pass 1: pooled fp32 value per owned chunk, kept in registers (<= 4 chunks per thread for dim <= 4096)
+    // pass 1: pooled fp32 value per owned chunk, kept in registers (<= 4 chunks per thread for dim <= 4096).
+    // Every thread walks the whole mask row anyway, so it counts the tokens itself (no serial pre-pass, no barrier);
+    // 8 token positions are loaded unconditionally and masked with an AND (a masked value becomes +0.0, and x + (+0.0) == x
+    // bit for bit because the running sum starts at +0.0 and can never be -0.0): the loads of a group are all in flight.
     float4 acc[4];
     int nown = 0;
     double ss = 0.0;
+    float inv_is_div = 1.f;
     for (int c = tid; c < nchunk && nown < 4; c += blockDim.x, ++nown) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         const T *h = hidden + (int64_t)b * L * dim + 4 * c;
-        for (int l = 0; l < L; ++l) {
-            if (m[l] != 0) {
-                float4 v = load4<T>(h + (int64_t)l * dim);
-                a.x += v.x;
-                a.y += v.y;
-                a.z += v.z;
-                a.w += v.w;
+        long long cnt = 0;
+        for (int l0 = 0; l0 < L; l0 += 8) {
+            uint32_t keep[8];
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int l = l0 + u < L ? l0 + u : L - 1;
+                const long long mv = m[l];
+                cnt += (l0 + u < L) ? mv : 0;            // the reference divides by mask.sum(1) (item_tower.py:145)
+                keep[u] = (l0 + u < L && mv != 0) ? 0xffffffffu : 0u;
+                v[u] = load4<T>(h + (int64_t)l * dim);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a.x += __uint_as_float(__float_as_uint(v[u].x) & keep[u]);
+                a.y += __uint_as_float(__float_as_uint(v[u].y) & keep[u]);
+                a.z += __uint_as_float(__float_as_uint(v[u].z) & keep[u]);
+                a.w += __uint_as_float(__float_as_uint(v[u].w) & keep[u]);
             }
         }
+        inv_is_div = (float)(int)cnt;
         a.x /= inv_is_div;
         a.y /= inv_is_div;
         a.z /= inv_is_div;
