@@ -37,12 +37,30 @@ __global__ __launch_bounds__(256) void bm25_round_kernel(const Bm25Round *__rest
     if (lo >= pr.end) return;
     const int64_t hi = lo + BM25_CHUNK < pr.end ? lo + BM25_CHUNK : pr.end;
     double *row = acc + (int64_t)pr.row * n_docs;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
-        const int32_t d = doc_ids[i];
-        const double f = (double)tf[i];
-        const double numer = (f * pr.idf) * k1p1;
-        const double denom = f + doc_k[d];
-        row[d] += numer / denom;
+    // the documents of one posting list are distinct, so the 8 read-modify-writes of a thread are independent: all ids and
+    // counts first, then both gathers, then the stores (written as a plain loop the accumulator store of one posting and
+    // the accumulator load of the next may alias, and every posting pays two dependent memory round trips)
+    constexpr int PER = BM25_CHUNK / 256;
+    int32_t d[PER];
+    double f[PER], kd[PER], old[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int64_t i = lo + threadIdx.x + u * 256;
+        const int64_t ic = i < hi ? i : hi - 1;
+        d[u] = doc_ids[ic];
+        f[u] = (double)tf[ic];
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        kd[u] = doc_k[d[u]];
+        old[u] = row[d[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int64_t i = lo + threadIdx.x + u * 256;
+        const double numer = (f[u] * pr.idf) * k1p1;
+        const double denom = f[u] + kd[u];
+        if (i < hi) row[d[u]] = old[u] + numer / denom;
     }
 }
 
