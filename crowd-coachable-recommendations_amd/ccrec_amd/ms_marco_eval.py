@@ -20,6 +20,7 @@ import torch
 from . import ops
 
 KEEP = 1001  # ms_marco_eval.py:230
+CANONICAL_COS_SIM_MACS = 4e9   # above this many multiply-adds cos_sim() switches from the fp64 to the MFMA score kernel
 
 
 def generate_embeddings(data_indices, data_dic, embedding_func, batch_size, embedding_size=768, name=None, pack=None,
@@ -70,7 +71,10 @@ def cos_sim(a: torch.Tensor, b: torch.Tensor):
         b = b.unsqueeze(0)
     a_n = ops.pack_bf16(a.cuda().float(), normalize=True)
     b_n = ops.pack_bf16(b.cuda().float(), normalize=True)
-    return ops.CorpusIndex(b_n).debug_scores(a_n, canonical=True)
+    # small matrices: the canonical fp64-ordered scores (bit-identical to the oracle); large ones: the MFMA tile kernel
+    # (fp32 accumulation of the same bf16 rows, within 1e-6 of the canonical value) -- the fp64 path is VALU-bound
+    big = a_n.shape[0] * b_n.shape[0] * a_n.shape[1] > CANONICAL_COS_SIM_MACS and a_n.shape[1] % 64 == 0
+    return ops.CorpusIndex(b_n).debug_scores(a_n, canonical=not big)
 
 
 class Retriever:

@@ -237,6 +237,24 @@ def test_packed_message_strided_merge_equals_single():
     assert torch.equal(mi, i1) and torch.equal(ms.view(torch.int32), s1.view(torch.int32))
 
 
+@pytest.mark.parametrize("na,nb", [(5, 300), (600, 9000)])
+def test_cos_sim_matches_reference_formula(na, nb):
+    """scripts/ms_marco_eval.py:155-162: normalize(a) @ normalize(b).T.  Small case: bit-identical to the oracle's
+    canonical scores of the normalised bf16 rows; large case (MFMA path): within 1e-3 of the fp32 formula, the
+    tolerance the bf16 rounding of the normalised rows sets."""
+    from ccrec_amd import ms_marco_eval as mm
+    g = torch.Generator().manual_seed(na)
+    a, b = torch.randn(na, 768, generator=g), torch.randn(nb, 768, generator=g)
+    got = mm.cos_sim(a, b)
+    ref = torch.nn.functional.normalize(a, p=2, dim=1) @ torch.nn.functional.normalize(b, p=2, dim=1).T
+    assert got.shape == (na, nb)
+    torch.testing.assert_close(got.cpu(), ref, rtol=0, atol=1e-3)
+    if na * nb * 768 <= mm.CANONICAL_COS_SIM_MACS:
+        can = orc.canonical_scores(orc.normalize_pack_bf16(a.numpy()), orc.normalize_pack_bf16(b.numpy()))
+        assert np.array_equal(got.cpu().numpy().view(np.uint32), can.view(np.uint32))
+    assert mm.cos_sim(a[0], b[:3]).shape == (1, 3)          # 1-D inputs are promoted like the reference does
+
+
 def test_assign_topk_golden(golden_dir):
     from ccrec_amd.rime_util import _assign_topk
     g = np.load(os.path.join(golden_dir, "g8_assign_topk.npz"))
