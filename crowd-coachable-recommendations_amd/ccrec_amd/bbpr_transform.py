@@ -54,8 +54,10 @@ class LowRankScore:
         return LowRankScore(self.item, self.user)
 
     def as_tensor(self, device=None):
-        """Dense canonical scores (small problems only: this materialises n_users x n_items fp32)."""
-        s = ops.CorpusIndex(self.item).debug_scores(self.user, canonical=True)
+        """Dense scores (this materialises n_users x n_items fp32): canonical fp64-ordered values for small problems,
+        the MFMA tile kernel (same bf16 rows, fp32 accumulation) above 4e9 multiply-adds."""
+        big = self.shape[0] * self.shape[1] * self.user.shape[1] > 4e9 and self.user.shape[1] % 64 == 0
+        s = ops.CorpusIndex(self.item).debug_scores(self.user, canonical=not big)
         return s if device is None else s.to(device)
 
     def numpy(self):
