@@ -156,24 +156,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
         auto issue = [&]() {
             char *buf = smem + (int)(iu & (RING - 1)) * SUB_BYTES;
             const int k0 = iks * SUB_K;
-            if constexpr ((DBG & 32) != 0) {
-                // timing-only: same bytes per sub-stage, but every 1-KiB piece reads 8 rows x 128 B (whole cache
-                // lines) instead of 16 rows x 64 B; rows alternate between the tile halves by sub-stage parity
-                const int r8 = wv * 8 + (lane >> 3) + (iks & 1) * 128;
-                const int col = (lane & 7) * 8 + (iks >> 1) * 64;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    int64_t drow = (r + it * a.ranges) * a.tile_stride * TILE_DOCS + i * 64 + r8;
-                    if (drow > a.n_rows - 1) drow = a.n_rows - 1;
-                    glds16(a.D + drow * a.dim + col, buf + (i * 512 + wv * 64) * 16);
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    int qrow = q0 + i * 64 + r8;
-                    if (qrow > a.n_q - 1) qrow = a.n_q - 1;
-                    glds16(a.Q + (int64_t)qrow * a.dim + col, buf + SUB_Q_REGION + (i * 512 + wv * 64) * 16);
-                }
-            } else if constexpr (!(DBG & 4)) {
+            if constexpr (!(DBG & 4)) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) glds16(dsrc[i] + k0, buf + (i * 512 + wv * 64) * 16);
 #pragma unroll
@@ -1096,7 +1079,7 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
 // The dynamic-LDS opt-in (> 64 KiB) is a per-device function attribute: set it on every launch (a cheap
 // host-side call) instead of caching a per-process flag that would be wrong for a second device.
 template <class K>
-static int launch_kernel(K kernel, size_t lds, const GemmArgs &a, int grid, hipStream_t s, bool &) {
+static int launch_kernel(K kernel, size_t lds, const GemmArgs &a, int grid, hipStream_t s) {
     CCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(GEMM_THREADS), lds, s, a);
     CCR_LAUNCH_CHECK();
@@ -1105,7 +1088,6 @@ static int launch_kernel(K kernel, size_t lds, const GemmArgs &a, int grid, hipS
 
 template <int EPI>
 static int launch_gemm(const GemmArgs &a, int grid, hipStream_t s) {
-    static bool c0 = false, c1 = false, cd = false;
     static int dbg = -1, stagger = 1;
     if (dbg < 0) {
         const char *e = getenv("CCR_GEMM_DBG");      // timing-only ablations of the main pass (WRONG results)
@@ -1116,30 +1098,26 @@ static int launch_gemm(const GemmArgs &a, int grid, hipStream_t s) {
     const size_t lds = RING * (size_t)SUB_BYTES;
     if ((EPI == EPI_FILTER || EPI == EPI_FILTER_GROUP) && dbg != 0) {
         switch (dbg) {
-            case 1: return launch_kernel(&gemm_topk_kernel<EPI, true, 1>, lds, a, grid, s, cd);
-            case 2: return launch_kernel(&gemm_topk_kernel<EPI, true, 2>, lds, a, grid, s, cd);
-            case 3: return launch_kernel(&gemm_topk_kernel<EPI, true, 3>, lds, a, grid, s, cd);
-            case 4: return launch_kernel(&gemm_topk_kernel<EPI, true, 4>, lds, a, grid, s, cd);
-            case 8: return launch_kernel(&gemm_topk_kernel<EPI, true, 8>, lds, a, grid, s, cd);
-            case 16: return launch_kernel(&gemm_topk_kernel<EPI, true, 16>, lds, a, grid, s, cd);
-            case 32: return launch_kernel(&gemm_topk_kernel<EPI, true, 32>, lds, a, grid, s, cd);
-            case 40: return launch_kernel(&gemm_topk_kernel<EPI, true, 40>, lds, a, grid, s, cd);
-            case 11: return launch_kernel(&gemm_topk_kernel<EPI, true, 11>, lds, a, grid, s, cd);
-            default: return launch_kernel(&gemm_topk_kernel<EPI, true, 12>, lds, a, grid, s, cd);
+            case 1: return launch_kernel(&gemm_topk_kernel<EPI, true, 1>, lds, a, grid, s);
+            case 2: return launch_kernel(&gemm_topk_kernel<EPI, true, 2>, lds, a, grid, s);
+            case 3: return launch_kernel(&gemm_topk_kernel<EPI, true, 3>, lds, a, grid, s);
+            case 4: return launch_kernel(&gemm_topk_kernel<EPI, true, 4>, lds, a, grid, s);
+            case 8: return launch_kernel(&gemm_topk_kernel<EPI, true, 8>, lds, a, grid, s);
+            case 11: return launch_kernel(&gemm_topk_kernel<EPI, true, 11>, lds, a, grid, s);
+            case 16: return launch_kernel(&gemm_topk_kernel<EPI, true, 16>, lds, a, grid, s);
+            default: break;   // unknown value: the production kernel
         }
     }
-    if (!stagger) return launch_kernel(&gemm_topk_kernel<EPI, false, 0>, lds, a, grid, s, c0);
-    return launch_kernel(&gemm_topk_kernel<EPI, true, 0>, lds, a, grid, s, c1);
+    if (!stagger) return launch_kernel(&gemm_topk_kernel<EPI, false, 0>, lds, a, grid, s);
+    return launch_kernel(&gemm_topk_kernel<EPI, true, 0>, lds, a, grid, s);
 }
 
 int launch_gemm_filter(const GemmArgs &a, int grid, hipStream_t s) { return launch_gemm<EPI_FILTER>(a, grid, s); }
 int launch_gemm16_filter(const GemmArgs &a, int grid, hipStream_t s) {
-    static bool c = false;
-    return launch_kernel(&gemm_topk16_kernel<EPI_FILTER, 0>, RING * (size_t)SUB_BYTES, a, grid, s, c);
+    return launch_kernel(&gemm_topk16_kernel<EPI_FILTER, 0>, RING * (size_t)SUB_BYTES, a, grid, s);
 }
 int launch_gemm16_store(const GemmArgs &a, int grid, hipStream_t s) {
-    static bool c = false;
-    return launch_kernel(&gemm_topk16_kernel<EPI_STORE, 0>, RING * (size_t)SUB_BYTES, a, grid, s, c);
+    return launch_kernel(&gemm_topk16_kernel<EPI_STORE, 0>, RING * (size_t)SUB_BYTES, a, grid, s);
 }
 int launch_gemm_filter_group(const GemmArgs &a, int grid, hipStream_t s) { return launch_gemm<EPI_FILTER_GROUP>(a, grid, s); }
 int launch_gemm_gmax(const GemmArgs &a, int grid, hipStream_t s) { return launch_gemm<EPI_GMAX>(a, grid, s); }
