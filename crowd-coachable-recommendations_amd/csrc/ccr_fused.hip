@@ -176,6 +176,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
         // (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) of the 32-row MFMA tile.
         auto epilogue = [&](int64_t vt) {
             const int64_t row_base = vt * a.tile_stride * TILE_DOCS + wd * 128 + 4 * h;
+            const uint32_t row32 = (uint32_t)row_base;
+            const int64_t left = a.n_rows - row_base;
+            const uint32_t rows_left = left <= 0 ? 0u : (left > 128 ? 128u : (uint32_t)left);   // rows of this block inside the shard
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
                 float sub[4][4], mdt[4];
@@ -224,10 +227,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
 #pragma unroll
                                     for (int e2 = 0; e2 < 4; ++e2) {
                                         const float v = acc[dt][qt][4 * g + e2];
-                                        const int64_t doc = row_base + dt * 32 + 8 * g + e2;
-                                        if (v >= t && doc < a.n_rows) {
+                                        // 32-bit row arithmetic (local rows < 2^32; rows_left = n_rows - first row of this
+                                        // lane's block, clamped): the hit path is instruction-bound beside the partner's MFMAs
+                                        const uint32_t off = (uint32_t)(dt * 32 + 8 * g + e2);
+                                        if (v >= t && off < rows_left) {
                                             if (ncand[qt] < (uint32_t)a.cap)
-                                                clist[qt][ncand[qt]] = make_uint2(__float_as_uint(v), (uint32_t)doc);
+                                                clist[qt][ncand[qt]] = make_uint2(__float_as_uint(v), row32 + off);
                                             ++ncand[qt];
                                         }
                                     }
