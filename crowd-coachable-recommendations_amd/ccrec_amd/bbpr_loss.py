@@ -31,3 +31,39 @@ def multiple_nrl_loss(qid_emb, pos_emb, neg_emb, inv_temperature=None, sim_type=
         pos_emb = torch.nn.functional.normalize(pos_emb, p=2, dim=1)
         neg_emb = torch.nn.functional.normalize(neg_emb, p=2, dim=1)
     return ops.inbatch_ce(qid_emb, pos_emb, neg_emb, inv_temperature)
+
+
+def compute_user_to_negatives(tr_prior_score):
+    """bbpr.py:216-227: {user: [hard negatives]} from the sparse prior (entries with value >= 1.0 are negatives; every
+    user that appears gets a list)."""
+    coo = tr_prior_score.coalesce() if not tr_prior_score.is_coalesced() else tr_prior_score
+    users, negs = coo.indices().tolist()
+    out = {}
+    for u, j, v in zip(users, negs, coo.values().tolist()):
+        out.setdefault(u, [])
+        if v >= 1.0:
+            out[u].append(j)
+    return out
+
+
+class MultipleNrlStep:
+    """training_and_validation_step of _BertBPR for objective == "multiple_nrl" (bbpr.py:149-152,187-214) as a callable:
+    batch [B,3] = (i, j, w) -> scalar loss with autograd through `forward`.
+
+    forward: item pointer tensor -> embeddings [n, dim] (the item tower on self.all_inputs[ptr] in the reference);
+    i_to_ptr / j_to_ptr: user / item index -> item pointer; user_to_negs: round-robin hard-negative lists (mutated)."""
+
+    def __init__(self, forward, i_to_ptr, j_to_ptr, user_to_negs):
+        self.forward, self.i_to_ptr, self.j_to_ptr, self.user_to_negs = forward, i_to_ptr, j_to_ptr, user_to_negs
+
+    def __call__(self, batch, batch_idx=0):
+        i, j, _w = batch.T
+        i, j = i.to(int), j.to(int)
+        with torch.no_grad():
+            nj = pick_round_robin_negatives(self.user_to_negs, i)
+        qid_emb = self.forward(self.i_to_ptr[i.ravel()]).reshape([*i.shape, -1])
+        pos_emb = self.forward(self.j_to_ptr[j.ravel()]).reshape([*j.shape, -1])
+        neg_emb = self.forward(self.j_to_ptr[nj]).reshape([*j.shape, -1])
+        return multiple_nrl_loss(qid_emb, pos_emb, neg_emb)
+
+    training_and_validation_step = __call__

@@ -57,3 +57,62 @@ def _assign_topk(S, k, tie_breaker=1e-10, device="cpu", batch_size=None):
 
 
 assign_topk = _assign_topk
+
+
+def perplexity(x):
+    """exp(entropy) of the normalised counts (src/rime_lite/util/__init__.py:158-160)."""
+    x = np.ravel(x) / np.sum(x)
+    return float(np.exp(-x @ np.log(np.where(x > 0, x, 1e-10))))
+
+
+def _dense_sum(x, axis):
+    return np.asarray(x.sum(axis)).ravel() if axis is not None else float(x.sum())
+
+
+def evaluate_assigned(target_csr, assigned_csr, score_mat=None, axis=None, min_total_recs=0, device="cpu"):
+    """src/rime_lite/metrics/__init__.py:52-84 for a sparse / dense target and a sparse assignment: precision, coverage,
+    perplexity (and recall along `axis`, objective mean when a score is given).  score_mat may be a low-rank lazy score
+    (bbpr_transform.LowRankScore, a (U, V) pair or an object with .left/.right): only the assigned cells are scored."""
+    target = sps.csr_matrix(target_csr)
+    assigned = sps.csr_matrix(assigned_csr)
+    hit = target.multiply(assigned)
+    hit_axis = _dense_sum(hit, axis) if axis is not None else float(hit.sum())
+    sum0, sum1 = _dense_sum(assigned, 0), _dense_sum(assigned, 1)
+    min_total_recs = max(min_total_recs, sum0.sum())
+    out = {
+        "prec": np.sum(hit_axis) / min_total_recs,
+        "recs/user": sum1.mean(),
+        "item_cov": (sum0 > 0).mean(),
+        "item_ppl": perplexity(sum0),
+        "user_cov": (sum1 > 0).mean(),
+        "user_ppl": perplexity(sum1),
+    }
+    if score_mat is not None:
+        coo = assigned.tocoo()
+        if hasattr(score_mat, "user") and hasattr(score_mat, "item"):
+            U, V = score_mat.user.float(), score_mat.item.float()
+        else:
+            fac = _factors(score_mat)
+            U, V = (fac[0], fac[1]) if fac is not None else (None, None)
+        if U is not None:
+            rows = torch.as_tensor(coo.row, dtype=torch.long, device=U.device)
+            cols = torch.as_tensor(coo.col, dtype=torch.long, device=U.device)
+            w = torch.as_tensor(coo.data, dtype=torch.float64, device=U.device)
+            obj_sum = float(((U[rows].double() * V[cols].double()).sum(1) * w).sum())
+        else:
+            dense = np.asarray(score_mat.numpy() if hasattr(score_mat, "numpy") else score_mat)
+            obj_sum = float((dense[coo.row, coo.col] * coo.data).sum())
+        out["obj_mean"] = float(obj_sum / min_total_recs)
+    if axis is not None:
+        ideal = np.ravel(target.sum(axis=axis))
+        # as the reference computes it (metrics/__init__.py:80-82): the hit counts keep the [n, 1] / [1, n] shape of a
+        # sparse .sum(axis), so along axis=1 the division by the flat `ideal` broadcasts to an n x n table before the mean
+        hits_2d = np.asarray(hit.sum(axis))
+        out["recall"] = (hits_2d / np.fmax(1, ideal)).mean()
+    return out
+
+
+def evaluate_item_rec(target_csr, score_mat, topk, device="cpu", **kw):
+    """src/rime_lite/metrics/__init__.py:87-89: top-k assignment of the (lazy) score, then evaluate_assigned along users."""
+    assigned_csr = _assign_topk(score_mat, topk, device=device, **kw)
+    return evaluate_assigned(target_csr, assigned_csr, score_mat, axis=1, device=device)

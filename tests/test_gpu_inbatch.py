@@ -52,3 +52,26 @@ def test_fwd_bwd_vs_oracle(B, dim):
     # deterministic: same bits on a second run
     loss2 = ops.inbatch_ce(qc.detach(), pc.detach(), nc.detach(), inv_t)
     assert float(loss2) == float(loss)
+
+
+@pytest.mark.parametrize("tag,B,sim", [("b8_dot", 8, "dot"), ("b32_cos", 32, "cos")])
+def test_training_step_mirror_vs_reference_golden(golden_dir, tag, B, sim):
+    """The whole training_and_validation_step (bbpr.py:149-214, multiple_nrl): fixture g7 was produced by calling the
+    reference's method with a table-lookup forward; the mirror is set up the same way (SURVEY 8b signature)."""
+    from ccrec_amd.bbpr_loss import MultipleNrlStep, compute_user_to_negatives
+    g = np.load(os.path.join(golden_dir, "g7_contrastive.npz"))
+    os.environ["CCREC_SIM_TYPE"] = sim
+    os.environ["CCREC_BBPR_INV_TEMPERATURE"] = "20"
+    E = torch.from_numpy(g[f"{tag}_E"]).cuda().requires_grad_(True)
+    # hard negatives from a sparse prior, as compute_user_to_negatives builds them: user u -> item B + u (value 1)
+    prior = torch.sparse_coo_tensor(torch.stack([torch.arange(B), B + torch.arange(B)]), torch.ones(B), (B, 2 * B))
+    negs = compute_user_to_negatives(prior)
+    assert negs == {u: [B + u] for u in range(B)}
+    step = MultipleNrlStep(lambda ptr: E[ptr], torch.arange(0, B), torch.arange(B, 3 * B), negs)
+    batch = torch.stack([torch.arange(B), torch.arange(B), torch.ones(B, dtype=torch.long)], 1)
+    loss = step.training_and_validation_step(batch, 0)
+    loss.backward()
+    assert abs(float(loss) - float(g[f"{tag}_loss"])) < 3e-2 * max(1.0, abs(float(g[f"{tag}_loss"])))
+    ref = g[f"{tag}_grad"]
+    assert np.abs(E.grad.cpu().numpy() - ref).max() < 6e-2 * np.abs(ref).max()
+    assert negs == {u: [B + u] for u in range(B)}          # round robin over a single negative leaves the list as it was

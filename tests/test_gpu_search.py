@@ -325,3 +325,24 @@ def test_rank_metrics_and_profile_tensors():
     qids, ti, ts = profile_to_tensors(prof, corpus_ids)
     assert np.array_equal(ti.numpy(), ids)
     assert tensors_to_profile(qids, corpus_ids, ti, ts) == prof
+
+
+def test_evaluate_item_rec_matches_reference(golden_dir):
+    """src/rime_lite/metrics/__init__.py:87-89 (SURVEY 8b signature) on a low-rank score: fixture g13 is the reference's
+    evaluate_item_rec on MatMulExpression(U @ V.T); U, V are bf16-exact so the fused top-k sees the same values."""
+    import scipy.sparse as sps
+    from ccrec_amd.rime_util import evaluate_item_rec, evaluate_assigned, _assign_topk
+    from ccrec_amd.bbpr_transform import LowRankScore
+    from ccrec_amd import ops
+    g = np.load(os.path.join(golden_dir, "g13_item_rec.npz"))
+    U, V, k = g["U"], g["V"], int(g["k"])
+    target = sps.csr_matrix((np.ones(len(g["target_indices"])), g["target_indices"], g["target_indptr"]), shape=(U.shape[0], V.shape[0]))
+    out = evaluate_item_rec(target, (U, V), k)
+    for key in ("prec", "recs/user", "item_cov", "item_ppl", "user_cov", "user_ppl", "obj_mean", "recall"):
+        ref = float(g["m_" + key.replace("/", "_")])
+        assert abs(out[key] - ref) <= 1e-6 * max(1.0, abs(ref)), (key, out[key], ref)
+    assert out["prec"] > 0.1
+    # the lazy low-rank score object gives the same numbers
+    S = LowRankScore(ops.pack_bf16(torch.from_numpy(U).cuda()), ops.pack_bf16(torch.from_numpy(V).cuda()))
+    out2 = evaluate_assigned(target, _assign_topk(S, k), S, axis=1)
+    assert all(abs(out2[key] - out[key]) < 1e-9 for key in out)

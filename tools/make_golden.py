@@ -23,6 +23,7 @@ Fixtures:
       namespace: the script itself is not importable -- it parses argv and loads datasets at import time)
   G11 generate_train_data (scripts/al_oracle_agent.py, the function's own source executed the same way)
   G12 BM25: the reference's bm_25.BM25 (imported) and ranking_bm25 (function source executed) on a toy corpus
+  G13 rime_lite.metrics.evaluate_item_rec on a MatMulExpression score (the §8b signature that consumes _assign_topk)
 """
 import contextlib
 import importlib.abc
@@ -371,12 +372,37 @@ def g_bm25():
     print("g12_bm25", dense.shape, len(model.vectorizer.vocabulary_))
 
 
+def g_item_rec():
+    """G13: evaluate_item_rec(target, MatMulExpression(U @ V.T), k) from the reference's rime_lite."""
+    _import_reference("dot")
+    import scipy.sparse as sps
+    from rime_lite.metrics import evaluate_item_rec
+    from rime_lite.util import auto_cast_lazy_score
+    g = torch.Generator().manual_seed(13)
+    U = bf16_exact(torch.randn(40, 64, generator=g) / 8).numpy()
+    V = bf16_exact(torch.randn(900, 64, generator=g) / 8).numpy()
+    rs = np.random.RandomState(13)
+    true = U.astype(np.float64) @ V.astype(np.float64).T
+    rows, cols = [], []
+    for u in range(40):                       # relevant items: a random third of each user's 30 best + 5 random ones
+        best = np.argsort(-true[u])[:30]
+        pick = set(best[rs.rand(30) < 0.33].tolist()) | set(rs.randint(0, 900, 5).tolist())
+        rows += [u] * len(pick)
+        cols += sorted(pick)
+    target = sps.csr_matrix((np.ones(len(rows)), (rows, cols)), shape=(40, 900))
+    S = auto_cast_lazy_score(U) @ auto_cast_lazy_score(V).T
+    out = evaluate_item_rec(target, S, 7, tie_breaker=0)
+    np.savez_compressed(os.path.join(OUT, "g13_item_rec.npz"), U=U, V=V, target_indptr=target.indptr, target_indices=target.indices,
+                        k=7, **{"m_" + k.replace("/", "_"): np.float64(v) for k, v in out.items()})
+    print("g13_item_rec", out)
+
+
 def main():
     """No arguments: every fixture.  `make_golden.py g10 g11`: only the named groups (g1 = all ranking fixtures)."""
     os.makedirs(OUT, exist_ok=True)
     want = set(sys.argv[1:])
     groups = [("g1", lambda: g_ranking(_import_reference("dot"))), ("g6", g_item_tower), ("g7", g_contrastive),
-              ("g8", g_assign_topk), ("g9", g_pack), ("g10", g_requests), ("g11", g_train_data), ("g12", g_bm25)]
+              ("g8", g_assign_topk), ("g9", g_pack), ("g10", g_requests), ("g11", g_train_data), ("g12", g_bm25), ("g13", g_item_rec)]
     for name, fn in groups:
         if not want or name in want:
             fn()
