@@ -93,10 +93,20 @@ def cpu_baseline(corpus_bf16, queries_bf16, nq_sample, k, gpu_ids):
     ids, _ = orc.reference_ranking(Eq, Ed, 2048, "dot")
     dt = time.time() - t0
     rec = orc.recall_at_k(gpu_ids[:nq_sample].cpu().numpy(), ids[:, :k])
+    # SURVEY 8d variant (ii), the best the host can do with the same libraries: fp32 Q @ D^T + torch.topk(k) per query
+    # block, no host score matrix, no full sort (reported beside the reference-faithful number, never instead of it)
+    nq2 = min(4 * nq_sample, queries_bf16.shape[0])
+    Eq2, Edt = queries_bf16[:nq2].float().cpu(), torch.from_numpy(Ed)
+    t0 = time.time()
+    for lo in range(0, nq2, 64):
+        (Eq2[lo:lo + 64] @ Edt.T).topk(k, dim=1)
+    dt2 = time.time() - t0
     return {"value": round(nq_sample / dt, 3), "unit": "queries/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{nq_sample} queries x full {Ed.shape[0]}-row corpus, fp32 matmul chunks of 2048 + per-row full sort, "
                       f"keep 1001 ({dt:.1f} s)",
-            "recall_at_k_of_gpu_vs_cpu": round(rec, 5)}
+            "recall_at_k_of_gpu_vs_cpu": round(rec, 5),
+            "best_effort_value": round(nq2 / dt2, 3),
+            "best_effort_sample": f"{nq2} queries, fp32 matmul + torch.topk({k}) in blocks of 64 queries ({dt2:.1f} s)"}
 
 
 def main():
