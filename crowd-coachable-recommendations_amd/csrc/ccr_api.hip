@@ -130,6 +130,7 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu) {
         // makespan (in tiles, + 0.15 tile of pipeline fill per item) of one launch over ranges [rb, re) of R: the
         // busiest XCD set is range class 0; its per_x workgroups take items round-robin, range r owns
         // ceil((tiles - r) / R) tiles
+        const double select_per_range = 0.1;   // tile units per range; measured: decides R = 88 over 144 below ~1.5 M rows
         auto makespan = [&](int64_t rb, int64_t re, int64_t Rt) -> double {
             std::vector<double> load((size_t)per_x, 0.0);
             int64_t i = 0;
@@ -151,7 +152,9 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu) {
             ra = std::min<int64_t>(ra, rbody / 4 / nrc * nrc);
             if (!(prog_on && ra >= nrc && rbody + ra <= 1024 / p.sublists && (double)p.tiles / (double)(rbody + ra) >= 8.0)) ra = 0;
             const int64_t Rt = rbody + ra;
-            const double cost = (ra ? makespan(0, ra, Rt) : 0.0) + makespan(ra, Rt, Rt) +
+            // + the select stage's share: it walks R x sublists sub-lists per query (~0.6 us per range at 3 452 queries)
+            //   -- decides between near-equal makespans on small shards
+            const double cost = (ra ? makespan(0, ra, Rt) : 0.0) + makespan(ra, Rt, Rt) + select_per_range * (double)Rt +
                                 1e-3 * std::abs((double)(rbody - target));   // ties: stay near 6 items per workgroup
             if (cost < best) {
                 best = cost;
