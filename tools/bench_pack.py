@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""HBM-bound pack kernel (6 B per element: 4 read + 2 written) next to the device's own copy rates, NQ shape.
+Prints one JSON line: achieved GB/s of ccr_pack_bf16_ex (with max-norm), torch's fp32->bf16 cast, and a plain
+fp32 device-to-device copy (8 B per element) as the practical ceiling of this box."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "crowd-coachable-recommendations_amd")]
+
+
+def timeit(fn, iters=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters
+
+
+def main():
+    from ccrec_amd import ops
+    n, d = 2_681_468, 768
+    x = torch.randn(n, d, device="cuda")
+    y16 = torch.empty(n, d, dtype=torch.bfloat16, device="cuda")
+    y32 = torch.empty_like(x)
+    mx = torch.zeros(1, device="cuda")
+    el = n * d
+    t_pack = timeit(lambda: ops.pack_bf16(x, out=y16, max_norm=mx))
+    t_plain = timeit(lambda: ops.pack_bf16(x, out=y16))
+    t_cast = timeit(lambda: y16.copy_(x))
+    t_copy = timeit(lambda: y32.copy_(x))
+    print(json.dumps({"rows": n, "dim": d,
+                      "ccr_pack_maxnorm_GBps": round(el * 6 / t_pack / 1e9, 1), "ccr_pack_GBps": round(el * 6 / t_plain / 1e9, 1),
+                      "torch_cast_GBps": round(el * 6 / t_cast / 1e9, 1), "fp32_copy_GBps": round(el * 8 / t_copy / 1e9, 1),
+                      "ms": {"ccr_pack_maxnorm": round(t_pack * 1e3, 3), "ccr_pack": round(t_plain * 1e3, 3),
+                             "torch_cast": round(t_cast * 1e3, 3), "fp32_copy": round(t_copy * 1e3, 3)}}))
+
+
+if __name__ == "__main__":
+    main()
