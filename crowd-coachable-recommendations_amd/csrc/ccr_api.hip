@@ -144,7 +144,19 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu) {
         // Phase A (progressive thresholds): the first ranges, at most one round of items; CCR_PROGRESSIVE=0 disables.
         const char *pe = getenv("CCR_PROGRESSIVE");
         const bool prog_on = !(pe && atoi(pe) == 0);
-        int64_t R = target, RA = 0;
+        // Cost of a candidate (in tile units of one workgroup): makespans of the launches + the select stage's share of R
+        // + the filter/select work the surviving candidates cause + a launch boundary per extra phase.  Survivors per query
+        // (measured: 3 280 from the 1/32 sample alone, 1 180 with one re-tightening at k = 100): a phase that covers the
+        // fraction f of the corpus with thresholds taken from a fraction g seen before lets through k * f / g rows.
+        const double fs = (double)sample / (double)p.tiles;
+        const double hit_w = 0.014, phase_w = 3.0;
+        auto survivors = [&](double fa, double fb) -> double {   // fa, fb: corpus fractions of phases A and B1 (0 = absent)
+            if (fa <= 0.0) return (double)k / fs;
+            if (fb <= 0.0) return (double)k * (fa / fs + (1.0 - fa) / fa);
+            return (double)k * (fa / fs + fb / fa + (1.0 - fa - fb) / (fa + fb));
+        };
+        const int max_phases = getenv("CCR_PHASES") ? atoi(getenv("CCR_PHASES")) : 3;   // 2: at most one re-tightening
+        int64_t R = target, RA = 0, RB = 0;
         double best = 1e300;
         for (int64_t rbody = std::max<int64_t>(NUM_XCD, target / 2 / NUM_XCD * NUM_XCD); rbody <= std::min(r_hi, target * 2);
              rbody += NUM_XCD) {
@@ -152,18 +164,35 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu) {
             ra = std::min<int64_t>(ra, rbody / 4 / nrc * nrc);
             if (!(prog_on && ra >= nrc && rbody + ra <= 1024 / p.sublists && (double)p.tiles / (double)(rbody + ra) >= 8.0)) ra = 0;
             const int64_t Rt = rbody + ra;
-            // + the select stage's share: it walks R x sublists sub-lists per query (~0.6 us per range at 3 452 queries)
-            //   -- decides between near-equal makespans on small shards
-            const double cost = (ra ? makespan(0, ra, Rt) : 0.0) + makespan(ra, Rt, Rt) + select_per_range * (double)Rt +
-                                1e-3 * std::abs((double)(rbody - target));   // ties: stay near 6 items per workgroup
-            if (cost < best) {
-                best = cost;
+            const double common = select_per_range * (double)Rt + 1e-3 * std::abs((double)(rbody - target));   // ties: near 6 items per workgroup
+            const double fa = (double)ra / (double)Rt;
+            const double two = (ra ? makespan(0, ra, Rt) + phase_w : 0.0) + makespan(ra, Rt, Rt) + hit_w * survivors(fa, 0.0) + common;
+            if (two < best) {
+                best = two;
                 R = Rt;
                 RA = ra;
+                RB = 0;
+            }
+            if (!ra || max_phases < 3) continue;
+            // a second re-tightening after m more rounds of items (m = 1..3): the middle phase then fills its rounds
+            for (int m = 1; m <= 3; ++m) {
+                const int64_t mid = (int64_t)m * per_x / qb_per * nrc;
+                const int64_t rb = ra + mid;
+                if (mid < nrc || rb + nrc > Rt) break;
+                const double fb = (double)mid / (double)Rt;
+                const double three = makespan(0, ra, Rt) + makespan(ra, rb, Rt) + makespan(rb, Rt, Rt) + 2.0 * phase_w +
+                                     hit_w * survivors(fa, fb) + common;
+                if (three < best) {
+                    best = three;
+                    R = Rt;
+                    RA = ra;
+                    RB = rb;
+                }
             }
         }
         p.ranges = (int)R;
         p.ranges_a = (int)RA;
+        p.ranges_b = (int)RB;
         const double ratio = (double)p.tiles / (double)sample;
         const double expect = (double)k * ratio * 1.3 + 64.0;  // survivors per query
         // candidates go to 4 sub-lists per (range, query): one per (wave row, lane half) of the GEMM tile
@@ -441,21 +470,24 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
         gm.store = reinterpret_cast<float *>(stamps);
     }
     CCR_HIP_CHECK(hipEventRecord(ix->ev[3], s));
-    gm.range_begin = 0;
-    gm.range_end = p.ranges_a > 0 ? p.ranges_a : p.ranges;
     auto main_pass = [&](const GemmArgs &ga) {
         if (p.mfma16) return launch_gemm16_filter(ga, p.grid, s);
         return p.group_records ? launch_gemm_filter_group(ga, p.grid, s) : launch_gemm_filter(ga, p.grid, s);
     };
-    rc = main_pass(gm);
-    if (rc != CCR_OK) return rc;
-    if (p.ranges_a > 0) {
-        rc = launch_threshold_update(cand, cnt, p.ranges_a * p.sublists, p.sublists, n_q, p.nq_pad, p.cap, k, delta, thr, s);
-        if (rc != CCR_OK) return rc;
-        gm.range_begin = p.ranges_a;
-        gm.range_end = p.ranges;
+    // progressive thresholds: launches over the range sets [0, ra), [ra, rb), [rb, R) with a re-tightening in between
+    const int bounds[4] = {0, p.ranges_a, p.ranges_b, p.ranges};
+    int done = 0;
+    for (int ph = 1; ph < 4; ++ph) {
+        if (bounds[ph] <= done) continue;
+        if (done > 0) {
+            rc = launch_threshold_update(cand, cnt, done * p.sublists, p.sublists, n_q, p.nq_pad, p.cap, k, delta, thr, s);
+            if (rc != CCR_OK) return rc;
+        }
+        gm.range_begin = done;
+        gm.range_end = bounds[ph];
         rc = main_pass(gm);
         if (rc != CCR_OK) return rc;
+        done = bounds[ph];
     }
     CCR_HIP_CHECK(hipEventRecord(ix->ev[4], s));
     if (want_stamps) {

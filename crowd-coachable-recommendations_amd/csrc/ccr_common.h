@@ -55,6 +55,7 @@ struct Plan {
     int64_t sample_stride;
     int ranges;           // corpus ranges of the main pass (multiple of NUM_XCD)
     int ranges_a;         // ranges scored by phase A (0 = single phase); thresholds are re-tightened after it
+    int ranges_b;          // end of the second phase (0: two phases)
     int qgroups;          // query-block groups over the XCDs
     int cap;              // candidate slots per sub-list
     int grid;             // persistent workgroups (multiple of NUM_XCD)

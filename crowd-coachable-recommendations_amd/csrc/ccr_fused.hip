@@ -713,20 +713,19 @@ __global__ __launch_bounds__(256) void threshold_kernel(const float *__restrict_
     }
 }
 
-constexpr int UPDATE_COMPACT = 4096;  // scores gathered into LDS by threshold_update_kernel
 
 // Progressive thresholds: after phase A of the main pass (ranges [0, ranges_a)), the k-th largest candidate
 // score found so far is a tighter valid lower bound of the k-th largest score (the candidates are real rows
 // with their real MFMA scores, whether or not a sub-list overflowed).  thr[q] = max(thr[q], kth - delta[q]).
 // grid = n_q, block = 256.
 __global__ __launch_bounds__(256) void threshold_update_kernel(const uint2 *__restrict__ cand, const uint32_t *__restrict__ cnt,
-                                                              int nsub, int sp, int nq_pad, int cap, int k,
+                                                              int nsub, int sp, int nq_pad, int cap, int k, int compact,
                                                               const float *__restrict__ delta, float *__restrict__ thr) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_val[];   // [compact] orderable scores of the candidates found so far
     __shared__ uint32_t s_hist[256];
     __shared__ uint32_t s_ctl[4];
     __shared__ uint32_t s_cnt[1024];
     __shared__ uint32_t s_total, s_maxc, s_fill;
-    __shared__ uint32_t s_val[UPDATE_COMPACT];   // orderable scores of the candidates found so far
     const int tid = threadIdx.x;
     const int q = blockIdx.x;
     if (tid == 0) {
@@ -752,37 +751,28 @@ __global__ __launch_bounds__(256) void threshold_update_kernel(const uint2 *__re
     auto sub_base = [&](int j) -> int64_t { return (((int64_t)(j / sp) * nq_pad + q) * sp + (j % sp)) * cap; };
     uint32_t kth;
     int need_eq;
-    if (s_total <= (uint32_t)UPDATE_COMPACT) {
-        // the sub-lists are sparse: one sweep over (sub-list, slot < longest list) with independent loads gathers the
-        // scores into LDS, the four radix passes then never touch global memory
+    {
+        // The sub-lists are sparse: one sweep over (sub-list, slot < longest list) with independent loads gathers the
+        // scores into LDS, the four radix passes then never touch global memory.  If more candidates exist than the LDS
+        // holds, the first `compact` the sweep meets are enough: the k-th largest score of ANY k or more real rows is a
+        // valid lower bound of the query's k-th largest score.
         const int maxc = (int)s_maxc;
-        const int M = (int)s_total;
         for (int i = tid; i < nsub * maxc; i += blockDim.x) {
             const int j = i / maxc, sl = i - j * maxc;
             if ((uint32_t)sl < s_cnt[j]) {
                 const uint32_t o = f32_orderable(__uint_as_float(cand[sub_base(j) + sl].x));
-                s_val[atomicAdd(&s_fill, 1u)] = o;
+                const uint32_t p = atomicAdd(&s_fill, 1u);
+                if (p < (uint32_t)compact) s_val[p] = o;
             }
         }
         __syncthreads();
+        const int M = (int)(s_total < (uint32_t)compact ? s_total : (uint32_t)compact);
         block_radix_select(
             [&](int64_t i, bool &skip) -> uint32_t {
                 (void)skip;
                 return s_val[i];
             },
             (int64_t)M, k, s_hist, s_ctl, kth, need_eq);
-    } else {
-        block_radix_select(
-            [&](int64_t i, bool &skip) -> uint32_t {
-                const int j = (int)(i / cap);
-                const int sl = (int)(i - (int64_t)j * cap);
-                if ((uint32_t)sl >= s_cnt[j]) {
-                    skip = true;
-                    return 0u;
-                }
-                return f32_orderable(__uint_as_float(cand[sub_base(j) + sl].x));
-            },
-            (int64_t)nsub * cap, k, s_hist, s_ctl, kth, need_eq);
     }
     if (tid == 0) {
         const float t1 = orderable_to_f32(kth) - delta[q];
@@ -1151,7 +1141,13 @@ int launch_threshold_update(const uint2 *cand, const uint32_t *cnt, int nsub, in
         set_error("threshold_update: %d sub-lists exceed 1024", nsub);
         return CCR_ERR_INVALID;
     }
-    hipLaunchKernelGGL(threshold_update_kernel, dim3(n_q), dim3(256), 0, s, cand, cnt, nsub, sp, nq_pad, cap, k, delta, thr);
+    // LDS score buffer: comfortably more than k (the bound tightens with the number of rows seen), 16 KiB at least
+    int compact = std::max(4096, 8 * pow2_ceil(k));
+    if (compact > 32768) compact = 32768;
+    const size_t lds = (size_t)compact * 4;
+    if (lds > 48 * 1024)
+        CCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&threshold_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(threshold_update_kernel, dim3(n_q), dim3(256), lds, s, cand, cnt, nsub, sp, nq_pad, cap, k, compact, delta, thr);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
 }
