@@ -98,6 +98,7 @@ class CorpusIndex:
         self.offset = int(global_row_offset)
         self._h = ctypes.c_void_p()
         self._ws = None
+        self._ws_need = {}
         with _on(self.corpus):
             if max_norm is None:
                 _lib.check(self._lib.ccr_index_create(_ptr(self.corpus), self.n_rows, self.dim, self.offset,
@@ -114,7 +115,9 @@ class CorpusIndex:
             self._lib.ccr_index_destroy(h)
 
     def _workspace(self, n_q, k):
-        need = int(self._lib.ccr_search_workspace_bytes(self._h, n_q, k))
+        need = self._ws_need.get((n_q, k))
+        if need is None:   # the planner runs three times in there: once per (n_q, k) is enough
+            need = self._ws_need[(n_q, k)] = int(self._lib.ccr_search_workspace_bytes(self._h, n_q, k))
         if self._ws is None or self._ws.numel() < need:
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.corpus.device)

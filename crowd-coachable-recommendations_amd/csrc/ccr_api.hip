@@ -272,6 +272,8 @@ struct ccr_index {
     int num_cu;
     int device;
     hipEvent_t ev[7];     // phase boundaries of the last search
+    Plan plan;            // plan of the last search and its key (the planner simulates item assignments: ~25 us)
+    int plan_nq, plan_k, plan_flags;
     ccr_search_stats stats;
 };
 
@@ -386,7 +388,13 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
     memset(&ix->stats, 0, sizeof(ix->stats));
     if (n_q == 0) return CCR_OK;
     hipStream_t s = (hipStream_t)stream;
-    const Plan p = make_plan(ix->n_rows, ix->dim, n_q, k, flags, ix->num_cu);
+    if (!(ix->plan_nq == n_q && ix->plan_k == k && ix->plan_flags == flags)) {
+        ix->plan = make_plan(ix->n_rows, ix->dim, n_q, k, flags, ix->num_cu);
+        ix->plan_nq = n_q;
+        ix->plan_k = k;
+        ix->plan_flags = flags;
+    }
+    const Plan p = ix->plan;
     if (!workspace || ws_bytes < p.total || (uintptr_t)workspace % 256 != 0) {
         set_error("ccr_search: workspace %zu bytes (256-byte aligned) required, got %zu at %p", p.total, ws_bytes, workspace);
         return CCR_ERR_WORKSPACE;
