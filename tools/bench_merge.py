@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Shard-merge kernel timing (ccr_merge_topk) for R shards x 3 452 queries x top-k, checked against the oracle."""
+import sys,time,torch,numpy as np
+sys.path[:0]=[".","crowd-coachable-recommendations_amd"]
+from ccrec_amd import ops
+from oracle import oracle as orc
+for R,k in ((2,100),(4,100),(8,100),(8,1001),(16,1001)):
+    # distinct scores per query (small integers, exact in fp32): per-shard lists must already be in canonical order, and
+    # random ids would put exact ties in the wrong order
+    ranks=torch.rand(3452,R*k,device="cuda").argsort(dim=1).float()            # a permutation of 0..R*k-1 per query
+    s=ranks.view(3452,R,k).permute(1,0,2).contiguous().sort(dim=2,descending=True).values
+    i=torch.randint(0,2681468,(R,3452,k),device="cuda")
+    a,b=ops.merge_topk(s,i)
+    os_,oi=orc.merge_topk(s[:, :40].cpu().numpy(), i[:, :40].cpu().numpy())
+    assert np.array_equal(a[:40].cpu().numpy(), os_) and np.array_equal(b[:40].cpu().numpy(), oi)
+    for _ in range(3): ops.merge_topk(s,i)
+    torch.cuda.synchronize(); t=time.perf_counter()
+    for _ in range(30): ops.merge_topk(s,i)
+    torch.cuda.synchronize(); print("R",R,"k",k,"merge", round((time.perf_counter()-t)/30*1e6,1),"us")
