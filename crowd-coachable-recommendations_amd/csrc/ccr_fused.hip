@@ -928,35 +928,43 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
     } else if (!bad && compact < k) {
         bad = true;   // the LDS budget cannot even hold k records (huge dim * k): exact dense path
     } else if (!bad) {
-        // More candidates than the LDS holds: select on the PREFIX that fits (sub-list order) -- its k-th largest score is
-        // a valid lower bound of the query's k-th largest -- then sweep again and keep only the records above that bound
-        // (minus the margin); they fit with room to spare (about k * total / compact records).
-        sweep_sublists<THREADS, 8>(tid, ranges, 0, (int)s_maxc, s_cnt, at,
-                                   [&](int j, int sl) { return s_off[j] + (uint32_t)sl < (uint32_t)compact; },
-                                   [&](int j, int sl, uint2 e) { s_comp[s_off[j] + sl] = e; });
-        __syncthreads();
-        uint32_t kth0 = 0;
-        int eq0 = 0;
-        block_radix_select(
-            [&](int64_t i, bool &skip) -> uint32_t {
-                (void)skip;
-                return f32_orderable(__uint_as_float(s_comp[i].x));
-            },
-            compact, k, s_hist, s_ctl, kth0, eq0);
-        const float keep = orderable_to_f32(kth0) - delta[q];
-        __syncthreads();   // every thread is done with the prefix before it is overwritten
-        sweep_sublists<THREADS, 8>(tid, ranges, 0, (int)s_maxc, s_cnt, at, [](int, int) { return true; },
-                                   [&](int, int, uint2 e) {
-                                       if (__uint_as_float(e.x) >= keep) {
-                                           const uint32_t p = atomicAdd(&s_fill, 1u);
-                                           if (p < (uint32_t)compact) s_comp[p] = e;
-                                       }
-                                   });
-        __syncthreads();
-        if (s_fill > (uint32_t)compact)
-            bad = true;   // (near-)constant scores: the exact dense path takes the query
-        else
+        // More candidates than the LDS holds.  The k-th largest score of ANY `compact` of them is a valid lower bound of
+        // the query's k-th largest, so: keep the first `compact` records that pass the current bound (none at first),
+        // and while more than that passed, tighten the bound to (k-th largest of the kept ones) - delta and sweep again.
+        // Every sweep at least halves what passes (the kept ones are a random part of what passed); 4 sweeps cover
+        // 16 x the LDS capacity, beyond that the exact dense path takes the query.
+        float keep = -INFINITY;
+        bool fits = false;
+        for (int round = 0; round < 4 && !fits; ++round) {
+            __syncthreads();   // everybody is done with s_comp / s_fill of the previous round
+            if (tid == 0) s_fill = 0u;
+            __syncthreads();
+            sweep_sublists<THREADS, 8>(tid, ranges, 0, (int)s_maxc, s_cnt, at, [](int, int) { return true; },
+                                       [&](int, int, uint2 e) {
+                                           if (__uint_as_float(e.x) >= keep) {
+                                               const uint32_t p = atomicAdd(&s_fill, 1u);
+                                               if (p < (uint32_t)compact) s_comp[p] = e;
+                                           }
+                                       });
+            __syncthreads();
+            if (s_fill <= (uint32_t)compact) {
+                fits = true;
+            } else {
+                uint32_t kth0 = 0;
+                int eq0 = 0;
+                block_radix_select(
+                    [&](int64_t i, bool &skip) -> uint32_t {
+                        (void)skip;
+                        return f32_orderable(__uint_as_float(s_comp[i].x));
+                    },
+                    compact, k, s_hist, s_ctl, kth0, eq0);
+                keep = orderable_to_f32(kth0) - delta[q];
+            }
+        }
+        if (fits)
             n_lds = (int)s_fill;
+        else
+            bad = true;   // (near-)constant scores or k close to the LDS capacity: the exact dense path takes the query
     }
     if (!bad) {
         const int M = n_lds;

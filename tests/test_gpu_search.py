@@ -346,3 +346,17 @@ def test_evaluate_item_rec_matches_reference(golden_dir):
     S = LowRankScore(ops.pack_bf16(torch.from_numpy(U).cuda()), ops.pack_bf16(torch.from_numpy(V).cuda()))
     out2 = evaluate_assigned(target, _assign_topk(S, k), S, axis=1)
     assert all(abs(out2[key] - out[key]) < 1e-9 for key in out)
+
+
+def test_max_k_overflowing_select_lds_stays_on_the_fused_path():
+    """k = 4096 (MAX_K): far more candidates per query than the select stage's LDS holds; the iterative bound
+    tightening must still deliver the exact canonical result without sending the queries to the dense path."""
+    from ccrec_amd import ops
+    n, nq, d, k = 400_000, 24, 768, 4096
+    Db, Qb = _rand_bits(n, d, 71), _rand_bits(nq, d, 72)
+    index = ops.CorpusIndex(_bf16(Db))
+    s0, i0 = index.search(_bf16(Qb), k, 2)
+    st = index.last_stats()
+    assert st["path"] == 1 and st["n_fallback"] == 0, st
+    s1, i1 = index.search(_bf16(Qb), k, 1)
+    assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
