@@ -23,15 +23,18 @@ def run_rank_step(tower, tokenizer, corpus, queries, qrels, step_qids, step, res
     work = os.path.join(results_dir, f"data_iteration_{step}")
     os.makedirs(work, exist_ok=True)
     path = os.path.join(work, "ranking_profile.pt")
+    ids = None
     if os.path.isfile(path):                                   # al_0_rank.py:115-118: resume from the saved profile
         profile = torch.load(path)
     else:
         encoder = LengthSortedEncoder(tower, tokenizer, **(encoder_kw or {}))
         with torch.autocast("cuda", enabled=bool(autocast)):
-            profile = ranking_sharded(corpus, queries, encoder, block_dict=block_dict)
+            profile, ids, _ = ranking_sharded(corpus, queries, encoder, block_dict=block_dict, with_tensors=True)
         torch.save(profile, path)
     corpus_ids = list(corpus)
-    qids, ids, _ = evaluation.profile_to_tensors(profile, corpus_ids)
+    qids = list(profile)
+    if ids is None:     # resumed: rebuild the id tensor from the dicts (the fresh path keeps the search's own tensor)
+        qids, ids, _ = evaluation.profile_to_tensors(profile, corpus_ids)
     pos = {pid: i for i, pid in enumerate(corpus_ids)}
     rel = [[pos[p] for p in qrels.get(q, {}) if p in pos] for q in qids]
     kmax = ids.shape[1]

@@ -122,11 +122,12 @@ def encode_local_shard(encoder, corpus_ids, corpus, sim, rank, world, max_norm=N
     return shard, lo, hi
 
 
-def ranking_sharded(corpus, queries, encoder, block_dict=None, rank=0, world=1, group=None, keep=None):
+def ranking_sharded(corpus, queries, encoder, block_dict=None, rank=0, world=1, group=None, keep=None, with_tensors=False):
     """Multi-GPU form of ms_marco_eval.ranking (scripts/ms_marco_eval.py:189-235): every rank encodes and indexes its
     own corpus rows, all ranks encode the (small) query set, per-shard fused top-k, one all-gather, merge.
     Returns the same rank-ordered {qid: {pid: score}} on every rank.  block_dict needs the single-shard Retriever
-    path (world == 1); with world > 1 blocked ids are applied after the merge."""
+    path (world == 1); with world > 1 blocked ids are applied after the merge.
+    with_tensors: return (profile, row ids [Q, keep] int64, scores [Q, keep]) -- the device tensors behind the dicts."""
     from .ms_marco_eval import KEEP, Retriever
     from .dist import sharded_search
     queries_ids, corpus_ids = list(queries.keys()), list(corpus.keys())
@@ -136,7 +137,7 @@ def ranking_sharded(corpus, queries, encoder, block_dict=None, rank=0, world=1, 
     max_norm = torch.zeros(1, dtype=torch.float32, device=q_bf16.device)
     shard, lo, hi = encode_local_shard(encoder, corpus_ids, corpus, sim, rank, world, max_norm=max_norm)
     if world == 1:
-        return Retriever(corpus_ids, shard, max_norm=max_norm).ranking_profile(queries_ids, q_bf16, block_dict, keep)
+        return Retriever(corpus_ids, shard, max_norm=max_norm).ranking_profile(queries_ids, q_bf16, block_dict, keep, with_tensors)
     index = ops.CorpusIndex(shard, global_row_offset=lo, max_norm=max_norm)
     n = len(corpus_ids)
     maxb = max((len(block_dict[q]) for q in queries_ids), default=0) if block_dict is not None else 0
@@ -154,5 +155,6 @@ def ranking_sharded(corpus, queries, encoder, block_dict=None, rank=0, world=1, 
         ptr[1:] = torch.cumsum(torch.tensor([len(b) for b in lists], dtype=torch.int64), 0)
         idx = torch.tensor([j for b in lists for j in b], dtype=torch.int64)
         scores, ids = ops.apply_block(scores, ids, ptr, idx, min(n, keep), n)
-    scores, ids = scores.cpu().tolist(), ids.cpu().tolist()
-    return {qid: dict(zip([corpus_ids[j] for j in row_i], row_s)) for qid, row_i, row_s in zip(queries_ids, ids, scores)}
+    scores_l, ids_l = scores.cpu().tolist(), ids.cpu().tolist()
+    profile = {qid: dict(zip([corpus_ids[j] for j in row_i], row_s)) for qid, row_i, row_s in zip(queries_ids, ids_l, scores_l)}
+    return (profile, ids, scores) if with_tensors else profile

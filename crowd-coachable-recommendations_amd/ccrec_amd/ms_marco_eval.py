@@ -114,7 +114,9 @@ class Retriever:
         s, i = self.index.search(queries_bf16, k_in)
         return ops.apply_block(s, i, ptr, idx + self.index.offset, k, n + self.index.offset)
 
-    def ranking_profile(self, queries_ids, queries_bf16, block_dict=None, keep=KEEP):
+    def ranking_profile(self, queries_ids, queries_bf16, block_dict=None, keep=KEEP, with_tensors=False):
+        """{qid: {pid: score}} in rank order.  with_tensors: also return the device tensors it was built from,
+        (row ids [Q, keep] int64 into corpus_ids, scores [Q, keep]) -- evaluation.rank_metrics takes them as they are."""
         block_lists = None
         if block_dict is not None:
             print("using block_dict")
@@ -124,10 +126,12 @@ class Retriever:
                 rows = [pos.get(pid, -1) for pid in block_dict[qid]]
                 assert -1 not in rows, "block id not found"
                 block_lists.append(rows)
-        scores, ids = self.search(queries_bf16, keep, block_lists)
-        scores, ids = scores.cpu().tolist(), (ids - self.index.offset).cpu().tolist()
+        scores_t, ids_t = self.search(queries_bf16, keep, block_lists)
+        ids_t = ids_t - self.index.offset
+        scores, ids = scores_t.cpu().tolist(), ids_t.cpu().tolist()
         cids = self.corpus_ids
-        return {qid: dict(zip([cids[j] for j in row_i], row_s)) for qid, row_i, row_s in zip(queries_ids, ids, scores)}
+        profile = {qid: dict(zip([cids[j] for j in row_i], row_s)) for qid, row_i, row_s in zip(queries_ids, ids, scores)}
+        return (profile, ids_t, scores_t) if with_tensors else profile
 
 
 def ranking(corpus, queries, embedding_func, batch_size, block_dict=None):
