@@ -60,11 +60,6 @@ __device__ __forceinline__ unsigned long long stamp() {
 template <int EPI, bool STAGGER, int DBG>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr bool SPLIT = (DBG & 64) == 0;      // second K half of a sub-stage read from LDS inside the MFMA phase
-    // LDS ring: three sub-stages of DMA in flight ahead of the consumer.  Four buffers suffice when a sub-stage is read
-    // completely in the mem phase; with SPLIT the trailing group still reads sub-stage u during the interval in which the
-    // leading group issues the DMA of u+4, so that DMA must land in a FIFTH buffer (not in the one of u).
-    constexpr int NRING = SPLIT ? 5 : 4;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -79,7 +74,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
     unsigned long long tprev = 0;
     if constexpr ((DBG & 16) != 0) tprev = stamp();
     if constexpr ((DBG & 4) != 0) {  // no-DMA ablation: zero operands (scores 0 stay below the thresholds)
-        for (int i = tid; i < NRING * SUB_BYTES / 16; i += GEMM_THREADS) reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
+        for (int i = tid; i < RING * SUB_BYTES / 16; i += GEMM_THREADS) reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
         __syncthreads();
     }
 
@@ -145,8 +140,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
 
         // ---- DMA issue stream (runs up to 3 sub-stages ahead of the consumer).  Per-thread source pointers
         // are recomputed once per tile; a sub-stage adds only the K offset.
-        int64_t it = 0;
-        int iks = 0, ibuf = 0;
+        int64_t iu = 0, it = 0;
+        int iks = 0;
         const uint16_t *dsrc[2];
         auto tile_ptrs = [&]() {
             const int64_t row0 = (DBG & 1) ? 0 : (r + it * a.ranges) * a.tile_stride * TILE_DOCS;
@@ -159,8 +154,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
         };
         tile_ptrs();
         auto issue = [&]() {
-            char *buf = smem + ibuf * SUB_BYTES;
-            ibuf = (ibuf + 1 == NRING) ? 0 : ibuf + 1;
+            char *buf = smem + (int)(iu & (RING - 1)) * SUB_BYTES;
             const int k0 = iks * SUB_K;
             if constexpr (!(DBG & 4)) {
 #pragma unroll
@@ -169,6 +163,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
                 for (int i = 0; i < 2; ++i)
                     glds16(qsrc[i] + ((DBG & 2) ? 0 : k0), buf + SUB_Q_REGION + (i * 512 + wv * 64) * 16);
             }
+            ++iu;
             if (++iks == KS2) {
                 iks = 0;
                 ++it;
@@ -270,7 +265,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
         CCR_BARRIER();
         if (g1) CCR_BARRIER();
 
-        int cks = 0, cbuf = 0;
+        int cks = 0;
         int64_t ct = 0;
         bool pending = false;
         int64_t pending_vt = 0;
@@ -290,20 +285,18 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
                     CCR_WAIT_VM(0);
             }
             CCR_STAMP(2)  // DMA wait
-            const char *buf = smem + cbuf * SUB_BYTES;
-            cbuf = (cbuf + 1 == NRING) ? 0 : cbuf + 1;
+            const char *buf = smem + (int)(u & (RING - 1)) * SUB_BYTES;
             bf16x8 af[2][4], bfr[2][2];
-            auto read_half = [&](int ks) __attribute__((always_inline)) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
                     af[ks][dt] = *reinterpret_cast<const bf16x8 *>(buf + a_base + dt * 2048 + cofs[ks]);
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt)
                     bfr[ks][qt] = *reinterpret_cast<const bf16x8 *>(buf + b_base + qt * 2048 + cofs[ks]);
-            };
-            read_half(0);
-            if (!SPLIT) read_half(1);
-            if (u + 3 < U) issue();  // 4 buffers: into the buffer of sub-stage u-1; 5 buffers: of u-2 (see the WAR notes)
+            }
+            if (u + 3 < U) issue();  // into the buffer of sub-stage u-1 (see the WAR note above)
             CCR_WAIT_LGKM0();        // operands in registers BEFORE the barrier; free behind the DMA issue
             CCR_STAMP(3)  // LDS reads + DMA issue
             CCR_BARRIER();
@@ -328,11 +321,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
             } else {
                 // no s_setprio(1) here: the partner wave's mem phase carries VALU work (filter, addresses) that a
                 // raised MFMA wave would starve (MI355X_MICROARCH 'Two waves per SIMD', item 2)
-                if (SPLIT) {   // the second K half comes out of LDS while the first eight MFMAs run (the ring's fifth buffer
-                               // keeps the trailing group's late reads clear of the leading group's next DMA)
-                    read_half(1);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
                 if (cks == 0) {  // first sub-stage of a tile: C = 0 (no accumulator clearing pass)
                     const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -346,10 +334,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
 #pragma unroll
                         for (int qt = 0; qt < 2; ++qt)
                             acc[dt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][dt], bfr[0][qt], acc[dt][qt], 0, 0, 0);
-                }
-                if (SPLIT) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    CCR_WAIT_LGKM0();
                 }
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
@@ -1114,7 +1098,7 @@ static int launch_gemm(const GemmArgs &a, int grid, hipStream_t s) {
         const char *st = getenv("CCR_GEMM_STAGGER");  // 0: both wave groups in phase (A/B of the ping-pong)
         stagger = st ? atoi(st) : 1;
     }
-    const size_t lds = 5 * (size_t)SUB_BYTES;   // ring of five 32-KiB sub-stages: the whole LDS of a CU
+    const size_t lds = RING * (size_t)SUB_BYTES;
     if ((EPI == EPI_FILTER || EPI == EPI_FILTER_GROUP) && dbg != 0) {
         switch (dbg) {
             case 1: return launch_kernel(&gemm_topk_kernel<EPI, true, 1>, lds, a, grid, s);
@@ -1124,7 +1108,6 @@ static int launch_gemm(const GemmArgs &a, int grid, hipStream_t s) {
             case 8: return launch_kernel(&gemm_topk_kernel<EPI, true, 8>, lds, a, grid, s);
             case 11: return launch_kernel(&gemm_topk_kernel<EPI, true, 11>, lds, a, grid, s);
             case 16: return launch_kernel(&gemm_topk_kernel<EPI, true, 16>, lds, a, grid, s);
-            case 64: return launch_kernel(&gemm_topk_kernel<EPI, true, 64>, lds, a, grid, s);
             default: break;   // unknown value: the production kernel
         }
     }
