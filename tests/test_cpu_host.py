@@ -153,3 +153,21 @@ def test_plan_batches_covers_every_text_once_under_the_budget():
     padded_total = sum(len(i) * p for i, p in batches)
     assert padded_total < 1.1 * lengths.sum() + 8 * 5000 and padded_total < 0.6 * 5000 * 200
     assert plan_batches([], 4096) == [] and plan_batches([9000], 4096)[0][1] == 9000
+
+
+def test_topk_message_layout_on_cpu():
+    """The packed exchange message {scores | ids}: views alias one byte buffer, the id block is 16-byte aligned, and
+    the gathered per-rank views are rank-strided (what ccr_merge_topk_strided consumes)."""
+    from ccrec_amd.dist import TopkMessage
+    m = TopkMessage(7, 5, "cpu", 3)            # 7 * 5 * 4 = 140 bytes of scores: the id block starts at 144
+    assert m.ids_at == 144 and m.nbytes == 144 + 7 * 5 * 8 + 8 and m.nbytes % 16 == 0
+    m.scores.fill_(1.5)
+    m.ids.copy_(torch.arange(35).view(7, 5) + (1 << 40))
+    assert m.send[:140].view(torch.float32).eq(1.5).all() and m.send[140:144].eq(0).all()
+    assert m.send[144:144 + 280].view(torch.int64)[34] == (1 << 40) + 34
+    for r in range(3):
+        m.recv.view(3, -1)[r].copy_(m.send)
+        m.recv.view(3, -1)[r][:4].view(torch.float32).fill_(float(r))
+    assert m.all_scores.shape == (3, 7, 5) and m.all_ids.shape == (3, 7, 5)
+    assert m.all_scores.stride() == (m.nbytes // 4, 5, 1) and m.all_ids.stride() == (m.nbytes // 8, 5, 1)
+    assert [float(m.all_scores[r, 0, 0]) for r in range(3)] == [0.0, 1.0, 2.0] and int(m.all_ids[2, 6, 4]) == (1 << 40) + 34
