@@ -94,12 +94,17 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu) {
 
     // sample pass: group maxima of 16 rows; need comfortably more groups than k
     const int64_t min_sample = (2 * (int64_t)k + GROUPS_PER_TILE - 1) / GROUPS_PER_TILE;
-    int64_t sample_div = 32;   // fraction of the tiles scored by the threshold pass (CCR_SAMPLE_DIV overrides)
+    int64_t sample_div = 32;   // fraction of the tiles scored by the threshold pass; the planner also prices 1/64
+    bool sample_div_forced = false;   // CCR_SAMPLE_DIV pins it
     {
         const char *e = getenv("CCR_SAMPLE_DIV");
-        if (e && atoi(e) >= 4 && atoi(e) <= 256) sample_div = atoi(e);
+        if (e && atoi(e) >= 4 && atoi(e) <= 256) {
+            sample_div = atoi(e);
+            sample_div_forced = true;
+        }
     }
-    int64_t sample = std::max<int64_t>({(p.tiles + sample_div - 1) / sample_div, min_sample, 4});
+    auto sample_for = [&](int64_t div) { return std::max<int64_t>({(p.tiles + div - 1) / div, min_sample, 4}); };
+    int64_t sample = sample_for(sample_div);
     bool fused = (dim % TILE_K == 0) && dim >= TILE_K && (sample * 4 <= p.full_tiles) && k <= MAX_K;
     if ((flags & CCR_SEARCH_FORCE_FUSED) && (dim % TILE_K == 0) && p.full_tiles >= 1) {
         // honour the request where at all possible: the sample may be the whole corpus
@@ -148,23 +153,34 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu) {
         // + the filter/select work the surviving candidates cause + a launch boundary per extra phase.  Survivors per query
         // (measured: 3 280 from the 1/32 sample alone, 1 180 with one re-tightening at k = 100): a phase that covers the
         // fraction f of the corpus with thresholds taken from a fraction g seen before lets through k * f / g rows.
-        const double fs = (double)sample / (double)p.tiles;
         const double hit_w = 0.014, phase_w = 3.0;
+        // the sample pass itself: its GEMM tiles (one unit each, spread over the grid) and the threshold kernel's four
+        // passes over the group maxima (0.19 ms = 8.4 units for 328 sample tiles x 3 584 queries)
+        auto sample_cost = [&](int64_t smp) -> double {
+            return (double)((smp * p.qblocks + p.grid - 1) / p.grid) + 0.0257 * (double)smp * (double)p.nq_pad / 3584.0;
+        };
+        int64_t best_sample = sample;
+        double best = 1e300;
+        int64_t R = target, RA = 0, RB = 0;
+        const int64_t sample_alt = (sample_div_forced || (flags & CCR_SEARCH_FORCE_FUSED)) ? sample : sample_for(2 * sample_div);
+        for (int pass = 0; pass < 2; ++pass) {
+        const int64_t smp = pass == 0 ? sample : sample_alt;
+        if (pass == 1 && smp == sample) break;
+        const double fs = (double)smp / (double)p.tiles;
+        const double smp_cost = sample_cost(smp);
         auto survivors = [&](double fa, double fb) -> double {   // fa, fb: corpus fractions of phases A and B1 (0 = absent)
             if (fa <= 0.0) return (double)k / fs;
             if (fb <= 0.0) return (double)k * (fa / fs + (1.0 - fa) / fa);
             return (double)k * (fa / fs + fb / fa + (1.0 - fa - fb) / (fa + fb));
         };
         const int max_phases = getenv("CCR_PHASES") ? atoi(getenv("CCR_PHASES")) : 3;   // 2: at most one re-tightening
-        int64_t R = target, RA = 0, RB = 0;
-        double best = 1e300;
         for (int64_t rbody = std::max<int64_t>(NUM_XCD, target / 2 / NUM_XCD * NUM_XCD); rbody <= std::min(r_hi, target * 2);
              rbody += NUM_XCD) {
             int64_t ra = (int64_t)per_x * nrc / qb_per / nrc * nrc;   // items = ra / nrc * qb_per <= per_x
             ra = std::min<int64_t>(ra, rbody / 4 / nrc * nrc);
             if (!(prog_on && ra >= nrc && rbody + ra <= 1024 / p.sublists && (double)p.tiles / (double)(rbody + ra) >= 8.0)) ra = 0;
             const int64_t Rt = rbody + ra;
-            const double common = select_per_range * (double)Rt + 1e-3 * std::abs((double)(rbody - target));   // ties: near 6 items per workgroup
+            const double common = smp_cost + select_per_range * (double)Rt + 1e-3 * std::abs((double)(rbody - target));   // ties: near 6 items per workgroup
             const double fa = (double)ra / (double)Rt;
             const double two = (ra ? makespan(0, ra, Rt) + phase_w : 0.0) + makespan(ra, Rt, Rt) + hit_w * survivors(fa, 0.0) + common;
             if (two < best) {
@@ -172,6 +188,7 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu) {
                 R = Rt;
                 RA = ra;
                 RB = 0;
+                best_sample = smp;
             }
             if (!ra || max_phases < 3) continue;
             // a second re-tightening after m more rounds of items (m = 1..3): the middle phase then fills its rounds
@@ -187,9 +204,14 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu) {
                     R = Rt;
                     RA = ra;
                     RB = rb;
+                    best_sample = smp;
                 }
             }
         }
+        }   // sample candidates
+        sample = best_sample;
+        p.sample_tiles = (int)sample;
+        p.sample_stride = std::max<int64_t>(1, p.full_tiles / sample);
         p.ranges = (int)R;
         p.ranges_a = (int)RA;
         p.ranges_b = (int)RB;
