@@ -27,13 +27,22 @@ __device__ __forceinline__ bf16x4 cvt4(float4 v) {
 // n8 = number of 8-element groups; tail handled by the scalar kernel below.
 __global__ __launch_bounds__(256) void pack_bf16_kernel(const float4 *__restrict__ src, bf16x8 *__restrict__ dst,
                                                        int64_t n8) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n8; i += stride) {
-        float4 a = src[2 * i], b = src[2 * i + 1];
-        bf16x4 lo = cvt4(a), hi = cvt4(b);
-        bf16x8 r = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        dst[i] = r;
+    // one block = 4 x 256 output vectors (8 KiB of bf16 from 16 KiB of fp32): the 8 loads of a thread are issued
+    // before the first conversion, consecutive lanes touch consecutive 32-byte segments
+    const int64_t base = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    float4 a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t i = base + u * 256;
+        const int64_t ic = i < n8 ? i : n8 - 1;
+        a[u] = src[2 * ic];
+        b[u] = src[2 * ic + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t i = base + u * 256;
+        const bf16x4 lo = cvt4(a[u]), hi = cvt4(b[u]);
+        if (i < n8) dst[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     }
 }
 
@@ -300,8 +309,7 @@ extern "C" int ccr_pack_bf16_ex(const float *src, uint16_t *dst, float *norms, f
         const int64_t n = rows * dim;
         const int64_t n8 = n / 8;
         if (n8 > 0) {
-            int64_t blocks = (n8 + 255) / 256;
-            if (blocks > 256 * 16) blocks = 256 * 16;
+            const int64_t blocks = (n8 + 1023) / 1024;
             hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
                                reinterpret_cast<const float4 *>(src), reinterpret_cast<bf16x8 *>(dst), n8);
             CCR_LAUNCH_CHECK();
