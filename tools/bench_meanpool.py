@@ -1,19 +1,42 @@
-import sys, time, torch
-sys.path[:0]=['/root/repo','/root/repo/crowd-coachable-recommendations_amd']
-from ccrec_amd import ops
-for dtype in (torch.float32, torch.bfloat16):
-    B,L,d=512,200,768
-    h=torch.randn(B,L,d,device='cuda').to(dtype)
-    lens=torch.randint(20,L+1,(B,),device='cuda')
-    mask=(torch.arange(L,device='cuda')[None,:]<lens[:,None]).long()
-    def ours():
-        return ops.meanpool_pack(h,mask,normalize=False,want_f32=False)
-    def ref():
-        x=h.masked_fill(~mask[...,None].bool(),0).sum(1)/mask.sum(1)[...,None]
-        return x.to(torch.bfloat16)
-    for name,fn in (("ours",ours),("torch",ref)):
-        for _ in range(5): fn()
-        torch.cuda.synchronize(); t0=time.perf_counter()
-        for _ in range(50): fn()
-        torch.cuda.synchronize(); dt=(time.perf_counter()-t0)/50
-        print(dtype, name, round(dt*1e6,1),"us", round(h.numel()*h.element_size()/dt/1e9,1),"GB/s")
+#!/usr/bin/env python3
+"""Masked-mean-pool + bf16 pack kernel (ccr_meanpool_pack_bf16) next to the reference's torch formulation
+(masked_fill, sum, divide, cast; src/ccrec/models/item_tower.py:141-146) at B = 512, L = 200, d = 768."""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "crowd-coachable-recommendations_amd")]
+
+
+def main():
+    from ccrec_amd import ops
+    B, L, d = 512, 200, 768
+    for dtype in (torch.float32, torch.bfloat16):
+        h = torch.randn(B, L, d, device="cuda").to(dtype)
+        lens = torch.randint(20, L + 1, (B,), device="cuda")
+        mask = (torch.arange(L, device="cuda")[None, :] < lens[:, None]).long()
+
+        def ours():
+            return ops.meanpool_pack(h, mask, normalize=False, want_f32=False)
+
+        def ref():
+            x = h.masked_fill(~mask[..., None].bool(), 0).sum(1) / mask.sum(1)[..., None]
+            return x.to(torch.bfloat16)
+
+        for name, fn in (("ccr_meanpool_pack_bf16", ours), ("torch", ref)):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                fn()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 50
+            print(dtype, name, round(dt * 1e6, 1), "us", round(h.numel() * h.element_size() / dt / 1e9, 1), "GB/s of hidden states")
+
+
+if __name__ == "__main__":
+    main()

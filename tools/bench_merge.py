@@ -1,7 +1,14 @@
 #!/usr/bin/env python3
 """Shard-merge kernel timing (ccr_merge_topk) for R shards x 3 452 queries x top-k, checked against the oracle."""
-import sys,time,torch,numpy as np
-sys.path[:0]=[".","crowd-coachable-recommendations_amd"]
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "crowd-coachable-recommendations_amd")]
 from ccrec_amd import ops
 from oracle import oracle as orc
 for R,k in ((2,100),(4,100),(8,100),(8,1001),(16,1001)):
