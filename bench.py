@@ -220,7 +220,9 @@ def main():
                    "step": "pack corpus shard fp32->bf16 + index build + pack queries + fused MFMA score/top-k"
                            + (" + RCCL all-gather + merge" if world > 1 else ""),
                    "parallelism": f"row-shard x{world}"},
-        "roofline": {"bound": "mfma", "kernel": "gemm_topk_kernel<EPI_FILTER> (main pass)", "achieved": round(achieved, 1),
+        "roofline": {"bound": "mfma", "kernel": ("gemm_topk16_kernel<EPI_FILTER> (main pass, v_mfma_f32_16x16x32_bf16)" if st.get("sublists") == 8
+                                                  else "gemm_topk_kernel<EPI_FILTER> (main pass, v_mfma_f32_32x32x16_bf16)"),
+                     "achieved": round(achieved, 1),
                      "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
                      "flops_per_launch": flops, "avg_launch_ms": round(avg_main, 4), "traffic": traffic},
         "phases_ms": {"sample_pass": round(st["ms_sample"], 3), "threshold": round(st["ms_threshold"], 3),
@@ -229,7 +231,7 @@ def main():
                       "corpus_pack": round(pack_ms, 3)},
         "pack_kernel": {"bound": "hbm", "achieved": round(pack_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(pack_gbs / HBM_PEAK_GBS, 4)},
-        "search_stats": {k_: st[k_] for k_ in ("path", "n_fallback", "sample_tiles", "ranges", "cap", "n_candidates")},
+        "search_stats": {k_: st[k_] for k_ in ("path", "n_fallback", "sample_tiles", "ranges", "sublists", "cap", "n_candidates")},
     }
     if rank == 0 and world == 1 and args.cpu_queries > 0:
         out["cpu_baseline"] = cpu_baseline(shard, qpack, min(args.cpu_queries, args.queries), args.k, state["ids"])

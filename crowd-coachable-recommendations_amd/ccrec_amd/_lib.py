@@ -23,7 +23,7 @@ EXPORTS = [
 
 class SearchStats(ctypes.Structure):
     _fields_ = [("path", ctypes.c_int32), ("n_fallback", ctypes.c_int32), ("sample_tiles", ctypes.c_int32),
-                ("ranges", ctypes.c_int32), ("cap", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("ranges", ctypes.c_int32), ("cap", ctypes.c_int32), ("sublists", ctypes.c_int32),
                 ("n_candidates", ctypes.c_int64), ("ms_sample", ctypes.c_float), ("ms_threshold", ctypes.c_float),
                 ("ms_main", ctypes.c_float), ("ms_select", ctypes.c_float), ("ms_fallback", ctypes.c_float),
                 ("ms_total", ctypes.c_float)]

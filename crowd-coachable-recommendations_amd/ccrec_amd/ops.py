@@ -148,7 +148,7 @@ class CorpusIndex:
     def last_stats(self):
         st = _lib.SearchStats()
         _lib.check(self._lib.ccr_search_last_stats(self._h, ctypes.byref(st)), "ccr_search_last_stats")
-        return {f: getattr(st, f) for f, _ in st._fields_ if f != "reserved"}
+        return {f: getattr(st, f) for f, _ in st._fields_}
 
     def debug_scores(self, queries_bf16, canonical):
         q = queries_bf16.contiguous()

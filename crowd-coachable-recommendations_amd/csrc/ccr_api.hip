@@ -67,7 +67,7 @@ static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * 
 constexpr size_t DENSE_SCRATCH_TARGET = (size_t)1 << 30;  // ~1 GiB of score rows per dense chunk
 constexpr int FALLBACK_ROWS = 16;
 #ifndef CCR_MFMA16_DEFAULT
-#define CCR_MFMA16_DEFAULT 0
+#define CCR_MFMA16_DEFAULT 1
 #endif                         // score rows reserved for flagged queries
 
 Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu) {
@@ -568,6 +568,7 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
     ix->stats.sample_tiles = p.sample_tiles;
     ix->stats.ranges = p.ranges;
     ix->stats.cap = p.cap;
+    ix->stats.sublists = p.sublists;
     ix->stats.n_candidates = (int64_t)host.ncand;
     if (host.nflag > 0) {
         rc = dense_for_list(ix, Q_bf16, flag_list, 0, (int)host.nflag, k, dense_scratch, p.dense_rows_per_chunk, out_scores,

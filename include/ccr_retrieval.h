@@ -50,8 +50,8 @@ typedef struct ccr_search_stats {
     int32_t n_fallback;        /* queries re-done by the dense path (candidate overflow / mass ties) */
     int32_t sample_tiles;      /* 256-row corpus tiles scored by the threshold (sample) pass */
     int32_t ranges;            /* corpus ranges of the main pass */
-    int32_t cap;               /* candidate slots per sub-list (4 sub-lists per (range, query)) */
-    int32_t reserved;
+    int32_t cap;               /* candidate slots per sub-list */
+    int32_t sublists;          /* sub-lists per (range, query): 8 = main pass on v_mfma_f32_16x16x32_bf16, 4 = 32x32x16 */
     int64_t n_candidates;      /* total stage-1 survivors over all queries */
     /* device time of each phase of the last search, from HIP events on the search stream (ms) */
     float ms_sample;           /* sample pass GEMM (group maxima) */

@@ -45,3 +45,22 @@ def test_random_shapes_all_paths_agree(seed):
         bits = lambda t: t.view(torch.int16).cpu().numpy().view(np.uint16)   # noqa: E731
         ref_i, ref_s = orc.canonical_search(bits(Qb), bits(Db), k)
         assert np.array_equal(i1.cpu().numpy() - off, ref_i) and np.array_equal(s1.cpu().numpy(), ref_s)
+
+
+@pytest.mark.parametrize("seed", [3, 5, 11, 17, 21])
+def test_mfma_32x32_variant_agrees(seed, monkeypatch):
+    """The main pass runs on v_mfma_f32_16x16x32_bf16 by default; CCR_MFMA16=0 selects the 32x32x16 kernel (4 instead of
+    8 candidate sub-lists per (range, query)).  Both must return the canonical result."""
+    from ccrec_amd import ops
+    rs = np.random.RandomState(seed)
+    n, nq, d, k = int(rs.randint(20_000, 180_000)), int(rs.randint(1, 600)), int(rs.choice([64, 384, 768])), int(rs.randint(1, 400))
+    g = torch.Generator().manual_seed(seed)
+    Db = ops.pack_bf16((torch.randn(n, d, generator=g) / d ** 0.5).cuda())
+    Qb = ops.pack_bf16((torch.randn(nq, d, generator=g) / d ** 0.5).cuda())
+    s_ref, i_ref = ops.CorpusIndex(Db).search(Qb, k, 1)           # exact dense path
+    for variant in ("0", "1"):
+        monkeypatch.setenv("CCR_MFMA16", variant)
+        index = ops.CorpusIndex(Db)                                 # the plan is cached per index: a fresh one per variant
+        s, i = index.search(Qb, k, 2)
+        assert index.last_stats()["path"] == 1
+        assert torch.equal(i, i_ref) and torch.equal(s.view(torch.int32), s_ref.view(torch.int32)), (variant, n, nq, d, k)
