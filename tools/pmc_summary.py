@@ -12,7 +12,13 @@ from collections import defaultdict
 
 root = sys.argv[1]
 acc = defaultdict(lambda: defaultdict(list))   # kernel -> counter -> per-dispatch values
-for f in glob.glob(os.path.join(root, "pass*", "**", "*counter_collection.csv"), recursive=True):
+# one CSV per pass: the newest (gpurun merges every call's files into the same local directory)
+files = []
+for d in sorted(glob.glob(os.path.join(root, "pass*"))):
+    cands = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    if cands:
+        files.append(max(cands, key=os.path.getmtime))
+for f in files:
     per_dispatch = defaultdict(float)
     names = {}
     for r in csv.DictReader(open(f)):
@@ -36,7 +42,7 @@ for k, ctrs in acc.items():
     # per bench step: the main pass is two launches (phase A + phase B) of the same kernel, so sum and divide
     out[short(k)] = {c: sum(v) / STEPS for c, v in ctrs.items()}
     out[short(k)]["dispatches_per_step"] = max(len(v) for v in ctrs.values()) / STEPS
-main = next((v for k, v in out.items() if k.startswith("void gemm_topk_kernel<0")), {})
+main = next((v for k, v in out.items() if k.startswith("void gemm_topk16_kernel<0") or k.startswith("void gemm_topk_kernel<0")), {})
 summary = {"note": "counter totals per bench step (all launches of a kernel summed)", "kernels": out}
 if "FETCH_SIZE" in main:
     rd = main["FETCH_SIZE"] * 1024 * 2          # gfx950: x2 for wide coalesced streaming reads
