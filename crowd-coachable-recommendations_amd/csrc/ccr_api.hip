@@ -87,7 +87,9 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu) {
     }
     {
         const char *e = getenv("CCR_MFMA16");   // main pass on v_mfma_f32_16x16x32_bf16 (row records only)
-        p.mfma16 = (e ? atoi(e) : CCR_MFMA16_DEFAULT) && !p.group_records ? 1 : 0;
+        // default: the 16x16x32 kernel up to k = 512; above that its eight sub-lists per (range, query) cost the select
+        // stage more than the main pass gains (config-4 shape, k = 1000: select 14.3 vs 9.0 ms at equal main-pass time)
+        p.mfma16 = (e ? atoi(e) : (CCR_MFMA16_DEFAULT && k <= 512)) && !p.group_records ? 1 : 0;
         p.sublists = p.mfma16 ? 8 : 4;
     }
     p.rescore_cap = p.group_records ? 16 * std::max(128, 2 * pow2_ceil(k)) : std::min(8192, std::max(256, 2 * pow2_ceil(k)));
@@ -153,7 +155,10 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu) {
         // + the filter/select work the surviving candidates cause + a launch boundary per extra phase.  Survivors per query
         // (measured: 3 280 from the 1/32 sample alone, 1 180 with one re-tightening at k = 100): a phase that covers the
         // fraction f of the corpus with thresholds taken from a fraction g seen before lets through k * f / g rows.
-        const double hit_w = 0.014, phase_w = 3.0;
+        // per-query costs are spread over the same workgroups as the GEMM tiles: they scale with the query count (the weights
+        // were measured at 3 452 queries = 14 query blocks)
+        const double qscale = (double)p.nq_pad / 3584.0;
+        const double hit_w = 0.014 * qscale, phase_w = 3.0;
         // the sample pass itself: its GEMM tiles (one unit each, spread over the grid) and the threshold kernel's four
         // passes over the group maxima (0.19 ms = 8.4 units for 328 sample tiles x 3 584 queries)
         auto sample_cost = [&](int64_t smp) -> double {
@@ -180,7 +185,7 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu) {
             ra = std::min<int64_t>(ra, rbody / 4 / nrc * nrc);
             if (!(prog_on && ra >= nrc && rbody + ra <= 1024 / p.sublists && (double)p.tiles / (double)(rbody + ra) >= 8.0)) ra = 0;
             const int64_t Rt = rbody + ra;
-            const double common = smp_cost + select_per_range * (double)Rt + 1e-3 * std::abs((double)(rbody - target));   // ties: near 6 items per workgroup
+            const double common = smp_cost + select_per_range * qscale * (double)Rt + 1e-3 * std::abs((double)(rbody - target));   // ties: near 6 items per workgroup
             const double fa = (double)ra / (double)Rt;
             const double two = (ra ? makespan(0, ra, Rt) + phase_w : 0.0) + makespan(ra, Rt, Rt) + hit_w * survivors(fa, 0.0) + common;
             if (two < best) {
