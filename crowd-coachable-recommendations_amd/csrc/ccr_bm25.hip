@@ -196,7 +196,7 @@ extern "C" int ccr_bm25_search(const ccr_bm25_index *ix, const int64_t *q_ptr_ho
             CCR_LAUNCH_CHECK();
         }
         const int64_t n = (int64_t)m * ix->n_docs;
-        hipLaunchKernelGGL(bm25_finish_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 256 * 32)), dim3(256), 0, s, acc, scores, n);
+        hipLaunchKernelGGL(bm25_finish_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, (int64_t)1 << 30)), dim3(256), 0, s, acc, scores, n);   // one cell per thread: streams faster than a capped grid-stride loop
         CCR_LAUNCH_CHECK();
         const int rc = launch_dense_select(scores, ix->n_docs, k, nullptr, q0, m, 0, out_scores, out_ids, s);
         if (rc != CCR_OK) return rc;
