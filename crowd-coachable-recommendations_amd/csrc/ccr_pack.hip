@@ -101,11 +101,17 @@ __global__ __launch_bounds__(256) void pack_rows_maxnorm_kernel(const float *__r
             wmax = fmaxf(wmax, sqrtf(t));
         }
     }
-    // record-breaking norms are rare (~ln N of them): look first, the atomic only when this wave would raise the maximum --
-    // that is what lets the grid be one short-lived wave per row group instead of a capped grid-stride loop
-    if (lane == 0) {
-        const uint32_t mine = __float_as_uint(wmax);
-        if (mine > __hip_atomic_load(max_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_bits, mine);
+    // Record-breaking norms are rare (~ln N of them): look first, the atomic only when this BLOCK would raise the maximum
+    // (one per block: the waves resident when the kernel starts all see the caller's zero and would otherwise queue up
+    // 8 K atomics on one address), and the stored value is inflated by 2^-11 so that near-equal maxima do not follow
+    // each other in -- it stays an upper bound, which is all the filter margin needs.
+    __shared__ float s_wmax[4];
+    if (lane == 0) s_wmax[threadIdx.x >> 6] = wmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float bmax = fmaxf(fmaxf(s_wmax[0], s_wmax[1]), fmaxf(s_wmax[2], s_wmax[3]));
+        if (__float_as_uint(bmax) > __hip_atomic_load(max_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(max_bits, __float_as_uint(bmax * 1.00048828125f));
     }
 }
 
