@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const float *__restrict
     // list (r, q) starts at scores[r * rs_scores + q * k] / ids[r * rs_ids + q * k] (rank strides in elements)
     const int q = blockIdx.y;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= R * k) return;
+    if (e >= R * k || q >= n_q) return;
     const int r = e / k, p = e - r * k;
     const float s = scores[r * rs_scores + (int64_t)q * k + p];
     const int64_t id = ids[r * rs_ids + (int64_t)q * k + p];
