@@ -160,9 +160,9 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu) {
         const double qscale = (double)p.nq_pad / 3584.0;
         const double hit_w = 0.014 * qscale, phase_w = 3.0;
         // the sample pass itself: its GEMM tiles (one unit each, spread over the grid) and the threshold kernel's four
-        // passes over the group maxima (0.19 ms = 8.4 units for 328 sample tiles x 3 584 queries)
+        // passes over the group maxima (0.11 ms = 4.9 units for 328 sample tiles x 3 584 queries)
         auto sample_cost = [&](int64_t smp) -> double {
-            return (double)((smp * p.qblocks + p.grid - 1) / p.grid) + 0.0257 * (double)smp * (double)p.nq_pad / 3584.0;
+            return (double)((smp * p.qblocks + p.grid - 1) / p.grid) + 0.015 * (double)smp * (double)p.nq_pad / 3584.0;
         };
         int64_t best_sample = sample;
         double best = 1e300;

@@ -646,12 +646,12 @@ __global__ __launch_bounds__(256) void threshold_kernel(const float *__restrict_
         const uint32_t prefix = s_prefix[ql];
         // 4 independent loads in flight per thread (the loop is latency-bound otherwise)
         int64_t i = ph;
-        for (; i + 48 < n_groups; i += 64) {
-            float v[4];
+        for (; i + 240 < n_groups; i += 256) {   // 16 independent loads in flight per thread
+            float v[16];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = gmax[(i + 16 * j) * nq_pad + q];
+            for (int j = 0; j < 16; ++j) v[j] = gmax[(i + 16 * j) * nq_pad + q];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 16; ++j) {
                 const uint32_t o = f32_orderable(v[j]);
                 if ((o & mask) == prefix) atomicAdd(&s_hist[ql][(o >> shift) & 255u], 1u);
             }
