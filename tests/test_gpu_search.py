@@ -360,3 +360,24 @@ def test_max_k_overflowing_select_lds_stays_on_the_fused_path():
     assert st["path"] == 1 and st["n_fallback"] == 0, st
     s1, i1 = index.search(_bf16(Qb), k, 1)
     assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
+
+
+def test_rescore_is_canonical_under_wide_dynamic_range():
+    """Canonical scores are fp64 sums in ascending element order; with products 2^50 apart inside one dot product the
+    fp64 partial sums DO round, so any shortcut that re-orders the sum would show here.  Both data sets must reproduce
+    the oracle bit for bit: (a) ordinary data, (b) elements scaled by 2^-30 / 2^+20 / 2^-25."""
+    from ccrec_amd import ops
+    n, nq, d, k = 40_000, 33, 768, 50
+    for wide in (False, True):
+        g = torch.Generator().manual_seed(77 + wide)
+        D = torch.randn(n, d, generator=g) / d ** 0.5
+        Q = torch.randn(nq, d, generator=g) / d ** 0.5
+        if wide:
+            D[:, 5::37] *= 2.0 ** -30
+            D[:, 11::41] *= 2.0 ** 20
+            Q[:, 7::29] *= 2.0 ** -25
+        Db, Qb = orc.pack_bf16(D.numpy()), orc.pack_bf16(Q.numpy())
+        s, i = ops.CorpusIndex(_bf16(Db)).search(_bf16(Qb), k, 2)
+        ref_i, ref_s = orc.canonical_search(Qb, Db, k)
+        assert np.array_equal(i.cpu().numpy(), ref_i), wide
+        assert np.array_equal(s.cpu().numpy().view(np.uint32), ref_s.view(np.uint32)), wide
