@@ -304,17 +304,25 @@ extern "C" int ccr_pack_bf16_ex(const float *src, uint16_t *dst, float *norms, f
                 const char *e = getenv("CCR_PACK_ROWS");
                 rows_per = e ? atoi(e) : 1;
             }
-            int64_t blocks = (rows + 4 * rows_per - 1) / (4 * rows_per);
-            if (blocks > 131072) blocks = 131072;   // measured best at the NQ shape: 16 K - 128 K blocks, one row per wave and trip
-            if (rows_per == 1)
-                hipLaunchKernelGGL(pack_rows_maxnorm_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, src,
-                                   reinterpret_cast<__bf16 *>(dst), rows, dim, max_bits);
-            else if (rows_per == 2)
-                hipLaunchKernelGGL(pack_rows_maxnorm_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, src,
-                                   reinterpret_cast<__bf16 *>(dst), rows, dim, max_bits);
-            else
-            hipLaunchKernelGGL(pack_rows_maxnorm_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, src,
-                               reinterpret_cast<__bf16 *>(dst), rows, dim, max_bits);
+            // A small seed launch first (256 rows): the blocks of the main launch then find a realistic maximum instead of
+            // the caller's zero, and only the few that exceed it touch the atomic (otherwise the ~2 K blocks resident at the
+            // start all queue up on that one address: ~40 us).
+            const int64_t seed = rows > 4096 ? 256 : 0;
+            for (int part = 0; part < 2; ++part) {
+                const int64_t r0 = part == 0 ? 0 : seed, r1 = part == 0 ? seed : rows;
+                if (r1 <= r0) continue;
+                const int64_t nr = r1 - r0;
+                int64_t blocks = (nr + 4 * rows_per - 1) / (4 * rows_per);
+                if (blocks > 131072) blocks = 131072;   // measured best at the NQ shape: 16 K - 128 K blocks, one row per wave and trip
+                const float *sp = src + r0 * dim;
+                __bf16 *dp = reinterpret_cast<__bf16 *>(dst) + r0 * dim;
+                if (rows_per == 1)
+                    hipLaunchKernelGGL(pack_rows_maxnorm_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, sp, dp, nr, dim, max_bits);
+                else if (rows_per == 2)
+                    hipLaunchKernelGGL(pack_rows_maxnorm_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, sp, dp, nr, dim, max_bits);
+                else
+                    hipLaunchKernelGGL(pack_rows_maxnorm_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, sp, dp, nr, dim, max_bits);
+            }
             CCR_LAUNCH_CHECK();
             return CCR_OK;
         }
