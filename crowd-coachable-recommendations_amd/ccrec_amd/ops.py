@@ -1,5 +1,6 @@
 """Tensor-level wrappers over the C ABI.  torch is plumbing here (device memory, streams); every
 arithmetic step runs in libccr_hip.so.  All ops raise if there is no ROCm device."""
+import contextlib
 import ctypes
 
 import torch
@@ -23,8 +24,15 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+_NO_SWITCH = contextlib.nullcontext()
+
+
 def _on(t):
-    """Run the call with t's device current (HIP kernels launch on the current device)."""
+    """Run the call with t's device current (HIP kernels launch on the current device).  The usual case -- it already
+    is -- costs one integer compare instead of a device-guard round trip (the calls sit between a stream sync and the
+    next kernel: host time here is GPU idle time)."""
+    if t.device.index == torch.cuda.current_device():
+        return _NO_SWITCH
     return torch.cuda.device(t.device)
 
 
