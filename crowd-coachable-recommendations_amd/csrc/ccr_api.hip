@@ -70,6 +70,97 @@ constexpr int FALLBACK_ROWS = 16;
 #define CCR_MFMA16_DEFAULT 1
 #endif                         // score rows reserved for flagged queries
 
+// ------------------------------------------------------------------ main-pass planner
+// Work items of the main pass are (range, query block); range r owns the tiles r, r + R, ...  An XCD set of per_x
+// workgroups walks (R / nrc) * qb_per items round-robin, so R (a multiple of 8, near 6 items per workgroup, items of at
+// least 8 tiles) is chosen to make that count sit just below a multiple of per_x -- NQ: 128 ranges give exactly 7 items per
+// workgroup where 112 left the last round 1/8 full.  The launches: phase A = one round of items with the sample
+// thresholds, a re-tightening (threshold_update_kernel), optionally a second re-tightening after whole rounds, the rest.
+//
+// Every candidate (sample size, R, phase split) is priced in TILE UNITS of one workgroup (one 256 x 256 x dim tile ~ 22 us):
+//   makespan of each launch    simulated static item assignment (+ 0.15 tile of pipeline fill per item)
+//   sample pass                its tiles spread over the grid + the threshold kernel's passes over the group maxima
+//   select stage               0.1 per range (it walks R x sublists sub-lists per query)
+//   surviving candidates       0.014 each (filter hit path + select), a phase that covers the corpus fraction f with
+//                              thresholds taken from a fraction g seen before lets through k * f / g rows per query
+//                              (measured: 3 280 from a 1/32 sample alone, 1 180 with one re-tightening at k = 100)
+//   launch boundary            3 per extra phase
+// The per-query terms were measured at 3 452 queries (14 query blocks) and scale with the query count.
+struct MainPassChoice {
+    int64_t sample, ranges, ranges_a, ranges_b;
+};
+
+static MainPassChoice choose_main_pass(const Plan &p, int k, int64_t sample_a, int64_t sample_b) {
+    const int nrc = NUM_XCD / p.qgroups, qb_per = p.qblocks / p.qgroups, per_x = p.grid / NUM_XCD;
+    const int64_t r_hi = std::min<int64_t>(1024 / p.sublists, round_up(std::max<int64_t>(1, p.tiles / 8), NUM_XCD));
+    const int64_t target = std::min<int64_t>(r_hi, round_up(std::max<int64_t>(NUM_XCD, (int64_t)p.grid * 6 / p.qblocks), NUM_XCD));
+    const char *pe = getenv("CCR_PROGRESSIVE");                                       // 0: single launch
+    const bool prog_on = !(pe && atoi(pe) == 0);
+    const int max_phases = getenv("CCR_PHASES") ? atoi(getenv("CCR_PHASES")) : 3;     // 2: at most one re-tightening
+    const double qscale = (double)p.nq_pad / 3584.0;
+    const double select_per_range = 0.1 * qscale, hit_w = 0.014 * qscale, phase_w = 3.0;
+
+    // the busiest XCD set is range class 0: its per_x workgroups take the items of ranges [rb, re) round-robin
+    auto makespan = [&](int64_t rb, int64_t re, int64_t Rt) -> double {
+        std::vector<double> load((size_t)per_x, 0.0);
+        int64_t i = 0;
+        for (int64_t r = rb; r < re; r += nrc)
+            for (int qi = 0; qi < qb_per; ++qi, ++i) {
+                const int64_t nt = (p.tiles - r + Rt - 1) / Rt;
+                if (nt > 0) load[(size_t)(i % per_x)] += (double)nt + 0.15;
+            }
+        return *std::max_element(load.begin(), load.end());
+    };
+    // 0.11 ms = 4.9 units of threshold kernel for 328 sample tiles x 3 584 queries
+    auto sample_cost = [&](int64_t smp) -> double {
+        return (double)((smp * p.qblocks + p.grid - 1) / p.grid) + 0.015 * (double)smp * qscale;
+    };
+
+    MainPassChoice best_choice = {sample_a, target, 0, 0};
+    double best = 1e300;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int64_t smp = pass == 0 ? sample_a : sample_b;
+        if (pass == 1 && smp == sample_a) break;
+        const double fs = (double)smp / (double)p.tiles;
+        const double smp_cost = sample_cost(smp);
+        auto survivors = [&](double fa, double fb) -> double {   // fa, fb: corpus fractions of phases A and B1 (0 = absent)
+            if (fa <= 0.0) return (double)k / fs;
+            if (fb <= 0.0) return (double)k * (fa / fs + (1.0 - fa) / fa);
+            return (double)k * (fa / fs + fb / fa + (1.0 - fa - fb) / (fa + fb));
+        };
+        for (int64_t rbody = std::max<int64_t>(NUM_XCD, target / 2 / NUM_XCD * NUM_XCD); rbody <= std::min(r_hi, target * 2);
+             rbody += NUM_XCD) {
+            int64_t ra = (int64_t)per_x * nrc / qb_per / nrc * nrc;   // phase A: items = ra / nrc * qb_per <= per_x (one round)
+            ra = std::min<int64_t>(ra, rbody / 4 / nrc * nrc);
+            if (!(prog_on && ra >= nrc && rbody + ra <= 1024 / p.sublists && (double)p.tiles / (double)(rbody + ra) >= 8.0)) ra = 0;
+            const int64_t Rt = rbody + ra;
+            const double common = smp_cost + select_per_range * (double)Rt +
+                                  1e-3 * std::abs((double)(rbody - target));   // ties: stay near 6 items per workgroup
+            const double fa = (double)ra / (double)Rt;
+            const double two = (ra ? makespan(0, ra, Rt) + phase_w : 0.0) + makespan(ra, Rt, Rt) + hit_w * survivors(fa, 0.0) + common;
+            if (two < best) {
+                best = two;
+                best_choice = {smp, Rt, ra, 0};
+            }
+            if (!ra || max_phases < 3) continue;
+            // a second re-tightening after m more rounds of items (m = 1..3): the middle phase then fills its rounds
+            for (int m = 1; m <= 3; ++m) {
+                const int64_t mid = (int64_t)m * per_x / qb_per * nrc;
+                const int64_t rb = ra + mid;
+                if (mid < nrc || rb + nrc > Rt) break;
+                const double fb = (double)mid / (double)Rt;
+                const double three = makespan(0, ra, Rt) + makespan(ra, rb, Rt) + makespan(rb, Rt, Rt) + 2.0 * phase_w +
+                                     hit_w * survivors(fa, fb) + common;
+                if (three < best) {
+                    best = three;
+                    best_choice = {smp, Rt, ra, rb};
+                }
+            }
+        }
+    }
+    return best_choice;
+}
+
 Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu) {
     Plan p;
     memset(&p, 0, sizeof(p));
@@ -123,98 +214,11 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu) {
         return o;
     };
     if (p.fused) {
-        p.sample_tiles = (int)sample;
-        p.sample_stride = std::max<int64_t>(1, p.full_tiles / sample);
-        // Main-pass ranges.  Work items are (range, query block); an XCD set of per_x workgroups walks
-        // (R / nrc) * qb_per equal items, so R is chosen (multiple of 8, near 6 items per workgroup, each item at
-        // least 8 tiles) to make that count as close below a multiple of per_x as possible -- NQ: R = 128 gives
-        // exactly 7 items per workgroup where R = 112 left the last round 1/8 full.  The choice is made by
-        // simulating the static item assignment (also covers the tile granularity of short ranges on small shards).
         p.qgroups = pick_qgroups(p.qblocks, dim);
-        const int nrc = NUM_XCD / p.qgroups, qb_per = p.qblocks / p.qgroups, per_x = p.grid / NUM_XCD;
-        const int64_t r_hi = std::min<int64_t>(1024 / p.sublists, round_up(std::max<int64_t>(1, p.tiles / 8), NUM_XCD));
-        const int64_t target = std::min<int64_t>(r_hi, round_up(std::max<int64_t>(NUM_XCD, (int64_t)p.grid * 6 / p.qblocks), NUM_XCD));
-        // makespan (in tiles, + 0.15 tile of pipeline fill per item) of one launch over ranges [rb, re) of R: the
-        // busiest XCD set is range class 0; its per_x workgroups take items round-robin, range r owns
-        // ceil((tiles - r) / R) tiles
-        const double select_per_range = 0.1;   // tile units per range; measured: decides R = 88 over 144 below ~1.5 M rows
-        auto makespan = [&](int64_t rb, int64_t re, int64_t Rt) -> double {
-            std::vector<double> load((size_t)per_x, 0.0);
-            int64_t i = 0;
-            for (int64_t r = rb; r < re; r += nrc)
-                for (int qi = 0; qi < qb_per; ++qi, ++i) {
-                    const int64_t nt = (p.tiles - r + Rt - 1) / Rt;
-                    if (nt > 0) load[(size_t)(i % per_x)] += (double)nt + 0.15;
-                }
-            return *std::max_element(load.begin(), load.end());
-        };
-        // Phase A (progressive thresholds): the first ranges, at most one round of items; CCR_PROGRESSIVE=0 disables.
-        const char *pe = getenv("CCR_PROGRESSIVE");
-        const bool prog_on = !(pe && atoi(pe) == 0);
-        // Cost of a candidate (in tile units of one workgroup): makespans of the launches + the select stage's share of R
-        // + the filter/select work the surviving candidates cause + a launch boundary per extra phase.  Survivors per query
-        // (measured: 3 280 from the 1/32 sample alone, 1 180 with one re-tightening at k = 100): a phase that covers the
-        // fraction f of the corpus with thresholds taken from a fraction g seen before lets through k * f / g rows.
-        // per-query costs are spread over the same workgroups as the GEMM tiles: they scale with the query count (the weights
-        // were measured at 3 452 queries = 14 query blocks)
-        const double qscale = (double)p.nq_pad / 3584.0;
-        const double hit_w = 0.014 * qscale, phase_w = 3.0;
-        // the sample pass itself: its GEMM tiles (one unit each, spread over the grid) and the threshold kernel's four
-        // passes over the group maxima (0.11 ms = 4.9 units for 328 sample tiles x 3 584 queries)
-        auto sample_cost = [&](int64_t smp) -> double {
-            return (double)((smp * p.qblocks + p.grid - 1) / p.grid) + 0.015 * (double)smp * (double)p.nq_pad / 3584.0;
-        };
-        int64_t best_sample = sample;
-        double best = 1e300;
-        int64_t R = target, RA = 0, RB = 0;
         const int64_t sample_alt = (sample_div_forced || (flags & CCR_SEARCH_FORCE_FUSED)) ? sample : sample_for(2 * sample_div);
-        for (int pass = 0; pass < 2; ++pass) {
-        const int64_t smp = pass == 0 ? sample : sample_alt;
-        if (pass == 1 && smp == sample) break;
-        const double fs = (double)smp / (double)p.tiles;
-        const double smp_cost = sample_cost(smp);
-        auto survivors = [&](double fa, double fb) -> double {   // fa, fb: corpus fractions of phases A and B1 (0 = absent)
-            if (fa <= 0.0) return (double)k / fs;
-            if (fb <= 0.0) return (double)k * (fa / fs + (1.0 - fa) / fa);
-            return (double)k * (fa / fs + fb / fa + (1.0 - fa - fb) / (fa + fb));
-        };
-        const int max_phases = getenv("CCR_PHASES") ? atoi(getenv("CCR_PHASES")) : 3;   // 2: at most one re-tightening
-        for (int64_t rbody = std::max<int64_t>(NUM_XCD, target / 2 / NUM_XCD * NUM_XCD); rbody <= std::min(r_hi, target * 2);
-             rbody += NUM_XCD) {
-            int64_t ra = (int64_t)per_x * nrc / qb_per / nrc * nrc;   // items = ra / nrc * qb_per <= per_x
-            ra = std::min<int64_t>(ra, rbody / 4 / nrc * nrc);
-            if (!(prog_on && ra >= nrc && rbody + ra <= 1024 / p.sublists && (double)p.tiles / (double)(rbody + ra) >= 8.0)) ra = 0;
-            const int64_t Rt = rbody + ra;
-            const double common = smp_cost + select_per_range * qscale * (double)Rt + 1e-3 * std::abs((double)(rbody - target));   // ties: near 6 items per workgroup
-            const double fa = (double)ra / (double)Rt;
-            const double two = (ra ? makespan(0, ra, Rt) + phase_w : 0.0) + makespan(ra, Rt, Rt) + hit_w * survivors(fa, 0.0) + common;
-            if (two < best) {
-                best = two;
-                R = Rt;
-                RA = ra;
-                RB = 0;
-                best_sample = smp;
-            }
-            if (!ra || max_phases < 3) continue;
-            // a second re-tightening after m more rounds of items (m = 1..3): the middle phase then fills its rounds
-            for (int m = 1; m <= 3; ++m) {
-                const int64_t mid = (int64_t)m * per_x / qb_per * nrc;
-                const int64_t rb = ra + mid;
-                if (mid < nrc || rb + nrc > Rt) break;
-                const double fb = (double)mid / (double)Rt;
-                const double three = makespan(0, ra, Rt) + makespan(ra, rb, Rt) + makespan(rb, Rt, Rt) + 2.0 * phase_w +
-                                     hit_w * survivors(fa, fb) + common;
-                if (three < best) {
-                    best = three;
-                    R = Rt;
-                    RA = ra;
-                    RB = rb;
-                    best_sample = smp;
-                }
-            }
-        }
-        }   // sample candidates
-        sample = best_sample;
+        const MainPassChoice choice = choose_main_pass(p, k, sample, sample_alt);
+        sample = choice.sample;
+        const int64_t R = choice.ranges, RA = choice.ranges_a, RB = choice.ranges_b;
         p.sample_tiles = (int)sample;
         p.sample_stride = std::max<int64_t>(1, p.full_tiles / sample);
         p.ranges = (int)R;
@@ -222,7 +226,7 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu) {
         p.ranges_b = (int)RB;
         const double ratio = (double)p.tiles / (double)sample;
         const double expect = (double)k * ratio * 1.3 + 64.0;  // survivors per query
-        // candidates go to 4 sub-lists per (range, query): one per (wave row, lane half) of the GEMM tile
+        // candidates go to `sublists` lists per (range, query): one per (wave row, lane part) of the GEMM tile
         int64_t cap = (int64_t)(4.0 * expect / (double)(R * p.sublists)) + 16;
         cap = round_up(std::min<int64_t>(std::max<int64_t>(cap, 16), 8192), 4);
         p.cap = (int)cap;
