@@ -30,10 +30,9 @@ int launch_threshold(const float *gmax, int64_t n_groups, int n_q, int nq_pad, i
                      const uint32_t *dmax_bits, int dim, float *thr, float *delta, hipStream_t s);
 int select_compact_entries(int dim, int ranges, int rescore_cap, int64_t want);
 int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, int sp, int n_q, int nq_pad, int cap, int k,
-                          int rescore_cap, int compact, int groups, int64_t n_rows, const float *delta, const uint16_t *Q,
+                          int rescore_cap, int compact, int64_t n_rows, const float *delta, const uint16_t *Q,
                           const uint16_t *D, int dim, int64_t id_offset, float *out_scores, int64_t *out_ids,
                           uint32_t *flag_count, uint32_t *flag_list, unsigned long long *stat_cand, hipStream_t s);
-int launch_gemm_filter_group(const GemmArgs &a, int grid, hipStream_t s);
 int launch_gemm16_filter(const GemmArgs &a, int grid, hipStream_t s);
 int launch_gemm16_store(const GemmArgs &a, int grid, hipStream_t s);
 int launch_threshold_update(const uint2 *cand, const uint32_t *cnt, int nsub, int sp, int n_q, int nq_pad, int cap, int k,
@@ -169,21 +168,14 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu) {
     p.tiles = (n_rows + TILE_DOCS - 1) / TILE_DOCS;
     p.full_tiles = n_rows / TILE_DOCS;
     p.grid = std::max(NUM_XCD, num_cu / NUM_XCD * NUM_XCD);
-    // small k: candidate records are 16-row MFMA fragments (cheap GEMM epilogue), all 16 rows of the kept
-    // fragments are re-scored; large k: one record per corpus row
-    // (opt-in until the 16x re-score is restructured: CCR_GROUP_RECORDS=1; see DESIGN.md "filter records")
-    {
-        const char *e = getenv("CCR_GROUP_RECORDS");
-        p.group_records = (e && atoi(e) == 1 && k <= 256) ? 1 : 0;
-    }
     {
         const char *e = getenv("CCR_MFMA16");   // main pass on v_mfma_f32_16x16x32_bf16 (row records only)
         // default: the 16x16x32 kernel up to k = 512; above that its eight sub-lists per (range, query) cost the select
         // stage more than the main pass gains (config-4 shape, k = 1000: select 14.3 vs 9.0 ms at equal main-pass time)
-        p.mfma16 = (e ? atoi(e) : (CCR_MFMA16_DEFAULT && k <= 512)) && !p.group_records ? 1 : 0;
+        p.mfma16 = (e ? atoi(e) : (CCR_MFMA16_DEFAULT && k <= 512)) ? 1 : 0;
         p.sublists = p.mfma16 ? 8 : 4;
     }
-    p.rescore_cap = p.group_records ? 16 * std::max(128, 2 * pow2_ceil(k)) : std::min(8192, std::max(256, 2 * pow2_ceil(k)));
+    p.rescore_cap = std::min(8192, std::max(256, 2 * pow2_ceil(k)));
 
     // sample pass: group maxima of 16 rows; need comfortably more groups than k
     const int64_t min_sample = (2 * (int64_t)k + GROUPS_PER_TILE - 1) / GROUPS_PER_TILE;
@@ -511,7 +503,7 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
     CCR_HIP_CHECK(hipEventRecord(ix->ev[3], s));
     auto main_pass = [&](const GemmArgs &ga) {
         if (p.mfma16) return launch_gemm16_filter(ga, p.grid, s);
-        return p.group_records ? launch_gemm_filter_group(ga, p.grid, s) : launch_gemm_filter(ga, p.grid, s);
+        return launch_gemm_filter(ga, p.grid, s);
     };
     // progressive thresholds: launches over the range sets [0, ra), [ra, rb), [rb, R) with a re-tightening in between
     const int bounds[4] = {0, p.ranges_a, p.ranges_b, p.ranges};
@@ -549,7 +541,7 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
         (void)hipFree(stamps);
     }
 
-    rc = launch_select_rescore(cand, cnt, p.ranges * p.sublists, p.sublists, n_q, p.nq_pad, p.cap, k, p.rescore_cap, p.select_compact, p.group_records, ix->n_rows, delta,
+    rc = launch_select_rescore(cand, cnt, p.ranges * p.sublists, p.sublists, n_q, p.nq_pad, p.cap, k, p.rescore_cap, p.select_compact, ix->n_rows, delta,
                                Q_bf16, ix->D, ix->dim,
                                ix->offset, out_scores, out_ids, flag_count, flag_list, stat_cand, s);
     if (rc != CCR_OK) return rc;

@@ -61,7 +61,6 @@ struct Plan {
     int grid;             // persistent workgroups (multiple of NUM_XCD)
     int rescore_cap;      // max rows re-scored per query (power of two)
     int select_compact;   // candidates per query the select kernel gathers into LDS
-    int group_records;    // 1: candidate records are 16-row MFMA fragments (k <= 256)
     int mfma16;           // 1: main pass on the 16x16x32 MFMA kernel
     int sublists;         // candidate sub-lists per (range, query): 4 (32x32x16 kernel) or 8 (16x16x32 kernel)
     // workspace layout (byte offsets)

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
         float thr[2] = {0.f, 0.f};
         uint32_t ncand[2] = {0u, 0u};
         uint2 *clist[2] = {nullptr, nullptr};
-        if (EPI == EPI_FILTER || EPI == EPI_FILTER_GROUP) {
+        if (EPI == EPI_FILTER) {
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
                 const int q = q0 + wq * 64 + qt * 32 + l31;
@@ -200,20 +200,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
 #pragma unroll
                     for (int dt = 0; dt < 4; ++dt)
                         a.gmax[(vt * GROUPS_PER_TILE + wd * 8 + dt * 2 + h) * a.nq_pad + q0 + ql] = mdt[dt];
-                } else if (EPI == EPI_FILTER_GROUP) {
-                    const float t = thr[qt];
-                    const float mall = fmaxf(fmaxf(mdt[0], mdt[1]), fmaxf(mdt[2], mdt[3]));
-                    if (__ballot(mall >= t) != 0ull) {
-#pragma unroll
-                        for (int dt = 0; dt < 4; ++dt) {
-                            const int64_t first = row_base + dt * 32;
-                            if (mdt[dt] >= t && first < a.n_rows) {  // rare, divergent
-                                if (ncand[qt] < (uint32_t)a.cap)
-                                    clist[qt][ncand[qt]] = make_uint2(__float_as_uint(mdt[dt]), (uint32_t)first);
-                                ++ncand[qt];
-                            }
-                        }
-                    }
                 } else if (EPI == EPI_FILTER) {
                     const float t = thr[qt];
                     const float mall = fmaxf(fmaxf(mdt[0], mdt[1]), fmaxf(mdt[2], mdt[3]));
@@ -360,7 +346,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
         if (pending) epilogue(pending_vt);
         if (STAGGER && !g1) CCR_BARRIER();  // every wave executes the same number of barriers
 
-        if (EPI == EPI_FILTER || EPI == EPI_FILTER_GROUP) {
+        if (EPI == EPI_FILTER) {
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt)
                 a.cnt[((int64_t)r * a.nq_pad + q0 + wq * 64 + qt * 32 + l31) * 4 + wd * 2 + h] = ncand[qt];
@@ -811,7 +797,7 @@ __device__ __forceinline__ void sweep_sublists(int tid, int n_lists, int first, 
 
 // Stage-2: per query, candidates -> exact canonical top-k.  grid = n_q, block = THREADS (256; 1024 for large k).
 // dyn LDS: [dim bf16 query row][sub-list counts][sub-list offsets][rescore_cap u64 keys][compact x 8-byte candidates]
-template <bool GROUPS, int THREADS>
+template <int THREADS>
 __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__restrict__ cand, const uint32_t *__restrict__ cnt,
                                                             int ranges, int sp, int nq_pad, int cap, int k, int rescore_cap, int compact,
                                                             int64_t n_rows, const float *__restrict__ delta,
@@ -833,7 +819,6 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
     __shared__ int s_flag;
     __shared__ uint32_t s_total, s_maxc, s_fill;
     __shared__ uint32_t s_ncoll;
-    __shared__ uint32_t s_grp[GROUPS ? 512 : 1];  // first rows of the kept fragments (rescore_cap / 16 <= 512)
 
     const int tid = threadIdx.x;
     const int q = blockIdx.x;
@@ -886,7 +871,7 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
 
     // sub-list j = (range j / sp, wave-row / lane part j % sp) lives at (((j / sp) * nq_pad + q) * sp + (j % sp)) * cap
     auto at = [&](int j, int sl) -> uint2 { return cand[(((int64_t)(j / sp) * nq_pad + q) * sp + (j % sp)) * cap + sl]; };
-    const int coll_cap = GROUPS ? rescore_cap / 16 : rescore_cap;
+    const int coll_cap = rescore_cap;
     uint32_t kth = 0;
     int need_eq = 0;
     int n_lds = 0;   // candidates resident in s_comp
@@ -992,13 +977,7 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
         }
         return;
     }
-    int ncoll = (int)s_ncoll;
-    if (GROUPS) {
-        // kept records are 16-row MFMA fragments: fragment g -> rows base + (e & 3) + 8 * (e >> 2), e = 0..15
-        for (int g = tid; g < ncoll; g += blockDim.x) s_grp[g] = (uint32_t)s_keys[g];
-        __syncthreads();
-        ncoll *= 16;
-    }
+    const int ncoll = (int)s_ncoll;
     const int np2 = pow2_ceil(ncoll);
     // Canonical re-score.  The candidate rows are scattered over the shard; a thread walking "its" row 16 bytes at a
     // time makes every wave-load touch 64 different cache lines (measured 1.5 TB/s at k = 1000).  Instead the rows are
@@ -1008,7 +987,7 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
     const size_t stage_bytes = (size_t)compact * 8;
     // (only in the 1024-thread large-k variant: at k <= 256 the ~100 rows per query are re-read from L2 / Infinity Cache
     // quickly enough by the direct walk, and the slice barriers cost more than they save)
-    const int SB = (GROUPS || THREADS < 1024) ? 0 : ((size_t)ncoll * 144 <= stage_bytes ? 128 : ((size_t)ncoll * 80 <= stage_bytes ? 64 : 0));
+    const int SB = THREADS < 1024 ? 0 : ((size_t)ncoll * 144 <= stage_bytes ? 128 : ((size_t)ncoll * 80 <= stage_bytes ? 64 : 0));
     if (SB != 0 && ncoll <= 2 * THREADS) {
         char *stage = reinterpret_cast<char *>(s_comp);
         const int stride = SB + 16;                 // +16: consecutive rows start 4 banks apart (conflict-free b128 reads)
@@ -1058,14 +1037,8 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
         for (int i = tid; i < np2; i += blockDim.x) {
             unsigned long long key = 0ull;
             if (i < ncoll) {
-                uint32_t row;
-                if (GROUPS) {
-                    const int e = i & 15;
-                    row = s_grp[i >> 4] + (uint32_t)((e & 3) + 8 * (e >> 2));
-                } else {
-                    row = (uint32_t)s_keys[i];
-                }
-                if (!GROUPS || (int64_t)row < n_rows) key = make_key(canonical_dot(s_q, D + (int64_t)row * dim, dim), row);
+                const uint32_t row = (uint32_t)s_keys[i];
+                key = make_key(canonical_dot(s_q, D + (int64_t)row * dim, dim), row);
             }
             s_keys[i] = key;
         }
@@ -1099,7 +1072,7 @@ static int launch_gemm(const GemmArgs &a, int grid, hipStream_t s) {
         stagger = st ? atoi(st) : 1;
     }
     const size_t lds = RING * (size_t)SUB_BYTES;
-    if ((EPI == EPI_FILTER || EPI == EPI_FILTER_GROUP) && dbg != 0) {
+    if (EPI == EPI_FILTER && dbg != 0) {
         switch (dbg) {
             case 1: return launch_kernel(&gemm_topk_kernel<EPI, true, 1>, lds, a, grid, s);
             case 2: return launch_kernel(&gemm_topk_kernel<EPI, true, 2>, lds, a, grid, s);
@@ -1122,7 +1095,6 @@ int launch_gemm16_filter(const GemmArgs &a, int grid, hipStream_t s) {
 int launch_gemm16_store(const GemmArgs &a, int grid, hipStream_t s) {
     return launch_kernel(&gemm_topk16_kernel<EPI_STORE, 0>, RING * (size_t)SUB_BYTES, a, grid, s);
 }
-int launch_gemm_filter_group(const GemmArgs &a, int grid, hipStream_t s) { return launch_gemm<EPI_FILTER_GROUP>(a, grid, s); }
 int launch_gemm_gmax(const GemmArgs &a, int grid, hipStream_t s) { return launch_gemm<EPI_GMAX>(a, grid, s); }
 int launch_gemm_store(const GemmArgs &a, int grid, hipStream_t s) { return launch_gemm<EPI_STORE>(a, grid, s); }
 
@@ -1177,11 +1149,11 @@ int select_compact_entries(int dim, int ranges, int rescore_cap, int64_t want) {
 }
 
 int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, int sp, int n_q, int nq_pad, int cap, int k,
-                          int rescore_cap, int compact, int groups, int64_t n_rows, const float *delta, const uint16_t *Q,
+                          int rescore_cap, int compact, int64_t n_rows, const float *delta, const uint16_t *Q,
                           const uint16_t *D, int dim, int64_t id_offset, float *out_scores, int64_t *out_ids,
                           uint32_t *flag_count, uint32_t *flag_list, unsigned long long *stat_cand, hipStream_t s) {
     const size_t lds = select_fixed_lds(dim, ranges, rescore_cap) + (size_t)compact * 8;
-    const bool wide = !groups && (rescore_cap > 512 || compact > 8192);   // 1024 threads: one re-scored row per thread at large k
+    const bool wide = rescore_cap > 512 || compact > 8192;   // 1024 threads: one re-scored row per thread at large k
     auto go = [&](auto kernel, int threads) -> int {
         if (lds > 48 * 1024)
             CCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1190,9 +1162,8 @@ int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, in
         CCR_LAUNCH_CHECK();
         return CCR_OK;
     };
-    if (groups) return go(&select_rescore_kernel<true, 256>, 256);
-    if (wide) return go(&select_rescore_kernel<false, 1024>, 1024);
-    return go(&select_rescore_kernel<false, 256>, 256);
+    if (wide) return go(&select_rescore_kernel<1024>, 1024);
+    return go(&select_rescore_kernel<256>, 256);
 }
 
 }  // namespace ccr

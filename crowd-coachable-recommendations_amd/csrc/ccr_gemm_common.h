@@ -7,10 +7,8 @@ namespace ccr {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { EPI_FILTER = 0, EPI_GMAX = 1, EPI_STORE = 2, EPI_FILTER_GROUP = 3 };
+enum { EPI_FILTER = 0, EPI_GMAX = 1, EPI_STORE = 2 };
 // EPI_FILTER       : candidate record = one corpus row        {MFMA score, row}
-// EPI_FILTER_GROUP : candidate record = one 16-row MFMA fragment {fragment max, first row}; the select
-//                    stage re-scores all 16 rows of the fragments it keeps (small k only)
 
 // LDS-DMA of 16 bytes per lane: the LDS destination is the wave-uniform base + lane * 16
 __device__ __forceinline__ void glds16(const void *gsrc, char *lds_wave_base) {
