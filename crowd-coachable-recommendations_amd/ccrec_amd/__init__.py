@@ -5,7 +5,15 @@ Mirrors (reference file:line):
   item_tower.ItemTowerBase / NaiveItemTower               src/ccrec/models/item_tower.py:8-151
   replica_cache.DataParallel.cache_replicas               src/ccrec/util/data_parallel.py:8-20
   rime_util._assign_topk                                  src/rime_lite/util/__init__.py:117-155
-  bbpr_loss.multiple_nrl_loss                             src/ccrec/models/bbpr.py:187-214
+  bbpr_loss.multiple_nrl_loss / MultipleNrlStep           src/ccrec/models/bbpr.py:149-227
+  bbpr_transform.get_all_embeddings / transform           src/ccrec/models/bbpr.py:466-550
+  rime_util.evaluate_item_rec / evaluate_assigned         src/rime_lite/metrics/__init__.py:52-89
+  al_rank.generate_ranking_profile                        scripts/al_0_rank.py:69-127
+  encode.LengthSortedEncoder / ranking_sharded            (variable-length encode, per-rank shards: SURVEY 8 f2)
+  al_request.build_requests / generate_train_data         scripts/al_0_rank.py:136-218, scripts/al_oracle_agent.py:134-186
+  bm25.BM25 / ranking_bm25                                scripts/bm_25.py, scripts/ms_marco_eval.py:165-186
+  evaluation.rank_metrics                                 scripts/al_0_rank.py:130-133 (BEIR evaluate_custom, mrr)
+  al_step.run_rank_step                                   scripts/al_0_rank.py:107-218 as one call
 Config: the CCREC_* environment variables of src/ccrec/__init__.py:8-25 (same names, defaults, options).
 """
 import os
