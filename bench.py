@@ -210,12 +210,17 @@ def main():
         except Exception:
             traffic = None
 
+    default_shape = (args.rows, args.queries, args.dim, args.k) == (N_ROWS, N_Q, DIM, TOP_K)
+    workload = ("configs[1]: NQ corpus top-100, corpus row-sharded over n_gpus" if default_shape else
+                f"custom shape (not the headline config): {args.rows:,} x {args.dim} corpus, {args.queries:,} queries, top-{args.k}, "
+                "corpus row-sharded over n_gpus")
     out = {
-        "metric": "queries/sec, exhaustive inner-product top-100 retrieval (NQ-shaped 2,681,468 x 768 bf16 corpus)",
+        "metric": ("queries/sec, exhaustive inner-product top-100 retrieval (NQ-shaped 2,681,468 x 768 bf16 corpus)" if default_shape
+                   else f"queries/sec, exhaustive inner-product top-{args.k} retrieval ({args.rows:,} x {args.dim} bf16 corpus)"),
         "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "configs[1]: NQ corpus top-100, corpus row-sharded over n_gpus", "corpus_rows": args.rows,
+        "config": {"workload": workload, "corpus_rows": args.rows,
                    "dim": args.dim, "queries": args.queries, "k": args.k,
                    "step": "pack corpus shard fp32->bf16 + index build + pack queries + fused MFMA score/top-k"
                            + (" + RCCL all-gather + merge" if world > 1 else ""),
