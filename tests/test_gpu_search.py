@@ -381,3 +381,22 @@ def test_rescore_is_canonical_under_wide_dynamic_range():
         ref_i, ref_s = orc.canonical_search(Qb, Db, k)
         assert np.array_equal(i.cpu().numpy(), ref_i), wide
         assert np.array_equal(s.cpu().numpy().view(np.uint32), ref_s.view(np.uint32)), wide
+
+
+def test_global_row_offset_beyond_32_bits():
+    """ids = local row + global_row_offset in int64 on every path (fused, dense, merge)."""
+    from ccrec_amd import ops
+    off = (1 << 40) + 123
+    n, nq, d, k = 20000, 9, 128, 50
+    Db, Qb = _rand_bits(n, d, 91), _rand_bits(nq, d, 92)
+    ref_i, ref_s = orc.canonical_search(Qb, Db, k, None)
+    index = ops.CorpusIndex(_bf16(Db), global_row_offset=off)
+    for flags in (FUSED, DENSE):
+        s, i = index.search(_bf16(Qb), k, flags)
+        assert i.dtype == torch.int64 and np.array_equal(i.cpu().numpy() - off, ref_i)
+        assert np.array_equal(s.cpu().numpy().view(np.uint32), ref_s.view(np.uint32))
+    half = n // 2
+    parts = [ops.CorpusIndex(_bf16(Db[lo:hi]), global_row_offset=off + lo).search(_bf16(Qb), k) for lo, hi in ((0, half), (half, n))]
+    ms, mi = ops.merge_topk(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+    assert np.array_equal(mi.cpu().numpy() - off, ref_i)
+
