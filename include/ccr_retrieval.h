@@ -124,6 +124,9 @@ int ccr_index_dim(const ccr_index *index);
  *   1 <= k <= min(n_rows, 4096).
  * The call returns after the results are complete on `stream` (it synchronises the stream once
  * to read the fallback count).
+ * Embeddings are expected to be finite.  NaN / Inf values do not fault: the filter margins become infinite, every
+ * query takes the exact dense path, +-Inf scores rank as numbers and NaN scores rank by bit pattern (not torch.sort's
+ * NaN-first rule) -- identically on every path.
  */
 size_t ccr_search_workspace_bytes(const ccr_index *index, int n_q, int k);
 int ccr_search(ccr_index *index, const uint16_t *Q_bf16, int n_q, int k, float *out_scores, int64_t *out_ids,

@@ -400,3 +400,26 @@ def test_global_row_offset_beyond_32_bits():
     ms, mi = ops.merge_topk(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
     assert np.array_equal(mi.cpu().numpy() - off, ref_i)
 
+
+def test_non_finite_embeddings_do_not_fault_and_are_path_independent():
+    """NaN / Inf rows and a NaN query: not a supported input (include/ccr_retrieval.h), but nothing faults or hangs, the
+    infinite filter margins send every query to the exact dense path, and forced-fused == forced-dense bit for bit."""
+    from ccrec_amd import ops
+    g = torch.Generator().manual_seed(1)
+    for n in (20000, 400):
+        D = torch.randn(n, 128, generator=g) / 128 ** 0.5
+        Q = torch.randn(6, 128, generator=g) / 128 ** 0.5
+        D[5] = float("nan")
+        D[7] = float("inf")
+        D[9, 3] = float("-inf")
+        Q[2] = float("nan")
+        index = ops.CorpusIndex(ops.pack_bf16(D.cuda()))
+        Qb = ops.pack_bf16(Q.cuda())
+        s_f, i_f = index.search(Qb, 10, FUSED)
+        st = index.last_stats()
+        s_d, i_d = index.search(Qb, 10, DENSE)
+        assert st["path"] == 1 and st["n_fallback"] == 6, st
+        assert torch.equal(i_f, i_d) and torch.equal(s_f.view(torch.int32), s_d.view(torch.int32))
+        finite = torch.isfinite(s_f[0])
+        assert finite.sum() >= 7 and torch.all(s_f[0][finite][:-1] >= s_f[0][finite][1:])
+
