@@ -84,7 +84,6 @@ def cpu_baseline(corpus_bf16, queries_bf16, nq_sample, k, gpu_ids):
     chunked fp32 matmul into a host [Q,N] matrix, per-row full descending sort, keep 1001) on the
     same bf16-rounded values, all host cores."""
     from oracle import oracle as orc
-    import numpy as np
     Ed = corpus_bf16.float().cpu().numpy()
     Eq = queries_bf16[:nq_sample].float().cpu().numpy()
     torch.set_num_threads(host_threads())
