@@ -171,3 +171,22 @@ def test_topk_message_layout_on_cpu():
     assert m.all_scores.shape == (3, 7, 5) and m.all_ids.shape == (3, 7, 5)
     assert m.all_scores.stride() == (m.nbytes // 4, 5, 1) and m.all_ids.stride() == (m.nbytes // 8, 5, 1)
     assert [float(m.all_scores[r, 0, 0]) for r in range(3)] == [0.0, 1.0, 2.0] and int(m.all_ids[2, 6, 4]) == (1 << 40) + 34
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    """The bench line committed under profiles/ (a real MI355X run of `python bench.py`) carries every field the driver reads."""
+    import json
+    path = os.path.join(ROOT, "profiles", "r01_bench_n1.json")
+    line = json.loads(open(path).read().strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["higher_is_better"] is True and line["vs_baseline"] is None
+    assert "workload" in line["config"] and "model" not in line["config"]
+    roof = line["roofline"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(roof)
+    assert roof["bound"] in ("hbm", "mfma") and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    cpu = line["cpu_baseline"]
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(cpu) and cpu["kind"] in ("port", "reference")
+    assert abs(line["value"] - line["config"]["queries"] / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-3
+
