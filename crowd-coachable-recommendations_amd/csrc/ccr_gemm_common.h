@@ -1,4 +1,4 @@
-// ccr_gemm_common.h -- definitions shared by the GEMM + top-k kernels (ccr_fused.hip, ccr_fused4w.hip).
+// ccr_gemm_common.h -- definitions shared by the GEMM + top-k kernels (ccr_fused.hip, experimental/gemm4w_proto.hip).
 #pragma once
 #include "ccr_common.h"
 
