@@ -52,6 +52,9 @@ namespace ccr {
                  "+v"(B[4]), "+v"(B[5])::"memory")
 
 constexpr int P4_THREADS = 256;
+#ifndef PROTO_MODE
+#define PROTO_MODE 0   // 0: timing skeleton; 3: test build that stores every raw MFMA score (a.store [n_q][n_rows])
+#endif
 constexpr int TQ = 384;
 constexpr int SUBB = (256 + TQ) * 64;   // 40960
 constexpr int QOFF = 256 * 64;          // 16384
@@ -131,6 +134,8 @@ __global__ __launch_bounds__(P4_THREADS) void gemm4w384_proto_kernel(const GemmA
             WAIT10(A0, B0);
         }
         int cks = 0, cbuf = 0;
+        int64_t ct = 0;
+        (void)ct;
         for (int64_t u = 0; u < U; ++u) {
             const uint32_t cb = lds0 + (uint32_t)cbuf * SUBB;
             const int nbuf = cbuf + 1 == RING3 ? 0 : cbuf + 1;
@@ -263,6 +268,396 @@ __global__ __launch_bounds__(P4_THREADS) void gemm4w384_proto_kernel(const GemmA
         asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(accv[7]) : "v"(A1[3]), "v"(B1[5]) : "memory");
             if (more) issue_done();
             WAIT10(A0, B0);
+            if (PROTO_MODE == 3 && cks == KS2 - 1) {   // test build: write the finished tile's raw MFMA scores
+                asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+                const int64_t row_t = (int64_t)(r + ct * a.ranges) * TILE_DOCS + wd * 128 + 4 * h;
+                const int64_t qcol = (int64_t)qb * TQ + wq * 192 + l31;
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a0" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 0] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a1" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 1] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a2" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 2] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a3" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 3] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a4" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 8] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a5" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 9] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a6" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 10] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a7" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 11] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a8" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 16] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a9" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 17] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a10" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 18] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a11" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 19] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a12" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 24] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a13" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 25] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a14" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 26] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a15" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 27] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a16" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 0] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a17" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 1] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a18" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 2] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a19" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 3] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a20" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 8] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a21" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 9] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a22" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 10] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a23" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 11] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a24" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 16] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a25" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 17] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a26" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 18] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a27" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 19] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a28" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 24] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a29" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 25] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a30" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 26] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a31" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 27] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a32" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 0] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a33" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 1] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a34" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 2] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a35" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 3] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a36" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 8] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a37" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 9] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a38" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 10] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a39" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 11] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a40" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 16] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a41" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 17] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a42" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 18] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a43" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 19] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a44" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 24] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a45" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 25] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a46" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 26] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a47" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 27] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a48" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 0] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a49" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 1] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a50" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 2] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a51" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 3] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a52" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 8] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a53" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 9] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a54" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 10] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a55" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 11] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a56" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 16] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a57" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 17] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a58" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 18] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a59" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 19] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a60" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 24] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a61" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 25] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a62" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 26] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a63" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 27] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a64" : "=v"(x)); a.store[(qcol + 128) * a.n_rows + row_t + 0] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a65" : "=v"(x)); a.store[(qcol + 128) * a.n_rows + row_t + 1] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a66" : "=v"(x)); a.store[(qcol + 128) * a.n_rows + row_t + 2] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a67" : "=v"(x)); a.store[(qcol + 128) * a.n_rows + row_t + 3] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a68" : "=v"(x)); a.store[(qcol + 128) * a.n_rows + row_t + 8] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a69" : "=v"(x)); a.store[(qcol + 128) * a.n_rows + row_t + 9] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a70" : "=v"(x)); a.store[(qcol + 128) * a.n_rows + row_t + 10] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a71" : "=v"(x)); a.store[(qcol + 128) * a.n_rows + row_t + 11] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a72" : "=v"(x)); a.store[(qcol + 128) * a.n_rows + row_t + 16] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a73" : "=v"(x)); a.store[(qcol + 128) * a.n_rows + row_t + 17] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a74" : "=v"(x)); a.store[(qcol + 128) * a.n_rows + row_t + 18] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a75" : "=v"(x)); a.store[(qcol + 128) * a.n_rows + row_t + 19] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a76" : "=v"(x)); a.store[(qcol + 128) * a.n_rows + row_t + 24] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a77" : "=v"(x)); a.store[(qcol + 128) * a.n_rows + row_t + 25] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a78" : "=v"(x)); a.store[(qcol + 128) * a.n_rows + row_t + 26] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a79" : "=v"(x)); a.store[(qcol + 128) * a.n_rows + row_t + 27] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a80" : "=v"(x)); a.store[(qcol + 160) * a.n_rows + row_t + 0] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a81" : "=v"(x)); a.store[(qcol + 160) * a.n_rows + row_t + 1] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a82" : "=v"(x)); a.store[(qcol + 160) * a.n_rows + row_t + 2] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a83" : "=v"(x)); a.store[(qcol + 160) * a.n_rows + row_t + 3] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a84" : "=v"(x)); a.store[(qcol + 160) * a.n_rows + row_t + 8] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a85" : "=v"(x)); a.store[(qcol + 160) * a.n_rows + row_t + 9] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a86" : "=v"(x)); a.store[(qcol + 160) * a.n_rows + row_t + 10] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a87" : "=v"(x)); a.store[(qcol + 160) * a.n_rows + row_t + 11] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a88" : "=v"(x)); a.store[(qcol + 160) * a.n_rows + row_t + 16] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a89" : "=v"(x)); a.store[(qcol + 160) * a.n_rows + row_t + 17] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a90" : "=v"(x)); a.store[(qcol + 160) * a.n_rows + row_t + 18] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a91" : "=v"(x)); a.store[(qcol + 160) * a.n_rows + row_t + 19] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a92" : "=v"(x)); a.store[(qcol + 160) * a.n_rows + row_t + 24] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a93" : "=v"(x)); a.store[(qcol + 160) * a.n_rows + row_t + 25] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a94" : "=v"(x)); a.store[(qcol + 160) * a.n_rows + row_t + 26] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a95" : "=v"(x)); a.store[(qcol + 160) * a.n_rows + row_t + 27] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a96" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 32] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a97" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 33] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a98" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 34] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a99" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 35] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a100" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 40] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a101" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 41] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a102" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 42] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a103" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 43] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a104" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 48] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a105" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 49] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a106" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 50] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a107" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 51] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a108" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 56] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a109" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 57] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a110" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 58] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a111" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 59] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a112" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 32] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a113" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 33] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a114" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 34] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a115" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 35] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a116" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 40] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a117" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 41] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a118" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 42] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a119" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 43] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a120" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 48] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a121" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 49] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a122" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 50] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a123" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 51] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a124" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 56] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a125" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 57] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a126" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 58] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a127" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 59] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a128" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 32] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a129" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 33] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a130" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 34] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a131" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 35] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a132" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 40] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a133" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 41] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a134" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 42] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a135" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 43] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a136" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 48] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a137" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 49] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a138" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 50] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a139" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 51] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a140" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 56] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a141" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 57] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a142" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 58] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a143" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 59] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a144" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 32] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a145" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 33] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a146" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 34] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a147" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 35] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a148" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 40] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a149" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 41] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a150" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 42] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a151" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 43] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a152" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 48] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a153" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 49] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a154" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 50] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a155" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 51] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a156" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 56] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a157" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 57] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a158" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 58] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a159" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 59] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a160" : "=v"(x)); a.store[(qcol + 128) * a.n_rows + row_t + 32] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a161" : "=v"(x)); a.store[(qcol + 128) * a.n_rows + row_t + 33] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a162" : "=v"(x)); a.store[(qcol + 128) * a.n_rows + row_t + 34] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a163" : "=v"(x)); a.store[(qcol + 128) * a.n_rows + row_t + 35] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a164" : "=v"(x)); a.store[(qcol + 128) * a.n_rows + row_t + 40] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a165" : "=v"(x)); a.store[(qcol + 128) * a.n_rows + row_t + 41] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a166" : "=v"(x)); a.store[(qcol + 128) * a.n_rows + row_t + 42] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a167" : "=v"(x)); a.store[(qcol + 128) * a.n_rows + row_t + 43] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a168" : "=v"(x)); a.store[(qcol + 128) * a.n_rows + row_t + 48] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a169" : "=v"(x)); a.store[(qcol + 128) * a.n_rows + row_t + 49] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a170" : "=v"(x)); a.store[(qcol + 128) * a.n_rows + row_t + 50] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a171" : "=v"(x)); a.store[(qcol + 128) * a.n_rows + row_t + 51] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a172" : "=v"(x)); a.store[(qcol + 128) * a.n_rows + row_t + 56] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a173" : "=v"(x)); a.store[(qcol + 128) * a.n_rows + row_t + 57] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a174" : "=v"(x)); a.store[(qcol + 128) * a.n_rows + row_t + 58] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a175" : "=v"(x)); a.store[(qcol + 128) * a.n_rows + row_t + 59] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a176" : "=v"(x)); a.store[(qcol + 160) * a.n_rows + row_t + 32] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a177" : "=v"(x)); a.store[(qcol + 160) * a.n_rows + row_t + 33] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a178" : "=v"(x)); a.store[(qcol + 160) * a.n_rows + row_t + 34] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a179" : "=v"(x)); a.store[(qcol + 160) * a.n_rows + row_t + 35] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a180" : "=v"(x)); a.store[(qcol + 160) * a.n_rows + row_t + 40] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a181" : "=v"(x)); a.store[(qcol + 160) * a.n_rows + row_t + 41] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a182" : "=v"(x)); a.store[(qcol + 160) * a.n_rows + row_t + 42] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a183" : "=v"(x)); a.store[(qcol + 160) * a.n_rows + row_t + 43] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a184" : "=v"(x)); a.store[(qcol + 160) * a.n_rows + row_t + 48] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a185" : "=v"(x)); a.store[(qcol + 160) * a.n_rows + row_t + 49] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a186" : "=v"(x)); a.store[(qcol + 160) * a.n_rows + row_t + 50] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a187" : "=v"(x)); a.store[(qcol + 160) * a.n_rows + row_t + 51] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a188" : "=v"(x)); a.store[(qcol + 160) * a.n_rows + row_t + 56] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a189" : "=v"(x)); a.store[(qcol + 160) * a.n_rows + row_t + 57] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a190" : "=v"(x)); a.store[(qcol + 160) * a.n_rows + row_t + 58] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a191" : "=v"(x)); a.store[(qcol + 160) * a.n_rows + row_t + 59] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a192" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 64] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a193" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 65] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a194" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 66] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a195" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 67] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a196" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 72] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a197" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 73] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a198" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 74] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a199" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 75] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a200" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 80] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a201" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 81] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a202" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 82] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a203" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 83] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a204" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 88] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a205" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 89] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a206" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 90] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a207" : "=v"(x)); a.store[(qcol + 0) * a.n_rows + row_t + 91] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a208" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 64] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a209" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 65] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a210" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 66] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a211" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 67] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a212" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 72] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a213" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 73] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a214" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 74] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a215" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 75] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a216" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 80] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a217" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 81] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a218" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 82] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a219" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 83] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a220" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 88] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a221" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 89] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a222" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 90] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a223" : "=v"(x)); a.store[(qcol + 32) * a.n_rows + row_t + 91] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a224" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 64] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a225" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 65] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a226" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 66] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a227" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 67] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a228" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 72] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a229" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 73] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a230" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 74] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a231" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 75] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a232" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 80] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a233" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 81] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a234" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 82] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a235" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 83] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a236" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 88] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a237" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 89] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a238" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 90] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a239" : "=v"(x)); a.store[(qcol + 64) * a.n_rows + row_t + 91] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a240" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 64] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a241" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 65] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a242" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 66] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a243" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 67] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a244" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 72] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a245" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 73] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a246" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 74] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a247" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 75] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a248" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 80] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a249" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 81] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a250" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 82] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a251" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 83] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a252" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 88] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a253" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 89] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a254" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 90] = x; }
+                { float x; asm volatile("v_accvgpr_read_b32 %0, a255" : "=v"(x)); a.store[(qcol + 96) * a.n_rows + row_t + 91] = x; }
+                a.store[(qcol + 128) * a.n_rows + row_t + 64] = accv[0][0];
+                a.store[(qcol + 128) * a.n_rows + row_t + 65] = accv[0][1];
+                a.store[(qcol + 128) * a.n_rows + row_t + 66] = accv[0][2];
+                a.store[(qcol + 128) * a.n_rows + row_t + 67] = accv[0][3];
+                a.store[(qcol + 128) * a.n_rows + row_t + 72] = accv[0][4];
+                a.store[(qcol + 128) * a.n_rows + row_t + 73] = accv[0][5];
+                a.store[(qcol + 128) * a.n_rows + row_t + 74] = accv[0][6];
+                a.store[(qcol + 128) * a.n_rows + row_t + 75] = accv[0][7];
+                a.store[(qcol + 128) * a.n_rows + row_t + 80] = accv[0][8];
+                a.store[(qcol + 128) * a.n_rows + row_t + 81] = accv[0][9];
+                a.store[(qcol + 128) * a.n_rows + row_t + 82] = accv[0][10];
+                a.store[(qcol + 128) * a.n_rows + row_t + 83] = accv[0][11];
+                a.store[(qcol + 128) * a.n_rows + row_t + 88] = accv[0][12];
+                a.store[(qcol + 128) * a.n_rows + row_t + 89] = accv[0][13];
+                a.store[(qcol + 128) * a.n_rows + row_t + 90] = accv[0][14];
+                a.store[(qcol + 128) * a.n_rows + row_t + 91] = accv[0][15];
+                a.store[(qcol + 160) * a.n_rows + row_t + 64] = accv[1][0];
+                a.store[(qcol + 160) * a.n_rows + row_t + 65] = accv[1][1];
+                a.store[(qcol + 160) * a.n_rows + row_t + 66] = accv[1][2];
+                a.store[(qcol + 160) * a.n_rows + row_t + 67] = accv[1][3];
+                a.store[(qcol + 160) * a.n_rows + row_t + 72] = accv[1][4];
+                a.store[(qcol + 160) * a.n_rows + row_t + 73] = accv[1][5];
+                a.store[(qcol + 160) * a.n_rows + row_t + 74] = accv[1][6];
+                a.store[(qcol + 160) * a.n_rows + row_t + 75] = accv[1][7];
+                a.store[(qcol + 160) * a.n_rows + row_t + 80] = accv[1][8];
+                a.store[(qcol + 160) * a.n_rows + row_t + 81] = accv[1][9];
+                a.store[(qcol + 160) * a.n_rows + row_t + 82] = accv[1][10];
+                a.store[(qcol + 160) * a.n_rows + row_t + 83] = accv[1][11];
+                a.store[(qcol + 160) * a.n_rows + row_t + 88] = accv[1][12];
+                a.store[(qcol + 160) * a.n_rows + row_t + 89] = accv[1][13];
+                a.store[(qcol + 160) * a.n_rows + row_t + 90] = accv[1][14];
+                a.store[(qcol + 160) * a.n_rows + row_t + 91] = accv[1][15];
+                a.store[(qcol + 0) * a.n_rows + row_t + 96] = accv[2][0];
+                a.store[(qcol + 0) * a.n_rows + row_t + 97] = accv[2][1];
+                a.store[(qcol + 0) * a.n_rows + row_t + 98] = accv[2][2];
+                a.store[(qcol + 0) * a.n_rows + row_t + 99] = accv[2][3];
+                a.store[(qcol + 0) * a.n_rows + row_t + 104] = accv[2][4];
+                a.store[(qcol + 0) * a.n_rows + row_t + 105] = accv[2][5];
+                a.store[(qcol + 0) * a.n_rows + row_t + 106] = accv[2][6];
+                a.store[(qcol + 0) * a.n_rows + row_t + 107] = accv[2][7];
+                a.store[(qcol + 0) * a.n_rows + row_t + 112] = accv[2][8];
+                a.store[(qcol + 0) * a.n_rows + row_t + 113] = accv[2][9];
+                a.store[(qcol + 0) * a.n_rows + row_t + 114] = accv[2][10];
+                a.store[(qcol + 0) * a.n_rows + row_t + 115] = accv[2][11];
+                a.store[(qcol + 0) * a.n_rows + row_t + 120] = accv[2][12];
+                a.store[(qcol + 0) * a.n_rows + row_t + 121] = accv[2][13];
+                a.store[(qcol + 0) * a.n_rows + row_t + 122] = accv[2][14];
+                a.store[(qcol + 0) * a.n_rows + row_t + 123] = accv[2][15];
+                a.store[(qcol + 32) * a.n_rows + row_t + 96] = accv[3][0];
+                a.store[(qcol + 32) * a.n_rows + row_t + 97] = accv[3][1];
+                a.store[(qcol + 32) * a.n_rows + row_t + 98] = accv[3][2];
+                a.store[(qcol + 32) * a.n_rows + row_t + 99] = accv[3][3];
+                a.store[(qcol + 32) * a.n_rows + row_t + 104] = accv[3][4];
+                a.store[(qcol + 32) * a.n_rows + row_t + 105] = accv[3][5];
+                a.store[(qcol + 32) * a.n_rows + row_t + 106] = accv[3][6];
+                a.store[(qcol + 32) * a.n_rows + row_t + 107] = accv[3][7];
+                a.store[(qcol + 32) * a.n_rows + row_t + 112] = accv[3][8];
+                a.store[(qcol + 32) * a.n_rows + row_t + 113] = accv[3][9];
+                a.store[(qcol + 32) * a.n_rows + row_t + 114] = accv[3][10];
+                a.store[(qcol + 32) * a.n_rows + row_t + 115] = accv[3][11];
+                a.store[(qcol + 32) * a.n_rows + row_t + 120] = accv[3][12];
+                a.store[(qcol + 32) * a.n_rows + row_t + 121] = accv[3][13];
+                a.store[(qcol + 32) * a.n_rows + row_t + 122] = accv[3][14];
+                a.store[(qcol + 32) * a.n_rows + row_t + 123] = accv[3][15];
+                a.store[(qcol + 64) * a.n_rows + row_t + 96] = accv[4][0];
+                a.store[(qcol + 64) * a.n_rows + row_t + 97] = accv[4][1];
+                a.store[(qcol + 64) * a.n_rows + row_t + 98] = accv[4][2];
+                a.store[(qcol + 64) * a.n_rows + row_t + 99] = accv[4][3];
+                a.store[(qcol + 64) * a.n_rows + row_t + 104] = accv[4][4];
+                a.store[(qcol + 64) * a.n_rows + row_t + 105] = accv[4][5];
+                a.store[(qcol + 64) * a.n_rows + row_t + 106] = accv[4][6];
+                a.store[(qcol + 64) * a.n_rows + row_t + 107] = accv[4][7];
+                a.store[(qcol + 64) * a.n_rows + row_t + 112] = accv[4][8];
+                a.store[(qcol + 64) * a.n_rows + row_t + 113] = accv[4][9];
+                a.store[(qcol + 64) * a.n_rows + row_t + 114] = accv[4][10];
+                a.store[(qcol + 64) * a.n_rows + row_t + 115] = accv[4][11];
+                a.store[(qcol + 64) * a.n_rows + row_t + 120] = accv[4][12];
+                a.store[(qcol + 64) * a.n_rows + row_t + 121] = accv[4][13];
+                a.store[(qcol + 64) * a.n_rows + row_t + 122] = accv[4][14];
+                a.store[(qcol + 64) * a.n_rows + row_t + 123] = accv[4][15];
+                a.store[(qcol + 96) * a.n_rows + row_t + 96] = accv[5][0];
+                a.store[(qcol + 96) * a.n_rows + row_t + 97] = accv[5][1];
+                a.store[(qcol + 96) * a.n_rows + row_t + 98] = accv[5][2];
+                a.store[(qcol + 96) * a.n_rows + row_t + 99] = accv[5][3];
+                a.store[(qcol + 96) * a.n_rows + row_t + 104] = accv[5][4];
+                a.store[(qcol + 96) * a.n_rows + row_t + 105] = accv[5][5];
+                a.store[(qcol + 96) * a.n_rows + row_t + 106] = accv[5][6];
+                a.store[(qcol + 96) * a.n_rows + row_t + 107] = accv[5][7];
+                a.store[(qcol + 96) * a.n_rows + row_t + 112] = accv[5][8];
+                a.store[(qcol + 96) * a.n_rows + row_t + 113] = accv[5][9];
+                a.store[(qcol + 96) * a.n_rows + row_t + 114] = accv[5][10];
+                a.store[(qcol + 96) * a.n_rows + row_t + 115] = accv[5][11];
+                a.store[(qcol + 96) * a.n_rows + row_t + 120] = accv[5][12];
+                a.store[(qcol + 96) * a.n_rows + row_t + 121] = accv[5][13];
+                a.store[(qcol + 96) * a.n_rows + row_t + 122] = accv[5][14];
+                a.store[(qcol + 96) * a.n_rows + row_t + 123] = accv[5][15];
+                a.store[(qcol + 128) * a.n_rows + row_t + 96] = accv[6][0];
+                a.store[(qcol + 128) * a.n_rows + row_t + 97] = accv[6][1];
+                a.store[(qcol + 128) * a.n_rows + row_t + 98] = accv[6][2];
+                a.store[(qcol + 128) * a.n_rows + row_t + 99] = accv[6][3];
+                a.store[(qcol + 128) * a.n_rows + row_t + 104] = accv[6][4];
+                a.store[(qcol + 128) * a.n_rows + row_t + 105] = accv[6][5];
+                a.store[(qcol + 128) * a.n_rows + row_t + 106] = accv[6][6];
+                a.store[(qcol + 128) * a.n_rows + row_t + 107] = accv[6][7];
+                a.store[(qcol + 128) * a.n_rows + row_t + 112] = accv[6][8];
+                a.store[(qcol + 128) * a.n_rows + row_t + 113] = accv[6][9];
+                a.store[(qcol + 128) * a.n_rows + row_t + 114] = accv[6][10];
+                a.store[(qcol + 128) * a.n_rows + row_t + 115] = accv[6][11];
+                a.store[(qcol + 128) * a.n_rows + row_t + 120] = accv[6][12];
+                a.store[(qcol + 128) * a.n_rows + row_t + 121] = accv[6][13];
+                a.store[(qcol + 128) * a.n_rows + row_t + 122] = accv[6][14];
+                a.store[(qcol + 128) * a.n_rows + row_t + 123] = accv[6][15];
+                a.store[(qcol + 160) * a.n_rows + row_t + 96] = accv[7][0];
+                a.store[(qcol + 160) * a.n_rows + row_t + 97] = accv[7][1];
+                a.store[(qcol + 160) * a.n_rows + row_t + 98] = accv[7][2];
+                a.store[(qcol + 160) * a.n_rows + row_t + 99] = accv[7][3];
+                a.store[(qcol + 160) * a.n_rows + row_t + 104] = accv[7][4];
+                a.store[(qcol + 160) * a.n_rows + row_t + 105] = accv[7][5];
+                a.store[(qcol + 160) * a.n_rows + row_t + 106] = accv[7][6];
+                a.store[(qcol + 160) * a.n_rows + row_t + 107] = accv[7][7];
+                a.store[(qcol + 160) * a.n_rows + row_t + 112] = accv[7][8];
+                a.store[(qcol + 160) * a.n_rows + row_t + 113] = accv[7][9];
+                a.store[(qcol + 160) * a.n_rows + row_t + 114] = accv[7][10];
+                a.store[(qcol + 160) * a.n_rows + row_t + 115] = accv[7][11];
+                a.store[(qcol + 160) * a.n_rows + row_t + 120] = accv[7][12];
+                a.store[(qcol + 160) * a.n_rows + row_t + 121] = accv[7][13];
+                a.store[(qcol + 160) * a.n_rows + row_t + 122] = accv[7][14];
+                a.store[(qcol + 160) * a.n_rows + row_t + 123] = accv[7][15];
+                ++ct;
+            }
             if (++cks == KS2) cks = 0;
             cbuf = nbuf;
         }
@@ -298,5 +693,23 @@ extern "C" int ccr_proto4w_time(const uint16_t *D, int64_t n_rows, int dim, cons
     (void)hipEventElapsedTime(&ms, e0, e1);
     *ms_out = ms / reps;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// PROTO_MODE=3 only: one launch that writes the raw MFMA scores [n_q][n_rows] (fp32) of the whole problem
+extern "C" int ccr_proto4w_scores(const uint16_t *D, int64_t n_rows, int dim, const uint16_t *Q, int n_q, int ranges, float *out) {
+    using namespace ccr;
+    if (PROTO_MODE != 3 || n_rows % TILE_DOCS || n_q % TQ || ranges % NUM_XCD) return -4;
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.D = D; g.n_rows = n_rows; g.dim = dim; g.Q = Q; g.n_q = n_q;
+    g.n_vt = n_rows / TILE_DOCS;
+    g.tile_stride = 1;
+    g.ranges = ranges;
+    g.store = out;
+    const size_t lds = RING3 * (size_t)SUBB;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm4w384_proto_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+    hipLaunchKernelGGL(gemm4w384_proto_kernel, dim3(256), dim3(P4_THREADS), lds, 0, g);
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
