@@ -58,5 +58,5 @@ init_env_defaults()
 
 from . import _lib  # noqa: E402
 from .ops import (  # noqa: E402,F401
-    CorpusIndex, apply_block, inbatch_ce, meanpool_pack, merge_topk, pack_bf16, require_gpu,
+    CorpusIndex, apply_block, colsum_bf16, inbatch_ce, meanpool, meanpool_pack, merge_topk, pack_bf16, require_gpu,
 )

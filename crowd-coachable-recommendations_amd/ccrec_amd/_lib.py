@@ -9,14 +9,16 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libccr_hip.so")
 CCR_OK = 0
 CCR_ERR_INVALID, CCR_ERR_HIP, CCR_ERR_WORKSPACE, CCR_ERR_BLOCK_ID = -1, -2, -3, -4
 DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
-SEARCH_DEFAULT, SEARCH_FORCE_DENSE, SEARCH_FORCE_FUSED = 0, 1, 2
+SEARCH_DEFAULT, SEARCH_FORCE_DENSE, SEARCH_FORCE_FUSED, SEARCH_ASYNC = 0, 1, 2, 4
+SCORES_CANONICAL, SCORES_MFMA = 0, 1
 
 EXPORTS = [
     "ccr_last_error", "ccr_version", "ccr_pack_bf16", "ccr_pack_bf16_ex", "ccr_meanpool_pack_bf16", "ccr_meanpool_pack_bf16_ex", "ccr_index_create",
     "ccr_index_create_with_norm", "ccr_index_destroy",
     "ccr_index_rows", "ccr_index_dim", "ccr_search_workspace_bytes", "ccr_search", "ccr_search_last_stats",
-    "ccr_merge_topk", "ccr_merge_topk_strided", "ccr_apply_block", "ccr_inbatch_ce_workspace_bytes", "ccr_inbatch_ce_fwd", "ccr_inbatch_ce_bwd", "ccr_inbatch_ce_bwd_dev", "ccr_rank_metrics", "ccr_debug_mfma_scores",
-    "ccr_debug_canonical_scores", "ccr_bm25_index_create", "ccr_bm25_index_destroy", "ccr_bm25_search_workspace_bytes",
+    "ccr_merge_topk", "ccr_merge_topk_strided", "ccr_apply_block", "ccr_inbatch_ce_workspace_bytes", "ccr_inbatch_ce_fwd", "ccr_inbatch_ce_bwd", "ccr_inbatch_ce_bwd_dev", "ccr_rank_metrics",
+    "ccr_search_finish", "ccr_scores", "ccr_search_blocked_workspace_bytes", "ccr_search_blocked",
+    "ccr_search_sparse_prior_workspace_bytes", "ccr_search_sparse_prior", "ccr_colsum_bf16", "ccr_meanpool_bwd", "ccr_bm25_index_create", "ccr_bm25_index_destroy", "ccr_bm25_search_workspace_bytes",
     "ccr_bm25_search",
 ]
 
@@ -72,8 +74,16 @@ def load():
     lib.ccr_inbatch_ce_bwd.argtypes = [vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp, vp, sz, vp]
     lib.ccr_inbatch_ce_bwd_dev.argtypes = [vp, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp, vp, sz, vp]
     lib.ccr_rank_metrics.argtypes = [vp, i32, i32, vp, vp, vp, i32, vp, vp, vp]
-    lib.ccr_debug_mfma_scores.argtypes = [vp, vp, i32, vp, vp]
-    lib.ccr_debug_canonical_scores.argtypes = [vp, vp, i32, vp, vp]
+    lib.ccr_search_finish.argtypes = [vp]
+    lib.ccr_scores.argtypes = [vp, vp, i32, i32, vp, vp]
+    lib.ccr_search_blocked_workspace_bytes.argtypes = [vp, i32, i32, vp]
+    lib.ccr_search_blocked_workspace_bytes.restype = sz
+    lib.ccr_search_blocked.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp, sz, i32, vp]
+    lib.ccr_search_sparse_prior_workspace_bytes.argtypes = [vp, i32, i32, vp]
+    lib.ccr_search_sparse_prior_workspace_bytes.restype = sz
+    lib.ccr_search_sparse_prior.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, sz, i32, vp]
+    lib.ccr_colsum_bf16.argtypes = [vp, i64, i32, vp, vp]
+    lib.ccr_meanpool_bwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
     lib.ccr_bm25_index_create.argtypes = [vp, vp, vp, vp, i64, i64, ctypes.c_double, ctypes.POINTER(vp)]
     lib.ccr_bm25_index_destroy.argtypes = [vp]
     lib.ccr_bm25_search_workspace_bytes.argtypes = [vp, i32, i32]

@@ -12,40 +12,48 @@ import warnings
 
 import torch
 
-from .replica_cache import DataParallel
 from .ms_marco_eval import ranking
+from .replica_cache import DataParallel
+
+PER_GPU_BATCH = 512   # al_0_rank.py:70-74: 512 texts per visible GPU and batch
+
+
+def unwrap_item_tower(model):
+    """The encoder that maps token tensors to embeddings: `model.item_tower`, or `model.model.item_tower` for the
+    ranker wrappers (BertBPR / BertMT keep the Lightning module in .model), or the object itself (al_0_rank.py:84-90)."""
+    for owner in (model, getattr(model, "model", None)):
+        tower = getattr(owner, "item_tower", None) if owner is not None else None
+        if tower is not None:
+            return tower
+    return model
+
+
+class TextEmbedder:
+    """The text -> embedding closure the script hands to ranking() (al_0_rank.py:76-81, 98-101), as an object:
+    tokenise with dynamic padding (`padding=True`), truncate at CCREC_MAX_LENGTH, run the encoder replicas."""
+
+    def __init__(self, runner, tokenizer, output_step, max_length):
+        self.runner, self.tokenizer, self.output_step = runner, tokenizer, output_step
+        self.tokenizer_kw = dict(padding=True, truncation=True, max_length=max_length, return_tensors="pt")
+
+    def __call__(self, texts):
+        return self.runner(**self.tokenizer(texts, **self.tokenizer_kw), output_step=self.output_step)
 
 
 def generate_ranking_profile(model, model_name, corpus, queries, block_dict=None, tokenizer=None):
     """al_0_rank.py:69-105.  Returns {qid: {pid: score}} in rank order."""
-    batch_size = 512
-    _gpu_ids = [i for i in range(torch.cuda.device_count())]
-    if torch.cuda.device_count() > 0:
-        batch_size = batch_size * len(_gpu_ids)
-
-    tokenizer_kw = {
-        "truncation": True,
-        "padding": True,
-        "max_length": int(os.environ.get("CCREC_MAX_LENGTH", 512)),
-        "return_tensors": "pt",
-    }
-    if tokenizer is None:
+    if tokenizer is None:   # needs the hub or a local cache; offline callers pass their tokenizer in
         from transformers import AutoTokenizer
         tokenizer = AutoTokenizer.from_pretrained(model_name)
-    model = (model.item_tower if hasattr(model, "item_tower")
-             else model.model.item_tower if hasattr(model, "model") else model)
-    model.eval()
-    model = DataParallel(model.cuda(), device_ids=_gpu_ids).cache_replicas()
-
-    embedding_type = os.environ["CCREC_EMBEDDING_TYPE"]
-    if embedding_type != "mean_pooling":
-        warnings.warn(f"{embedding_type} != mean_pooling for contriever models")
-
-    def embedding_func(x):
-        tokens = tokenizer(x, **tokenizer_kw)
-        return model(**tokens, output_step=embedding_type)
-
-    return ranking(corpus, queries, embedding_func, batch_size, block_dict)
+    gpus = list(range(torch.cuda.device_count()))
+    tower = unwrap_item_tower(model)
+    tower.eval()
+    runner = DataParallel(tower.cuda(), device_ids=gpus).cache_replicas()
+    output_step = os.environ["CCREC_EMBEDDING_TYPE"]
+    if output_step != "mean_pooling":
+        warnings.warn(f"{output_step} != mean_pooling for contriever models")
+    embed = TextEmbedder(runner, tokenizer, output_step, int(os.environ.get("CCREC_MAX_LENGTH", 512)))
+    return ranking(corpus, queries, embed, PER_GPU_BATCH * max(1, len(gpus)), block_dict)
 
 
 def cached_ranking_profile(path_to_ranking_profile, make_model, model_name, corpus, queries, block_dict=None,

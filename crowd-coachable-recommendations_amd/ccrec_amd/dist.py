@@ -60,12 +60,18 @@ def merge_gathered(gs, gi, merge_fn=None):
     return (merge_fn or ops.merge_topk)(gs, gi)
 
 
-def sharded_search(index, queries_bf16, k, group=None, merge_fn=None, search_fn=None, message=None):
+def sharded_search(index, queries_bf16, k, group=None, merge_fn=None, search_fn=None, message=None, block=None, n_total=None):
     """index: this rank's CorpusIndex (built with global_row_offset = its shard's first row).
-    message: optional reusable TopkMessage(n_q, k, device, world) -- the search then writes straight into it."""
+    message: optional reusable TopkMessage(n_q, k, device, world) -- the search then writes straight into it.
+    block: (ptr, idx) CSR of per-query blocked GLOBAL row ids (the same on every rank; each shard applies its own part).
+    n_total: rows of the whole corpus; k is clamped to it (a corpus smaller than k cannot fill k ranks)."""
+    if n_total is not None:
+        k = min(k, int(n_total))
     k_local = min(k, index.n_rows)
     multi = dist.is_initialized() and dist.get_world_size(group) > 1
-    if multi and search_fn is None and k_local == k:   # the kernel writes the exchange message itself
+    if block is not None and search_fn is None:
+        scores, ids = index.search_blocked(queries_bf16, k_local, block[0], block[1])
+    elif multi and search_fn is None and k_local == k:   # the kernel writes the exchange message itself
         if message is None:
             message = TopkMessage(queries_bf16.shape[0], k, queries_bf16.device, dist.get_world_size(group))
         scores, ids = index.search(queries_bf16, k, out=(message.scores, message.ids))
@@ -73,10 +79,14 @@ def sharded_search(index, queries_bf16, k, group=None, merge_fn=None, search_fn=
         scores, ids = (search_fn or index.search)(queries_bf16, k_local)
     if not multi:
         return scores, ids
-    if k_local < k:  # tiny shard: pad so that every rank gathers the same shape
+    if k_local < k:
+        # tiny shard: pad so that every rank gathers the same shape.  Pads score -inf and carry DISTINCT ids (per rank and
+        # slot), so the merge's rank-by-counting stays a permutation and every output slot is written even when the whole
+        # corpus holds fewer than k rows (the tail is then (-inf, pad id) -- pass n_total to clamp k instead).
         pad = k - k_local
+        rank = dist.get_rank(group)
         scores = torch.cat([scores, torch.full((scores.shape[0], pad), -float("inf"), device=scores.device)], 1)
-        ids = torch.cat([ids, torch.full((ids.shape[0], pad), torch.iinfo(torch.int64).max, dtype=torch.int64,
-                                         device=ids.device)], 1)
+        pad_ids = torch.iinfo(torch.int64).max - (rank * k + torch.arange(pad, dtype=torch.int64, device=ids.device))
+        ids = torch.cat([ids, pad_ids.expand(ids.shape[0], pad)], 1)
     gs, gi = all_gather_topk(scores, ids, group, message)
     return merge_gathered(gs, gi, merge_fn)

@@ -125,8 +125,8 @@ def encode_local_shard(encoder, corpus_ids, corpus, sim, rank, world, max_norm=N
 def ranking_sharded(corpus, queries, encoder, block_dict=None, rank=0, world=1, group=None, keep=None, with_tensors=False):
     """Multi-GPU form of ms_marco_eval.ranking (scripts/ms_marco_eval.py:189-235): every rank encodes and indexes its
     own corpus rows, all ranks encode the (small) query set, per-shard fused top-k, one all-gather, merge.
-    Returns the same rank-ordered {qid: {pid: score}} on every rank.  block_dict needs the single-shard Retriever
-    path (world == 1); with world > 1 blocked ids are applied after the merge.
+    Returns the same rank-ordered {qid: {pid: score}} on every rank.  block_dict: each shard scores its own blocked rows
+    -1e6 (ccr_search_blocked, lists of any length) before the exchange, so the merged list is the reference's.
     with_tensors: return (profile, row ids [Q, keep] int64, scores [Q, keep]) -- the device tensors behind the dicts."""
     from .ms_marco_eval import KEEP, Retriever
     from .dist import sharded_search
@@ -140,21 +140,18 @@ def ranking_sharded(corpus, queries, encoder, block_dict=None, rank=0, world=1, 
         return Retriever(corpus_ids, shard, max_norm=max_norm).ranking_profile(queries_ids, q_bf16, block_dict, keep, with_tensors)
     index = ops.CorpusIndex(shard, global_row_offset=lo, max_norm=max_norm)
     n = len(corpus_ids)
-    maxb = max((len(block_dict[q]) for q in queries_ids), default=0) if block_dict is not None else 0
-    k = min(n, keep + maxb)
-    scores, ids = sharded_search(index, q_bf16, k, group=group)
-    if block_dict is not None:
+    block = None
+    if block_dict is not None:   # every rank passes the whole lists; a shard applies the ids that fall inside it
         print("using block_dict")
+        from .ms_marco_eval import block_csr
         pos = {pid: i for i, pid in enumerate(corpus_ids)}
         lists = []
         for qid in queries_ids:
-            rows = sorted({pos.get(pid, -1) for pid in block_dict[qid]})
+            rows = [pos.get(pid, -1) for pid in block_dict[qid]]
             assert -1 not in rows, "block id not found"
             lists.append(rows)
-        ptr = torch.zeros(len(lists) + 1, dtype=torch.int64)
-        ptr[1:] = torch.cumsum(torch.tensor([len(b) for b in lists], dtype=torch.int64), 0)
-        idx = torch.tensor([j for b in lists for j in b], dtype=torch.int64)
-        scores, ids = ops.apply_block(scores, ids, ptr, idx, min(n, keep), n)
+        block = block_csr(lists, n)
+    scores, ids = sharded_search(index, q_bf16, min(n, keep), group=group, block=block, n_total=n)
     scores_l, ids_l = scores.cpu().tolist(), ids.cpu().tolist()
     profile = {qid: dict(zip([corpus_ids[j] for j in row_i], row_s)) for qid, row_i, row_s in zip(queries_ids, ids_l, scores_l)}
     return (profile, ids, scores) if with_tensors else profile

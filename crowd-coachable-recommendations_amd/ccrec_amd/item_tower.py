@@ -117,6 +117,9 @@ class NaiveItemTower(ItemTowerBase):
         if output_step in _POOL_STEPS:
             assert hidden is not None, "cannot create mean pooling from cls"
             packed, cosine = _POOL_STEPS[output_step]
+            if not packed and torch.is_grad_enabled() and hidden.requires_grad:
+                # training forward (bbpr.py:130-141 calls the tower with gradients on): same kernel, with a backward
+                return ops.meanpool(hidden, inputs["attention_mask"])
             pooled_f32, pooled_bf16 = ops.meanpool_pack(hidden, inputs["attention_mask"], normalize=cosine,
                                                         want_f32=not packed, want_bf16=packed)
             return pooled_bf16 if packed else pooled_f32

@@ -6,7 +6,7 @@ What changes under the hood (reference line -> here):
   :141-149  per-batch D2H copy + vstack of fp32 embeddings -> batches are packed to bf16 on device
             into one resident shard (pack= keyword), fp32 [N,768] never materialises;
   :204-218  host [Q,N] score matrix filled by chunked matmuls     -> CorpusIndex.search (fused MFMA top-k);
-  :224-227  scores[block_ind] = -1e6                               -> over-fetch + ccr_apply_block;
+  :224-227  scores[block_ind] = -1e6                               -> ccr_search_blocked (block lists of any length);
   :228-230  per-row H2D + full sort, keep 1001                     -> the same search call (k = min(1001, N)).
 Order rule: score descending, corpus index ascending on equal scores (the reference's sort leaves
 tie order unspecified).
@@ -74,7 +74,18 @@ def cos_sim(a: torch.Tensor, b: torch.Tensor):
     # small matrices: the canonical fp64-ordered scores (bit-identical to the oracle); large ones: the MFMA tile kernel
     # (fp32 accumulation of the same bf16 rows, within 1e-6 of the canonical value) -- the fp64 path is VALU-bound
     big = a_n.shape[0] * b_n.shape[0] * a_n.shape[1] > CANONICAL_COS_SIM_MACS and a_n.shape[1] % 64 == 0
-    return ops.CorpusIndex(b_n).debug_scores(a_n, canonical=not big)
+    return ops.CorpusIndex(b_n).scores(a_n, "mfma" if big else "canonical")
+
+
+def block_csr(block_lists, n_rows):
+    """Per-query lists of blocked corpus rows -> CSR (ptr [Q+1], idx) with the rows of a query ascending and unique.
+    AssertionError("block id not found") on a row outside [0, n_rows), as ms_marco_eval.py:226."""
+    flat = [sorted(set(int(j) for j in b)) for b in block_lists]
+    ptr = torch.zeros(len(flat) + 1, dtype=torch.int64)
+    ptr[1:] = torch.cumsum(torch.tensor([len(f) for f in flat], dtype=torch.int64), 0)
+    idx = torch.tensor([j for f in flat for j in f], dtype=torch.int64)
+    assert idx.numel() == 0 or (int(idx.min()) >= 0 and int(idx.max()) < n_rows), "block id not found"
+    return ptr, idx
 
 
 class Retriever:
@@ -93,26 +104,13 @@ class Retriever:
         return self._pos
 
     def search(self, queries_bf16, k, block_lists=None):
-        """-> (scores [Q,k], ids [Q,k]) on device.  block_lists: per query list of blocked corpus rows."""
+        """-> (scores [Q,k], ids [Q,k]) on device.  block_lists: per query list of blocked corpus rows (any length)."""
         n = self.index.n_rows
         k = min(k, n)
         if block_lists is None:
             return self.index.search(queries_bf16, k)
-        lens = [len(b) for b in block_lists]
-        maxb = max(lens) if lens else 0
-        k_in = min(n, k + maxb)
-        if k_in > 4096:
-            raise NotImplementedError(f"k + longest block list = {k + maxb} exceeds the 4096-row search limit")
-        ptr = torch.zeros(len(block_lists) + 1, dtype=torch.int64)
-        ptr[1:] = torch.cumsum(torch.tensor(lens, dtype=torch.int64), 0)
-        flat = [sorted(set(int(j) for j in b)) for b in block_lists]
-        if any(len(f) != l for f, l in zip(flat, lens)):  # duplicates collapse: recompute the CSR
-            lens = [len(f) for f in flat]
-            ptr[1:] = torch.cumsum(torch.tensor(lens, dtype=torch.int64), 0)
-        idx = torch.tensor([j for f in flat for j in f], dtype=torch.int64)
-        assert idx.numel() == 0 or (int(idx.min()) >= 0 and int(idx.max()) < n), "block id not found"
-        s, i = self.index.search(queries_bf16, k_in)
-        return ops.apply_block(s, i, ptr, idx + self.index.offset, k, n + self.index.offset)
+        ptr, idx = block_csr(block_lists, n)
+        return self.index.search_blocked(queries_bf16, k, ptr, idx + self.index.offset)
 
     def ranking_profile(self, queries_ids, queries_bf16, block_dict=None, keep=KEEP, with_tensors=False):
         """{qid: {pid: score}} in rank order.  with_tensors: also return the device tensors it was built from,

@@ -91,6 +91,35 @@ def meanpool_pack(hidden, mask, normalize=False, want_f32=True, want_bf16=True, 
     return f32, b16
 
 
+class _MeanPool(torch.autograd.Function):
+    """Differentiable masked mean pooling (item_tower.py:141-146): forward = the fused pooling kernel (fp32 rows),
+    backward = ccr_meanpool_bwd (grad / count broadcast over the unmasked tokens)."""
+
+    @staticmethod
+    def forward(ctx, hidden, mask):
+        pooled, _ = meanpool_pack(hidden.detach(), mask, normalize=False, want_f32=True, want_bf16=False)
+        ctx.save_for_backward(mask.to(device=hidden.device, dtype=torch.int64).contiguous())
+        ctx.shape, ctx.dtype = tuple(hidden.shape), hidden.dtype
+        return pooled
+
+    @staticmethod
+    def backward(ctx, grad):
+        lib = require_gpu()
+        (mask,) = ctx.saved_tensors
+        B, L, dim = ctx.shape
+        g = grad.detach().to(torch.float32).contiguous()
+        dh = torch.empty(B, L, dim, dtype=ctx.dtype, device=g.device)
+        with _on(g):
+            _lib.check(lib.ccr_meanpool_bwd(_ptr(g), _ptr(mask), _ptr(dh), _DTYPES[ctx.dtype], B, L, dim, _stream(g)),
+                       "ccr_meanpool_bwd")
+        return dh, None
+
+
+def meanpool(hidden, mask):
+    """Masked mean pooling [B, L, dim] -> fp32 [B, dim] that autograd can differentiate (the training forward)."""
+    return _MeanPool.apply(hidden, mask)
+
+
 class CorpusIndex:
     """A resident bf16 corpus shard + its search state (ccr_index).  Build once per AL step, query many.
 
@@ -131,9 +160,11 @@ class CorpusIndex:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.corpus.device)
         return self._ws
 
-    def search(self, queries_bf16, k, flags=_lib.SEARCH_DEFAULT, out=None):
+    def search(self, queries_bf16, k, flags=_lib.SEARCH_DEFAULT, out=None, defer=False):
         """-> (scores [n_q, k] fp32, ids [n_q, k] int64 global), canonical order.
-        out=(scores, ids): contiguous [n_q, k] destinations (e.g. views of a packed all-gather message)."""
+        out=(scores, ids): contiguous [n_q, k] destinations (e.g. views of a packed all-gather message).
+        defer=True: CCR_SEARCH_ASYNC -- the call returns without synchronising the stream; call finish() before trusting
+        the result of an input that may flag more than 16 queries (finish() also fills last_stats())."""
         q = queries_bf16
         assert q.is_cuda and q.dtype == torch.bfloat16 and q.dim() == 2 and q.shape[1] == self.dim
         q = q.contiguous()
@@ -148,9 +179,76 @@ class CorpusIndex:
         if n_q == 0:
             return scores, ids
         ws = self._workspace(n_q, k)
+        if defer:
+            flags = int(flags) | _lib.SEARCH_ASYNC
+            self._deferred = (q, scores, ids)   # keep the operands alive until finish()
         with _on(q):
             _lib.check(self._lib.ccr_search(self._h, _ptr(q), n_q, k, _ptr(scores), _ptr(ids), _ptr(ws), ws.numel(),
                                             int(flags), _stream(q)), "ccr_search")
+        return scores, ids
+
+    def finish(self):
+        """Complete a deferred search: synchronises its stream, re-does flagged queries beyond the on-stream chunk."""
+        with _on(self.corpus):
+            _lib.check(self._lib.ccr_search_finish(self._h), "ccr_search_finish")
+        self._deferred = None
+
+    def _special_args(self, queries_bf16, ptr, idx):
+        q = queries_bf16
+        assert q.is_cuda and q.dtype == torch.bfloat16 and q.dim() == 2 and q.shape[1] == self.dim
+        q = q.contiguous()
+        ptr = torch.as_tensor(ptr, dtype=torch.int64).cpu().contiguous()
+        assert ptr.numel() == q.shape[0] + 1
+        idx = torch.as_tensor(idx, dtype=torch.int64).to(q.device).contiguous()
+        assert idx.numel() == int(ptr[-1])
+        return q, ptr, idx
+
+    def _special_ws(self, need):
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.corpus.device)
+        return self._ws
+
+    def search_blocked(self, queries_bf16, k, block_ptr, block_idx, flags=_lib.SEARCH_DEFAULT):
+        """Search with per-query blocked GLOBAL ids (CSR: block_ptr [n_q + 1] on the host, block_idx ascending and unique
+        inside a query; any length -- ms_marco_eval.py:224-227): blocked columns score -1e6, they are kept not removed.
+        Ids outside this shard are ignored.  -> (scores [n_q, k], ids [n_q, k])."""
+        q, ptr, idx = self._special_args(queries_bf16, block_ptr, block_idx)
+        n_q = q.shape[0]
+        scores = torch.empty(n_q, k, dtype=torch.float32, device=q.device)
+        ids = torch.empty(n_q, k, dtype=torch.int64, device=q.device)
+        if n_q == 0:
+            return scores, ids
+        pp = ctypes.c_void_p(ptr.data_ptr())
+        need = int(self._lib.ccr_search_blocked_workspace_bytes(self._h, n_q, k, pp))
+        if need == 0:
+            raise _lib.CcrError("ccr_search_blocked: " + self._lib.ccr_last_error().decode("utf-8", "replace"))
+        ws = self._special_ws(need)
+        with _on(q):
+            _lib.check(self._lib.ccr_search_blocked(self._h, _ptr(q), n_q, k, pp, _ptr(idx), _ptr(scores), _ptr(ids), _ptr(ws),
+                                                    ws.numel(), int(flags), _stream(q)), "ccr_search_blocked")
+        return scores, ids
+
+    def search_sparse_prior(self, queries_bf16, k, prior_ptr, prior_idx, prior_val, flags=_lib.SEARCH_DEFAULT):
+        """Top-k of (low-rank score + sparse prior) (bbpr.py:592-595).  CSR prior over GLOBAL column ids (ascending, unique
+        per row, <= 4096 per row), fp64 values.  -> (final scores [n_q, k] fp64, ids [n_q, k]) by (final desc, id asc)."""
+        q, ptr, idx = self._special_args(queries_bf16, prior_ptr, prior_idx)
+        val = torch.as_tensor(prior_val, dtype=torch.float64).to(q.device).contiguous()
+        assert val.numel() == idx.numel()
+        n_q = q.shape[0]
+        scores = torch.empty(n_q, k, dtype=torch.float64, device=q.device)
+        ids = torch.empty(n_q, k, dtype=torch.int64, device=q.device)
+        if n_q == 0:
+            return scores, ids
+        pp = ctypes.c_void_p(ptr.data_ptr())
+        need = int(self._lib.ccr_search_sparse_prior_workspace_bytes(self._h, n_q, k, pp))
+        if need == 0:
+            raise _lib.CcrError("ccr_search_sparse_prior: " + self._lib.ccr_last_error().decode("utf-8", "replace"))
+        ws = self._special_ws(need)
+        with _on(q):
+            _lib.check(self._lib.ccr_search_sparse_prior(self._h, _ptr(q), n_q, k, pp, _ptr(idx), _ptr(val), _ptr(scores),
+                                                         _ptr(ids), _ptr(ws), ws.numel(), int(flags), _stream(q)),
+                       "ccr_search_sparse_prior")
         return scores, ids
 
     def last_stats(self):
@@ -158,12 +256,17 @@ class CorpusIndex:
         _lib.check(self._lib.ccr_search_last_stats(self._h, ctypes.byref(st)), "ccr_search_last_stats")
         return {f: getattr(st, f) for f, _ in st._fields_}
 
-    def debug_scores(self, queries_bf16, canonical):
+    def scores(self, queries_bf16, mode="canonical"):
+        """Dense score matrix [n_q, n_rows] fp32 (ccr_scores).  mode "canonical": the fp64-ordered values the ranking
+        reports; "mfma": the same bf16 rows through the MFMA tile kernel (fp32 accumulation; dim % 64 == 0)."""
         q = queries_bf16.contiguous()
+        assert q.is_cuda and q.dtype == torch.bfloat16 and q.dim() == 2 and q.shape[1] == self.dim
         out = torch.empty(q.shape[0], self.n_rows, dtype=torch.float32, device=q.device)
-        fn = self._lib.ccr_debug_canonical_scores if canonical else self._lib.ccr_debug_mfma_scores
+        if q.shape[0] == 0:
+            return out
+        m = {"canonical": _lib.SCORES_CANONICAL, "mfma": _lib.SCORES_MFMA}[mode]
         with _on(q):
-            _lib.check(fn(self._h, _ptr(q), q.shape[0], _ptr(out), _stream(q)), "ccr_debug_scores")
+            _lib.check(self._lib.ccr_scores(self._h, _ptr(q), q.shape[0], m, _ptr(out), _stream(q)), "ccr_scores")
         return out
 
 
@@ -204,6 +307,17 @@ def apply_block(scores, ids, block_ptr, block_idx, k_out, n_rows_total):
                                        _ptr(block_idx), int(n_rows_total), _ptr(os_), _ptr(oi), k_out, _stream(scores)),
                    "ccr_apply_block")
     return os_, oi
+
+
+def colsum_bf16(x):
+    """Column sums of a bf16 [rows, dim] cuda matrix in fp64 (ccr_colsum_bf16) -> [dim] float64."""
+    lib = require_gpu()
+    assert x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2
+    x = x.contiguous()
+    out = torch.empty(x.shape[1], dtype=torch.float64, device=x.device)
+    with _on(x):
+        _lib.check(lib.ccr_colsum_bf16(_ptr(x), x.shape[0], x.shape[1], _ptr(out), _stream(x)), "ccr_colsum_bf16")
+    return out
 
 
 class _InBatchCE(torch.autograd.Function):

@@ -31,16 +31,49 @@ def _factors(S):
     return None
 
 
+def _csr_of_ones(indices, shape):
+    return sps.csr_matrix((np.ones(indices.size), np.ravel(indices), np.arange(0, indices.size + 1, indices.shape[1])),
+                          shape=shape)
+
+
+def _low_rank_plus_sparse(S):
+    """rime_lite's ElementWiseExpression(add, [low-rank, LazySparseMatrix]) (score_array.py:300-318) -> our lazy type."""
+    import operator
+    from .bbpr_transform import LowRankPlusSparse, LowRankScore
+    if getattr(S, "op", None) is not operator.add or len(getattr(S, "children", ())) != 2:
+        return None
+    low, prior = None, None
+    for c in S.children:
+        if sps.issparse(getattr(c, "c", None)):
+            prior = c.c
+        elif isinstance(c, LowRankScore):
+            low = c
+        else:
+            fac = _factors(c)
+            if fac is not None:
+                ops.require_gpu()
+                U, V = (_pad8(t) for t in fac)
+                low = LowRankScore(ops.pack_bf16(U.cuda()), ops.pack_bf16(V.cuda()))
+    return LowRankPlusSparse(low, prior) if low is not None and prior is not None else None
+
+
+def _pad8(t):
+    pad = (-t.shape[1]) % 8   # the kernels want dim % 8 == 0; zero columns do not change any dot product
+    return torch.nn.functional.pad(t, (0, pad)) if pad else t
+
+
 def _assign_topk(S, k, tie_breaker=1e-10, device="cpu", batch_size=None):
-    if hasattr(S, "topk") and hasattr(S, "user") and hasattr(S, "item"):   # bbpr_transform.LowRankScore
+    if hasattr(S, "topk") and hasattr(S, "shape") and not isinstance(S, torch.Tensor):   # LowRankScore / LowRankPlusSparse
         _, ids = S.topk(k)
-        indices = ids.cpu().numpy()
-        return sps.csr_matrix((np.ones(indices.size), np.ravel(indices), np.arange(0, indices.size + 1, indices.shape[1])),
-                              shape=S.shape)
+        return _csr_of_ones(ids.cpu().numpy(), S.shape)
+    lps = _low_rank_plus_sparse(S)
+    if lps is not None:
+        _, ids = lps.topk(k)
+        return _csr_of_ones(ids.cpu().numpy(), lps.shape)
     fac = _factors(S)
     if fac is None:
-        raise NotImplementedError("ccrec_amd._assign_topk handles low-rank (left @ right) scores; "
-                                  "dense/sparse LazyScore expressions stay on rime_lite's own path")
+        raise NotImplementedError("ccrec_amd._assign_topk handles low-rank (left @ right) scores with an optional sparse "
+                                  "prior; other LazyScore expressions stay on rime_lite's own path")
     U, V = fac
     ops.require_gpu()
     dim = U.shape[1]
@@ -89,6 +122,9 @@ def evaluate_assigned(target_csr, assigned_csr, score_mat=None, axis=None, min_t
     }
     if score_mat is not None:
         coo = assigned.tocoo()
+        prior = None
+        if hasattr(score_mat, "low") and hasattr(score_mat, "prior"):   # bbpr_transform.LowRankPlusSparse
+            score_mat, prior = score_mat.low, score_mat.prior
         if hasattr(score_mat, "user") and hasattr(score_mat, "item"):
             U, V = score_mat.user.float(), score_mat.item.float()
         else:
@@ -99,6 +135,8 @@ def evaluate_assigned(target_csr, assigned_csr, score_mat=None, axis=None, min_t
             cols = torch.as_tensor(coo.col, dtype=torch.long, device=U.device)
             w = torch.as_tensor(coo.data, dtype=torch.float64, device=U.device)
             obj_sum = float(((U[rows].double() * V[cols].double()).sum(1) * w).sum())
+            if prior is not None:   # the assigned cells' share of the sparse prior
+                obj_sum += float(prior.multiply(assigned).sum())
         else:
             dense = np.asarray(score_mat.numpy() if hasattr(score_mat, "numpy") else score_mat)
             obj_sum = float((dense[coo.row, coo.col] * coo.data).sum())

@@ -7,7 +7,7 @@
 #include <mutex>
 #include <vector>
 
-#include "ccr_common.h"
+#include "ccr_index.h"
 #include "ccr_topk_device.h"
 
 namespace ccr {
@@ -21,34 +21,30 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
-// ------------------------------------------------------------------ kernels implemented elsewhere
-int launch_gemm_filter(const GemmArgs &a, int grid, hipStream_t s);
-int launch_gemm_gmax(const GemmArgs &a, int grid, hipStream_t s);
-int launch_gemm_store(const GemmArgs &a, int grid, hipStream_t s);
-int launch_row_norms_bf16(const uint16_t *X, int64_t rows, int dim, float *norms, uint32_t *max_bits, hipStream_t s);
-int launch_threshold(const float *gmax, int64_t n_groups, int n_q, int nq_pad, int k, const float *qnorm,
-                     const uint32_t *dmax_bits, int dim, float *thr, float *delta, hipStream_t s);
-int select_compact_entries(int dim, int ranges, int rescore_cap, int64_t want);
-int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, int sp, int n_q, int nq_pad, int cap, int k,
-                          int rescore_cap, int compact, int64_t n_rows, const float *delta, const uint16_t *Q,
-                          const uint16_t *D, int dim, int64_t id_offset, float *out_scores, int64_t *out_ids,
-                          uint32_t *flag_count, uint32_t *flag_list, unsigned long long *stat_cand, hipStream_t s);
-int launch_gemm16_filter(const GemmArgs &a, int grid, hipStream_t s);
-int launch_gemm16_store(const GemmArgs &a, int grid, hipStream_t s);
-int launch_threshold_update(const uint2 *cand, const uint32_t *cnt, int nsub, int sp, int n_q, int nq_pad, int cap, int k,
-                            const float *delta, float *thr, hipStream_t s);
-int launch_dense_scores(const uint16_t *D, int64_t n_rows, int dim, const uint16_t *Q, const uint32_t *qlist,
-                        int q_begin, int nq_chunk, float *out, hipStream_t s);
-int launch_dense_select(const float *scores, int64_t n_rows, int k, const uint32_t *qlist, int q_begin, int nq_chunk,
-                        int64_t id_offset, float *out_scores, int64_t *out_ids, hipStream_t s);
-
 // ------------------------------------------------------------------ planner
 // Query-block groups per XCD set: the smallest divisor of qblocks among {1,2,4,8} that keeps one XCD's
 // query rows (qblocks / groups blocks of 256 rows) within ~3 MiB of its 4-MiB L2.
-static int pick_qgroups(int qblocks, int dim) {
-    const char *e = getenv("CCR_QGROUPS");
-    if (e) {
-        const int v = atoi(e);
+static int env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+Knobs read_knobs() {
+    Knobs kn;
+    kn.qgroups = env_int("CCR_QGROUPS", 0);
+    kn.progressive = env_int("CCR_PROGRESSIVE", 1);
+    kn.max_phases = env_int("CCR_PHASES", 3);
+    kn.mfma16 = env_int("CCR_MFMA16", -1);
+    kn.sample_div = env_int("CCR_SAMPLE_DIV", 0);
+    kn.gemm_dbg = env_int("CCR_GEMM_DBG", 0);
+    kn.stagger = env_int("CCR_GEMM_STAGGER", 1);
+    kn.tighten = env_int("CCR_TIGHTEN", 1);
+    return kn;
+}
+
+static int pick_qgroups(int qblocks, int dim, const Knobs &kn) {
+    {
+        const int v = kn.qgroups;
         if ((v == 1 || v == 2 || v == 4 || v == 8) && qblocks % v == 0) return v;
     }
     const size_t block_bytes = (size_t)TILE_Q * dim * 2;
@@ -64,10 +60,9 @@ static int pick_qgroups(int qblocks, int dim) {
 static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
 constexpr size_t DENSE_SCRATCH_TARGET = (size_t)1 << 30;  // ~1 GiB of score rows per dense chunk
-constexpr int FALLBACK_ROWS = 16;
 #ifndef CCR_MFMA16_DEFAULT
 #define CCR_MFMA16_DEFAULT 1
-#endif                         // score rows reserved for flagged queries
+#endif
 
 // ------------------------------------------------------------------ main-pass planner
 // Work items of the main pass are (range, query block); range r owns the tiles r, r + R, ...  An XCD set of per_x
@@ -89,13 +84,12 @@ struct MainPassChoice {
     int64_t sample, ranges, ranges_a, ranges_b;
 };
 
-static MainPassChoice choose_main_pass(const Plan &p, int k, int64_t sample_a, int64_t sample_b) {
+static MainPassChoice choose_main_pass(const Plan &p, int k, int64_t sample_a, int64_t sample_b, const Knobs &kn) {
     const int nrc = NUM_XCD / p.qgroups, qb_per = p.qblocks / p.qgroups, per_x = p.grid / NUM_XCD;
     const int64_t r_hi = std::min<int64_t>(1024 / p.sublists, round_up(std::max<int64_t>(1, p.tiles / 8), NUM_XCD));
     const int64_t target = std::min<int64_t>(r_hi, round_up(std::max<int64_t>(NUM_XCD, (int64_t)p.grid * 6 / p.qblocks), NUM_XCD));
-    const char *pe = getenv("CCR_PROGRESSIVE");                                       // 0: single launch
-    const bool prog_on = !(pe && atoi(pe) == 0);
-    const int max_phases = getenv("CCR_PHASES") ? atoi(getenv("CCR_PHASES")) : 3;     // 2: at most one re-tightening
+    const bool prog_on = kn.progressive != 0;   // 0: single launch
+    const int max_phases = kn.max_phases;        // 2: at most one re-tightening
     const double qscale = (double)p.nq_pad / 3584.0;
     const double select_per_range = 0.1 * qscale, hit_w = 0.014 * qscale, phase_w = 3.0;
 
@@ -160,7 +154,7 @@ static MainPassChoice choose_main_pass(const Plan &p, int k, int64_t sample_a, i
     return best_choice;
 }
 
-Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu) {
+Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu, const Knobs &kn) {
     Plan p;
     memset(&p, 0, sizeof(p));
     p.nq_pad = (int)round_up(n_q, TILE_Q);
@@ -169,10 +163,10 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu) {
     p.full_tiles = n_rows / TILE_DOCS;
     p.grid = std::max(NUM_XCD, num_cu / NUM_XCD * NUM_XCD);
     {
-        const char *e = getenv("CCR_MFMA16");   // main pass on v_mfma_f32_16x16x32_bf16 (row records only)
+        // CCR_MFMA16: main pass on v_mfma_f32_16x16x32_bf16 (row records only)
         // default: the 16x16x32 kernel up to k = 512; above that its eight sub-lists per (range, query) cost the select
         // stage more than the main pass gains (config-4 shape, k = 1000: select 14.3 vs 9.0 ms at equal main-pass time)
-        p.mfma16 = (e ? atoi(e) : (CCR_MFMA16_DEFAULT && k <= 512)) ? 1 : 0;
+        p.mfma16 = (kn.mfma16 >= 0 ? kn.mfma16 : (CCR_MFMA16_DEFAULT && k <= 512)) ? 1 : 0;
         p.sublists = p.mfma16 ? 8 : 4;
     }
     p.rescore_cap = std::min(8192, std::max(256, 2 * pow2_ceil(k)));
@@ -182,9 +176,8 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu) {
     int64_t sample_div = 32;   // fraction of the tiles scored by the threshold pass; the planner also prices 1/64
     bool sample_div_forced = false;   // CCR_SAMPLE_DIV pins it
     {
-        const char *e = getenv("CCR_SAMPLE_DIV");
-        if (e && atoi(e) >= 4 && atoi(e) <= 256) {
-            sample_div = atoi(e);
+        if (kn.sample_div >= 4 && kn.sample_div <= 256) {
+            sample_div = kn.sample_div;
             sample_div_forced = true;
         }
     }
@@ -206,9 +199,9 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu) {
         return o;
     };
     if (p.fused) {
-        p.qgroups = pick_qgroups(p.qblocks, dim);
+        p.qgroups = pick_qgroups(p.qblocks, dim, kn);
         const int64_t sample_alt = (sample_div_forced || (flags & CCR_SEARCH_FORCE_FUSED)) ? sample : sample_for(2 * sample_div);
-        const MainPassChoice choice = choose_main_pass(p, k, sample, sample_alt);
+        const MainPassChoice choice = choose_main_pass(p, k, sample, sample_alt, kn);
         sample = choice.sample;
         const int64_t R = choice.ranges, RA = choice.ranges_a, RB = choice.ranges_b;
         p.sample_tiles = (int)sample;
@@ -285,21 +278,6 @@ void slab_give(int device, uint32_t *p) {
 }
 }  // namespace
 
-struct ccr_index {
-    const uint16_t *D;
-    int64_t n_rows;
-    int dim;
-    int64_t offset;
-    uint32_t *dmax_bits;  // device: bits of the max row norm (a slot of the per-device slab below)
-    bool have_events;
-    int num_cu;
-    int device;
-    hipEvent_t ev[7];     // phase boundaries of the last search
-    Plan plan;            // plan of the last search and its key (the planner simulates item assignments: ~25 us)
-    int plan_nq, plan_k, plan_flags;
-    ccr_search_stats stats;
-};
-
 extern "C" const char *ccr_last_error(void) { return g_err; }
 extern "C" int ccr_version(void) { return 100; }
 
@@ -319,6 +297,7 @@ static int index_create_impl(const uint16_t *D_bf16, int64_t n_rows, int dim, in
     ix->n_rows = n_rows;
     ix->dim = dim;
     ix->offset = global_row_offset;
+    ix->knobs = read_knobs();
     // on any failure below the partially built index is released before returning
     auto build = [&]() -> int {
         CCR_HIP_CHECK(hipGetDevice(&ix->device));
@@ -374,31 +353,86 @@ extern "C" int ccr_index_dim(const ccr_index *ix) { return ix ? ix->dim : -1; }
 
 extern "C" size_t ccr_search_workspace_bytes(const ccr_index *ix, int n_q, int k) {
     if (!ix || n_q <= 0 || k <= 0) return 0;
-    // the larger of the two plans, so that flags may be chosen at call time
-    Plan a = make_plan(ix->n_rows, ix->dim, n_q, k, CCR_SEARCH_DEFAULT, ix->num_cu);
-    Plan b = make_plan(ix->n_rows, ix->dim, n_q, k, CCR_SEARCH_FORCE_DENSE, ix->num_cu);
-    Plan c = make_plan(ix->n_rows, ix->dim, n_q, k, CCR_SEARCH_FORCE_FUSED, ix->num_cu);
+    // the larger of the three plans, so that flags may be chosen at call time
+    Plan a = make_plan(ix->n_rows, ix->dim, n_q, k, CCR_SEARCH_DEFAULT, ix->num_cu, ix->knobs);
+    Plan b = make_plan(ix->n_rows, ix->dim, n_q, k, CCR_SEARCH_FORCE_DENSE, ix->num_cu, ix->knobs);
+    Plan c = make_plan(ix->n_rows, ix->dim, n_q, k, CCR_SEARCH_FORCE_FUSED, ix->num_cu, ix->knobs);
     return std::max({a.total, b.total, c.total}) + 256;
 }
 
 extern "C" int ccr_search_last_stats(const ccr_index *ix, ccr_search_stats *stats) {
     CCR_REQUIRE(ix && stats, "ccr_search_last_stats: null pointer");
+    CCR_REQUIRE(!ix->pending.active, "ccr_search_last_stats: an asynchronous search is pending (call ccr_search_finish first)");
     *stats = ix->stats;
     return CCR_OK;
 }
 
+// Exact dense path for n queries: the rows d_qlist[lo .. lo + n) (or q_begin + lo ... when d_qlist is null), results to the
+// same rows of the outputs.
 static int dense_for_list(const ccr_index *ix, const uint16_t *Q, const uint32_t *d_qlist, int q_begin, int n, int k,
                           float *scratch, int64_t rows_per_chunk, float *out_scores, int64_t *out_ids, hipStream_t s) {
     for (int lo = 0; lo < n; lo += (int)rows_per_chunk) {
         const int m = std::min<int64_t>(rows_per_chunk, n - lo);
-        int rc = launch_dense_scores(ix->D, ix->n_rows, ix->dim, Q, d_qlist ? d_qlist + lo : nullptr, q_begin + lo, m,
+        int rc = launch_dense_scores(ix->D, ix->n_rows, ix->dim, Q, d_qlist ? d_qlist + lo : nullptr, q_begin + lo, m, nullptr,
                                      scratch, s);
         if (rc != CCR_OK) return rc;
-        rc = launch_dense_select(scratch, ix->n_rows, k, d_qlist ? d_qlist + lo : nullptr, q_begin + lo, m, ix->offset,
+        rc = launch_dense_select(scratch, ix->n_rows, k, d_qlist ? d_qlist + lo : nullptr, q_begin + lo, m, nullptr, ix->offset,
                                  out_scores, out_ids, s);
         if (rc != CCR_OK) return rc;
     }
     return CCR_OK;
+}
+
+// Completion of a fused search: read how many queries the select stage flagged, run the exact dense path for those the
+// on-stream chunk (asynchronous mode) did not cover, fill the statistics.  Synchronises the stream.
+static int search_complete(ccr_index *ix) {
+    auto &pd = ix->pending;
+    const Plan &p = ix->plan;
+    hipStream_t s = pd.stream;
+    char *ws = pd.ws;
+    const bool was_async = pd.active;
+    pd.active = false;
+    struct {
+        uint32_t nflag, pad;
+        unsigned long long ncand;
+    } host;
+    CCR_HIP_CHECK(hipMemcpyAsync(&host, ws + p.off_flag, sizeof(host), hipMemcpyDeviceToHost, s));
+    CCR_HIP_CHECK(hipStreamSynchronize(s));
+    {
+        float a = 0, b = 0;
+        CCR_HIP_CHECK(hipEventElapsedTime(&ix->stats.ms_sample, ix->ev[1], ix->ev[2]));
+        CCR_HIP_CHECK(hipEventElapsedTime(&a, ix->ev[0], ix->ev[1]));
+        CCR_HIP_CHECK(hipEventElapsedTime(&b, ix->ev[2], ix->ev[3]));
+        ix->stats.ms_threshold = a + b;
+        CCR_HIP_CHECK(hipEventElapsedTime(&ix->stats.ms_main, ix->ev[3], ix->ev[4]));
+        CCR_HIP_CHECK(hipEventElapsedTime(&ix->stats.ms_select, ix->ev[4], ix->ev[5]));
+        CCR_HIP_CHECK(hipEventElapsedTime(&ix->stats.ms_total, ix->ev[0], ix->ev[5]));
+    }
+    ix->stats.path = 1;
+    ix->stats.n_fallback = (int32_t)host.nflag;
+    ix->stats.sample_tiles = p.sample_tiles;
+    ix->stats.ranges = p.ranges;
+    ix->stats.cap = p.cap;
+    ix->stats.sublists = p.sublists;
+    ix->stats.n_candidates = (int64_t)host.ncand;
+    const int done_on_stream = was_async ? FALLBACK_ROWS : 0;
+    if ((int)host.nflag > done_on_stream) {
+        const uint32_t *flag_list = (const uint32_t *)(ws + p.off_flag + 64);
+        int rc = dense_for_list(ix, pd.Q, flag_list + done_on_stream, 0, (int)host.nflag - done_on_stream, pd.k,
+                                (float *)(ws + p.off_dense), p.dense_rows_per_chunk, pd.out_scores, pd.out_ids, s);
+        if (rc != CCR_OK) return rc;
+        CCR_HIP_CHECK(hipEventRecord(ix->ev[6], s));
+        CCR_HIP_CHECK(hipStreamSynchronize(s));
+        CCR_HIP_CHECK(hipEventElapsedTime(&ix->stats.ms_fallback, ix->ev[5], ix->ev[6]));
+        ix->stats.ms_total += ix->stats.ms_fallback;
+    }
+    return CCR_OK;
+}
+
+extern "C" int ccr_search_finish(ccr_index *ix) {
+    CCR_REQUIRE(ix, "ccr_search_finish: null index");
+    if (!ix->pending.active) return CCR_OK;
+    return search_complete(ix);
 }
 
 extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k, float *out_scores, int64_t *out_ids,
@@ -408,14 +442,17 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
     CCR_REQUIRE(k >= 1 && k <= MAX_K && (int64_t)k <= ix->n_rows, "ccr_search: k=%d must be in [1, min(n_rows=%lld, %d)]", k,
                 (long long)ix->n_rows, MAX_K);
     CCR_REQUIRE((uintptr_t)Q_bf16 % 16 == 0, "ccr_search: query pointer must be 16-byte aligned");
+    CCR_REQUIRE(!ix->pending.active, "ccr_search: an asynchronous search is pending on this index (call ccr_search_finish first)");
     memset(&ix->stats, 0, sizeof(ix->stats));
     if (n_q == 0) return CCR_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (!(ix->plan_nq == n_q && ix->plan_k == k && ix->plan_flags == flags)) {
-        ix->plan = make_plan(ix->n_rows, ix->dim, n_q, k, flags, ix->num_cu);
+    const bool async = (flags & CCR_SEARCH_ASYNC) != 0;
+    const int plan_flags = flags & ~CCR_SEARCH_ASYNC;
+    if (!(ix->plan_nq == n_q && ix->plan_k == k && ix->plan_flags == plan_flags)) {
+        ix->plan = make_plan(ix->n_rows, ix->dim, n_q, k, plan_flags, ix->num_cu, ix->knobs);
         ix->plan_nq = n_q;
         ix->plan_k = k;
-        ix->plan_flags = flags;
+        ix->plan_flags = plan_flags;
     }
     const Plan p = ix->plan;
     if (!workspace || ws_bytes < p.total || (uintptr_t)workspace % 256 != 0) {
@@ -435,6 +472,7 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
         int rc0 = dense_for_list(ix, Q_bf16, nullptr, 0, n_q, k, dense_scratch, p.dense_rows_per_chunk, out_scores, out_ids, s);
         if (rc0 != CCR_OK) return rc0;
         CCR_HIP_CHECK(hipEventRecord(ix->ev[6], s));
+        if (async) return CCR_OK;   // nothing to complete: the dense path has no flagged queries (no timing statistics either)
         CCR_HIP_CHECK(hipStreamSynchronize(s));
         CCR_HIP_CHECK(hipEventElapsedTime(&ix->stats.ms_total, ix->ev[0], ix->ev[6]));
         ix->stats.ms_fallback = ix->stats.ms_total;
@@ -466,6 +504,8 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
     g.nq_pad = p.nq_pad;
     g.qblocks = p.qblocks;
     g.qgroups = p.qgroups;
+    g.dbg = ix->knobs.gemm_dbg;
+    g.stagger = ix->knobs.stagger;
 
     // sample pass -> group maxima -> thresholds
     GemmArgs gs = g;
@@ -493,8 +533,7 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
     gm.cnt = cnt;
     gm.cap = p.cap;
     unsigned long long *stamps = nullptr;   // CCR_GEMM_DBG=16: in-kernel cycle stamps of the main pass (diagnostic build)
-    const char *dbg_env = getenv("CCR_GEMM_DBG");
-    const bool want_stamps = dbg_env && atoi(dbg_env) == 16;
+    const bool want_stamps = ix->knobs.gemm_dbg == 16;
     if (want_stamps) {
         CCR_HIP_CHECK(hipMalloc((void **)&stamps, (size_t)p.grid * 64 * 8));
         CCR_HIP_CHECK(hipMemsetAsync(stamps, 0, (size_t)p.grid * 64 * 8, s));
@@ -545,48 +584,39 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
                                Q_bf16, ix->D, ix->dim,
                                ix->offset, out_scores, out_ids, flag_count, flag_list, stat_cand, s);
     if (rc != CCR_OK) return rc;
-
-    // one small readback: how many queries need the exact fallback
-    struct {
-        uint32_t nflag, pad;
-        unsigned long long ncand;
-    } host;
     CCR_HIP_CHECK(hipEventRecord(ix->ev[5], s));
-    CCR_HIP_CHECK(hipMemcpyAsync(&host, flag_count, sizeof(host), hipMemcpyDeviceToHost, s));
-    CCR_HIP_CHECK(hipStreamSynchronize(s));
-    {
-        float a = 0, b = 0;
-        CCR_HIP_CHECK(hipEventElapsedTime(&ix->stats.ms_sample, ix->ev[1], ix->ev[2]));
-        CCR_HIP_CHECK(hipEventElapsedTime(&a, ix->ev[0], ix->ev[1]));
-        CCR_HIP_CHECK(hipEventElapsedTime(&b, ix->ev[2], ix->ev[3]));
-        ix->stats.ms_threshold = a + b;
-        CCR_HIP_CHECK(hipEventElapsedTime(&ix->stats.ms_main, ix->ev[3], ix->ev[4]));
-        CCR_HIP_CHECK(hipEventElapsedTime(&ix->stats.ms_select, ix->ev[4], ix->ev[5]));
-        CCR_HIP_CHECK(hipEventElapsedTime(&ix->stats.ms_total, ix->ev[0], ix->ev[5]));
-    }
-    ix->stats.path = 1;
-    ix->stats.n_fallback = (int32_t)host.nflag;
-    ix->stats.sample_tiles = p.sample_tiles;
-    ix->stats.ranges = p.ranges;
-    ix->stats.cap = p.cap;
-    ix->stats.sublists = p.sublists;
-    ix->stats.n_candidates = (int64_t)host.ncand;
-    if (host.nflag > 0) {
-        rc = dense_for_list(ix, Q_bf16, flag_list, 0, (int)host.nflag, k, dense_scratch, p.dense_rows_per_chunk, out_scores,
-                            out_ids, s);
+
+    ix->pending.Q = Q_bf16;
+    ix->pending.n_q = n_q;
+    ix->pending.k = k;
+    ix->pending.out_scores = out_scores;
+    ix->pending.out_ids = out_ids;
+    ix->pending.ws = ws;
+    ix->pending.stream = s;
+    if (async) {
+        // The host does not learn the flag count here.  One chunk of the exact dense path runs on the stream for the first
+        // FALLBACK_ROWS flagged queries (its kernels read the count on the device and exit at once when it is zero);
+        // ccr_search_finish() covers the rest -- more than that many flagged queries means mass ties or adversarial data.
+        rc = launch_dense_scores(ix->D, ix->n_rows, ix->dim, Q_bf16, flag_list, 0, FALLBACK_ROWS, flag_count, dense_scratch, s);
         if (rc != CCR_OK) return rc;
-        CCR_HIP_CHECK(hipEventRecord(ix->ev[6], s));
-        CCR_HIP_CHECK(hipStreamSynchronize(s));
-        CCR_HIP_CHECK(hipEventElapsedTime(&ix->stats.ms_fallback, ix->ev[5], ix->ev[6]));
-        ix->stats.ms_total += ix->stats.ms_fallback;
+        rc = launch_dense_select(dense_scratch, ix->n_rows, k, flag_list, 0, FALLBACK_ROWS, flag_count, ix->offset, out_scores,
+                                 out_ids, s);
+        if (rc != CCR_OK) return rc;
+        ix->pending.active = true;
+        return CCR_OK;
     }
-    return CCR_OK;
+    ix->pending.active = false;
+    return search_complete(ix);
 }
 
-// ------------------------------------------------------------------ diagnostics
-extern "C" int ccr_debug_mfma_scores(const ccr_index *ix, const uint16_t *Q_bf16, int n_q, float *out, void *stream) {
-    CCR_REQUIRE(ix && Q_bf16 && out && n_q > 0, "ccr_debug_mfma_scores: bad argument");
-    CCR_REQUIRE(ix->dim % TILE_K == 0, "ccr_debug_mfma_scores: dim %% 64 != 0");
+// ------------------------------------------------------------------ dense score matrix
+extern "C" int ccr_scores(const ccr_index *ix, const uint16_t *Q_bf16, int n_q, int mode, float *out, void *stream) {
+    CCR_REQUIRE(ix && Q_bf16 && out && n_q > 0, "ccr_scores: bad argument");
+    CCR_REQUIRE((uintptr_t)Q_bf16 % 16 == 0, "ccr_scores: query pointer must be 16-byte aligned");
+    if (mode == CCR_SCORES_CANONICAL)
+        return launch_dense_scores(ix->D, ix->n_rows, ix->dim, Q_bf16, nullptr, 0, n_q, nullptr, out, (hipStream_t)stream);
+    CCR_REQUIRE(mode == CCR_SCORES_MFMA, "ccr_scores: unknown mode %d", mode);
+    CCR_REQUIRE(ix->dim % TILE_K == 0, "ccr_scores: CCR_SCORES_MFMA needs dim %% 64 == 0 (dim=%d)", ix->dim);
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.D = ix->D;
@@ -603,13 +633,8 @@ extern "C" int ccr_debug_mfma_scores(const ccr_index *ix, const uint16_t *Q_bf16
     g.range_begin = 0;
     g.range_end = g.ranges;
     g.store = out;
+    g.stagger = 1;
     const int grid = std::max(NUM_XCD, ix->num_cu / NUM_XCD * NUM_XCD);
-    const char *e16 = getenv("CCR_MFMA16");
-    if (e16 ? atoi(e16) : CCR_MFMA16_DEFAULT) return launch_gemm16_store(g, grid, (hipStream_t)stream);
+    if (ix->knobs.mfma16 >= 0 ? ix->knobs.mfma16 : CCR_MFMA16_DEFAULT) return launch_gemm16_store(g, grid, (hipStream_t)stream);
     return launch_gemm_store(g, grid, (hipStream_t)stream);
-}
-
-extern "C" int ccr_debug_canonical_scores(const ccr_index *ix, const uint16_t *Q_bf16, int n_q, float *out, void *stream) {
-    CCR_REQUIRE(ix && Q_bf16 && out && n_q > 0, "ccr_debug_canonical_scores: bad argument");
-    return launch_dense_scores(ix->D, ix->n_rows, ix->dim, Q_bf16, nullptr, 0, n_q, out, (hipStream_t)stream);
 }

@@ -92,9 +92,9 @@ struct GemmArgs {
     // EPI_STORE (debug)
     float *store;         // [n_q][n_rows]
     int dbg;              // timing-only ablations (CCR_GEMM_DBG; results are WRONG when non-zero)
+    int stagger;          // 32x32x16 kernel: 1 = the two wave groups run one barrier interval apart (production), 0 = in phase
 };
 
-Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu);
 
 // ---- device helpers
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }

@@ -4,7 +4,7 @@
 // queries the fused path flags (candidate overflow, mass ties), (c) by tests as a second
 // implementation of the canonical definition.  No margins anywhere: scores are canonical and
 // keys are unique, so the result is the canonical order by construction.
-#include "ccr_common.h"
+#include "ccr_index.h"
 #include "ccr_topk_device.h"
 
 namespace ccr {
@@ -18,7 +18,13 @@ constexpr int LDP = 68;  // padded leading dimension (floats)
 // grid = (ceil(n_rows/DT), ceil(nq_chunk/QT)), block = 256 (thread = 4 queries x 4 docs).
 __global__ __launch_bounds__(256) void dense_scores_kernel(const uint16_t *__restrict__ D, int64_t n_rows, int dim,
                                                           const uint16_t *__restrict__ Q, const uint32_t *__restrict__ qlist,
-                                                          int q_begin, int nq_chunk, float *__restrict__ out) {
+                                                          int q_begin, int nq_chunk, const uint32_t *__restrict__ count_dev,
+                                                          float *__restrict__ out) {
+    if (count_dev) {   // on-stream fallback chunk: only the first *count_dev - q_begin list entries exist
+        const int have = (int)*count_dev - q_begin;
+        if (have < nq_chunk) nq_chunk = have;
+        if (nq_chunk <= (int)blockIdx.y * QT) return;
+    }
     __shared__ __attribute__((aligned(16))) float Qs[DK][LDP];
     __shared__ __attribute__((aligned(16))) float Ds[DK][LDP];
     const int tid = threadIdx.x;
@@ -84,11 +90,13 @@ __global__ __launch_bounds__(256) void dense_scores_kernel(const uint16_t *__res
 }
 
 // Exact top-k of each score row.  grid = nq_chunk, block = 256, dyn LDS = pow2_ceil(k) * 8 bytes.
-// Output row = qlist ? qlist[qi] : q_begin + qi.
+// Output row = out_rows ? out_rows[qi] : q_begin + qi.
 __global__ __launch_bounds__(256) void dense_select_kernel(const float *__restrict__ scores, int64_t n_rows, int k,
-                                                          const uint32_t *__restrict__ qlist, int q_begin,
+                                                          const uint32_t *__restrict__ out_rows, int q_begin,
+                                                          const uint32_t *__restrict__ count_dev,
                                                           int64_t id_offset, float *__restrict__ out_scores,
                                                           int64_t *__restrict__ out_ids) {
+    if (count_dev && (int)blockIdx.x >= (int)*count_dev - q_begin) return;
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];
     __shared__ uint32_t s_hist[256];
     __shared__ uint32_t s_ctl[4];
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(256) void dense_select_kernel(const float *__restri
     __syncthreads();
     block_bitonic_sort_desc(s_keys, kp2);
 
-    const int64_t orow = qlist ? (int64_t)qlist[qi] : (int64_t)(q_begin + qi);
+    const int64_t orow = out_rows ? (int64_t)out_rows[qi] : (int64_t)(q_begin + qi);
     for (int i = tid; i < k; i += blockDim.x) {
         const unsigned long long key = s_keys[i];
         out_scores[orow * k + i] = key_score(key);
@@ -160,17 +168,17 @@ __global__ __launch_bounds__(256) void dense_select_kernel(const float *__restri
 }
 
 int launch_dense_scores(const uint16_t *D, int64_t n_rows, int dim, const uint16_t *Q, const uint32_t *qlist,
-                        int q_begin, int nq_chunk, float *out, hipStream_t s) {
+                        int q_begin, int nq_chunk, const uint32_t *count_dev, float *out, hipStream_t s) {
     dim3 grid((unsigned)((n_rows + DT - 1) / DT), (unsigned)((nq_chunk + QT - 1) / QT));
-    hipLaunchKernelGGL(dense_scores_kernel, grid, dim3(256), 0, s, D, n_rows, dim, Q, qlist, q_begin, nq_chunk, out);
+    hipLaunchKernelGGL(dense_scores_kernel, grid, dim3(256), 0, s, D, n_rows, dim, Q, qlist, q_begin, nq_chunk, count_dev, out);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
 }
 
-int launch_dense_select(const float *scores, int64_t n_rows, int k, const uint32_t *qlist, int q_begin, int nq_chunk,
-                        int64_t id_offset, float *out_scores, int64_t *out_ids, hipStream_t s) {
+int launch_dense_select(const float *scores, int64_t n_rows, int k, const uint32_t *out_rows, int q_begin, int nq_chunk,
+                        const uint32_t *count_dev, int64_t id_offset, float *out_scores, int64_t *out_ids, hipStream_t s) {
     const size_t lds = (size_t)pow2_ceil(k) * 8;
-    hipLaunchKernelGGL(dense_select_kernel, dim3(nq_chunk), dim3(256), lds, s, scores, n_rows, k, qlist, q_begin,
+    hipLaunchKernelGGL(dense_select_kernel, dim3(nq_chunk), dim3(256), lds, s, scores, n_rows, k, out_rows, q_begin, count_dev,
                        id_offset, out_scores, out_ids);
     CCR_LAUNCH_CHECK();
     return CCR_OK;

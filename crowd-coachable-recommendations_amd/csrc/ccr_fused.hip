@@ -20,6 +20,10 @@
 // (row>>2)&3 on the SOURCE address and on the fragment read (conflict-free ds_read_b128).
 #include <stdlib.h>
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 #include "ccr_gemm_common.h"
 #include "ccr_topk_device.h"
 
@@ -1052,11 +1056,24 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
 }
 
 // ---------------------------------------------------------------------------------------------
-// The dynamic-LDS opt-in (> 64 KiB) is a per-device function attribute: set it on every launch (a cheap
-// host-side call) instead of caching a per-process flag that would be wrong for a second device.
+// The dynamic-LDS opt-in (> 64 KiB) is a per-device function attribute: it is set the first time a kernel is launched
+// on a device and remembered per (kernel, device) -- not on every launch.
+static int ensure_dynamic_lds(const void *kernel, size_t lds) {
+    static std::mutex mu;
+    static std::set<std::pair<const void *, int>> done;
+    int dev = 0;
+    CCR_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({kernel, dev})) return CCR_OK;
+    CCR_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    done.insert({kernel, dev});
+    return CCR_OK;
+}
+
 template <class K>
 static int launch_kernel(K kernel, size_t lds, const GemmArgs &a, int grid, hipStream_t s) {
-    CCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kernel), lds);
+    if (rc != CCR_OK) return rc;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(GEMM_THREADS), lds, s, a);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
@@ -1064,13 +1081,7 @@ static int launch_kernel(K kernel, size_t lds, const GemmArgs &a, int grid, hipS
 
 template <int EPI>
 static int launch_gemm(const GemmArgs &a, int grid, hipStream_t s) {
-    static int dbg = -1, stagger = 1;
-    if (dbg < 0) {
-        const char *e = getenv("CCR_GEMM_DBG");      // timing-only ablations of the main pass (WRONG results)
-        dbg = e ? atoi(e) : 0;
-        const char *st = getenv("CCR_GEMM_STAGGER");  // 0: both wave groups in phase (A/B of the ping-pong)
-        stagger = st ? atoi(st) : 1;
-    }
+    const int dbg = a.dbg;   // CCR_GEMM_DBG, read once at index creation: timing-only ablations of the main pass (WRONG results)
     const size_t lds = RING * (size_t)SUB_BYTES;
     if (EPI == EPI_FILTER && dbg != 0) {
         switch (dbg) {
@@ -1084,7 +1095,7 @@ static int launch_gemm(const GemmArgs &a, int grid, hipStream_t s) {
             default: break;   // unknown value: the production kernel
         }
     }
-    if (!stagger) return launch_kernel(&gemm_topk_kernel<EPI, false, 0>, lds, a, grid, s);
+    if (!a.stagger) return launch_kernel(&gemm_topk_kernel<EPI, false, 0>, lds, a, grid, s);   // CCR_GEMM_STAGGER=0 (A/B of the ping-pong)
     return launch_kernel(&gemm_topk_kernel<EPI, true, 0>, lds, a, grid, s);
 }
 
@@ -1125,8 +1136,10 @@ int launch_threshold_update(const uint2 *cand, const uint32_t *cnt, int nsub, in
     int compact = std::max(4096, 8 * pow2_ceil(k));
     if (compact > 32768) compact = 32768;
     const size_t lds = (size_t)compact * 4;
-    if (lds > 48 * 1024)
-        CCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&threshold_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (lds > 48 * 1024) {
+        const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&threshold_update_kernel), 128 * 1024);
+        if (rc != CCR_OK) return rc;
+    }
     hipLaunchKernelGGL(threshold_update_kernel, dim3(n_q), dim3(256), lds, s, cand, cnt, nsub, sp, nq_pad, cap, k, compact, delta, thr);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
@@ -1155,8 +1168,10 @@ int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, in
     const size_t lds = select_fixed_lds(dim, ranges, rescore_cap) + (size_t)compact * 8;
     const bool wide = rescore_cap > 512 || compact > 8192;   // 1024 threads: one re-scored row per thread at large k
     auto go = [&](auto kernel, int threads) -> int {
-        if (lds > 48 * 1024)
-            CCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (lds > 48 * 1024) {
+            const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kernel), SELECT_LDS_BUDGET + 8192);
+            if (rc != CCR_OK) return rc;
+        }
         hipLaunchKernelGGL(kernel, dim3(n_q), dim3(threads), lds, s, cand, cnt, ranges, sp, nq_pad, cap, k, rescore_cap, compact,
                            n_rows, delta, Q, D, dim, id_offset, out_scores, out_ids, flag_count, flag_list, stat_cand);
         CCR_LAUNCH_CHECK();

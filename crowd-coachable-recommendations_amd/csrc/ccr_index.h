@@ -1,0 +1,75 @@
+// ccr_index.h -- the index object and the launchers shared by the host-side translation units
+// (ccr_api.hip: planner + ccr_search; ccr_special.hip: blocked / sparse-prior searches).
+#pragma once
+#include "ccr_common.h"
+
+namespace ccr {
+
+// Tuning / diagnostic knobs from the environment, read ONCE when an index is created (never inside a search).
+struct Knobs {
+    int qgroups;       // CCR_QGROUPS      0 = planner's choice, else 1/2/4/8
+    int progressive;   // CCR_PROGRESSIVE  0 = single main-pass launch
+    int max_phases;    // CCR_PHASES       2 = at most one re-tightening (default 3)
+    int mfma16;        // CCR_MFMA16       -1 = planner's choice, 0 = 32x32x16 kernel, 1 = 16x16x32 kernel
+    int sample_div;    // CCR_SAMPLE_DIV   0 = planner's choice, else the pinned sample fraction 1/div
+    int gemm_dbg;      // CCR_GEMM_DBG     timing-only ablations of the main pass (WRONG results when non-zero)
+    int stagger;       // CCR_GEMM_STAGGER 0 = both wave groups of the 32x32x16 kernel in phase
+    int tighten;       // CCR_TIGHTEN      0 = no in-launch threshold publication (default 1)
+};
+Knobs read_knobs();
+
+constexpr int FALLBACK_ROWS = 16;   // dense score rows reserved for flagged queries (one on-stream chunk)
+
+Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu, const Knobs &kn);
+
+// kernels implemented in the other translation units
+int launch_gemm_filter(const GemmArgs &a, int grid, hipStream_t s);
+int launch_gemm_gmax(const GemmArgs &a, int grid, hipStream_t s);
+int launch_gemm_store(const GemmArgs &a, int grid, hipStream_t s);
+int launch_gemm16_filter(const GemmArgs &a, int grid, hipStream_t s);
+int launch_gemm16_store(const GemmArgs &a, int grid, hipStream_t s);
+int launch_row_norms_bf16(const uint16_t *X, int64_t rows, int dim, float *norms, uint32_t *max_bits, hipStream_t s);
+int launch_threshold(const float *gmax, int64_t n_groups, int n_q, int nq_pad, int k, const float *qnorm,
+                     const uint32_t *dmax_bits, int dim, float *thr, float *delta, hipStream_t s);
+int select_compact_entries(int dim, int ranges, int rescore_cap, int64_t want);
+int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, int sp, int n_q, int nq_pad, int cap, int k,
+                          int rescore_cap, int compact, int64_t n_rows, const float *delta, const uint16_t *Q,
+                          const uint16_t *D, int dim, int64_t id_offset, float *out_scores, int64_t *out_ids,
+                          uint32_t *flag_count, uint32_t *flag_list, unsigned long long *stat_cand, hipStream_t s);
+int launch_threshold_update(const uint2 *cand, const uint32_t *cnt, int nsub, int sp, int n_q, int nq_pad, int cap, int k,
+                            const float *delta, float *thr, hipStream_t s);
+// dense exact path.  qlist: query rows to score (nullptr: q_begin + qi); out_rows: destination rows of the select
+// (nullptr: q_begin + qi); count_dev (device, may be null): only the first *count_dev - q_begin entries of the list exist
+// (the on-stream fallback chunk of an asynchronous search -- the host does not know the count yet).
+int launch_dense_scores(const uint16_t *D, int64_t n_rows, int dim, const uint16_t *Q, const uint32_t *qlist,
+                        int q_begin, int nq_chunk, const uint32_t *count_dev, float *out, hipStream_t s);
+int launch_dense_select(const float *scores, int64_t n_rows, int k, const uint32_t *out_rows, int q_begin, int nq_chunk,
+                        const uint32_t *count_dev, int64_t id_offset, float *out_scores, int64_t *out_ids, hipStream_t s);
+
+}  // namespace ccr
+
+struct ccr_index {
+    const uint16_t *D;
+    int64_t n_rows;
+    int dim;
+    int64_t offset;
+    uint32_t *dmax_bits;  // device: bits of the max row norm (a slot of the per-device slab)
+    bool have_events;
+    int num_cu;
+    int device;
+    ccr::Knobs knobs;
+    hipEvent_t ev[7];     // phase boundaries of the last search
+    ccr::Plan plan;       // plan of the last search and its key (the planner simulates item assignments: ~25 us)
+    int plan_nq, plan_k, plan_flags;
+    ccr_search_stats stats;
+    // an asynchronous search (CCR_SEARCH_ASYNC) that ccr_search_finish has not completed yet
+    struct {
+        bool active;
+        const uint16_t *Q;
+        int n_q, k;
+        float *out_scores;
+        int64_t *out_ids;
+        char *ws;
+        hipStream_t stream;
+    } pending;
+};

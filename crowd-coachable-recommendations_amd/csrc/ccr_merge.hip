@@ -1,4 +1,4 @@
-// ccr_merge.hip -- shard merge after the RCCL all-gather, and the block_dict post-filter.
+// ccr_merge.hip -- shard merge after the RCCL all-gather (the block_dict post-filter lives in ccr_special.hip).
 #include "ccr_common.h"
 
 namespace ccr {
@@ -86,59 +86,6 @@ __global__ __launch_bounds__(1024) void merge_topk_lds_kernel(const float *__res
     }
 }
 
-// block_dict post-filter on an over-fetched canonical list.  grid = n_q, block = 256.
-__global__ __launch_bounds__(256) void apply_block_kernel(const float *__restrict__ in_scores, const int64_t *__restrict__ in_ids,
-                                                         int k_in, const int64_t *__restrict__ block_ptr,
-                                                         const int64_t *__restrict__ block_idx, float *__restrict__ out_scores,
-                                                         int64_t *__restrict__ out_ids, int k_out) {
-    __shared__ int s_wave[4];
-    __shared__ int s_base;
-    const int q = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int64_t b0 = block_ptr[q], b1 = block_ptr[q + 1];
-    if (tid == 0) s_base = 0;
-    __syncthreads();
-    for (int c0 = 0; c0 < k_in; c0 += blockDim.x) {
-        const int i = c0 + tid;
-        bool keep = false;
-        float s = 0.f;
-        int64_t id = 0;
-        if (i < k_in) {
-            s = in_scores[(int64_t)q * k_in + i];
-            id = in_ids[(int64_t)q * k_in + i];
-            int64_t lo = b0, hi = b1;
-            while (lo < hi) {
-                const int64_t mid = (lo + hi) >> 1;
-                if (block_idx[mid] < id)
-                    lo = mid + 1;
-                else
-                    hi = mid;
-            }
-            keep = !(lo < b1 && block_idx[lo] == id);
-        }
-        const unsigned long long m = __ballot(keep);
-        if (lane == 0) s_wave[wv] = __popcll(m);
-        __syncthreads();
-        int off = s_base;
-        for (int w = 0; w < wv; ++w) off += s_wave[w];
-        const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
-        if (keep && pos < k_out) {
-            out_scores[(int64_t)q * k_out + pos] = s;
-            out_ids[(int64_t)q * k_out + pos] = id;
-        }
-        __syncthreads();
-        if (tid == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-        __syncthreads();
-        if (s_base >= k_out) return;
-    }
-    // fewer unblocked rows than k_out: the blocked ids follow, ascending, at -1e6 (ms_marco_eval.py:227)
-    const int have = s_base;
-    for (int64_t j = tid; j < b1 - b0 && have + j < k_out; j += blockDim.x) {
-        out_scores[(int64_t)q * k_out + have + j] = -1e6f;
-        out_ids[(int64_t)q * k_out + have + j] = block_idx[b0 + j];
-    }
-}
-
 }  // namespace ccr
 
 using namespace ccr;
@@ -171,18 +118,4 @@ extern "C" int ccr_merge_topk_strided(const float *scores, const int64_t *ids, i
 extern "C" int ccr_merge_topk(const float *scores, const int64_t *ids, int R, int n_q, int k, float *out_scores,
                               int64_t *out_ids, void *stream) {
     return ccr_merge_topk_strided(scores, ids, (int64_t)n_q * k, (int64_t)n_q * k, R, n_q, k, out_scores, out_ids, stream);
-}
-
-extern "C" int ccr_apply_block(const float *in_scores, const int64_t *in_ids, int n_q, int k_in, const int64_t *block_ptr,
-                               const int64_t *block_idx, int64_t n_rows_total, float *out_scores, int64_t *out_ids, int k_out,
-                               void *stream) {
-    CCR_REQUIRE(in_scores && in_ids && block_ptr && out_scores && out_ids, "ccr_apply_block: null pointer");
-    CCR_REQUIRE(n_q >= 0 && k_in >= 1 && k_out >= 1 && k_out <= k_in, "ccr_apply_block: bad shape n_q=%d k_in=%d k_out=%d", n_q,
-                k_in, k_out);
-    (void)n_rows_total;
-    if (n_q == 0) return CCR_OK;
-    hipLaunchKernelGGL(apply_block_kernel, dim3(n_q), dim3(256), 0, (hipStream_t)stream, in_scores, in_ids, k_in, block_ptr,
-                       block_idx, out_scores, out_ids, k_out);
-    CCR_LAUNCH_CHECK();
-    return CCR_OK;
 }

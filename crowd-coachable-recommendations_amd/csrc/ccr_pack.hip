@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256) void pack_rows_maxnorm_kernel(const float *__r
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const int n8 = dim >> 3;
-    float wmax = 0.f;
+    uint32_t wbits = 0u;   // max of the norms as ordered bit patterns: non-negative floats order as unsigned, and a NaN
+                           // (0x7fc00000 > +inf) stays on top, so a NaN row makes the maximum NaN (fmaxf would drop it)
     // ROWS rows per iteration: 2*ROWS 16-byte loads in flight per lane (pure HBM stream, read once -> nontemporal)
     for (int64_t r = ROWS * wave; r < rows; r += ROWS * nwaves) {
         float ss[ROWS];
@@ -98,20 +99,22 @@ __global__ __launch_bounds__(256) void pack_rows_maxnorm_kernel(const float *__r
             float t = ss[j];
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
-            wmax = fmaxf(wmax, sqrtf(t));
+            const uint32_t nb = __float_as_uint(sqrtf(t)) & 0x7fffffffu;
+            wbits = nb > wbits ? nb : wbits;
         }
     }
     // Record-breaking norms are rare (~ln N of them): look first, the atomic only when this BLOCK would raise the maximum
     // (one per block: the waves resident when the kernel starts all see the caller's zero and would otherwise queue up
     // 8 K atomics on one address), and the stored value is inflated by 2^-11 so that near-equal maxima do not follow
     // each other in -- it stays an upper bound, which is all the filter margin needs.
-    __shared__ float s_wmax[4];
-    if (lane == 0) s_wmax[threadIdx.x >> 6] = wmax;
+    __shared__ uint32_t s_wmax[4];
+    if (lane == 0) s_wmax[threadIdx.x >> 6] = wbits;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float bmax = fmaxf(fmaxf(s_wmax[0], s_wmax[1]), fmaxf(s_wmax[2], s_wmax[3]));
-        if (__float_as_uint(bmax) > __hip_atomic_load(max_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMax(max_bits, __float_as_uint(bmax * 1.00048828125f));
+        const uint32_t b01 = s_wmax[0] > s_wmax[1] ? s_wmax[0] : s_wmax[1], b23 = s_wmax[2] > s_wmax[3] ? s_wmax[2] : s_wmax[3];
+        const uint32_t bmax = b01 > b23 ? b01 : b23;
+        if (bmax > __hip_atomic_load(max_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(max_bits, bmax >= 0x7f800000u ? bmax : __float_as_uint(__uint_as_float(bmax) * 1.00048828125f));
     }
 }
 
@@ -284,9 +287,82 @@ __global__ __launch_bounds__(256) void meanpool_pack_kernel(const T *__restrict_
     }
 }
 
+// Backward of the masked mean pooling: d hidden[b][l][:] = mask[b][l] ? grad[b][:] / count_b : 0 (item_tower.py:141-146 under
+// autograd).  One workgroup per batch row: the count once, then a stream of stores over the token axis.
+template <typename T>
+__device__ __forceinline__ void store4(T *p, float4 v);
+template <>
+__device__ __forceinline__ void store4<float>(float *p, float4 v) {
+    *reinterpret_cast<float4 *>(p) = v;
+}
+template <>
+__device__ __forceinline__ void store4<_Float16>(_Float16 *p, float4 v) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    h4 o = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+    *reinterpret_cast<h4 *>(p) = o;
+}
+template <>
+__device__ __forceinline__ void store4<__bf16>(__bf16 *p, float4 v) {
+    *reinterpret_cast<bf16x4 *>(p) = cvt4(v);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void meanpool_bwd_kernel(const float *__restrict__ grad, const int64_t *__restrict__ mask,
+                                                          T *__restrict__ dhidden, int L, int dim) {
+    __shared__ long long s_cnt[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int64_t *m = mask + (int64_t)b * L;
+    long long c = 0;
+    for (int l = tid; l < L; l += blockDim.x) c += m[l];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+    if ((tid & 63) == 0) s_cnt[tid >> 6] = c;
+    __syncthreads();
+    long long cnt = 0;
+    for (int w = 0; w < (int)((blockDim.x + 63) >> 6); ++w) cnt += s_cnt[w];
+    const float den = (float)(int)cnt;
+    const int nchunk = dim >> 2;
+    for (int ch = tid; ch < nchunk; ch += blockDim.x) {
+        float4 g = reinterpret_cast<const float4 *>(grad + (int64_t)b * dim)[ch];
+        g.x /= den;
+        g.y /= den;
+        g.z /= den;
+        g.w /= den;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        T *o = dhidden + (int64_t)b * L * dim + 4 * ch;
+        for (int l = 0; l < L; ++l) store4<T>(o + (int64_t)l * dim, m[l] != 0 ? g : z);
+    }
+}
+
 }  // namespace ccr
 
 using namespace ccr;
+
+extern "C" int ccr_meanpool_bwd(const float *grad, const int64_t *mask, void *dhidden, int hidden_dtype, int B, int L, int dim,
+                                void *stream) {
+    CCR_REQUIRE(grad && mask && dhidden, "ccr_meanpool_bwd: null pointer");
+    CCR_REQUIRE(B >= 0 && L > 0 && dim > 0 && dim % 4 == 0, "ccr_meanpool_bwd: bad shape B=%d L=%d dim=%d (dim %% 4 == 0)", B, L, dim);
+    if (B == 0) return CCR_OK;
+    hipStream_t s = (hipStream_t)stream;
+    int threads = ((dim / 4 + 63) / 64) * 64;
+    if (threads > 256) threads = 256;
+    switch (hidden_dtype) {
+        case CCR_DTYPE_F32:
+            hipLaunchKernelGGL(meanpool_bwd_kernel<float>, dim3(B), dim3(threads), 0, s, grad, mask, (float *)dhidden, L, dim);
+            break;
+        case CCR_DTYPE_F16:
+            hipLaunchKernelGGL(meanpool_bwd_kernel<_Float16>, dim3(B), dim3(threads), 0, s, grad, mask, (_Float16 *)dhidden, L, dim);
+            break;
+        case CCR_DTYPE_BF16:
+            hipLaunchKernelGGL(meanpool_bwd_kernel<__bf16>, dim3(B), dim3(threads), 0, s, grad, mask, (__bf16 *)dhidden, L, dim);
+            break;
+        default:
+            set_error("ccr_meanpool_bwd: unknown hidden_dtype %d", hidden_dtype);
+            return CCR_ERR_INVALID;
+    }
+    CCR_LAUNCH_CHECK();
+    return CCR_OK;
+}
 
 extern "C" int ccr_pack_bf16_ex(const float *src, uint16_t *dst, float *norms, float *max_norm, int64_t rows, int dim,
                                 int normalize, void *stream) {

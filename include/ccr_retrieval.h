@@ -41,6 +41,11 @@ extern "C" {
 #define CCR_SEARCH_DEFAULT 0
 #define CCR_SEARCH_FORCE_DENSE 1   /* exact brute-force path for every query (tests, tiny corpora) */
 #define CCR_SEARCH_FORCE_FUSED 2   /* MFMA fused path even where the planner would pick dense */
+#define CCR_SEARCH_ASYNC 4         /* do not synchronise: results complete on `stream` once ccr_search_finish() has run */
+
+/* ccr_scores modes */
+#define CCR_SCORES_CANONICAL 0     /* fp64-ordered canonical scores (bit-identical to the ranking's scores) */
+#define CCR_SCORES_MFMA 1          /* the same bf16 rows through the MFMA tile kernel (fp32 accumulation, |err| < 1e-6) */
 
 typedef struct ccr_index ccr_index;
 
@@ -99,6 +104,12 @@ int ccr_meanpool_pack_bf16_ex(const void *hidden, int hidden_dtype, const int64_
                               float *dst_f32, const int64_t *dst_rows, float *max_norm, int B, int L, int dim,
                               int normalize, void *stream);
 
+/* Backward of the pooling for the training forward (the reference's tower is called with gradients on in
+ * src/ccrec/models/bbpr.py:130-141,195-197): dhidden[b][l][:] = mask[b][l] ? grad[b][:] / sum(mask[b]) : 0.
+ *   grad [B][dim] fp32 (gradient w.r.t. the un-normalised pooled rows), dhidden [B][L][dim] of hidden_dtype. */
+int ccr_meanpool_bwd(const float *grad, const int64_t *mask, void *dhidden, int hidden_dtype, int B, int L, int dim,
+                     void *stream);
+
 /*
  * Build a search index over a resident bf16 corpus shard (borrowed pointer, no copy).
  * Replaces: the host-resident fp32 passage matrix of scripts/ms_marco_eval.py:199-201,208-210.
@@ -123,7 +134,11 @@ int ccr_index_dim(const ccr_index *index);
  *   Q_bf16 [n_q][dim]; out_scores [n_q][k] fp32; out_ids [n_q][k] int64 (global ids)
  *   1 <= k <= min(n_rows, 4096).
  * The call returns after the results are complete on `stream` (it synchronises the stream once
- * to read the fallback count).
+ * to read the fallback count).  With CCR_SEARCH_ASYNC in `flags` it returns without synchronising: the kernels are
+ * enqueued, including one on-stream chunk of the exact path that covers up to 16 flagged queries; the caller may enqueue
+ * more work (e.g. the shard exchange) and must call ccr_search_finish(index) -- which synchronises, re-does any further
+ * flagged queries and fills the statistics -- before it trusts the results of an input that can flag more than that
+ * (ccr_search_last_stats().n_fallback tells).  Buffers and workspace must stay valid until then.
  * Embeddings are expected to be finite.  NaN / Inf values do not fault: the filter margins become infinite, every
  * query takes the exact dense path, +-Inf scores rank as numbers and NaN scores rank by bit pattern (not torch.sort's
  * NaN-first rule) -- identically on every path.
@@ -131,7 +146,54 @@ int ccr_index_dim(const ccr_index *index);
 size_t ccr_search_workspace_bytes(const ccr_index *index, int n_q, int k);
 int ccr_search(ccr_index *index, const uint16_t *Q_bf16, int n_q, int k, float *out_scores, int64_t *out_ids,
                void *workspace, size_t ws_bytes, int flags, void *stream);
+int ccr_search_finish(ccr_index *index);
 int ccr_search_last_stats(const ccr_index *index, ccr_search_stats *stats /* host */);
+
+/*
+ * Dense score matrix of n_q queries against the shard: out [n_q][n_rows] fp32.
+ * Replaces: cos_sim / the chunked `Q @ chunk^T` of scripts/ms_marco_eval.py:155-162,212-215 and
+ * src/ccrec/models/bbpr.py:485-492,536-540 when a caller really wants the matrix (small problems; the ranking path
+ * never materialises it).  mode: CCR_SCORES_CANONICAL or CCR_SCORES_MFMA (dim % 64 == 0).
+ */
+int ccr_scores(const ccr_index *index, const uint16_t *Q_bf16, int n_q, int mode, float *out, void *stream);
+
+/*
+ * Search with per-query blocked ids of ANY length (the reference blocks any number of ids per query:
+ * scripts/ms_marco_eval.py:224-227, scores[block_ind] = -1e6, kept not removed).
+ *   block_ptr_host [n_q + 1] (HOST), block_idx [block_ptr_host[n_q]] int64 GLOBAL ids (DEVICE), ascending and unique inside
+ *   each query; ids outside this shard's [offset, offset + n_rows) are ignored (row-sharded search: every rank passes the
+ *   whole list).  Queries with k + len <= min(n_rows, 4096) over-fetch through the fused path and post-filter
+ *   (ccr_apply_block); longer lists take the exact dense path with the blocked columns set to -1e6 before the selection.
+ *   Result: canonical order of the modified scores, exactly k entries per query.
+ */
+size_t ccr_search_blocked_workspace_bytes(const ccr_index *index, int n_q, int k, const int64_t *block_ptr_host);
+int ccr_search_blocked(ccr_index *index, const uint16_t *Q_bf16, int n_q, int k, const int64_t *block_ptr_host,
+                       const int64_t *block_idx, float *out_scores, int64_t *out_ids, void *workspace, size_t ws_bytes,
+                       int flags, void *stream);
+
+/*
+ * Top-k of (low-rank score + sparse prior), the post-fit expression of the ranker API:
+ *   bbpr.transform(gnd) + gnd.prior_score -> evaluate_item_rec(..., k)   (src/ccrec/models/bbpr.py:592-595;
+ *   _assign_topk src/rime_lite/util/__init__.py:117-155 over ElementWiseExpression(add, [dense, sparse]),
+ *   src/rime_lite/util/score_array.py:300-318).
+ *   prior CSR: prior_ptr_host [n_q + 1] (HOST), prior_idx int64 GLOBAL column ids ascending and unique per row (DEVICE),
+ *   prior_val fp64 (DEVICE); at most 4096 entries per row.
+ *   final(q, j) = (double) canonical_score(q, j) + prior(q, j)  (fp64, as torch promotes fp32 + fp64);
+ *   out_scores fp64 [n_q][k], out_ids [n_q][k] in the order (final desc, id asc).
+ * Exact for any prior values (negative ones included): the candidates are the top-(k + nnz_q) of the low-rank score
+ * plus every prior column of the row (those are re-scored canonically).
+ */
+size_t ccr_search_sparse_prior_workspace_bytes(const ccr_index *index, int n_q, int k, const int64_t *prior_ptr_host);
+int ccr_search_sparse_prior(ccr_index *index, const uint16_t *Q_bf16, int n_q, int k, const int64_t *prior_ptr_host,
+                            const int64_t *prior_idx, const double *prior_val, double *out_scores, int64_t *out_ids,
+                            void *workspace, size_t ws_bytes, int flags, void *stream);
+
+/*
+ * Column sums of a bf16 matrix in fp64: out[c] = sum_r X[r][c] (fixed order per column block, deterministic).
+ * Used by score_op(S, "sum") for a low-rank S = U V^T: sum_ij S_ij = colsum(U) . colsum(V)
+ * (src/rime_lite/util/score_array.py:460-474 without materialising any batch of S).
+ */
+int ccr_colsum_bf16(const uint16_t *X, int64_t rows, int dim, double *out /* [dim] device */, void *stream);
 
 /*
  * Merge R per-shard top-k lists (after the RCCL all-gather) into the global top-k.
@@ -188,14 +250,6 @@ int ccr_inbatch_ce_bwd_dev(const uint16_t *Qe, const uint16_t *Pe, const uint16_
  */
 int ccr_rank_metrics(const int64_t *ids, int n_q, int k, const int64_t *qrel_ptr, const int64_t *qrel_idx,
                      const int32_t *k_values, int n_k, float *out_rr, int32_t *out_hits, void *stream);
-
-/*
- * Test/diagnostic entry points (not part of the drop-in surface).
- *   ccr_debug_mfma_scores: the raw MFMA (bf16 x bf16 -> fp32) score matrix [n_q][n_rows] the filter sees.
- *   ccr_debug_canonical_scores: the canonical fp64-ordered scores [n_q][n_rows].
- */
-int ccr_debug_mfma_scores(const ccr_index *index, const uint16_t *Q_bf16, int n_q, float *out, void *stream);
-int ccr_debug_canonical_scores(const ccr_index *index, const uint16_t *Q_bf16, int n_q, float *out, void *stream);
 
 /*
  * BM25 as a sparse scorer (the lexical leg of the candidate builder).

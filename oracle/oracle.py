@@ -172,6 +172,37 @@ def merge_topk(scores, ids):
     return os_, oi
 
 
+def sparse_prior_search(Qb, Db, indptr, indices, data, k):
+    """Top-k of (canonical low-rank score + sparse prior), the restatement of `_assign_topk(transform(D) + D.prior_score, k)`
+    (src/rime_lite/util/__init__.py:117-155 over ElementWiseExpression(add, [dense, sparse]), score_array.py:300-318;
+    call site src/ccrec/models/bbpr.py:592-595): final = (double) canonical_score + prior (torch promotes fp32 + fp64 to
+    fp64), order (final desc, column asc).  -> (ids [nq, k] int64, finals [nq, k] float64)."""
+    L = canonical_scores(Qb, Db).astype(np.float64)
+    indptr, indices, data = np.asarray(indptr, np.int64), np.asarray(indices, np.int64), np.asarray(data, np.float64)
+    for q in range(L.shape[0]):
+        sl = slice(indptr[q], indptr[q + 1])
+        np.add.at(L[q], indices[sl], data[sl])
+    L = L + 0.0
+    ids = np.empty((L.shape[0], k), np.int64)
+    sc = np.empty((L.shape[0], k), np.float64)
+    cols = np.arange(L.shape[1])
+    for q in range(L.shape[0]):
+        o = np.lexsort((cols, -L[q]))[:k]
+        ids[q], sc[q] = o, L[q][o]
+    return ids, sc
+
+
+def score_op(Qb, Db, op, indptr=None, indices=None, data=None):
+    """score_array.py:460-474: max / min / sum over the whole (low-rank [+ sparse prior]) score matrix, from the canonical
+    scores in fp64 (the reference reduces fp32 / fp64 batches with torch.max / min / sum)."""
+    L = canonical_scores(Qb, Db).astype(np.float64)
+    if indptr is not None:
+        for q in range(L.shape[0]):
+            sl = slice(indptr[q], indptr[q + 1])
+            np.add.at(L[q], np.asarray(indices[sl], np.int64), np.asarray(data[sl], np.float64))
+    return float({"max": np.max, "min": np.min, "sum": np.sum}[op](L))
+
+
 # ----------------------------------------------------------------------------- reference-faithful CPU path
 def reference_cos_sim(a, b):
     """ms_marco_eval.py:155-162 in fp32."""

@@ -119,15 +119,27 @@ def _worker(rank, world, port, n, nq, k, out_dir):
         s, i = orc.merge_topk(gs.numpy(), gi.numpy())
         return torch.from_numpy(s), torch.from_numpy(i)
 
-    s, i = sharded_search(Shard(), None, k, merge_fn=merge_fn, search_fn=search_fn)
-    ref_i, ref_s = orc.canonical_search(Qb, Db, k)
-    ok = np.array_equal(i.numpy(), ref_i) and np.array_equal(s.numpy(), ref_s)
+    if n >= k:
+        s, i = sharded_search(Shard(), None, k, merge_fn=merge_fn, search_fn=search_fn)
+        ref_i, ref_s = orc.canonical_search(Qb, Db, k)
+        ok = np.array_equal(i.numpy(), ref_i) and np.array_equal(s.numpy(), ref_s)
+    else:
+        # the whole corpus holds fewer than k rows: n_total clamps k; without it the tail is (-inf, distinct pad ids) --
+        # every output slot written, never uninitialised memory
+        ref_i, ref_s = orc.canonical_search(Qb, Db, n)
+        s, i = sharded_search(Shard(), None, k, merge_fn=merge_fn, search_fn=search_fn, n_total=n)
+        ok = tuple(i.shape) == (nq, n) and np.array_equal(i.numpy(), ref_i) and np.array_equal(s.numpy(), ref_s)
+        s, i = sharded_search(Shard(), None, k, merge_fn=merge_fn, search_fn=search_fn)
+        ok = ok and tuple(i.shape) == (nq, k) and np.array_equal(i.numpy()[:, :n], ref_i) and np.array_equal(s.numpy()[:, :n], ref_s)
+        tail_i, tail_s = i.numpy()[:, n:], s.numpy()[:, n:]
+        ok = ok and bool(np.isneginf(tail_s).all()) and bool((tail_i > 2 ** 62).all())
+        ok = ok and all(len(set(r.tolist())) == k - n for r in tail_i)
     open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if ok else "MISMATCH")
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,k", [(1000, 50), (9, 8)])   # second case: a shard smaller than k (padding path)
+@pytest.mark.parametrize("n,k", [(1000, 50), (9, 8), (5, 8)])   # a shard smaller than k (padding path); a CORPUS smaller than k
 def test_sharded_search_gloo_world2(tmp_path, n, k):
     import torch.multiprocessing as mp
     port = _free_port()
@@ -190,3 +202,75 @@ def test_committed_bench_line_has_the_contract_fields():
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(cpu) and cpu["kind"] in ("port", "reference")
     assert abs(line["value"] - line["config"]["queries"] / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-3
 
+
+
+def test_replica_cache_replicate_returns_cached_copies_for_a_device_subset(monkeypatch):
+    """src/ccrec/util/data_parallel.py:8-20: after cache_replicas(), torch's DataParallel.forward asks replicate() for the
+    devices that received a chunk and must get the STORED copies (no new broadcast).  No GPU here: the broadcast, scatter,
+    parallel_apply and gather are faked, torch's own forward() and our replicate() are the code under test."""
+    import copy
+    import torch
+    from ccrec_amd import replica_cache
+
+    broadcasts = []
+
+    def fake_broadcast(module, device_ids, detach=False):
+        broadcasts.append((list(device_ids), detach))
+        out = []
+        for d in device_ids:
+            m = copy.deepcopy(module)
+            m.tag = d
+            out.append(m)
+        return out
+
+    monkeypatch.setattr(replica_cache, "_broadcast_module", fake_broadcast)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(4, 3)
+            self.tag = "source"
+            self.calls = 0
+
+        def forward(self, x):
+            self.calls += 1
+            return self.lin(x)
+
+    dp = replica_cache.DataParallel(Net())     # CPU host: torch leaves device_ids empty
+    assert dp.cache_replicas() is dp and broadcasts == []            # nothing to copy without devices
+    dp.device_ids, dp.output_device, dp.src_device_obj = [0, 1, 2], 0, torch.device("cpu")
+    assert dp.cache_replicas() is dp
+    assert broadcasts == [([0, 1, 2], True)]                          # one detached broadcast
+    copies = dp._by_device
+    assert [copies[d].tag for d in (0, 1, 2)] == [0, 1, 2]
+    # a device subset, in any order, returns the stored objects themselves
+    assert [m.tag for m in dp.replicate(dp.module, [0, 2])] == [0, 2]
+    assert dp.replicate(dp.module, [2, 1])[0] is copies[2]
+    # torch's DataParallel.forward: a batch of 5 rows split over two of the three devices -> replicate(module, [0, 1])
+    dp.scatter = lambda inputs, kwargs, device_ids: (((inputs[0][:3],), (inputs[0][3:],)), ({}, {}))
+    dp.parallel_apply = lambda replicas, inputs, kwargs: [m(*i, **k) for m, i, k in zip(replicas, inputs, kwargs)]
+    dp.gather = lambda outputs, output_device: torch.cat(outputs, 0)
+    x = torch.randn(5, 4)
+    y = dp(x)
+    assert torch.allclose(y, dp.module.lin(x))
+    assert (copies[0].calls, copies[1].calls, copies[2].calls, dp.module.calls) == (1, 1, 0, 0)
+    assert broadcasts == [([0, 1, 2], True)]                          # forward did not broadcast again
+    # without the cache the class behaves like torch's (replicate goes to the broadcast)
+    fresh = replica_cache.DataParallel(Net())
+    fresh.device_ids = [0, 1]
+    monkeypatch.setattr(torch.nn.DataParallel, "replicate", lambda self, module, device_ids: ["torch", list(device_ids)])
+    assert fresh.replicate(fresh.module, [0, 1]) == ["torch", [0, 1]]
+
+
+def test_unwrap_item_tower_shapes():
+    """al_0_rank.py:84-90: BertBPR/BertMT-style wrappers, bare Lightning modules and plain towers."""
+    from ccrec_amd.al_rank import unwrap_item_tower
+
+    class T:
+        pass
+
+    tower = T()
+    with_attr, wrapper = T(), T()
+    with_attr.item_tower = tower
+    wrapper.model = with_attr
+    assert unwrap_item_tower(with_attr) is tower and unwrap_item_tower(wrapper) is tower and unwrap_item_tower(tower) is tower

@@ -65,6 +65,83 @@ def test_nq_config_properties():
     assert torch.equal(mi, i) and torch.equal(ms, s)
 
 
+def _check_against_oracle(D, Q, s, i, k, sub, offset=0):
+    """The size-independent property scheme of test_nq_config_properties for any shape: canonical order, every returned
+    score re-computed by the oracle bit for bit, and completeness on the queries `sub` (an fp32 sweep of the WHOLE shard --
+    torch's own matmul, chunked on the device -- pre-selects every row within 1e-4 of the k-th score; the oracle re-scores
+    those canonically and its canonical order must reproduce the list)."""
+    n = D.shape[0]
+    s_np, i_np = s.cpu().numpy(), i.cpu().numpy() - offset
+    ds = np.diff(s_np.astype(np.float64), axis=1)
+    assert (ds <= 0).all()
+    assert ((ds < 0) | (np.diff(i_np, axis=1) > 0)).all()
+    assert i_np.min() >= 0 and i_np.max() < n
+    Db, Qb = _bits(D), _bits(Q)
+    ref = orc.canonical_scores_pairs(Qb, Db, i_np)
+    assert np.array_equal(ref.view(np.uint32), s_np.view(np.uint32))
+    Qs = Q[torch.as_tensor(sub, device=Q.device)].float()
+    kth = torch.as_tensor(s_np[sub, -1], device=Q.device)
+    cands = [[] for _ in sub]
+    for lo in range(0, n, 1 << 20):
+        a = D[lo:lo + (1 << 20)].float() @ Qs.T                      # [chunk, len(sub)]
+        hit = (a >= (kth - 1e-4)[None, :]).nonzero()
+        for c in range(len(sub)):
+            cands[c].append((hit[hit[:, 1] == c, 0] + lo).cpu().numpy())
+    for c, q in enumerate(sub):
+        cand = np.concatenate(cands[c])
+        assert len(cand) >= k
+        cs = orc.canonical_scores_pairs(Qb[q:q + 1], Db, cand[None, :])[0]
+        o = np.lexsort((cand, -cs.astype(np.float64)))[:k]
+        assert np.array_equal(cand[o], i_np[q]) and np.array_equal(cs[o], s_np[q])
+
+
+def test_msmarco_config_shard_and_full_properties():
+    """BASELINE.json configs[2]: MS-MARCO passages 8,841,823 x 768, 6,980 queries, top-100 -- the single-GPU shape and the
+    per-rank shard of its 8-way row sharding (1,105,228 rows, global ids with the rank's offset), against the oracle."""
+    from ccrec_amd import ops
+    n, nq, d, k = 8_841_823, 6_980, 768, 100
+    D, Q = _gen(n, d, 1234), _gen(nq, d, 4321)
+    sub = np.r_[0:6, 3488:3493, 6975:6980]
+    index = ops.CorpusIndex(D)
+    s, i = index.search(Q, k)
+    st = index.last_stats()
+    print(st)
+    assert st["path"] == 1 and st["n_fallback"] == 0
+    _check_against_oracle(D, Q, s, i, k, sub)
+    # rank 3 of 8: rows [lo, hi) of the same corpus; the shard's list must be the full list restricted to the shard
+    from ccrec_amd.dist import shard_bounds
+    lo, hi = shard_bounds(n, 8, 3)
+    assert hi - lo in (1_105_227, 1_105_228)
+    shard = D[lo:hi]
+    ix = ops.CorpusIndex(shard, global_row_offset=lo)
+    s8, i8 = ix.search(Q, k)
+    st8 = ix.last_stats()
+    print(st8)
+    assert st8["path"] == 1 and st8["n_fallback"] == 0 and int(i8.min()) >= lo and int(i8.max()) < hi
+    _check_against_oracle(shard, Q, s8, i8, k, sub, offset=lo)
+    inside = (i >= lo) & (i < hi)                                   # full-corpus winners that live in this shard ...
+    for q in sub:
+        mine = i[q][inside[q]]
+        assert torch.equal(mine, i8[q][: mine.numel()])              # ... lead the shard's own list, in the same order
+
+
+def test_config4_shard_properties():
+    """BASELINE.json configs[3]: one rank's shard of the synthetic 50 M x 1024 corpus (6,250,000 rows, 12.8 GB bf16),
+    10,000 queries, top-1000, against the oracle."""
+    from ccrec_amd import ops
+    n, nq, d, k = 6_250_000, 10_000, 1024, 1000
+    D, Q = _gen(n, d, 1234 + 5), _gen(nq, d, 4321)
+    lo = 5 * n                                                       # rank 5's global row offset (beyond int32)
+    index = ops.CorpusIndex(D, global_row_offset=lo)
+    s, i = index.search(Q, k)
+    st = index.last_stats()
+    print(st)
+    assert st["path"] == 1 and st["n_fallback"] == 0
+    sub = np.r_[0:6, 4998:5003, 9995:10000]
+    _check_against_oracle(D, Q, s, i, k, sub, offset=lo)
+    assert all(len(set(row.tolist())) == k for row in i.cpu().numpy()[::997])
+
+
 def test_top1000_fused_equals_dense_at_1m():
     """config-4-shaped k (top-1000) on a 1M-row shard: the fused path must equal the exact dense path."""
     from ccrec_amd import ops

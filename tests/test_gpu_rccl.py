@@ -65,3 +65,31 @@ def test_topk_message_through_rccl_world1():
         assert t.item() == 1.25
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_two_ranks_rehearsal_in_a_fresh_process(tmp_path):
+    """The N > 1 branch of bench.py exactly as the driver launches it (`python -m torch.distributed.run ... bench.py
+    --gpus 2`), rehearsed on this one GPU: both ranks share cuda:0 and exchange over gloo.  The JSON line must parse and
+    the merged ids must equal the 1-rank run's (the corpus is the same global stream, row-sharded)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "2", "--warmup", "1", "--rows", "200000", "--queries", "300", "--cpu-queries", "0", "--no-secondary"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dump-ids", str(tmp_path / "one.pt")] + common,
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2",
+                          "--dist-backend", "gloo", "--same-device", "--dump-ids", str(tmp_path / "two.pt")] + common,
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert two.returncode == 0, two.stderr[-2000:]
+    lines = [ln for ln in two.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, two.stdout[-2000:]                  # rank 0 prints ONE JSON line
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["scaling"] == "strong" and rec["value"] > 0
+    assert rec["config"]["parallelism"] == "row-shard x2" and rec["cpu_baseline"] is None
+    assert rec["roofline"]["bound"] == "mfma" and rec["search_stats"]["n_fallback"] == 0
+    a, b = torch.load(tmp_path / "one.pt"), torch.load(tmp_path / "two.pt")
+    assert a.shape == (300, 100) and torch.equal(a, b)

@@ -107,10 +107,10 @@ def test_canonical_and_mfma_scores():
     from ccrec_amd import ops
     Db, Qb = _rand_bits(700, 768, 1), _rand_bits(37, 768, 2)
     index = ops.CorpusIndex(_bf16(Db))
-    can = index.debug_scores(_bf16(Qb), canonical=True).cpu().numpy()
+    can = index.scores(_bf16(Qb), "canonical").cpu().numpy()
     ref = orc.canonical_scores(Qb, Db)
     assert np.array_equal(can.view(np.uint32), ref.view(np.uint32))
-    mf = index.debug_scores(_bf16(Qb), canonical=False).cpu().numpy()
+    mf = index.scores(_bf16(Qb), "mfma").cpu().numpy()
     # MFMA fp32 accumulation: bounded by gamma * ||q|| * ||d|| (the filter margin); report the measured error
     qn, dn = orc.row_norms_bf16(Qb), orc.row_norms_bf16(Db)
     bound = 768 * 2.0 ** -23 * qn[:, None] * dn[None, :]
@@ -122,7 +122,7 @@ def test_canonical_and_mfma_scores():
     Di = orc.pack_bf16(rs.randint(-8, 9, size=(515, 128)).astype(np.float32))
     Qi = orc.pack_bf16(rs.randint(-8, 9, size=(261, 128)).astype(np.float32))
     ix2 = ops.CorpusIndex(_bf16(Di))
-    mf2 = ix2.debug_scores(_bf16(Qi), canonical=False).cpu().numpy()
+    mf2 = ix2.scores(_bf16(Qi), "mfma").cpu().numpy()
     assert np.array_equal(mf2, orc.canonical_scores(Qi, Di))
 
 

@@ -109,6 +109,21 @@ def test_assign_topk(golden_dir):
     assert np.array_equal(g["indptr"], np.arange(0, ref.size + 1, k))
 
 
+def test_sparse_prior_topk_and_score_op(golden_dir):
+    """g14 = the reference's rime_lite on (U @ V.T + sparse prior): _assign_topk, score_op (bbpr.py:592-595)."""
+    g = _load(golden_dir, "g14_sparse_prior.npz")
+    k = int(g["k"])
+    Ub, Vb = orc.pack_bf16(g["U"]), orc.pack_bf16(g["V"])
+    ids, fin = orc.sparse_prior_search(Ub, Vb, g["prior_indptr"], g["prior_indices"], g["prior_data"], k)
+    assert np.array_equal(ids, g["indices"])                      # gaps between ranked finals are >> the fp32 matmul noise
+    np.testing.assert_allclose(fin, g["topk_scores"], rtol=0, atol=2e-6 + 1e-9 * 1e5)
+    for op in ("max", "min", "sum"):
+        low = orc.score_op(Ub, Vb, op)
+        both = orc.score_op(Ub, Vb, op, g["prior_indptr"], g["prior_indices"], g["prior_data"])
+        np.testing.assert_allclose(low, float(g["low_" + op]), rtol=1e-5, atol=2e-4)
+        np.testing.assert_allclose(both, float(g["sum_" + op]), rtol=1e-6, atol=2e-4)
+
+
 def test_pack_bf16_bits(golden_dir):
     g = _load(golden_dir, "g9_pack_bf16.npz")
     bits = orc.pack_bf16(g["x"])

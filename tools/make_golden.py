@@ -24,6 +24,8 @@ Fixtures:
   G11 generate_train_data (scripts/al_oracle_agent.py, the function's own source executed the same way)
   G12 BM25: the reference's bm_25.BM25 (imported) and ranking_bm25 (function source executed) on a toy corpus
   G13 rime_lite.metrics.evaluate_item_rec on a MatMulExpression score (the §8b signature that consumes _assign_topk)
+  G14 low-rank + sparse prior: _assign_topk / evaluate_item_rec / score_op on
+      ElementWiseExpression(add, [U @ V.T, sparse]) -- the post-fit expression of bbpr.py:592-595 (reranking_prior 1e5)
 """
 import contextlib
 import importlib.abc
@@ -397,12 +399,65 @@ def g_item_rec():
     print("g13_item_rec", out)
 
 
+def g_sparse_prior():
+    """G14: the reference's rime_lite on `transform(D) + D.prior_score`-shaped scores (dense low-rank + sparse prior)."""
+    _import_reference("dot")
+    import scipy.sparse as sps
+    from rime_lite.metrics import evaluate_item_rec
+    from rime_lite.util import _assign_topk, auto_cast_lazy_score
+    from rime_lite.util.score_array import score_op
+    g = torch.Generator().manual_seed(14)
+    nu, ni, d, k = 60, 1200, 64, 5
+    U = bf16_exact(torch.randn(nu, d, generator=g) / 8).numpy()
+    V = bf16_exact(torch.randn(ni, d, generator=g) / 8).numpy()
+    rs = np.random.RandomState(14)
+    rows, cols, vals = [], [], []
+    for u in range(nu):
+        if u == 7:      # almost every column carries a prior: more entries than any over-fetch can hold
+            c = np.sort(rs.choice(ni, ni - 2, replace=False))
+            v = rs.uniform(-0.5, 0.5, c.size)
+        elif u == 11:   # no prior at all
+            c, v = np.zeros(0, np.int64), np.zeros(0)
+        else:
+            c = np.sort(rs.choice(ni, rs.randint(1, 7), replace=False))
+            v = np.where(rs.rand(c.size) < 0.5, 1e5, rs.uniform(-2.0, 2.0, c.size))   # reranking_prior=1e5 + small +- values
+        rows += [u] * c.size
+        cols += c.tolist()
+        vals += v.tolist()
+    P = sps.csr_matrix((np.asarray(vals, np.float64), (rows, cols)), shape=(nu, ni))
+    low = auto_cast_lazy_score(U) @ auto_cast_lazy_score(V).T
+    S = low + auto_cast_lazy_score(P)
+    with contextlib.redirect_stdout(io.StringIO()):
+        csr = _assign_topk(S, k, tie_breaker=0)
+        true = (U.astype(np.float64) @ V.astype(np.float64).T) + P.toarray()
+        t_rows, t_cols = [], []
+        for u in range(nu):                   # relevant items: half of each user's 4 best under the combined score
+            best = np.argsort(-true[u])[:4]
+            pick = sorted(set(best[rs.rand(4) < 0.5].tolist()) | {int(rs.randint(0, ni))})
+            t_rows += [u] * len(pick)
+            t_cols += pick
+        target = sps.csr_matrix((np.ones(len(t_rows)), (t_rows, t_cols)), shape=(nu, ni))
+        metrics = evaluate_item_rec(target, S, 1, tie_breaker=0)
+        ops_low = {op: float(score_op(low, op)) for op in ("max", "min", "sum")}
+        ops_sum = {op: float(score_op(S, op)) for op in ("max", "min", "sum")}
+    full = S.as_tensor("cpu").numpy()
+    np.savez_compressed(os.path.join(OUT, "g14_sparse_prior.npz"), U=U, V=V, prior_indptr=P.indptr.astype(np.int64),
+                        prior_indices=P.indices.astype(np.int64), prior_data=P.data.astype(np.float64), k=k,
+                        indices=csr.indices.reshape(nu, k).astype(np.int64),
+                        topk_scores=np.take_along_axis(full, csr.indices.reshape(nu, k), 1).astype(np.float64),
+                        target_indptr=target.indptr, target_indices=target.indices,
+                        **{"m_" + kk.replace("/", "_"): np.float64(v) for kk, v in metrics.items()},
+                        **{"low_" + kk: np.float64(v) for kk, v in ops_low.items()},
+                        **{"sum_" + kk: np.float64(v) for kk, v in ops_sum.items()})
+    print("g14_sparse_prior", metrics, ops_low, ops_sum)
+
+
 def main():
     """No arguments: every fixture.  `make_golden.py g10 g11`: only the named groups (g1 = all ranking fixtures)."""
     os.makedirs(OUT, exist_ok=True)
     want = set(sys.argv[1:])
     groups = [("g1", lambda: g_ranking(_import_reference("dot"))), ("g6", g_item_tower), ("g7", g_contrastive),
-              ("g8", g_assign_topk), ("g9", g_pack), ("g10", g_requests), ("g11", g_train_data), ("g12", g_bm25), ("g13", g_item_rec)]
+              ("g8", g_assign_topk), ("g9", g_pack), ("g10", g_requests), ("g11", g_train_data), ("g12", g_bm25), ("g13", g_item_rec), ("g14", g_sparse_prior)]
     for name, fn in groups:
         if not want or name in want:
             fn()
