@@ -165,8 +165,7 @@ def test_sparse_prior_random_vs_oracle_both_routes():
     assert np.array_equal(ids.cpu().numpy() - (1 << 33), ref_i)
     assert np.array_equal(fin.cpu().numpy().view(np.uint64), ref_f.view(np.uint64))
     with pytest.raises(Exception, match="4096"):
-        bad = np.zeros(nq + 1, np.int64)
-        bad[1:] = 4097
+        bad = np.arange(nq + 1, dtype=np.int64) * 4097
         index.search_sparse_prior(_bf16(Qb), k, bad, np.tile(np.arange(4097), nq) + (1 << 33), np.zeros(4097 * nq))
 
 
