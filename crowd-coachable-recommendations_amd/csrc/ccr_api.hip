@@ -3,6 +3,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <math.h>
+
 #include <algorithm>
 #include <mutex>
 #include <vector>
@@ -210,11 +212,53 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu, c
         p.ranges_a = (int)RA;
         p.ranges_b = (int)RB;
         const double ratio = (double)p.tiles / (double)sample;
-        const double expect = (double)k * ratio * 1.3 + 64.0;  // survivors per query
-        // candidates go to `sublists` lists per (range, query): one per (wave row, lane part) of the GEMM tile
-        int64_t cap = (int64_t)(4.0 * expect / (double)(R * p.sublists)) + 16;
-        cap = round_up(std::min<int64_t>(std::max<int64_t>(cap, 16), 8192), 4);
-        p.cap = (int)cap;
+        const double expect = (double)k * ratio * 1.3 + 64.0;  // survivors per query under the sample thresholds alone
+        // Sub-list capacities, one per phase (segment).  A phase whose thresholds were taken from a corpus fraction g lets
+        // k / g rows per query through, spread over R * sublists sub-lists.  Two noise terms on top of that mean:
+        //   the threshold itself is the k-th order statistic of what was seen: its pass rate is Gamma(k)-distributed, an
+        //     upper quantile of it is (k + 4.75 sqrt(k) + 8) / k times the mean (15 x at k = 1, 1.6 x at k = 100, 1.16 x at
+        //     k = 1000) -- times 1.25 for uneven data;
+        //   the count of one sub-list is Poisson around its share: + 6 sigma + 16.
+        // An overflowing sub-list only flags its query for the exact path, so the model needs to be safe, not a bound.
+        const double fs = 1.0 / ratio, nlists = (double)R * p.sublists;
+        const double xk = 1.25 * ((double)k + 4.75 * sqrt((double)k) + 8.0) / (double)k;
+        auto cap_for = [&](double g) -> int {
+            const double mean = xk * (double)k / (g * nlists);
+            const int64_t c = (int64_t)(mean + 6.0 * sqrt(mean)) + 16;
+            return (int)round_up(std::min<int64_t>(std::max<int64_t>(c, 16), 8192), 4);
+        };
+        const double fa = (double)RA / (double)R, fb = (double)(RB > RA ? RB - RA : 0) / (double)R;
+        // the re-tightening selects among at most `compact` of the candidates found so far (launch_threshold_update): when
+        // phase A is expected to leave more than that, the bound is the k-th of a subset and passes proportionally more
+        const double upd_compact = std::min(32768.0, std::max(4096.0, 8.0 * pow2_ceil(k)));
+        auto seen = [&](double g, double found) { return found > upd_compact ? g * upd_compact / found : g; };
+        const double found_a = (double)k * fa / fs;
+        CandLayout &L = p.cand;
+        memset(&L, 0, sizeof(L));
+        const int seg_end_v[3] = {RA ? (int)RA : (int)R, RB > RA ? (int)RB : (int)R, (int)R};
+        int64_t recs = 0;
+        L.nseg = 0;
+        int prev_end = 0;
+        for (int g = 0; g < 3; ++g) {
+            L.seg_end[g] = INT32_MAX;
+            L.cap[g] = 16;
+            L.base[g] = recs;
+        }
+        for (int g = 0; g < 3; ++g) {
+            if (seg_end_v[g] <= prev_end) continue;
+            const int sg = L.nseg++;
+            double frac_seen = fs;                                  // phase A: the sample
+            if (sg == 1) frac_seen = fa >= 2.0 * fs ? seen(fa, found_a) : fs;
+            if (sg == 2) frac_seen = fa >= 2.0 * fs ? seen(fa + fb, found_a + (double)k * fb / fa) : fs;
+            L.seg_end[sg] = seg_end_v[g];
+            L.cap[sg] = cap_for(std::min(1.0, std::max(frac_seen, fs)));
+            L.base[sg] = recs;
+            recs += (int64_t)(seg_end_v[g] - prev_end) * p.nq_pad * p.sublists * L.cap[sg];
+            recs = round_up(recs, 32);
+            prev_end = seg_end_v[g];
+        }
+        L.seg_end[L.nseg - 1] = INT32_MAX;   // the last segment is open-ended (sub-list lookups never fall off the table)
+        p.cap = L.cap[0];
         // survivors per query reaching the select stage: ~12 k after the progressive re-tightening, `expect` without it
         p.select_compact = select_compact_entries(dim, p.ranges * p.sublists, p.rescore_cap,
                                                   (int64_t)((RA ? 16.0 * k + 512.0 : expect) * 1.25));
@@ -222,7 +266,7 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu, c
         p.off_thr = take((size_t)p.nq_pad * 4 * 2);  // thr then delta
         p.off_gmax = take((size_t)p.sample_tiles * GROUPS_PER_TILE * p.nq_pad * 4);
         p.off_cnt = take((size_t)p.ranges * p.nq_pad * p.sublists * 4);
-        p.off_cand = take((size_t)p.ranges * p.nq_pad * p.sublists * p.cap * 8);
+        p.off_cand = take((size_t)recs * 8);
         p.off_flag = take(64 + (size_t)n_q * 4);
         p.dense_rows_per_chunk = FALLBACK_ROWS;
         p.off_dense = take((size_t)FALLBACK_ROWS * n_rows * 4);
@@ -529,9 +573,7 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
     gm.tile_stride = 1;
     gm.ranges = p.ranges;
     gm.thr = thr;
-    gm.cand = cand;
     gm.cnt = cnt;
-    gm.cap = p.cap;
     unsigned long long *stamps = nullptr;   // CCR_GEMM_DBG=16: in-kernel cycle stamps of the main pass (diagnostic build)
     const bool want_stamps = ix->knobs.gemm_dbg == 16;
     if (want_stamps) {
@@ -550,11 +592,18 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
     for (int ph = 1; ph < 4; ++ph) {
         if (bounds[ph] <= done) continue;
         if (done > 0) {
-            rc = launch_threshold_update(cand, cnt, done * p.sublists, p.sublists, n_q, p.nq_pad, p.cap, k, delta, thr, s);
+            rc = launch_threshold_update(cand, cnt, done * p.sublists, p.sublists, n_q, p.nq_pad, p.cand, k, delta, thr, s);
             if (rc != CCR_OK) return rc;
         }
         gm.range_begin = done;
         gm.range_end = bounds[ph];
+        {   // this launch's segment of the candidate area (a launch never straddles two segments)
+            int cap_seg = 0;
+            const long long first = cand_sublist(p.cand, done, 0, 0, p.nq_pad, p.sublists, cap_seg);
+            gm.cand = cand + first;
+            gm.cap = cap_seg;
+            gm.cand_range0 = done;
+        }
         rc = main_pass(gm);
         if (rc != CCR_OK) return rc;
         done = bounds[ph];
@@ -580,7 +629,7 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
         (void)hipFree(stamps);
     }
 
-    rc = launch_select_rescore(cand, cnt, p.ranges * p.sublists, p.sublists, n_q, p.nq_pad, p.cap, k, p.rescore_cap, p.select_compact, ix->n_rows, delta,
+    rc = launch_select_rescore(cand, cnt, p.ranges * p.sublists, p.sublists, n_q, p.nq_pad, p.cand, k, p.rescore_cap, p.select_compact, ix->n_rows, delta,
                                Q_bf16, ix->D, ix->dim,
                                ix->offset, out_scores, out_ids, flag_count, flag_list, stat_cand, s);
     if (rc != CCR_OK) return rc;

@@ -45,6 +45,22 @@ constexpr int GROUPS_PER_TILE = 16; // group maxima per (sample tile, query): 2 
 constexpr int MAX_K = 4096;
 constexpr int NUM_XCD = 8;
 
+// Candidate storage of the main pass.  The ranges of one launch (phase) form a segment with its own sub-list capacity:
+// the later phases run under re-tightened thresholds and need far fewer slots per sub-list than phase A.
+// Sub-list (range r, query q, part s) of segment g starts at record base[g] + (((r - begin(g)) * nq_pad + q) * sp + s) * cap[g].
+struct CandLayout {
+    int nseg;
+    int seg_end[3];     // exclusive end range of each segment (ascending; unused entries = INT_MAX)
+    int cap[3];
+    long long base[3];  // in 8-byte records from the start of the candidate area
+};
+__host__ __device__ __forceinline__ long long cand_sublist(const CandLayout &L, int r, int q, int s, int nq_pad, int sp, int &cap) {
+    const int g = (r >= L.seg_end[0] ? 1 : 0) + (r >= L.seg_end[1] ? 1 : 0);
+    const int r0 = g ? L.seg_end[g - 1] : 0;
+    cap = L.cap[g];
+    return L.base[g] + ((((long long)(r - r0) * nq_pad + q) * sp + s) * (long long)cap);
+}
+
 struct Plan {
     int fused;            // 1 = fused MFMA path usable
     int nq_pad;           // n_q rounded up to TILE_Q
@@ -57,7 +73,8 @@ struct Plan {
     int ranges_a;         // ranges scored by phase A (0 = single phase); thresholds are re-tightened after it
     int ranges_b;          // end of the second phase (0: two phases)
     int qgroups;          // query-block groups over the XCDs
-    int cap;              // candidate slots per sub-list
+    int cap;              // candidate slots per sub-list (the largest segment's: statistics)
+    CandLayout cand;      // per-phase segments of the candidate area
     int grid;             // persistent workgroups (multiple of NUM_XCD)
     int rescore_cap;      // max rows re-scored per query (power of two)
     int select_compact;   // candidates per query the select kernel gathers into LDS
@@ -84,9 +101,10 @@ struct GemmArgs {
     int range_begin, range_end;  // this launch covers ranges [range_begin, range_end), both multiples of 8
     // EPI_FILTER
     const float *thr;     // [nq_pad]
-    uint2 *cand;          // [ranges][nq_pad][4][cap] {score bits, local row}; 4 = (wave row, lane half)
-    uint32_t *cnt;        // [ranges][nq_pad][4]
+    uint2 *cand;          // this launch's segment: [range - cand_range0][nq_pad][sublists][cap] {score bits, local row}
+    uint32_t *cnt;        // [ranges][nq_pad][sublists]
     int cap;
+    int cand_range0;      // first range of the segment `cand` points at
     // EPI_GMAX
     float *gmax;          // [n_vt * 16][nq_pad]
     // EPI_STORE (debug)

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
             for (int qt = 0; qt < 2; ++qt) {
                 const int q = q0 + wq * 64 + qt * 32 + l31;
                 thr[qt] = (q < a.n_q) ? a.thr[q] : __builtin_nanf("");
-                clist[qt] = a.cand + (((int64_t)r * a.nq_pad + q) * 4 + wd * 2 + h) * a.cap;
+                clist[qt] = a.cand + (((int64_t)(r - a.cand_range0) * a.nq_pad + q) * 4 + wd * 2 + h) * a.cap;
             }
             // make hipcc wait for the threshold loads HERE, before any LDS-DMA is in flight: its own
             // wait at the first use inside the tile epilogue would be vmcnt(0) and drain the DMA ring
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
             for (int qt = 0; qt < 4; ++qt) {
                 const int q = q0 + wq * 64 + qt * 16 + l15;
                 thr[qt] = (q < a.n_q) ? a.thr[q] : __builtin_nanf("");
-                clist[qt] = a.cand + (((int64_t)r * a.nq_pad + q) * 8 + wd * 4 + lq) * a.cap;
+                clist[qt] = a.cand + (((int64_t)(r - a.cand_range0) * a.nq_pad + q) * 8 + wd * 4 + lq) * a.cap;
             }
             asm volatile("" : "+v"(thr[0]), "+v"(thr[1]), "+v"(thr[2]), "+v"(thr[3]));
         }
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(256) void threshold_kernel(const float *__restrict_
 // with their real MFMA scores, whether or not a sub-list overflowed).  thr[q] = max(thr[q], kth - delta[q]).
 // grid = n_q, block = 256.
 __global__ __launch_bounds__(256) void threshold_update_kernel(const uint2 *__restrict__ cand, const uint32_t *__restrict__ cnt,
-                                                              int nsub, int sp, int nq_pad, int cap, int k, int compact,
+                                                              int nsub, int sp, int nq_pad, const CandLayout lay, int k, int compact,
                                                               const float *__restrict__ delta, float *__restrict__ thr) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_val[];   // [compact] orderable scores of the candidates found so far
     __shared__ uint32_t s_hist[256];
@@ -727,6 +727,8 @@ __global__ __launch_bounds__(256) void threshold_update_kernel(const uint2 *__re
     uint32_t my = 0, mymax = 0;
     for (int j = tid; j < nsub; j += blockDim.x) {
         uint32_t c = cnt[((int64_t)(j / sp) * nq_pad + q) * sp + (j % sp)];
+        int cap;
+        (void)cand_sublist(lay, j / sp, q, j % sp, nq_pad, sp, cap);
         if (c > (uint32_t)cap) c = (uint32_t)cap;
         s_cnt[j] = c;
         my += c;
@@ -738,7 +740,10 @@ __global__ __launch_bounds__(256) void threshold_update_kernel(const uint2 *__re
     }
     __syncthreads();
     if (s_total < (uint32_t)k) return;  // not enough rows seen yet: keep the sample threshold
-    auto sub_base = [&](int j) -> int64_t { return (((int64_t)(j / sp) * nq_pad + q) * sp + (j % sp)) * cap; };
+    auto sub_base = [&](int j) -> int64_t {
+        int cap;
+        return cand_sublist(lay, j / sp, q, j % sp, nq_pad, sp, cap);
+    };
     uint32_t kth;
     int need_eq;
     {
@@ -803,7 +808,7 @@ __device__ __forceinline__ void sweep_sublists(int tid, int n_lists, int first, 
 // dyn LDS: [dim bf16 query row][sub-list counts][sub-list offsets][rescore_cap u64 keys][compact x 8-byte candidates]
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__restrict__ cand, const uint32_t *__restrict__ cnt,
-                                                            int ranges, int sp, int nq_pad, int cap, int k, int rescore_cap, int compact,
+                                                            int ranges, int sp, int nq_pad, const CandLayout lay, int k, int rescore_cap, int compact,
                                                             int64_t n_rows, const float *__restrict__ delta,
                                                             const uint16_t *__restrict__ Q, const uint16_t *__restrict__ D,
                                                             int dim, int64_t id_offset, float *__restrict__ out_scores,
@@ -840,6 +845,8 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
     uint32_t my = 0, mymax = 0;
     for (int j = tid * per; j < min(ranges, tid * per + per); ++j) {
         uint32_t c = cnt[((int64_t)(j / sp) * nq_pad + q) * sp + (j % sp)];
+        int cap;
+        (void)cand_sublist(lay, j / sp, q, j % sp, nq_pad, sp, cap);
         if (c > (uint32_t)cap) {
             s_flag = 1;  // overflow: some survivors were dropped
             c = (uint32_t)cap;
@@ -873,8 +880,12 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
     if (tid == 0 && stat_cand) atomicAdd(stat_cand, (unsigned long long)s_total);
     bool bad = (s_flag != 0) || (s_total < (uint32_t)k);
 
-    // sub-list j = (range j / sp, wave-row / lane part j % sp) lives at (((j / sp) * nq_pad + q) * sp + (j % sp)) * cap
-    auto at = [&](int j, int sl) -> uint2 { return cand[(((int64_t)(j / sp) * nq_pad + q) * sp + (j % sp)) * cap + sl]; };
+    // sub-list j = (range j / sp, wave-row / lane part j % sp): cand_sublist() gives its first record and capacity
+    auto sub_base = [&](int j) -> int64_t {
+        int cap;
+        return cand_sublist(lay, j / sp, q, j % sp, nq_pad, sp, cap);
+    };
+    auto at = [&](int j, int sl) -> uint2 { return cand[sub_base(j) + sl]; };
     const int coll_cap = rescore_cap;
     uint32_t kth = 0;
     int need_eq = 0;
@@ -892,7 +903,7 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
             for (int t = 0; t < MAXPER; ++t) {
                 const int j = tid * per + t;
                 if (t < per && j < ranges) {
-                    const uint4 *src = reinterpret_cast<const uint4 *>(cand + (((int64_t)(j / sp) * nq_pad + q) * sp + (j % sp)) * cap);
+                    const uint4 *src = reinterpret_cast<const uint4 *>(cand + sub_base(j));
 #pragma unroll
                     for (int w = 0; w < 4; ++w) v[t][w] = src[w];
                 }
@@ -1126,7 +1137,7 @@ int launch_threshold(const float *gmax, int64_t n_groups, int n_q, int nq_pad, i
     return CCR_OK;
 }
 
-int launch_threshold_update(const uint2 *cand, const uint32_t *cnt, int nsub, int sp, int n_q, int nq_pad, int cap, int k,
+int launch_threshold_update(const uint2 *cand, const uint32_t *cnt, int nsub, int sp, int n_q, int nq_pad, const CandLayout &lay, int k,
                             const float *delta, float *thr, hipStream_t s) {
     if (nsub > 1024) {
         set_error("threshold_update: %d sub-lists exceed 1024", nsub);
@@ -1140,7 +1151,7 @@ int launch_threshold_update(const uint2 *cand, const uint32_t *cnt, int nsub, in
         const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&threshold_update_kernel), 128 * 1024);
         if (rc != CCR_OK) return rc;
     }
-    hipLaunchKernelGGL(threshold_update_kernel, dim3(n_q), dim3(256), lds, s, cand, cnt, nsub, sp, nq_pad, cap, k, compact, delta, thr);
+    hipLaunchKernelGGL(threshold_update_kernel, dim3(n_q), dim3(256), lds, s, cand, cnt, nsub, sp, nq_pad, lay, k, compact, delta, thr);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
 }
@@ -1161,7 +1172,7 @@ int select_compact_entries(int dim, int ranges, int rescore_cap, int64_t want) {
     return (int)std::min<int64_t>(std::max<int64_t>(want, 2048), fit) / 256 * 256;
 }
 
-int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, int sp, int n_q, int nq_pad, int cap, int k,
+int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, int sp, int n_q, int nq_pad, const CandLayout &lay, int k,
                           int rescore_cap, int compact, int64_t n_rows, const float *delta, const uint16_t *Q,
                           const uint16_t *D, int dim, int64_t id_offset, float *out_scores, int64_t *out_ids,
                           uint32_t *flag_count, uint32_t *flag_list, unsigned long long *stat_cand, hipStream_t s) {
@@ -1172,7 +1183,7 @@ int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, in
             const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kernel), SELECT_LDS_BUDGET + 8192);
             if (rc != CCR_OK) return rc;
         }
-        hipLaunchKernelGGL(kernel, dim3(n_q), dim3(threads), lds, s, cand, cnt, ranges, sp, nq_pad, cap, k, rescore_cap, compact,
+        hipLaunchKernelGGL(kernel, dim3(n_q), dim3(threads), lds, s, cand, cnt, ranges, sp, nq_pad, lay, k, rescore_cap, compact,
                            n_rows, delta, Q, D, dim, id_offset, out_scores, out_ids, flag_count, flag_list, stat_cand);
         CCR_LAUNCH_CHECK();
         return CCR_OK;

@@ -32,11 +32,11 @@ int launch_row_norms_bf16(const uint16_t *X, int64_t rows, int dim, float *norms
 int launch_threshold(const float *gmax, int64_t n_groups, int n_q, int nq_pad, int k, const float *qnorm,
                      const uint32_t *dmax_bits, int dim, float *thr, float *delta, hipStream_t s);
 int select_compact_entries(int dim, int ranges, int rescore_cap, int64_t want);
-int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, int sp, int n_q, int nq_pad, int cap, int k,
+int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, int sp, int n_q, int nq_pad, const CandLayout &lay, int k,
                           int rescore_cap, int compact, int64_t n_rows, const float *delta, const uint16_t *Q,
                           const uint16_t *D, int dim, int64_t id_offset, float *out_scores, int64_t *out_ids,
                           uint32_t *flag_count, uint32_t *flag_list, unsigned long long *stat_cand, hipStream_t s);
-int launch_threshold_update(const uint2 *cand, const uint32_t *cnt, int nsub, int sp, int n_q, int nq_pad, int cap, int k,
+int launch_threshold_update(const uint2 *cand, const uint32_t *cnt, int nsub, int sp, int n_q, int nq_pad, const CandLayout &lay, int k,
                             const float *delta, float *thr, hipStream_t s);
 // dense exact path.  qlist: query rows to score (nullptr: q_begin + qi); out_rows: destination rows of the select
 // (nullptr: q_begin + qi); count_dev (device, may be null): only the first *count_dev - q_begin entries of the list exist

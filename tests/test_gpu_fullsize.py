@@ -186,3 +186,30 @@ def test_prime_pantry_shaped_ranking_with_brand_blocks():
         assert [int(p[1:]) for p in got] == ref_i[c].tolist()
         assert np.array_equal(np.array(list(got.values()), np.float32).view(np.uint32), ref_s[c].view(np.uint32))
         assert ids[j] not in list(got)[: 1001 - longest]            # the query's own item is blocked (self-block)
+
+
+@pytest.mark.parametrize("k", [100, 1001])
+def test_clustered_non_iid_corpus_vs_oracle(k):
+    """bench.py --data clustered (1,024 Gaussian clusters, log-normal row norms, 3 % exact duplicate rows) at 400 k rows:
+    the fused path must stay on its fast route (no query sent to the exact fallback, survivors near the iid count) and
+    reproduce the oracle bit for bit on a query subsample -- duplicates are exact ties, ordered by id."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import gen_rows
+    from ccrec_amd import ops
+    n, nq, d = 400_000, 700, 768
+    D = ops.pack_bf16(gen_rows(n, d, 1234, "cuda", "clustered"))
+    Q = ops.pack_bf16(gen_rows(nq, d, 4321, "cuda", "clustered"))
+    norms = D.float().norm(dim=1)
+    assert float(norms.max() / norms.median()) > 2.5               # a real spread of row norms
+    index = ops.CorpusIndex(D)
+    s, i = index.search(Q, k, 2)
+    st = index.last_stats()
+    print(st)
+    assert st["path"] == 1 and st["n_fallback"] == 0
+    assert st["n_candidates"] / nq < 40 * k                       # iid data: ~17 k (k = 100) / ~8 k (k = 1001) per query
+    sub = np.r_[0:8, 346:354, 692:700]
+    _check_against_oracle(D, Q, s, i, k, sub)
+    s_np = s.cpu().numpy()
+    assert (np.diff(s_np, axis=1) == 0).any()                       # the duplicates do produce exact ties in the lists
