@@ -57,7 +57,18 @@ def both_overlapped():
     index.finish()
 
 
+def both_overlapped_search_first():
+    index.search(q, 100, defer=True)
+    side.wait_stream(torch.cuda.current_stream()) if False else None
+    with torch.cuda.stream(side):
+        ops.pack_bf16(src, out=other, max_norm=mx)
+    torch.cuda.current_stream().wait_stream(side)
+    index.finish()
+
+
 a, b, c, d = timed(search_only), timed(pack_only), timed(both_serial), timed(both_overlapped)
+e = timed(both_overlapped_search_first)
+print(f"overlapped with the search launched first: {e:.3f} ms")
 index.search(q, 100)
 print(f"rows={rows} queries={nq}: search {a:.3f} ms, pack {b:.3f} ms, serial {c:.3f} ms, overlapped {d:.3f} ms "
       f"(ideal max = {max(a, b):.3f}); main pass alone {index.last_stats()['ms_main']:.3f} ms")

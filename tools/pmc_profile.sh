@@ -13,7 +13,7 @@ for CTRS in "FETCH_SIZE" \
             "GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_LDS_UNALIGNED_STALL SQ_INSTS_VALU"; do
   i=$((i+1))
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d "$ROOT/$OUT/pass$i" -- \
-      python3 "$ROOT/bench.py" --steps 1 --warmup 1 --cpu-queries 0 "$@" > "$ROOT/$OUT/pass$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "$ROOT/$OUT/pass$i.log"; }
+      python3 "$ROOT/bench.py" --steps 1 --warmup 1 --cpu-queries 0 --no-secondary "$@" > "$ROOT/$OUT/pass$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "$ROOT/$OUT/pass$i.log"; }
   echo "pass $i done: $CTRS"
 done
 python3 "$ROOT/tools/pmc_summary.py" "$ROOT/$OUT" > "$ROOT/$OUT/summary.json"
