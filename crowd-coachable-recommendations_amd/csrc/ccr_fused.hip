@@ -1069,7 +1069,7 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
 // ---------------------------------------------------------------------------------------------
 // The dynamic-LDS opt-in (> 64 KiB) is a per-device function attribute: it is set the first time a kernel is launched
 // on a device and remembered per (kernel, device) -- not on every launch.
-static int ensure_dynamic_lds(const void *kernel, size_t lds) {
+int ensure_dynamic_lds(const void *kernel, size_t lds) {
     static std::mutex mu;
     static std::set<std::pair<const void *, int>> done;
     int dev = 0;
