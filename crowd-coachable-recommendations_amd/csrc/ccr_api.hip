@@ -9,7 +9,6 @@
 #include <mutex>
 #include <vector>
 
-#include "ccr_gemm_common.h"
 #include "ccr_index.h"
 #include "ccr_topk_device.h"
 
@@ -665,42 +664,6 @@ extern "C" int ccr_scores(const ccr_index *ix, const uint16_t *Q_bf16, int n_q, 
     CCR_REQUIRE((uintptr_t)Q_bf16 % 16 == 0, "ccr_scores: query pointer must be 16-byte aligned");
     if (mode == CCR_SCORES_CANONICAL)
         return launch_dense_scores(ix->D, ix->n_rows, ix->dim, Q_bf16, nullptr, 0, n_q, nullptr, out, (hipStream_t)stream);
-    if (mode == 2 || mode == 3) {   // diagnostics of the twelve-wave kernel: 2 = its raw scores, 3 = a filter pass that keeps nothing (timing)
-        CCR_REQUIRE(ix->dim % TILE_K == 0, "ccr_scores: dim %% 64 != 0");
-        GemmArgs g;
-        memset(&g, 0, sizeof(g));
-        g.D = ix->D;
-        g.n_rows = ix->n_rows;
-        g.dim = ix->dim;
-        g.Q = Q_bf16;
-        g.n_q = n_q;
-        g.nq_pad = (int)round_up(n_q, W12_TILE_Q);
-        g.qblocks = g.nq_pad / W12_TILE_Q;
-        g.n_vt = (ix->n_rows + W12_TILE_DOCS - 1) / W12_TILE_DOCS;
-        g.tile_stride = 1;
-        g.qgroups = 1;
-        for (int gq = 2; gq <= NUM_XCD; gq *= 2)
-            if (g.qblocks % gq == 0 && (size_t)(g.qblocks / (gq / 2)) * W12_TILE_Q * ix->dim * 2 > ((size_t)3 << 20)) g.qgroups = gq;
-        const int grid = std::max(NUM_XCD, ix->num_cu / NUM_XCD * NUM_XCD);
-        const int64_t want = std::max<int64_t>(NUM_XCD, (int64_t)grid * 6 / g.qblocks);
-        g.ranges = (int)round_up(std::min<int64_t>(want, g.n_vt), NUM_XCD);
-        if (mode == 3 && getenv("CCR_W12_RANGES")) g.ranges = atoi(getenv("CCR_W12_RANGES"));
-        if (mode == 3 && getenv("CCR_W12_QGROUPS")) g.qgroups = atoi(getenv("CCR_W12_QGROUPS"));
-        g.range_begin = 0;
-        g.range_end = g.ranges;
-        if (mode == 2) {
-            g.store = out;
-            return launch_gemm12_store(g, grid, (hipStream_t)stream);
-        }
-        // mode 3: `out` is scratch of at least nq_pad * (1 + 16 * ranges) floats: thresholds (NaN: nothing passes) + counts
-        float *thr = out;
-        CCR_HIP_CHECK(hipMemsetAsync(thr, 0xff, (size_t)g.nq_pad * 4, (hipStream_t)stream));
-        g.thr = thr;
-        g.cnt = reinterpret_cast<uint32_t *>(out + g.nq_pad);
-        g.cand = reinterpret_cast<uint2 *>(out);
-        g.cap = 0;
-        return launch_gemm12_filter(g, grid, (hipStream_t)stream);
-    }
     CCR_REQUIRE(mode == CCR_SCORES_MFMA, "ccr_scores: unknown mode %d", mode);
     CCR_REQUIRE(ix->dim % TILE_K == 0, "ccr_scores: CCR_SCORES_MFMA needs dim %% 64 == 0 (dim=%d)", ix->dim);
     GemmArgs g;

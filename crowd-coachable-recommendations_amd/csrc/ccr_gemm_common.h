@@ -23,14 +23,6 @@ constexpr int SUB_BYTES = (TILE_DOCS + TILE_Q) * SUB_K * 2;  // 32768
 constexpr int SUB_Q_REGION = TILE_DOCS * SUB_K * 2;           // 16384
 constexpr int RING = 4;
 
-// twelve-wave kernel (ccr_fused12.hip): 384 corpus rows x 192 queries, [384 x 64 B][192 x 64 B] per sub-stage
-constexpr int W12_TILE_DOCS = 384;
-constexpr int W12_TILE_Q = 192;
-constexpr int W12_THREADS = 768;
-constexpr int W12_SUB_BYTES = (W12_TILE_DOCS + W12_TILE_Q) * SUB_K * 2;  // 36864
-constexpr int W12_Q_REGION = W12_TILE_DOCS * SUB_K * 2;                   // 24576
-constexpr int W12_SUBLISTS = 16;   // candidate sub-lists per (range, query): 4 wave rows x 4 lane quads
-
 // hipcc neither waits for LDS-DMA in __syncthreads() nor counts it for us: every wait is explicit
 #define CCR_BARRIER() asm volatile("s_barrier" ::: "memory")
 #define CCR_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")

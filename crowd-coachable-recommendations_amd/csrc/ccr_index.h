@@ -28,8 +28,6 @@ int launch_gemm_gmax(const GemmArgs &a, int grid, hipStream_t s);
 int launch_gemm_store(const GemmArgs &a, int grid, hipStream_t s);
 int launch_gemm16_filter(const GemmArgs &a, int grid, hipStream_t s);
 int launch_gemm16_store(const GemmArgs &a, int grid, hipStream_t s);
-int launch_gemm12_filter(const GemmArgs &a, int grid, hipStream_t s);   // twelve-wave kernel (ccr_fused12.hip)
-int launch_gemm12_store(const GemmArgs &a, int grid, hipStream_t s);
 int ensure_dynamic_lds(const void *kernel, size_t lds);   // per (kernel, device) opt-in to > 64 KiB of dynamic LDS
 int launch_row_norms_bf16(const uint16_t *X, int64_t rows, int dim, float *norms, uint32_t *max_bits, hipStream_t s);
 int launch_threshold(const float *gmax, int64_t n_groups, int n_q, int nq_pad, int k, const float *qnorm,
