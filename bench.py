@@ -49,8 +49,9 @@ def parse():
     ap.add_argument("--queries", type=int, default=N_Q)
     ap.add_argument("--dim", type=int, default=DIM)
     ap.add_argument("--k", type=int, default=TOP_K)
-    ap.add_argument("--data", default="gaussian", choices=["gaussian", "clustered"],
-                    help="gaussian: iid N(0, 1/dim) rows (BASELINE.md); clustered: 1,024 clusters, log-normal norms, 3 %% duplicates")
+    ap.add_argument("--data", default="gaussian", choices=["gaussian", "clustered", "sorted"],
+                    help="gaussian: iid N(0, 1/dim) rows (BASELINE.md); clustered: 1,024 clusters, log-normal norms, 3 %% duplicates; "
+                         "sorted: the same with every cluster's rows CONTIGUOUS (a corpus in topical order)")
     ap.add_argument("--cpu-queries", type=int, default=64, help="query sample of the CPU baseline (0 = skip)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the MS-MARCO-scale and k = 1001 side runs")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU rehearsal of N > 1)")
@@ -81,12 +82,12 @@ def host_threads():
 
 def gen_rows(n, dim, seed, device, data="gaussian", chunk=262144):
     """fp32 rows generated on device in chunks.  gaussian: N(0,1) / sqrt(dim).
-    clustered: 1,024 cluster centres (seeded, shared by corpus and queries), row = 0.8 centre + 0.6 noise (unit scale),
+    clustered / sorted: 1,024 cluster centres (seeded, shared by corpus and queries), row = 0.8 centre + 0.6 noise (unit scale),
     times a log-normal norm (sigma 0.35); 3 % of the rows of a chunk are exact duplicates of other rows of that chunk."""
     g = torch.Generator(device=device).manual_seed(seed)
     out = torch.empty(n, dim, dtype=torch.float32, device=device)
     centres = None
-    if data == "clustered":
+    if data in ("clustered", "sorted"):
         gc = torch.Generator(device=device).manual_seed(777)
         centres = torch.randn(1024, dim, generator=gc, device=device) * dim ** -0.5
     for lo in range(0, n, chunk):
@@ -95,6 +96,8 @@ def gen_rows(n, dim, seed, device, data="gaussian", chunk=262144):
         x = torch.randn(m, dim, generator=g, device=device) * dim ** -0.5
         if centres is not None:
             cid = torch.randint(0, 1024, (m,), generator=g, device=device)
+            if data == "sorted" and seed == 1234:   # corpus rows in topical order: cluster c owns rows [c n / 1024, (c + 1) n / 1024)
+                cid = (torch.arange(lo, hi, device=device, dtype=torch.int64) * 1024 // n).clamp_(max=1023)
             x = 0.8 * centres[cid] + 0.6 * x
             x *= torch.exp(0.35 * torch.randn(m, 1, generator=g, device=device))
             ndup = int(0.03 * m)
@@ -281,7 +284,8 @@ def main():
                    else f"queries/sec, exhaustive inner-product top-{args.k} retrieval ({args.rows:,} x {args.dim} bf16 corpus)"),
         "value": round(r["qps"], 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(r["ms_per_step"], 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic" if args.data == "gaussian" else "synthetic (clustered, log-normal norms, 3% duplicates)",
+        "dtype": "bf16", "data": {"gaussian": "synthetic", "clustered": "synthetic (clustered, log-normal norms, 3% duplicates)",
+                                   "sorted": "synthetic (clustered in topical row order, log-normal norms, 3% duplicates)"}[args.data],
         "config": {"workload": workload, "corpus_rows": args.rows,
                    "dim": args.dim, "queries": args.queries, "k": args.k,
                    "step": "pack corpus shard fp32->bf16 + index build + pack queries + fused MFMA score/top-k"

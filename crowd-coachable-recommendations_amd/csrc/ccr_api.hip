@@ -222,9 +222,12 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu, c
         // An overflowing sub-list only flags its query for the exact path, so the model needs to be safe, not a bound.
         const double fs = 1.0 / ratio, nlists = (double)R * p.sublists;
         const double xk = 1.25 * ((double)k + 4.75 * sqrt((double)k) + 8.0) / (double)k;
+        // Allowance: one WHOLE tile may pass for a query (a corpus in topical order: all 256 rows of a tile belong to the
+        // query's cluster); that is TILE_DOCS / sublists rows for one sub-list on top of its regular share.
+        const int64_t tile_rows = TILE_DOCS / p.sublists;
         auto cap_for = [&](double g) -> int {
             const double mean = xk * (double)k / (g * nlists);
-            const int64_t c = (int64_t)(mean + 6.0 * sqrt(mean)) + 16;
+            const int64_t c = (int64_t)(mean + 6.0 * sqrt(mean)) + 16 + tile_rows;   // the model's share PLUS one whole tile
             return (int)round_up(std::min<int64_t>(std::max<int64_t>(c, 16), 8192), 4);
         };
         const double fa = (double)RA / (double)R, fb = (double)(RB > RA ? RB - RA : 0) / (double)R;
@@ -270,6 +273,8 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu, c
         p.off_flag = take(64 + (size_t)n_q * 4);
         p.dense_rows_per_chunk = FALLBACK_ROWS;
         p.off_dense = take((size_t)FALLBACK_ROWS * n_rows * 4);
+        // retry pass of flagged queries: compact query rows, thresholds + margins, the two lists, counts, second flag area
+        p.off_retry = take((size_t)p.nq_pad * dim * 2 + (size_t)p.nq_pad * 8 + (size_t)n_q * 12 + 64 + 64 + (size_t)n_q * 4 + 256 * 8);
     } else {
         int64_t rows = (int64_t)(DENSE_SCRATCH_TARGET / ((size_t)n_rows * 4));
         rows = std::min<int64_t>(std::max<int64_t>(rows, 1), n_q);
@@ -427,8 +432,42 @@ static int dense_for_list(const ccr_index *ix, const uint16_t *Q, const uint32_t
     return CCR_OK;
 }
 
-// Completion of a fused search: read how many queries the select stage flagged, run the exact dense path for those the
-// on-stream chunk (asynchronous mode) did not cover, fill the statistics.  Synchronises the stream.
+// The main pass over all ranges: one launch per phase (segment of the candidate area), the thresholds re-tightened from
+// the candidates found so far between two launches when `retighten` is set.
+static int run_main_pass(const ccr_index *ix, const Plan &p, GemmArgs gm, uint2 *cand, uint32_t *cnt, float *thr, const float *delta,
+                         int n_q, int k, bool retighten, hipStream_t s) {
+    const int bounds[4] = {0, p.ranges_a, p.ranges_b, p.ranges};
+    int done = 0;
+    for (int ph = 1; ph < 4; ++ph) {
+        if (bounds[ph] <= done) continue;
+        if (done > 0 && retighten) {
+            const int rc = launch_threshold_update(cand, cnt, done * p.sublists, p.sublists, n_q, p.nq_pad, p.cand, k, delta, thr, s);
+            if (rc != CCR_OK) return rc;
+        }
+        gm.range_begin = done;
+        gm.range_end = bounds[ph];
+        {   // this launch's segment of the candidate area (a launch never straddles two segments)
+            int cap_seg = 0;
+            const long long first = cand_sublist(p.cand, done, 0, 0, p.nq_pad, p.sublists, cap_seg);
+            gm.cand = cand + first;
+            gm.cap = cap_seg;
+            gm.cand_range0 = done;
+        }
+        const int rc = p.mfma16 ? launch_gemm16_filter(gm, p.grid, s) : launch_gemm_filter(gm, p.grid, s);
+        if (rc != CCR_OK) return rc;
+        done = bounds[ph];
+    }
+    return CCR_OK;
+}
+
+// Completion of a fused search: read how many queries the select stage flagged and re-do them.
+//   * a query whose candidates were dropped (sub-list overflow: a corpus in topical order floods the lists of the query's
+//     own cluster) is RETRIED on the fused path: its truncated lists still hold real rows, so the k-th largest of them is a
+//     valid -- and now nearly final -- threshold; the flagged queries are compacted and one more main pass + select runs
+//     for them alone (about one corpus pass per 256 flagged queries instead of 1.8 ms of fp64 scoring per query);
+//   * a query the selection cannot finish (mass ties around the cut) and a query flagged again by the retry take the exact
+//     dense path.
+// Synchronises the stream.
 static int search_complete(ccr_index *ix) {
     auto &pd = ix->pending;
     const Plan &p = ix->plan;
@@ -459,17 +498,133 @@ static int search_complete(ccr_index *ix) {
     ix->stats.cap = p.cap;
     ix->stats.sublists = p.sublists;
     ix->stats.n_candidates = (int64_t)host.ncand;
-    const int done_on_stream = was_async ? FALLBACK_ROWS : 0;
-    if ((int)host.nflag > done_on_stream) {
-        const uint32_t *flag_list = (const uint32_t *)(ws + p.off_flag + 64);
-        int rc = dense_for_list(ix, pd.Q, flag_list + done_on_stream, 0, (int)host.nflag - done_on_stream, pd.k,
-                                (float *)(ws + p.off_dense), p.dense_rows_per_chunk, pd.out_scores, pd.out_ids, s);
+    const int begin = was_async ? std::min<int>(FALLBACK_ROWS, (int)host.nflag) : 0;   // the on-stream chunk took these
+    ix->stats.n_dense = begin;
+    if ((int)host.nflag <= begin) return CCR_OK;
+
+    const int n_q = pd.n_q, k = pd.k;
+    uint32_t *flag_list = (uint32_t *)(ws + p.off_flag + 64);
+    float *thr = (float *)(ws + p.off_thr);
+    float *delta = thr + p.nq_pad;
+    uint32_t *cnt = (uint32_t *)(ws + p.off_cnt);
+    uint2 *cand = (uint2 *)(ws + p.off_cand);
+    float *dense_scratch = (float *)(ws + p.off_dense);
+    // retry area: [Q2 nq_pad x dim bf16][thr2 nq_pad][delta2 nq_pad][retry_list n_q][dense_list n_q][counts 64 B][flag2 64 B + n_q]
+    char *ra = ws + p.off_retry;
+    auto carve = [&](size_t bytes) {
+        char *o = ra;
+        ra += (bytes + 255) / 256 * 256;
+        return o;
+    };
+    uint16_t *Q2 = (uint16_t *)carve((size_t)p.nq_pad * ix->dim * 2);
+    float *thr2 = (float *)carve((size_t)p.nq_pad * 4);
+    float *delta2 = (float *)carve((size_t)p.nq_pad * 4);
+    uint32_t *retry_list = (uint32_t *)carve((size_t)n_q * 4);
+    uint32_t *dense_list = (uint32_t *)carve((size_t)n_q * 4);
+    uint32_t *counts = (uint32_t *)carve(64);
+    uint32_t *flag2 = (uint32_t *)carve(64 + (size_t)n_q * 4);
+
+    uint32_t *list_b = (uint32_t *)carve((size_t)n_q * 4);   // second retry list (the rounds ping-pong between the two)
+    int rc = launch_partition_flags(flag_list, begin, (int)host.nflag, retry_list, dense_list, counts, s);
+    if (rc != CCR_OK) return rc;
+    uint32_t hc[2] = {0, 0};
+    CCR_HIP_CHECK(hipMemcpyAsync(hc, counts, 8, hipMemcpyDeviceToHost, s));
+    CCR_HIP_CHECK(hipStreamSynchronize(s));
+    int n_cur = (int)hc[0], n_dense = (int)hc[1];
+    uint32_t *cur = retry_list, *nxt = list_b;
+    const int64_t area_recs = (int64_t)((p.off_flag - p.off_cand) / 8);   // records the candidate area holds
+    const int nsub_all = p.ranges * p.sublists;
+    CandLayout prev_lay = p.cand;
+    int prev_n = n_q, prev_pad = p.nq_pad;
+    for (int round = 0; round < 3 && n_cur > 0 && nsub_all <= 1024; ++round) {
+        // thresholds re-tightened from everything the previous attempt recorded (truncated lists included)
+        if (round == 0) {
+            rc = launch_threshold_update(cand, cnt, nsub_all, p.sublists, n_q, p.nq_pad, p.cand, k, delta, thr, s);
+            if (rc != CCR_OK) return rc;
+        } else {
+            rc = launch_threshold_update(cand, cnt, nsub_all, p.sublists, prev_n, prev_pad, prev_lay, k, delta2, thr2, s);
+            if (rc != CCR_OK) return rc;
+            rc = launch_scatter_thresholds(nxt, prev_n, thr2, thr, s);   // nxt still holds the previous round's list
+            if (rc != CCR_OK) return rc;
+        }
+        rc = launch_gather_queries(pd.Q, ix->dim, cur, n_cur, thr, delta, Q2, thr2, delta2, s);
         if (rc != CCR_OK) return rc;
-        CCR_HIP_CHECK(hipEventRecord(ix->ev[6], s));
+        // the flagged queries alone: fewer queries share the candidate area, so every sub-list gets a larger capacity
+        const int pad2 = (int)round_up(n_cur, TILE_Q);
+        int64_t cap2 = area_recs / ((int64_t)nsub_all * pad2);
+        cap2 = std::min<int64_t>(8192, cap2 / 4 * 4);
+        if (cap2 < 16) break;
+        CandLayout lay2;
+        memset(&lay2, 0, sizeof(lay2));
+        lay2.nseg = 1;
+        lay2.seg_end[0] = lay2.seg_end[1] = lay2.seg_end[2] = INT32_MAX;
+        lay2.cap[0] = lay2.cap[1] = lay2.cap[2] = (int)cap2;
+        CCR_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)nsub_all * pad2 * 4, s));
+        CCR_HIP_CHECK(hipMemsetAsync(flag2, 0, 64, s));
+        GemmArgs g;
+        memset(&g, 0, sizeof(g));
+        g.D = ix->D;
+        g.n_rows = ix->n_rows;
+        g.dim = ix->dim;
+        g.Q = Q2;
+        g.n_q = n_cur;
+        g.nq_pad = pad2;
+        g.qblocks = pad2 / TILE_Q;
+        g.qgroups = pick_qgroups(g.qblocks, ix->dim, ix->knobs);
+        g.stagger = ix->knobs.stagger;
+        g.n_vt = p.tiles;
+        g.tile_stride = 1;
+        g.ranges = p.ranges;
+        g.thr = thr2;
+        g.cnt = cnt;
+        g.cand = cand;
+        g.cap = (int)cap2;
+        g.cand_range0 = 0;
+        g.range_begin = 0;
+        g.range_end = p.ranges;
+        rc = p.mfma16 ? launch_gemm16_filter(g, p.grid, s) : launch_gemm_filter(g, p.grid, s);
+        if (rc != CCR_OK) return rc;
+        rc = launch_select_rescore(cand, cnt, nsub_all, p.sublists, n_cur, pad2, lay2, k, p.rescore_cap, p.select_compact, ix->n_rows, delta2,
+                                   Q2, ix->D, ix->dim, ix->offset, pd.out_scores, pd.out_ids, flag2, flag2 + 16, nullptr, cur, s);
+        if (rc != CCR_OK) return rc;
+        ix->stats.n_retried += n_cur;
+        uint32_t again = 0;
+        CCR_HIP_CHECK(hipMemcpyAsync(&again, flag2, 4, hipMemcpyDeviceToHost, s));
         CCR_HIP_CHECK(hipStreamSynchronize(s));
-        CCR_HIP_CHECK(hipEventElapsedTime(&ix->stats.ms_fallback, ix->ev[5], ix->ev[6]));
-        ix->stats.ms_total += ix->stats.ms_fallback;
+        prev_lay = lay2;
+        prev_n = n_cur;
+        prev_pad = pad2;
+        std::swap(cur, nxt);   // nxt = this round's list (needed by the next scatter), cur = buffer for the next list
+        if (again == 0) {
+            n_cur = 0;
+            break;
+        }
+        rc = launch_partition_flags(flag2 + 16, 0, (int)again, cur, dense_list + n_dense, counts, s);
+        if (rc != CCR_OK) return rc;
+        CCR_HIP_CHECK(hipMemcpyAsync(hc, counts, 8, hipMemcpyDeviceToHost, s));
+        CCR_HIP_CHECK(hipStreamSynchronize(s));
+        n_dense += (int)hc[1];
+        if ((int)hc[0] >= prev_n) {   // no progress (every retried query overflowed again): the dense path takes them
+            n_cur = (int)hc[0];
+            break;
+        }
+        n_cur = (int)hc[0];
     }
+    int n_again = 0;
+    if (n_cur > 0) {   // still flagged after the retry rounds (or no retry possible)
+        rc = dense_for_list(ix, pd.Q, cur, 0, n_cur, k, dense_scratch, p.dense_rows_per_chunk, pd.out_scores, pd.out_ids, s);
+        if (rc != CCR_OK) return rc;
+        n_again = n_cur;
+    }
+    if (n_dense > 0) {
+        rc = dense_for_list(ix, pd.Q, dense_list, 0, n_dense, k, dense_scratch, p.dense_rows_per_chunk, pd.out_scores, pd.out_ids, s);
+        if (rc != CCR_OK) return rc;
+    }
+    ix->stats.n_dense += n_again + n_dense;
+    CCR_HIP_CHECK(hipEventRecord(ix->ev[6], s));
+    CCR_HIP_CHECK(hipStreamSynchronize(s));
+    CCR_HIP_CHECK(hipEventElapsedTime(&ix->stats.ms_fallback, ix->ev[5], ix->ev[6]));
+    ix->stats.ms_total += ix->stats.ms_fallback;
     return CCR_OK;
 }
 
@@ -582,32 +737,8 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
         gm.store = reinterpret_cast<float *>(stamps);
     }
     CCR_HIP_CHECK(hipEventRecord(ix->ev[3], s));
-    auto main_pass = [&](const GemmArgs &ga) {
-        if (p.mfma16) return launch_gemm16_filter(ga, p.grid, s);
-        return launch_gemm_filter(ga, p.grid, s);
-    };
-    // progressive thresholds: launches over the range sets [0, ra), [ra, rb), [rb, R) with a re-tightening in between
-    const int bounds[4] = {0, p.ranges_a, p.ranges_b, p.ranges};
-    int done = 0;
-    for (int ph = 1; ph < 4; ++ph) {
-        if (bounds[ph] <= done) continue;
-        if (done > 0) {
-            rc = launch_threshold_update(cand, cnt, done * p.sublists, p.sublists, n_q, p.nq_pad, p.cand, k, delta, thr, s);
-            if (rc != CCR_OK) return rc;
-        }
-        gm.range_begin = done;
-        gm.range_end = bounds[ph];
-        {   // this launch's segment of the candidate area (a launch never straddles two segments)
-            int cap_seg = 0;
-            const long long first = cand_sublist(p.cand, done, 0, 0, p.nq_pad, p.sublists, cap_seg);
-            gm.cand = cand + first;
-            gm.cap = cap_seg;
-            gm.cand_range0 = done;
-        }
-        rc = main_pass(gm);
-        if (rc != CCR_OK) return rc;
-        done = bounds[ph];
-    }
+    rc = run_main_pass(ix, p, gm, cand, cnt, thr, delta, n_q, k, true, s);
+    if (rc != CCR_OK) return rc;
     CCR_HIP_CHECK(hipEventRecord(ix->ev[4], s));
     if (want_stamps) {
         std::vector<unsigned long long> h((size_t)p.grid * 64);
@@ -631,7 +762,7 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
 
     rc = launch_select_rescore(cand, cnt, p.ranges * p.sublists, p.sublists, n_q, p.nq_pad, p.cand, k, p.rescore_cap, p.select_compact, ix->n_rows, delta,
                                Q_bf16, ix->D, ix->dim,
-                               ix->offset, out_scores, out_ids, flag_count, flag_list, stat_cand, s);
+                               ix->offset, out_scores, out_ids, flag_count, flag_list, stat_cand, nullptr, s);
     if (rc != CCR_OK) return rc;
     CCR_HIP_CHECK(hipEventRecord(ix->ev[5], s));
 

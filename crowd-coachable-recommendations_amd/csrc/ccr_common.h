@@ -43,6 +43,7 @@ constexpr int TILE_K = 64;          // K step (bf16 elements) = 128 B per row
 constexpr int GEMM_THREADS = 512;   // 8 waves: 2 (doc halves) x 4 (query quarters)
 constexpr int GROUPS_PER_TILE = 16; // group maxima per (sample tile, query): 2 wave rows x 4 MFMA tiles x 2 lane halves
 constexpr int MAX_K = 4096;
+constexpr uint32_t FLAG_DENSE = 0x80000000u;   // flagged-list entry: the query needs the exact dense path (not a retry)
 constexpr int NUM_XCD = 8;
 
 // Candidate storage of the main pass.  The ranges of one launch (phase) form a segment with its own sub-list capacity:
@@ -81,7 +82,7 @@ struct Plan {
     int mfma16;           // 1: main pass on the 16x16x32 MFMA kernel
     int sublists;         // candidate sub-lists per (range, query): 4 (32x32x16 kernel) or 8 (16x16x32 kernel)
     // workspace layout (byte offsets)
-    size_t off_qnorm, off_thr, off_gmax, off_cnt, off_cand, off_flag, off_dense, total;
+    size_t off_qnorm, off_thr, off_gmax, off_cnt, off_cand, off_flag, off_dense, off_retry, total;
     int64_t dense_rows_per_chunk;  // queries per dense chunk
 };
 

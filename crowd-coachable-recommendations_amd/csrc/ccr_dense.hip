@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void dense_scores_kernel(const uint16_t *__res
     if (drow > n_rows - 1) drow = n_rows - 1;
     int qi = q0 + srow;
     if (qi > nq_chunk - 1) qi = nq_chunk - 1;
-    const int qrow = qlist ? (int)qlist[qi] : q_begin + qi;
+    const int qrow = qlist ? (int)(qlist[qi] & ~FLAG_DENSE) : q_begin + qi;
     const uint16_t *dsrc = D + drow * dim + schunk * 8;
     const uint16_t *qsrc = Q + (int64_t)qrow * dim + schunk * 8;
     // compute role
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void dense_select_kernel(const float *__restri
     __syncthreads();
     block_bitonic_sort_desc(s_keys, kp2);
 
-    const int64_t orow = out_rows ? (int64_t)out_rows[qi] : (int64_t)(q_begin + qi);
+    const int64_t orow = out_rows ? (int64_t)(out_rows[qi] & ~FLAG_DENSE) : (int64_t)(q_begin + qi);
     for (int i = tid; i < k; i += blockDim.x) {
         const unsigned long long key = s_keys[i];
         out_scores[orow * k + i] = key_score(key);

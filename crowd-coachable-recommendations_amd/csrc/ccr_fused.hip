@@ -744,30 +744,44 @@ __global__ __launch_bounds__(256) void threshold_update_kernel(const uint2 *__re
         int cap;
         return cand_sublist(lay, j / sp, q, j % sp, nq_pad, sp, cap);
     };
-    uint32_t kth;
+    uint32_t kth = 0;
     int need_eq;
     {
         // The sub-lists are sparse: one sweep over (sub-list, slot < longest list) with independent loads gathers the
         // scores into LDS, the four radix passes then never touch global memory.  If more candidates exist than the LDS
-        // holds, the first `compact` the sweep meets are enough: the k-th largest score of ANY k or more real rows is a
-        // valid lower bound of the query's k-th largest score.
+        // holds, the first `compact` the sweep meets give a first bound (the k-th largest score of ANY k or more real rows
+        // is a valid lower bound of the query's k-th largest score); the sweep is then repeated over the records at or above
+        // that bound -- far fewer -- until they all fit, so the final bound is the k-th largest of EVERYTHING recorded (a
+        // corpus in topical order leaves the good rows in a few sub-lists that a first-come subset would miss).
         const int maxc = (int)s_maxc;
-        for (int i = tid; i < nsub * maxc; i += blockDim.x) {
-            const int j = i / maxc, sl = i - j * maxc;
-            if ((uint32_t)sl < s_cnt[j]) {
-                const uint32_t o = f32_orderable(__uint_as_float(cand[sub_base(j) + sl].x));
-                const uint32_t p = atomicAdd(&s_fill, 1u);
-                if (p < (uint32_t)compact) s_val[p] = o;
+        uint32_t keep = 0u;   // orderable bound: records below it are skipped
+        for (int round = 0; round < 4; ++round) {
+            __syncthreads();
+            if (tid == 0) s_fill = 0;
+            __syncthreads();
+            for (int i = tid; i < nsub * maxc; i += blockDim.x) {
+                const int j = i / maxc, sl = i - j * maxc;
+                if ((uint32_t)sl < s_cnt[j]) {
+                    const uint32_t o = f32_orderable(__uint_as_float(cand[sub_base(j) + sl].x));
+                    if (o >= keep) {
+                        const uint32_t p = atomicAdd(&s_fill, 1u);
+                        if (p < (uint32_t)compact) s_val[p] = o;
+                    }
+                }
             }
+            __syncthreads();
+            const uint32_t filled = s_fill;
+            const int M = (int)(filled < (uint32_t)compact ? filled : (uint32_t)compact);
+            if (M < k) break;   // (ties at the bound cut off by the LDS size: keep the bound of the previous round)
+            block_radix_select(
+                [&](int64_t i, bool &skip) -> uint32_t {
+                    (void)skip;
+                    return s_val[i];
+                },
+                (int64_t)M, k, s_hist, s_ctl, kth, need_eq);
+            if (filled <= (uint32_t)compact || kth <= keep) break;   // everything at or above the bound was seen / no progress
+            keep = kth;
         }
-        __syncthreads();
-        const int M = (int)(s_total < (uint32_t)compact ? s_total : (uint32_t)compact);
-        block_radix_select(
-            [&](int64_t i, bool &skip) -> uint32_t {
-                (void)skip;
-                return s_val[i];
-            },
-            (int64_t)M, k, s_hist, s_ctl, kth, need_eq);
     }
     if (tid == 0) {
         const float t1 = orderable_to_f32(kth) - delta[q];
@@ -814,7 +828,8 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
                                                             int dim, int64_t id_offset, float *__restrict__ out_scores,
                                                             int64_t *__restrict__ out_ids, uint32_t *__restrict__ flag_count,
                                                             uint32_t *__restrict__ flag_list,
-                                                            unsigned long long *__restrict__ stat_cand) {
+                                                            unsigned long long *__restrict__ stat_cand,
+                                                            const uint32_t *__restrict__ out_rows) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
     const size_t cnt_bytes = ((size_t)(ranges + 1) * 4 + 15) & ~(size_t)15;
     uint16_t *s_q = reinterpret_cast<uint16_t *>(sm);
@@ -878,7 +893,12 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
         __syncthreads();
     }
     if (tid == 0 && stat_cand) atomicAdd(stat_cand, (unsigned long long)s_total);
+    // A query the fused path cannot finish is flagged.  Two kinds: candidates were DROPPED (a sub-list overflowed, or fewer
+    // than k rows passed) -- the caller retries the main pass for it under the re-tightened threshold its truncated lists
+    // still give (FLAG_RETRY); or the selection itself cannot be done here (mass ties around the cut, k beyond the LDS
+    // budget) -- only the exact dense path helps (FLAG_DENSE, the top bit of the list entry).
     bool bad = (s_flag != 0) || (s_total < (uint32_t)k);
+    bool dense_only = (s_flag == 0) && bad;   // nothing was dropped and still fewer than k rows passed: a retry cannot find more
 
     // sub-list j = (range j / sp, wave-row / lane part j % sp): cand_sublist() gives its first record and capacity
     auto sub_base = [&](int j) -> int64_t {
@@ -926,7 +946,7 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
         __syncthreads();
         n_lds = (int)s_total;
     } else if (!bad && compact < k) {
-        bad = true;   // the LDS budget cannot even hold k records (huge dim * k): exact dense path
+        bad = dense_only = true;   // the LDS budget cannot even hold k records (huge dim * k): exact dense path
     } else if (!bad) {
         // More candidates than the LDS holds.  The k-th largest score of ANY `compact` of them is a valid lower bound of
         // the query's k-th largest, so: keep the first `compact` records that pass the current bound (none at first),
@@ -964,7 +984,7 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
         if (fits)
             n_lds = (int)s_fill;
         else
-            bad = true;   // (near-)constant scores or k close to the LDS capacity: the exact dense path takes the query
+            bad = dense_only = true;   // (near-)constant scores or k close to the LDS capacity: the exact dense path takes the query
     }
     if (!bad) {
         const int M = n_lds;
@@ -983,12 +1003,12 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
             }
         }
         __syncthreads();
-        if (s_ncoll > (uint32_t)coll_cap) bad = true;  // mass ties around the cut
+        if (s_ncoll > (uint32_t)coll_cap) bad = dense_only = true;  // mass ties around the cut
     }
     if (bad) {
         if (tid == 0) {
             const uint32_t p = atomicAdd(flag_count, 1u);
-            flag_list[p] = (uint32_t)q;
+            flag_list[p] = (out_rows ? out_rows[q] : (uint32_t)q) | (dense_only ? FLAG_DENSE : 0u);
         }
         return;
     }
@@ -1059,10 +1079,53 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
         }
     }
     block_bitonic_sort_desc(s_keys, np2);
+    const int64_t orow = out_rows ? (int64_t)out_rows[q] : (int64_t)q;   // retry pass: compacted query i -> original row
     for (int i = tid; i < k; i += blockDim.x) {
         const unsigned long long key = s_keys[i];
-        out_scores[(int64_t)q * k + i] = key_score(key);
-        out_ids[(int64_t)q * k + i] = id_offset + (int64_t)key_idx(key);
+        out_scores[orow * k + i] = key_score(key);
+        out_ids[orow * k + i] = id_offset + (int64_t)key_idx(key);
+    }
+}
+
+// Retry pass set-up: split the flagged list into the queries to retry and the ones that need the dense path, and gather
+// the retried queries' rows, thresholds and margins into compact arrays.  One workgroup; counts[0] = retried, counts[1] = dense.
+__global__ __launch_bounds__(256) void partition_flags_kernel(const uint32_t *__restrict__ flags, int begin, int n,
+                                                             uint32_t *__restrict__ retry_list, uint32_t *__restrict__ dense_list,
+                                                             uint32_t *__restrict__ counts) {   // dense_list: the caller's append position
+    __shared__ uint32_t s_n[2];
+    if (threadIdx.x == 0) s_n[0] = s_n[1] = 0;
+    __syncthreads();
+    // order inside the two lists does not matter (each entry is a whole query)
+    for (int i = begin + threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t f = flags[i];
+        if (f & FLAG_DENSE)
+            dense_list[atomicAdd(&s_n[1], 1u)] = f & ~FLAG_DENSE;
+        else
+            retry_list[atomicAdd(&s_n[0], 1u)] = f;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) counts[threadIdx.x] = s_n[threadIdx.x];
+}
+
+// thr[list[i]] = thr2[i]: the re-tightened thresholds of a retry round go back to the original query order
+__global__ __launch_bounds__(256) void scatter_thresholds_kernel(const uint32_t *__restrict__ list, int n, const float *__restrict__ thr2,
+                                                                float *__restrict__ thr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) thr[list[i]] = thr2[i];
+}
+
+__global__ __launch_bounds__(256) void gather_queries_kernel(const uint16_t *__restrict__ Q, int dim, const uint32_t *__restrict__ list,
+                                                            int n, const float *__restrict__ thr, const float *__restrict__ delta,
+                                                            uint16_t *__restrict__ Q2, float *__restrict__ thr2,
+                                                            float *__restrict__ delta2) {
+    const int i = blockIdx.x;
+    if (i >= n) return;
+    const uint32_t q = list[i];
+    for (int c = threadIdx.x; c < dim / 8; c += blockDim.x)
+        reinterpret_cast<uint4 *>(Q2 + (int64_t)i * dim)[c] = reinterpret_cast<const uint4 *>(Q + (int64_t)q * dim)[c];
+    if (threadIdx.x == 0) {
+        thr2[i] = thr[q];
+        delta2[i] = delta[q];
     }
 }
 
@@ -1172,10 +1235,33 @@ int select_compact_entries(int dim, int ranges, int rescore_cap, int64_t want) {
     return (int)std::min<int64_t>(std::max<int64_t>(want, 2048), fit) / 256 * 256;
 }
 
+int launch_partition_flags(const uint32_t *flags, int begin, int n, uint32_t *retry_list, uint32_t *dense_list, uint32_t *counts,
+                           hipStream_t s) {
+    hipLaunchKernelGGL(partition_flags_kernel, dim3(1), dim3(256), 0, s, flags, begin, n, retry_list, dense_list, counts);
+    CCR_LAUNCH_CHECK();
+    return CCR_OK;
+}
+
+int launch_scatter_thresholds(const uint32_t *list, int n, const float *thr2, float *thr, hipStream_t s) {
+    if (n <= 0) return CCR_OK;
+    hipLaunchKernelGGL(scatter_thresholds_kernel, dim3((n + 255) / 256), dim3(256), 0, s, list, n, thr2, thr);
+    CCR_LAUNCH_CHECK();
+    return CCR_OK;
+}
+
+int launch_gather_queries(const uint16_t *Q, int dim, const uint32_t *list, int n, const float *thr, const float *delta, uint16_t *Q2,
+                          float *thr2, float *delta2, hipStream_t s) {
+    if (n <= 0) return CCR_OK;
+    hipLaunchKernelGGL(gather_queries_kernel, dim3(n), dim3(256), 0, s, Q, dim, list, n, thr, delta, Q2, thr2, delta2);
+    CCR_LAUNCH_CHECK();
+    return CCR_OK;
+}
+
 int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, int sp, int n_q, int nq_pad, const CandLayout &lay, int k,
                           int rescore_cap, int compact, int64_t n_rows, const float *delta, const uint16_t *Q,
                           const uint16_t *D, int dim, int64_t id_offset, float *out_scores, int64_t *out_ids,
-                          uint32_t *flag_count, uint32_t *flag_list, unsigned long long *stat_cand, hipStream_t s) {
+                          uint32_t *flag_count, uint32_t *flag_list, unsigned long long *stat_cand, const uint32_t *out_rows,
+                          hipStream_t s) {
     const size_t lds = select_fixed_lds(dim, ranges, rescore_cap) + (size_t)compact * 8;
     const bool wide = rescore_cap > 512 || compact > 8192;   // 1024 threads: one re-scored row per thread at large k
     auto go = [&](auto kernel, int threads) -> int {
@@ -1184,7 +1270,7 @@ int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, in
             if (rc != CCR_OK) return rc;
         }
         hipLaunchKernelGGL(kernel, dim3(n_q), dim3(threads), lds, s, cand, cnt, ranges, sp, nq_pad, lay, k, rescore_cap, compact,
-                           n_rows, delta, Q, D, dim, id_offset, out_scores, out_ids, flag_count, flag_list, stat_cand);
+                           n_rows, delta, Q, D, dim, id_offset, out_scores, out_ids, flag_count, flag_list, stat_cand, out_rows);
         CCR_LAUNCH_CHECK();
         return CCR_OK;
     };

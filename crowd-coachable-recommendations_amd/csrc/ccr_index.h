@@ -36,7 +36,13 @@ int select_compact_entries(int dim, int ranges, int rescore_cap, int64_t want);
 int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, int sp, int n_q, int nq_pad, const CandLayout &lay, int k,
                           int rescore_cap, int compact, int64_t n_rows, const float *delta, const uint16_t *Q,
                           const uint16_t *D, int dim, int64_t id_offset, float *out_scores, int64_t *out_ids,
-                          uint32_t *flag_count, uint32_t *flag_list, unsigned long long *stat_cand, hipStream_t s);
+                          uint32_t *flag_count, uint32_t *flag_list, unsigned long long *stat_cand, const uint32_t *out_rows,
+                          hipStream_t s);
+int launch_partition_flags(const uint32_t *flags, int begin, int n, uint32_t *retry_list, uint32_t *dense_list, uint32_t *counts,
+                           hipStream_t s);
+int launch_scatter_thresholds(const uint32_t *list, int n, const float *thr2, float *thr, hipStream_t s);
+int launch_gather_queries(const uint16_t *Q, int dim, const uint32_t *list, int n, const float *thr, const float *delta, uint16_t *Q2,
+                          float *thr2, float *delta2, hipStream_t s);
 int launch_threshold_update(const uint2 *cand, const uint32_t *cnt, int nsub, int sp, int n_q, int nq_pad, const CandLayout &lay, int k,
                             const float *delta, float *thr, hipStream_t s);
 // dense exact path.  qlist: query rows to score (nullptr: q_begin + qi); out_rows: destination rows of the select

@@ -52,7 +52,7 @@ typedef struct ccr_index ccr_index;
 /* statistics of the last ccr_search on an index (host struct, filled after the call returns) */
 typedef struct ccr_search_stats {
     int32_t path;              /* 0 = dense exact, 1 = fused MFMA */
-    int32_t n_fallback;        /* queries re-done by the dense path (candidate overflow / mass ties) */
+    int32_t n_fallback;        /* queries the first fused attempt flagged (candidate overflow / mass ties) */
     int32_t sample_tiles;      /* 256-row corpus tiles scored by the threshold (sample) pass */
     int32_t ranges;            /* corpus ranges of the main pass */
     int32_t cap;               /* candidate slots per sub-list */
@@ -63,8 +63,10 @@ typedef struct ccr_search_stats {
     float ms_threshold;        /* query norms + threshold select */
     float ms_main;             /* main pass GEMM + filter (the dominant kernel) */
     float ms_select;           /* stage-2 select + canonical re-score */
-    float ms_fallback;         /* dense fallback for flagged queries (0 if none) */
+    float ms_fallback;         /* retry pass + dense path for flagged queries (0 if none) */
     float ms_total;
+    int32_t n_retried;         /* flagged queries re-done by the fused retry pass (thresholds re-tightened from their own lists) */
+    int32_t n_dense;           /* flagged queries that took the exact dense path (mass ties, flagged again, on-stream chunk) */
 } ccr_search_stats;
 
 const char *ccr_last_error(void);

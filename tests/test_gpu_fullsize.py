@@ -213,3 +213,37 @@ def test_clustered_non_iid_corpus_vs_oracle(k):
     _check_against_oracle(D, Q, s, i, k, sub)
     s_np = s.cpu().numpy()
     assert (np.diff(s_np, axis=1) == 0).any()                       # the duplicates do produce exact ties in the lists
+
+
+@pytest.mark.parametrize("k,big_cluster", [(100, False), (1001, False), (100, True)])
+def test_topically_sorted_corpus_retries_on_the_fused_path(k, big_cluster):
+    """A corpus in topical order (bench.py --data sorted: every cluster's rows contiguous, like passages of one article):
+    whole tiles pass for a query and the sample misses its cluster, so candidate sub-lists overflow.  Such queries must be
+    RETRIED on the fused path (thresholds re-tightened from their truncated lists), not sent to the 1.8-ms-per-query dense
+    path; results stay bit-exact.  big_cluster: 16 clusters of 25,000 rows -- several whole tiles of one range pass."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import gen_rows
+    from ccrec_amd import ops
+    n, nq, d = 400_000, 600, 768
+    rows = gen_rows(n, d, 1234, "cuda", "sorted")
+    if big_cluster:   # fold the 1,024 clusters into 16 big ones by re-using centres: rows of cluster c move towards centre c // 64
+        g = torch.Generator(device="cuda").manual_seed(777)
+        centres = torch.randn(1024, d, generator=g, device="cuda") * d ** -0.5
+        cid = (torch.arange(n, device="cuda") * 1024 // n).clamp_(max=1023)
+        rows = rows + 0.8 * (centres[cid // 64 * 64] - centres[cid]) * rows.norm(dim=1, keepdim=True)
+    D = ops.pack_bf16(rows)
+    Q = ops.pack_bf16(gen_rows(nq, d, 4321, "cuda", "sorted"))
+    index = ops.CorpusIndex(D)
+    s, i = index.search(Q, k, 2)
+    st = index.last_stats()
+    print(st)
+    assert st["path"] == 1
+    if st["n_fallback"]:
+        assert st["n_retried"] >= st["n_fallback"] - st["n_dense"] and st["n_dense"] <= max(8, st["n_fallback"] // 20), st
+        assert st["ms_fallback"] < 60.0, st                          # the dense path alone would need ~0.3 ms per flagged query here
+    sub = np.r_[0:8, 296:304, 592:600]
+    _check_against_oracle(D, Q, s, i, k, sub)
+    s1, i1 = index.search(Q[:64], k, 1)                              # exact dense path on a query block
+    assert torch.equal(i[:64], i1) and torch.equal(s[:64].view(torch.int32), s1.view(torch.int32))
