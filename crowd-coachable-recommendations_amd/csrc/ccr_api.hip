@@ -40,7 +40,7 @@ Knobs read_knobs() {
     kn.sample_div = env_int("CCR_SAMPLE_DIV", 0);
     kn.gemm_dbg = env_int("CCR_GEMM_DBG", 0);
     kn.stagger = env_int("CCR_GEMM_STAGGER", 1);
-    kn.tighten = env_int("CCR_TIGHTEN", 1);
+    kn.max_lists = env_int("CCR_MAX_LISTS", 0);
     return kn;
 }
 
@@ -88,7 +88,11 @@ struct MainPassChoice {
 
 static MainPassChoice choose_main_pass(const Plan &p, int k, int64_t sample_a, int64_t sample_b, const Knobs &kn) {
     const int nrc = NUM_XCD / p.qgroups, qb_per = p.qblocks / p.qgroups, per_x = p.grid / NUM_XCD;
-    const int64_t r_hi = std::min<int64_t>(1024 / p.sublists, round_up(std::max<int64_t>(1, p.tiles / 8), NUM_XCD));
+    // the select stage walks ranges x sublists sub-lists per query: 1 024 with its 256-thread form, 2 048 with the 1 024-thread
+    // form large k uses anyway (rescore_cap > 512)
+    int64_t max_lists = p.rescore_cap > 512 ? 2048 : 1024;
+    if (kn.max_lists >= 64 && kn.max_lists < max_lists) max_lists = kn.max_lists;
+    const int64_t r_hi = std::min<int64_t>(max_lists / p.sublists, round_up(std::max<int64_t>(1, p.tiles / 8), NUM_XCD));
     const int64_t target = std::min<int64_t>(r_hi, round_up(std::max<int64_t>(NUM_XCD, (int64_t)p.grid * 6 / p.qblocks), NUM_XCD));
     const bool prog_on = kn.progressive != 0;   // 0: single launch
     const int max_phases = kn.max_phases;        // 2: at most one re-tightening
@@ -127,7 +131,7 @@ static MainPassChoice choose_main_pass(const Plan &p, int k, int64_t sample_a, i
              rbody += NUM_XCD) {
             int64_t ra = (int64_t)per_x * nrc / qb_per / nrc * nrc;   // phase A: items = ra / nrc * qb_per <= per_x (one round)
             ra = std::min<int64_t>(ra, rbody / 4 / nrc * nrc);
-            if (!(prog_on && ra >= nrc && rbody + ra <= 1024 / p.sublists && (double)p.tiles / (double)(rbody + ra) >= 8.0)) ra = 0;
+            if (!(prog_on && ra >= nrc && rbody + ra <= max_lists / p.sublists && (double)p.tiles / (double)(rbody + ra) >= 8.0)) ra = 0;
             const int64_t Rt = rbody + ra;
             const double common = smp_cost + select_per_range * (double)Rt +
                                   1e-3 * std::abs((double)(rbody - target));   // ties: stay near 6 items per workgroup
@@ -156,7 +160,7 @@ static MainPassChoice choose_main_pass(const Plan &p, int k, int64_t sample_a, i
     return best_choice;
 }
 
-Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu, const Knobs &kn) {
+static Plan make_plan_for(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu, const Knobs &kn, int mfma16) {
     Plan p;
     memset(&p, 0, sizeof(p));
     p.nq_pad = (int)round_up(n_q, TILE_Q);
@@ -165,10 +169,7 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu, c
     p.full_tiles = n_rows / TILE_DOCS;
     p.grid = std::max(NUM_XCD, num_cu / NUM_XCD * NUM_XCD);
     {
-        // CCR_MFMA16: main pass on v_mfma_f32_16x16x32_bf16 (row records only)
-        // default: the 16x16x32 kernel up to k = 512; above that its eight sub-lists per (range, query) cost the select
-        // stage more than the main pass gains (config-4 shape, k = 1000: select 14.3 vs 9.0 ms at equal main-pass time)
-        p.mfma16 = (kn.mfma16 >= 0 ? kn.mfma16 : (CCR_MFMA16_DEFAULT && k <= 512)) ? 1 : 0;
+        p.mfma16 = mfma16;   // main pass on v_mfma_f32_16x16x32_bf16 (8 sub-lists per (range, query)) or 32x32x16 (4)
         p.sublists = p.mfma16 ? 8 : 4;
     }
     p.rescore_cap = std::min(8192, std::max(256, 2 * pow2_ceil(k)));
@@ -285,6 +286,19 @@ Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu, c
     }
     p.total = off;
     return p;
+}
+
+// Which main-pass kernel: CCR_MFMA16 pins it.  Otherwise the 16x16x32 kernel (the chip holds a higher clock on that MFMA shape)
+// whenever its eight sub-lists per (range, query) do not force FEWER ranges than the 32x32x16 plan wants: up to k = 512 always
+// (measured), above that when the four-sub-list plan's range count times 8 stays within the select stage's 2 048
+// sub-lists (config-4 shard, k = 1000, 62 ranges: main pass 111 vs 120 ms, select 8.9 vs 9.4 ms).
+Plan make_plan(int64_t n_rows, int dim, int n_q, int k, int flags, int num_cu, const Knobs &kn) {
+    if (kn.mfma16 >= 0) return make_plan_for(n_rows, dim, n_q, k, flags, num_cu, kn, kn.mfma16 ? 1 : 0);
+    if (!CCR_MFMA16_DEFAULT) return make_plan_for(n_rows, dim, n_q, k, flags, num_cu, kn, 0);
+    if (k <= 512) return make_plan_for(n_rows, dim, n_q, k, flags, num_cu, kn, 1);
+    const Plan p32 = make_plan_for(n_rows, dim, n_q, k, flags, num_cu, kn, 0);
+    if (p32.fused && p32.ranges * 8 <= 2048) return make_plan_for(n_rows, dim, n_q, k, flags, num_cu, kn, 1);
+    return p32;
 }
 
 }  // namespace ccr
@@ -536,7 +550,7 @@ static int search_complete(ccr_index *ix) {
     const int nsub_all = p.ranges * p.sublists;
     CandLayout prev_lay = p.cand;
     int prev_n = n_q, prev_pad = p.nq_pad;
-    for (int round = 0; round < 3 && n_cur > 0 && nsub_all <= 1024; ++round) {
+    for (int round = 0; round < 3 && n_cur > 0 && nsub_all <= 2048; ++round) {
         // thresholds re-tightened from everything the previous attempt recorded (truncated lists included)
         if (round == 0) {
             rc = launch_threshold_update(cand, cnt, nsub_all, p.sublists, n_q, p.nq_pad, p.cand, k, delta, thr, s);

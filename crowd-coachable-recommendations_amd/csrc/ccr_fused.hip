@@ -714,7 +714,7 @@ __global__ __launch_bounds__(256) void threshold_update_kernel(const uint2 *__re
     extern __shared__ __attribute__((aligned(16))) uint32_t s_val[];   // [compact] orderable scores of the candidates found so far
     __shared__ uint32_t s_hist[256];
     __shared__ uint32_t s_ctl[4];
-    __shared__ uint32_t s_cnt[1024];
+    __shared__ uint32_t s_cnt[2048];
     __shared__ uint32_t s_total, s_maxc, s_fill;
     const int tid = threadIdx.x;
     const int q = blockIdx.x;
@@ -1202,8 +1202,8 @@ int launch_threshold(const float *gmax, int64_t n_groups, int n_q, int nq_pad, i
 
 int launch_threshold_update(const uint2 *cand, const uint32_t *cnt, int nsub, int sp, int n_q, int nq_pad, const CandLayout &lay, int k,
                             const float *delta, float *thr, hipStream_t s) {
-    if (nsub > 1024) {
-        set_error("threshold_update: %d sub-lists exceed 1024", nsub);
+    if (nsub > 2048) {
+        set_error("threshold_update: %d sub-lists exceed 2048", nsub);
         return CCR_ERR_INVALID;
     }
     // LDS score buffer: comfortably more than k (the bound tightens with the number of rows seen), 16 KiB at least
@@ -1263,7 +1263,7 @@ int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, in
                           uint32_t *flag_count, uint32_t *flag_list, unsigned long long *stat_cand, const uint32_t *out_rows,
                           hipStream_t s) {
     const size_t lds = select_fixed_lds(dim, ranges, rescore_cap) + (size_t)compact * 8;
-    const bool wide = rescore_cap > 512 || compact > 8192;   // 1024 threads: one re-scored row per thread at large k
+    const bool wide = rescore_cap > 512 || compact > 8192 || ranges > 1024;   // 1024 threads: one re-scored row per thread at large k
     auto go = [&](auto kernel, int threads) -> int {
         if (lds > 48 * 1024) {
             const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kernel), SELECT_LDS_BUDGET + 8192);

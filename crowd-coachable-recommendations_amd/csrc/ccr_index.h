@@ -14,7 +14,7 @@ struct Knobs {
     int sample_div;    // CCR_SAMPLE_DIV   0 = planner's choice, else the pinned sample fraction 1/div
     int gemm_dbg;      // CCR_GEMM_DBG     timing-only ablations of the main pass (WRONG results when non-zero)
     int stagger;       // CCR_GEMM_STAGGER 0 = both wave groups of the 32x32x16 kernel in phase
-    int tighten;       // CCR_TIGHTEN      0 = no in-launch threshold publication (default 1)
+    int max_lists;     // CCR_MAX_LISTS    0 = planner's limit, else a cap on ranges x sublists (A/B of the select stage's walk)
 };
 Knobs read_knobs();
 
