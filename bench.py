@@ -158,11 +158,14 @@ class Workload:
         self.qpack = torch.empty(queries, dim, dtype=torch.bfloat16, device=dev)
         self.k_local = min(k, self.hi - self.lo)
         self.max_norm = torch.zeros(1, dtype=torch.float32, device=dev)
-        # N > 1: the search writes its top-k straight into the packed exchange message (one all-gather per step)
-        self.message = None
+        # N > 1: the search writes its top-k straight into the packed exchange message (one all-gather per step).  Two
+        # messages: the all-gather of step i runs on the communication stream while step i + 1 packs and searches.
+        self.messages = None
+        self.prev = None   # (message, work handle, index) of the step whose exchange is still in flight
+        self.nstep = 0
         if world > 1:
             assert self.k_local == k, "shard smaller than k"
-            self.message = TopkMessage(queries, k, dev, world)
+            self.messages = [TopkMessage(queries, k, dev, world) for _ in range(2)]
         self.index = self.scores = self.ids = None
 
     def step(self):
@@ -172,18 +175,35 @@ class Workload:
         index = ops.CorpusIndex(self.shard, global_row_offset=self.lo, max_norm=self.max_norm)
         ops.pack_bf16(self.queries_f32, out=self.qpack)
         if self.world > 1:
-            # asynchronous search: the all-gather and the merge are enqueued behind it without a host round trip; finish()
-            # (one synchronisation, needed before the results are used anyway) reports flagged queries beyond the on-stream chunk
-            index.search(self.qpack, self.k_local, out=(self.message.scores, self.message.ids), defer=True)
-            s, i = ops.merge_topk(*self.message.gather())
-            index.finish()
+            # asynchronous search (no host round trip), then the all-gather on the communication stream; the exchange of the
+            # PREVIOUS step is completed (wait + merge) behind this step's search, so its latency hides behind compute.
+            msg = self.messages[self.nstep % 2]
+            self.nstep += 1
+            index.search(self.qpack, self.k_local, out=(msg.scores, msg.ids), defer=True)
+            work = msg.gather_async()
+            self.drain()
+            index.finish()   # the synchronisation the results need anyway; reports flagged queries beyond the on-stream chunk
             if index.last_stats()["n_fallback"] > 16:   # mass ties: the exchange ran ahead of the complete lists -- redo it
-                s, i = ops.merge_topk(*self.message.gather())
+                work.wait()
+                work = msg.gather_async()
+            self.prev = (msg, work, index)
+            self.index = index
         else:
             s, i = index.search(self.qpack, self.k_local)
-        self.index, self.scores, self.ids = index, s, i
+            self.index, self.scores, self.ids = index, s, i
+
+    def drain(self):
+        """Complete the exchange still in flight: wait for its all-gather, merge the gathered per-shard lists."""
+        from ccrec_amd import ops
+        if self.prev is None:
+            return
+        msg, work, _ = self.prev
+        work.wait()
+        self.scores, self.ids = ops.merge_topk(msg.all_scores, msg.all_ids)
+        self.prev = None
 
     def fence(self):
+        self.drain()
         if self.world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -214,7 +234,7 @@ class Workload:
                 "achieved_tflops": achieved, "n_fallback_max": max(m["n_fallback"] for m in stats)}
 
     def release(self):
-        self.corpus_f32 = self.queries_f32 = self.shard = self.qpack = self.index = self.scores = self.ids = self.message = None
+        self.corpus_f32 = self.queries_f32 = self.shard = self.qpack = self.index = self.scores = self.ids = self.messages = self.prev = None
         torch.cuda.empty_cache()
 
 
@@ -289,7 +309,7 @@ def main():
         "config": {"workload": workload, "corpus_rows": args.rows,
                    "dim": args.dim, "queries": args.queries, "k": args.k,
                    "step": "pack corpus shard fp32->bf16 + index build + pack queries + fused MFMA score/top-k"
-                           + (" + RCCL all-gather + merge" if world > 1 else ""),
+                           + (" + RCCL all-gather + merge (the exchange of step i overlaps the pack and search of step i + 1)" if world > 1 else ""),
                    "parallelism": f"row-shard x{world}"},
         "roofline": roofline_obj(r, traffic, traffic_source),
         "phases_ms": dict(phases_obj(st), corpus_pack=round(pack_ms, 3)),

@@ -40,6 +40,12 @@ class TopkMessage:
         dist.all_gather_into_tensor(self.recv, self.send, group=group)
         return self.all_scores, self.all_ids
 
+    def gather_async(self, group=None):
+        """Start the all-gather on the communication stream and return its work handle: kernels enqueued afterwards on
+        the compute stream (the next step's pack and search) overlap with it; call work.wait() before merging
+        `all_scores` / `all_ids`.  The message must not be rewritten before that wait (double-buffer it)."""
+        return dist.all_gather_into_tensor(self.recv, self.send, group=group, async_op=True)
+
 
 def all_gather_topk(scores, ids, group=None, message=None):
     """[Q,k] per rank -> rank-strided ([R,Q,k], [R,Q,k]) views on every rank, one collective.

@@ -49,6 +49,12 @@ def test_topk_message_through_rccl_world1():
         assert gs.shape == (1, nq, k) and gi.shape == (1, nq, k)
         ms, mi = merge_gathered(gs, gi)
         assert torch.equal(mi, i1) and torch.equal(ms.view(torch.int32), s1.view(torch.int32))
+        # the asynchronous form bench.py pipelines across steps: the collective runs on RCCL's stream, wait() orders the merge behind it
+        m.recv.zero_()
+        work = m.gather_async()
+        work.wait()
+        ms2, mi2 = merge_gathered(m.all_scores, m.all_ids)
+        assert torch.equal(mi2, i1) and torch.equal(ms2.view(torch.int32), s1.view(torch.int32))
         # separate tensors are copied into the message first
         gs2, gi2 = all_gather_topk(s1, i1)
         assert torch.equal(gs2[0], s1) and torch.equal(gi2[0], i1)
