@@ -41,6 +41,13 @@ def get_all_embeddings(item_titles, tokenizer, tokenizer_kw, model, batch_size, 
     return out
 
 
+def _row_index(key, n, device):
+    if isinstance(key, slice):
+        key = range(n)[key]
+    idx = torch.as_tensor(np.atleast_1d(np.asarray(key)), dtype=torch.long)
+    return (idx % n).to(device)   # rime_lite's dense slicing takes the row index modulo the row count (score_array.py:227-231)
+
+
 class LowRankScore:
     """Lazy [n_users, n_items] score = U V^T over packed bf16 rows (duck-types the .shape / .T / as_tensor
     surface of rime_lite's LazyScoreBase that the evaluation code touches)."""
@@ -66,6 +73,21 @@ class LowRankScore:
         if self._index is None:
             self._index = ops.CorpusIndex(self.item)
         return self._index
+
+    def __getitem__(self, key):
+        """Row (user) subset, as rime_lite's lazy scores are sliced for batching (score_array.py:98-100, 332-333):
+        an int, a slice or an index array."""
+        rows = _row_index(key, self.shape[0], self.user.device)
+        out = LowRankScore(self.user[rows], self.item)
+        out._index = self._index   # same item rows: the search index carries over
+        return out
+
+    @staticmethod
+    def collate_fn(batch):
+        """Stack row subsets of ONE score back together (score_array.py:335-338)."""
+        out = LowRankScore(torch.cat([b.user for b in batch], 0), batch[0].item)
+        out._index = batch[0]._index
+        return out
 
     def as_tensor(self, device=None):
         """Dense scores (this materialises n_users x n_items fp32): canonical fp64-ordered values for small problems,
@@ -122,6 +144,14 @@ class LowRankPlusSparse:
         return LowRankPlusSparse(self.low, self.prior + sps.csr_matrix(c, dtype=np.float64))
 
     __radd__ = __add__
+
+    def __getitem__(self, key):
+        rows = _row_index(key, self.shape[0], "cpu").numpy()
+        return LowRankPlusSparse(self.low[rows], self.prior[rows])
+
+    @staticmethod
+    def collate_fn(batch):
+        return LowRankPlusSparse(LowRankScore.collate_fn([b.low for b in batch]), sps.vstack([b.prior for b in batch], "csr"))
 
     def as_tensor(self, device=None):
         dense = self.low.as_tensor().double()

@@ -425,3 +425,41 @@ def test_bertbpr_transform_dataset_and_get_all_embeddings(monkeypatch):
     # the debug branches of the reference's transform (bbpr.py:510-521)
     bbpr.random = True
     assert tuple(bbpr.transform(D).shape) == (5, 120)
+
+
+def test_lazy_scores_slice_like_rime_lite_and_odd_widths_take_the_fused_path():
+    """LazyScoreBase supports row slicing + collate_fn for batching (score_array.py:98-100, 227-231, 332-338); factor widths
+    that are not a multiple of 64 (here 100) are zero-padded so the fused MFMA search applies."""
+    from ccrec_amd import ops
+    from ccrec_amd.bbpr_transform import LowRankPlusSparse, LowRankScore
+    from ccrec_amd.rime_util import _assign_topk
+    g = torch.Generator().manual_seed(8)
+    nu, ni, d, k = 37, 6000, 100, 9
+    U = (torch.randn(nu, d, generator=g) / 10).to(torch.bfloat16).float()
+    V = (torch.randn(ni, d, generator=g) / 10).to(torch.bfloat16).float()
+    Ub, Vb = orc.pack_bf16(U.numpy()), orc.pack_bf16(V.numpy())
+    ref_i, _ = orc.canonical_search(Ub, Vb, k)
+    csr = _assign_topk((U, V), k)                                       # (U, V) means U @ V.T
+    assert np.array_equal(csr.indices.reshape(nu, k), ref_i)
+    pad = torch.nn.functional.pad
+    S = LowRankScore(ops.pack_bf16(pad(U, (0, 28)).cuda()), ops.pack_bf16(pad(V, (0, 28)).cuda()))
+    _, ids = S.topk(k)
+    assert S.index().last_stats()["path"] == 1                           # fused: 128-wide padded factors
+    assert np.array_equal(ids.cpu().numpy(), ref_i)
+    # slicing: int, slice, index array (modulo the row count, as LazyDenseMatrix does), then collate_fn
+    parts = [S[0], S[1:20], S[np.array([20, 21, 22 + nu])], S[23:]]
+    assert [p.shape for p in parts] == [(1, ni), (19, ni), (3, ni), (nu - 23, ni)]
+    back = LowRankScore.collate_fn(parts)
+    assert back.shape == S.shape and torch.equal(back.user, S.user)
+    _, ids2 = back.topk(k)
+    assert np.array_equal(ids2.cpu().numpy(), ref_i)
+    P = sps.random(nu, ni, density=0.002, random_state=4, format="csr") * 3.0
+    R = S + P
+    Rs = LowRankPlusSparse.collate_fn([R[:10], R[10:]])
+    f1, i1 = R.topk(k)
+    f2, i2 = Rs.topk(k)
+    assert torch.equal(i1, i2) and torch.equal(f1, f2)
+    Pc = sps.csr_matrix(P)
+    Pc.sort_indices()
+    ref_pi, _ = orc.sparse_prior_search(Ub, Vb, Pc.indptr, Pc.indices, Pc.data, k)
+    assert np.array_equal(i1.cpu().numpy(), ref_pi)
