@@ -41,6 +41,7 @@ Knobs read_knobs() {
     kn.gemm_dbg = env_int("CCR_GEMM_DBG", 0);
     kn.stagger = env_int("CCR_GEMM_STAGGER", 1);
     kn.max_lists = env_int("CCR_MAX_LISTS", 0);
+    kn.ranges = env_int("CCR_RANGES", 0);
     return kn;
 }
 
@@ -83,7 +84,8 @@ constexpr size_t DENSE_SCRATCH_TARGET = (size_t)1 << 30;  // ~1 GiB of score row
 //   launch boundary            3 per extra phase
 // The per-query terms were measured at 3 452 queries (14 query blocks) and scale with the query count.
 struct MainPassChoice {
-    int64_t sample, ranges, ranges_a, ranges_b;
+    int64_t sample, ranges;
+    int item_a, item_b;   // phase ends in work items of one XCD set (0 = absent)
 };
 
 static MainPassChoice choose_main_pass(const Plan &p, int k, int64_t sample_a, int64_t sample_b, const Knobs &kn) {
@@ -98,18 +100,6 @@ static MainPassChoice choose_main_pass(const Plan &p, int k, int64_t sample_a, i
     const int max_phases = kn.max_phases;        // 2: at most one re-tightening
     const double qscale = (double)p.nq_pad / 3584.0;
     const double select_per_range = 0.1 * qscale, hit_w = 0.014 * qscale, phase_w = 3.0;
-
-    // the busiest XCD set is range class 0: its per_x workgroups take the items of ranges [rb, re) round-robin
-    auto makespan = [&](int64_t rb, int64_t re, int64_t Rt) -> double {
-        std::vector<double> load((size_t)per_x, 0.0);
-        int64_t i = 0;
-        for (int64_t r = rb; r < re; r += nrc)
-            for (int qi = 0; qi < qb_per; ++qi, ++i) {
-                const int64_t nt = (p.tiles - r + Rt - 1) / Rt;
-                if (nt > 0) load[(size_t)(i % per_x)] += (double)nt + 0.15;
-            }
-        return *std::max_element(load.begin(), load.end());
-    };
     // 0.11 ms = 4.9 units of threshold kernel for 328 sample tiles x 3 584 queries
     auto sample_cost = [&](int64_t smp) -> double {
         return (double)((smp * p.qblocks + p.grid - 1) / p.grid) + 0.015 * (double)smp * qscale;
@@ -127,32 +117,40 @@ static MainPassChoice choose_main_pass(const Plan &p, int k, int64_t sample_a, i
             if (fb <= 0.0) return (double)k * (fa / fs + (1.0 - fa) / fa);
             return (double)k * (fa / fs + fb / fa + (1.0 - fa - fb) / (fa + fb));
         };
-        for (int64_t rbody = std::max<int64_t>(NUM_XCD, target / 2 / NUM_XCD * NUM_XCD); rbody <= std::min(r_hi, target * 2);
-             rbody += NUM_XCD) {
-            int64_t ra = (int64_t)per_x * nrc / qb_per / nrc * nrc;   // phase A: items = ra / nrc * qb_per <= per_x (one round)
-            ra = std::min<int64_t>(ra, rbody / 4 / nrc * nrc);
-            if (!(prog_on && ra >= nrc && rbody + ra <= max_lists / p.sublists && (double)p.tiles / (double)(rbody + ra) >= 8.0)) ra = 0;
-            const int64_t Rt = rbody + ra;
-            const double common = smp_cost + select_per_range * (double)Rt +
-                                  1e-3 * std::abs((double)(rbody - target));   // ties: stay near 6 items per workgroup
-            const double fa = (double)ra / (double)Rt;
-            const double two = (ra ? makespan(0, ra, Rt) + phase_w : 0.0) + makespan(ra, Rt, Rt) + hit_w * survivors(fa, 0.0) + common;
+        // Every XCD set holds the same items = (R / classes) * blocks_per_group, all of ceil(tiles / R) tiles at most, dealt
+        // round-robin to its per_x workgroups: a launch over n items takes ceil(n / per_x) rounds.  Phases end at ITEM
+        // indices, so phase A is exactly one full round (and the middle phase whole rounds) for any R.
+        // R stays a multiple of the XCD count (not just of the range classes): the retry pass of flagged queries re-uses the
+        // ranges with its own, possibly different, query grouping
+        const int64_t r_lo = std::max<int64_t>(NUM_XCD, target / 2 / NUM_XCD * NUM_XCD);
+        for (int64_t R = r_lo; R <= std::min(r_hi, target * 2); R += NUM_XCD) {
+            if (kn.ranges > 0 && R != std::min<int64_t>(r_hi, std::max<int64_t>(r_lo, round_up(kn.ranges, NUM_XCD)))) continue;
+            const int64_t items = R / nrc * qb_per;
+            const double item_cost = (double)((p.tiles + R - 1) / R) + 0.15;   // + pipeline fill per item
+            auto rounds = [&](int64_t n) { return (double)((n + per_x - 1) / per_x); };
+            const double common = smp_cost + select_per_range * (double)R + 1e-3 * std::abs((double)(R - target));
+            const double single = rounds(items) * item_cost + hit_w * survivors(0.0, 0.0) + common;
+            if (single < best) {
+                best = single;
+                best_choice = {smp, R, 0, 0};
+            }
+            if (!(prog_on && items > per_x && (double)p.tiles / (double)R >= 8.0)) continue;
+            // the thresholds after phase A come from the ranges it completed (+ the started one for part of the queries)
+            const double fa = (double)per_x / (double)items;
+            const double two = (1.0 + rounds(items - per_x)) * item_cost + phase_w + hit_w * survivors(fa, 0.0) + common;
             if (two < best) {
                 best = two;
-                best_choice = {smp, Rt, ra, 0};
+                best_choice = {smp, R, per_x, 0};
             }
-            if (!ra || max_phases < 3) continue;
-            // a second re-tightening after m more rounds of items (m = 1..3): the middle phase then fills its rounds
-            for (int m = 1; m <= 3; ++m) {
-                const int64_t mid = (int64_t)m * per_x / qb_per * nrc;
-                const int64_t rb = ra + mid;
-                if (mid < nrc || rb + nrc > Rt) break;
-                const double fb = (double)mid / (double)Rt;
-                const double three = makespan(0, ra, Rt) + makespan(ra, rb, Rt) + makespan(rb, Rt, Rt) + 2.0 * phase_w +
-                                     hit_w * survivors(fa, fb) + common;
+            if (max_phases < 3) continue;
+            for (int m = 1; m <= 3; ++m) {   // a second re-tightening after m more rounds
+                const int64_t ib = (int64_t)per_x * (1 + m);
+                if (ib >= items) break;
+                const double fb = (double)m * per_x / (double)items;
+                const double three = (1.0 + m + rounds(items - ib)) * item_cost + 2.0 * phase_w + hit_w * survivors(fa, fb) + common;
                 if (three < best) {
                     best = three;
-                    best_choice = {smp, Rt, ra, rb};
+                    best_choice = {smp, R, per_x, (int)ib};
                 }
             }
         }
@@ -206,12 +204,17 @@ static Plan make_plan_for(int64_t n_rows, int dim, int n_q, int k, int flags, in
         const int64_t sample_alt = (sample_div_forced || (flags & CCR_SEARCH_FORCE_FUSED)) ? sample : sample_for(2 * sample_div);
         const MainPassChoice choice = choose_main_pass(p, k, sample, sample_alt, kn);
         sample = choice.sample;
-        const int64_t R = choice.ranges, RA = choice.ranges_a, RB = choice.ranges_b;
+        const int64_t R = choice.ranges;
         p.sample_tiles = (int)sample;
         p.sample_stride = std::max<int64_t>(1, p.full_tiles / sample);
         p.ranges = (int)R;
-        p.ranges_a = (int)RA;
-        p.ranges_b = (int)RB;
+        p.item_a = choice.item_a;
+        p.item_b = choice.item_b;
+        // ranges that hold items of a phase: the candidate segments (a range started in phase A keeps phase A's capacity)
+        const int nrc_p = NUM_XCD / p.qgroups, qb_per_p = p.qblocks / p.qgroups;
+        const int64_t items_p = R / nrc_p * qb_per_p;
+        const int64_t RA = p.item_a ? std::min<int64_t>(R, (int64_t)nrc_p * ((p.item_a + qb_per_p - 1) / qb_per_p)) : 0;
+        const int64_t RB = p.item_b ? std::min<int64_t>(R, (int64_t)nrc_p * ((p.item_b + qb_per_p - 1) / qb_per_p)) : 0;
         const double ratio = (double)p.tiles / (double)sample;
         const double expect = (double)k * ratio * 1.3 + 64.0;  // survivors per query under the sample thresholds alone
         // Sub-list capacities, one per phase (segment).  A phase whose thresholds were taken from a corpus fraction g lets
@@ -231,7 +234,10 @@ static Plan make_plan_for(int64_t n_rows, int dim, int n_q, int k, int flags, in
             const int64_t c = (int64_t)(mean + 6.0 * sqrt(mean)) + 16 + tile_rows;   // the model's share PLUS one whole tile
             return (int)round_up(std::min<int64_t>(std::max<int64_t>(c, 16), 8192), 4);
         };
-        const double fa = (double)RA / (double)R, fb = (double)(RB > RA ? RB - RA : 0) / (double)R;
+        // corpus fractions the re-tightenings have SEEN: the ranges completed by then
+        const double fa = p.item_a ? (double)(p.item_a / qb_per_p) * nrc_p / (double)R : 0.0;
+        const double fb = p.item_b ? std::max(0.0, (double)(p.item_b / qb_per_p) * nrc_p / (double)R - fa) : 0.0;
+        (void)items_p;
         // the re-tightening selects among at most `compact` of the candidates found so far (launch_threshold_update): when
         // phase A is expected to leave more than that, the bound is the k-th of a subset and passes proportionally more
         const double upd_compact = std::min(32768.0, std::max(4096.0, 8.0 * pow2_ceil(k)));
@@ -446,27 +452,26 @@ static int dense_for_list(const ccr_index *ix, const uint16_t *Q, const uint32_t
     return CCR_OK;
 }
 
-// The main pass over all ranges: one launch per phase (segment of the candidate area), the thresholds re-tightened from
-// the candidates found so far between two launches when `retighten` is set.
+// The main pass: one launch per phase (work items [begin, end) of every XCD set), the thresholds re-tightened from the candidates
+// of the ranges completed so far between two launches when `retighten` is set.
 static int run_main_pass(const ccr_index *ix, const Plan &p, GemmArgs gm, uint2 *cand, uint32_t *cnt, float *thr, const float *delta,
                          int n_q, int k, bool retighten, hipStream_t s) {
-    const int bounds[4] = {0, p.ranges_a, p.ranges_b, p.ranges};
+    const int nrc = NUM_XCD / gm.qgroups, qb_per = gm.qblocks / gm.qgroups;
+    const int items = p.ranges / nrc * qb_per;
+    const int bounds[4] = {0, retighten ? p.item_a : 0, retighten ? p.item_b : 0, items};
+    gm.cand = cand;
+    gm.lay = p.cand;
     int done = 0;
     for (int ph = 1; ph < 4; ++ph) {
         if (bounds[ph] <= done) continue;
-        if (done > 0 && retighten) {
-            const int rc = launch_threshold_update(cand, cnt, done * p.sublists, p.sublists, n_q, p.nq_pad, p.cand, k, delta, thr, s);
+        if (done > 0) {
+            const int rl_full = done / qb_per, part = done % qb_per;   // complete range rows; blocks done of the started one
+            const int rc = launch_threshold_update(cand, cnt, rl_full * nrc * p.sublists, part ? (rl_full + 1) * nrc * p.sublists : 0, part,
+                                                   qb_per, p.sublists, n_q, p.nq_pad, p.cand, k, delta, thr, s);
             if (rc != CCR_OK) return rc;
         }
-        gm.range_begin = done;
-        gm.range_end = bounds[ph];
-        {   // this launch's segment of the candidate area (a launch never straddles two segments)
-            int cap_seg = 0;
-            const long long first = cand_sublist(p.cand, done, 0, 0, p.nq_pad, p.sublists, cap_seg);
-            gm.cand = cand + first;
-            gm.cap = cap_seg;
-            gm.cand_range0 = done;
-        }
+        gm.item_begin = done;
+        gm.item_end = bounds[ph];
         const int rc = p.mfma16 ? launch_gemm16_filter(gm, p.grid, s) : launch_gemm_filter(gm, p.grid, s);
         if (rc != CCR_OK) return rc;
         done = bounds[ph];
@@ -553,10 +558,10 @@ static int search_complete(ccr_index *ix) {
     for (int round = 0; round < 3 && n_cur > 0 && nsub_all <= 2048; ++round) {
         // thresholds re-tightened from everything the previous attempt recorded (truncated lists included)
         if (round == 0) {
-            rc = launch_threshold_update(cand, cnt, nsub_all, p.sublists, n_q, p.nq_pad, p.cand, k, delta, thr, s);
+            rc = launch_threshold_update(cand, cnt, nsub_all, 0, 0, 1, p.sublists, n_q, p.nq_pad, p.cand, k, delta, thr, s);
             if (rc != CCR_OK) return rc;
         } else {
-            rc = launch_threshold_update(cand, cnt, nsub_all, p.sublists, prev_n, prev_pad, prev_lay, k, delta2, thr2, s);
+            rc = launch_threshold_update(cand, cnt, nsub_all, 0, 0, 1, p.sublists, prev_n, prev_pad, prev_lay, k, delta2, thr2, s);
             if (rc != CCR_OK) return rc;
             rc = launch_scatter_thresholds(nxt, prev_n, thr2, thr, s);   // nxt still holds the previous round's list
             if (rc != CCR_OK) return rc;
@@ -592,10 +597,9 @@ static int search_complete(ccr_index *ix) {
         g.thr = thr2;
         g.cnt = cnt;
         g.cand = cand;
-        g.cap = (int)cap2;
-        g.cand_range0 = 0;
-        g.range_begin = 0;
-        g.range_end = p.ranges;
+        g.lay = lay2;
+        g.item_begin = 0;
+        g.item_end = INT32_MAX;
         rc = p.mfma16 ? launch_gemm16_filter(g, p.grid, s) : launch_gemm_filter(g, p.grid, s);
         if (rc != CCR_OK) return rc;
         rc = launch_select_rescore(cand, cnt, nsub_all, p.sublists, n_cur, pad2, lay2, k, p.rescore_cap, p.select_compact, ix->n_rows, delta2,
@@ -726,8 +730,8 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
     gs.tile_stride = p.sample_stride;
     gs.ranges = (int)round_up(std::min<int64_t>(p.ranges, std::max<int64_t>(NUM_XCD, p.sample_tiles / 4)), NUM_XCD);
     gs.gmax = gmax;
-    gs.range_begin = 0;
-    gs.range_end = gs.ranges;
+    gs.item_begin = 0;
+    gs.item_end = INT32_MAX;
     CCR_HIP_CHECK(hipEventRecord(ix->ev[1], s));
     rc = launch_gemm_gmax(gs, p.grid, s);
     if (rc != CCR_OK) return rc;
@@ -824,8 +828,8 @@ extern "C" int ccr_scores(const ccr_index *ix, const uint16_t *Q_bf16, int n_q, 
     g.tile_stride = 1;
     g.ranges = (int)round_up(std::min<int64_t>(64, g.n_vt), NUM_XCD);
     g.qgroups = 1;
-    g.range_begin = 0;
-    g.range_end = g.ranges;
+    g.item_begin = 0;
+    g.item_end = INT32_MAX;
     g.store = out;
     g.stagger = 1;
     const int grid = std::max(NUM_XCD, ix->num_cu / NUM_XCD * NUM_XCD);

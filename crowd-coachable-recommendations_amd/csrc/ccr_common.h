@@ -55,6 +55,13 @@ struct CandLayout {
     int cap[3];
     long long base[3];  // in 8-byte records from the start of the candidate area
 };
+// segment of range r: capacity, first range, first record
+__host__ __device__ __forceinline__ void cand_segment(const CandLayout &L, int r, int &cap, int &r0, long long &base) {
+    const int g = (r >= L.seg_end[0] ? 1 : 0) + (r >= L.seg_end[1] ? 1 : 0);
+    r0 = g ? L.seg_end[g - 1] : 0;
+    cap = L.cap[g];
+    base = L.base[g];
+}
 __host__ __device__ __forceinline__ long long cand_sublist(const CandLayout &L, int r, int q, int s, int nq_pad, int sp, int &cap) {
     const int g = (r >= L.seg_end[0] ? 1 : 0) + (r >= L.seg_end[1] ? 1 : 0);
     const int r0 = g ? L.seg_end[g - 1] : 0;
@@ -71,8 +78,8 @@ struct Plan {
     int sample_tiles;     // tiles scored by the threshold pass
     int64_t sample_stride;
     int ranges;           // corpus ranges of the main pass (multiple of NUM_XCD)
-    int ranges_a;         // ranges scored by phase A (0 = single phase); thresholds are re-tightened after it
-    int ranges_b;          // end of the second phase (0: two phases)
+    int item_a;           // phase A = work items [0, item_a) of every XCD set (0 = single phase); thresholds are re-tightened after it
+    int item_b;           // end of the second phase in items (0: two phases)
     int qgroups;          // query-block groups over the XCDs
     int cap;              // candidate slots per sub-list (the largest segment's: statistics)
     CandLayout cand;      // per-phase segments of the candidate area
@@ -99,13 +106,14 @@ struct GemmArgs {
     int64_t tile_stride;
     int ranges;           // item (r, qb) covers virtual tiles r, r + ranges, ...
     int qgroups;          // query-block groups spread over the XCDs (1, 2, 4 or 8; divides qblocks)
-    int range_begin, range_end;  // this launch covers ranges [range_begin, range_end), both multiples of 8
+    // Work items of an XCD set are numbered item = (range / classes) * blocks_per_group + block_in_group; a launch covers the
+    // items [item_begin, item_end) of every XCD set, so a phase can be EXACTLY whole rounds of items whatever the range count
+    int item_begin, item_end;
     // EPI_FILTER
     const float *thr;     // [nq_pad]
-    uint2 *cand;          // this launch's segment: [range - cand_range0][nq_pad][sublists][cap] {score bits, local row}
+    uint2 *cand;          // candidate area {score bits, local row}; sub-list addresses and capacities from `lay`
     uint32_t *cnt;        // [ranges][nq_pad][sublists]
-    int cap;
-    int cand_range0;      // first range of the segment `cand` points at
+    CandLayout lay;
     // EPI_GMAX
     float *gmax;          // [n_vt * 16][nq_pad]
     // EPI_STORE (debug)

@@ -103,12 +103,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
     const int rc = xcd / a.qgroups;
     const int nrc = NUM_XCD / a.qgroups;           // range classes
     const int qb_per = a.qblocks / a.qgroups;      // query blocks of this XCD (qgroups divides qblocks)
-    const int rl0 = a.range_begin / nrc;
-    const int rl_x = (a.range_end - a.range_begin) / nrc;
-    const int count_x = rl_x * qb_per;
+    const int count_x = (a.ranges / nrc) * qb_per;   // items of this XCD set over the whole pass
+    const int item_end = a.item_end < count_x ? a.item_end : count_x;
 
-    for (int item = jx; item < count_x; item += per_x) {
-        const int rl = rl0 + item / qb_per;
+    for (int item = a.item_begin + jx; item < item_end; item += per_x) {
+        const int rl = item / qb_per;
         const int qb = qg * qb_per + item % qb_per;
         const int r = rc + nrc * rl;
         const int64_t ntile = (a.n_vt - r + a.ranges - 1) / a.ranges;
@@ -120,12 +119,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
         float thr[2] = {0.f, 0.f};
         uint32_t ncand[2] = {0u, 0u};
         uint2 *clist[2] = {nullptr, nullptr};
+        int cap = 0;
         if (EPI == EPI_FILTER) {
+            int seg_r0;
+            long long seg_base;
+            cand_segment(a.lay, r, cap, seg_r0, seg_base);   // this range's segment of the candidate area (wave-uniform)
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
                 const int q = q0 + wq * 64 + qt * 32 + l31;
                 thr[qt] = (q < a.n_q) ? a.thr[q] : __builtin_nanf("");
-                clist[qt] = a.cand + (((int64_t)(r - a.cand_range0) * a.nq_pad + q) * 4 + wd * 2 + h) * a.cap;
+                clist[qt] = a.cand + seg_base + (((int64_t)(r - seg_r0) * a.nq_pad + q) * 4 + wd * 2 + h) * cap;
             }
             // make hipcc wait for the threshold loads HERE, before any LDS-DMA is in flight: its own
             // wait at the first use inside the tile epilogue would be vmcnt(0) and drain the DMA ring
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
                                         // lane's block, clamped): the hit path is instruction-bound beside the partner's MFMAs
                                         const uint32_t off = (uint32_t)(dt * 32 + 8 * g + e2);
                                         if (v >= t && off < rows_left) {
-                                            if (ncand[qt] < (uint32_t)a.cap)
+                                            if (ncand[qt] < (uint32_t)cap)
                                                 clist[qt][ncand[qt]] = make_uint2(__float_as_uint(v), row32 + off);
                                             ++ncand[qt];
                                         }
@@ -404,12 +407,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
     const int rc = xcd / a.qgroups;
     const int nrc = NUM_XCD / a.qgroups;
     const int qb_per = a.qblocks / a.qgroups;
-    const int rl0 = a.range_begin / nrc;
-    const int rl_x = (a.range_end - a.range_begin) / nrc;
-    const int count_x = rl_x * qb_per;
+    const int count_x = (a.ranges / nrc) * qb_per;   // items of this XCD set over the whole pass
+    const int item_end = a.item_end < count_x ? a.item_end : count_x;
 
-    for (int item = jx; item < count_x; item += per_x) {
-        const int rl = rl0 + item / qb_per;
+    for (int item = a.item_begin + jx; item < item_end; item += per_x) {
+        const int rl = item / qb_per;
         const int qb = qg * qb_per + item % qb_per;
         const int r = rc + nrc * rl;
         const int64_t ntile = (a.n_vt - r + a.ranges - 1) / a.ranges;
@@ -419,12 +421,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
         float thr[4] = {0.f, 0.f, 0.f, 0.f};
         uint32_t ncand[4] = {0u, 0u, 0u, 0u};
         uint2 *clist[4] = {nullptr, nullptr, nullptr, nullptr};
+        int cap = 0;
         if (EPI == EPI_FILTER) {
+            int seg_r0;
+            long long seg_base;
+            cand_segment(a.lay, r, cap, seg_r0, seg_base);   // this range's segment of the candidate area (wave-uniform)
 #pragma unroll
             for (int qt = 0; qt < 4; ++qt) {
                 const int q = q0 + wq * 64 + qt * 16 + l15;
                 thr[qt] = (q < a.n_q) ? a.thr[q] : __builtin_nanf("");
-                clist[qt] = a.cand + (((int64_t)(r - a.cand_range0) * a.nq_pad + q) * 8 + wd * 4 + lq) * a.cap;
+                clist[qt] = a.cand + seg_base + (((int64_t)(r - seg_r0) * a.nq_pad + q) * 8 + wd * 4 + lq) * cap;
             }
             asm volatile("" : "+v"(thr[0]), "+v"(thr[1]), "+v"(thr[2]), "+v"(thr[3]));
         }
@@ -488,7 +494,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
                                     const float v = acc[dt][qt][e];
                                     const int64_t doc = row_base + dt * 16 + e;
                                     if (v >= t && doc < a.n_rows) {
-                                        if (ncand[qt] < (uint32_t)a.cap)
+                                        if (ncand[qt] < (uint32_t)cap)
                                             clist[qt][ncand[qt]] = make_uint2(__float_as_uint(v), (uint32_t)doc);
                                         ++ncand[qt];
                                     }
@@ -709,7 +715,8 @@ __global__ __launch_bounds__(256) void threshold_kernel(const float *__restrict_
 // with their real MFMA scores, whether or not a sub-list overflowed).  thr[q] = max(thr[q], kth - delta[q]).
 // grid = n_q, block = 256.
 __global__ __launch_bounds__(256) void threshold_update_kernel(const uint2 *__restrict__ cand, const uint32_t *__restrict__ cnt,
-                                                              int nsub, int sp, int nq_pad, const CandLayout lay, int k, int compact,
+                                                              int nsub_full, int nsub_part, int part_blocks, int qb_per, int sp,
+                                                              int nq_pad, const CandLayout lay, int k, int compact,
                                                               const float *__restrict__ delta, float *__restrict__ thr) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_val[];   // [compact] orderable scores of the candidates found so far
     __shared__ uint32_t s_hist[256];
@@ -718,6 +725,9 @@ __global__ __launch_bounds__(256) void threshold_update_kernel(const uint2 *__re
     __shared__ uint32_t s_total, s_maxc, s_fill;
     const int tid = threadIdx.x;
     const int q = blockIdx.x;
+    // sub-lists complete so far: those of the fully scored ranges, plus one more row of ranges for the queries whose block
+    // (position inside its XCD group) was already scored in the partially finished one
+    const int nsub = ((q / TILE_Q) % qb_per) < part_blocks ? nsub_part : nsub_full;
     if (tid == 0) {
         s_total = 0;
         s_maxc = 0;
@@ -1200,10 +1210,11 @@ int launch_threshold(const float *gmax, int64_t n_groups, int n_q, int nq_pad, i
     return CCR_OK;
 }
 
-int launch_threshold_update(const uint2 *cand, const uint32_t *cnt, int nsub, int sp, int n_q, int nq_pad, const CandLayout &lay, int k,
-                            const float *delta, float *thr, hipStream_t s) {
-    if (nsub > 2048) {
-        set_error("threshold_update: %d sub-lists exceed 2048", nsub);
+int launch_threshold_update(const uint2 *cand, const uint32_t *cnt, int nsub, int nsub_part, int part_blocks, int qb_per, int sp, int n_q,
+                            int nq_pad, const CandLayout &lay, int k, const float *delta, float *thr, hipStream_t s) {
+    if (nsub_part < nsub) nsub_part = nsub;
+    if (nsub_part > 2048) {
+        set_error("threshold_update: %d sub-lists exceed 2048", nsub_part);
         return CCR_ERR_INVALID;
     }
     // LDS score buffer: comfortably more than k (the bound tightens with the number of rows seen), 16 KiB at least
@@ -1214,7 +1225,8 @@ int launch_threshold_update(const uint2 *cand, const uint32_t *cnt, int nsub, in
         const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&threshold_update_kernel), 128 * 1024);
         if (rc != CCR_OK) return rc;
     }
-    hipLaunchKernelGGL(threshold_update_kernel, dim3(n_q), dim3(256), lds, s, cand, cnt, nsub, sp, nq_pad, lay, k, compact, delta, thr);
+    hipLaunchKernelGGL(threshold_update_kernel, dim3(n_q), dim3(256), lds, s, cand, cnt, nsub, nsub_part, part_blocks, qb_per > 0 ? qb_per : 1, sp,
+                       nq_pad, lay, k, compact, delta, thr);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
 }

@@ -14,6 +14,7 @@ struct Knobs {
     int sample_div;    // CCR_SAMPLE_DIV   0 = planner's choice, else the pinned sample fraction 1/div
     int gemm_dbg;      // CCR_GEMM_DBG     timing-only ablations of the main pass (WRONG results when non-zero)
     int stagger;       // CCR_GEMM_STAGGER 0 = both wave groups of the 32x32x16 kernel in phase
+    int ranges;        // CCR_RANGES       0 = planner's choice, else the pinned range count (rounded to a multiple of 8)
     int max_lists;     // CCR_MAX_LISTS    0 = planner's limit, else a cap on ranges x sublists (A/B of the select stage's walk)
 };
 Knobs read_knobs();
@@ -43,8 +44,9 @@ int launch_partition_flags(const uint32_t *flags, int begin, int n, uint32_t *re
 int launch_scatter_thresholds(const uint32_t *list, int n, const float *thr2, float *thr, hipStream_t s);
 int launch_gather_queries(const uint16_t *Q, int dim, const uint32_t *list, int n, const float *thr, const float *delta, uint16_t *Q2,
                           float *thr2, float *delta2, hipStream_t s);
-int launch_threshold_update(const uint2 *cand, const uint32_t *cnt, int nsub, int sp, int n_q, int nq_pad, const CandLayout &lay, int k,
-                            const float *delta, float *thr, hipStream_t s);
+// nsub: sub-lists of the fully scored ranges; queries whose block position inside its XCD group is < part_blocks have nsub_part
+int launch_threshold_update(const uint2 *cand, const uint32_t *cnt, int nsub, int nsub_part, int part_blocks, int qb_per, int sp, int n_q,
+                            int nq_pad, const CandLayout &lay, int k, const float *delta, float *thr, hipStream_t s);
 // dense exact path.  qlist: query rows to score (nullptr: q_begin + qi); out_rows: destination rows of the select
 // (nullptr: q_begin + qi); count_dev (device, may be null): only the first *count_dev - q_begin entries of the list exist
 // (the on-stream fallback chunk of an asynchronous search -- the host does not know the count yet).
