@@ -88,7 +88,7 @@ struct MainPassChoice {
     int item_a, item_b;   // phase ends in work items of one XCD set (0 = absent)
 };
 
-static MainPassChoice choose_main_pass(const Plan &p, int k, int64_t sample_a, int64_t sample_b, const Knobs &kn) {
+static MainPassChoice choose_main_pass(const Plan &p, int k, int64_t sample_a, int64_t sample_b, int64_t sample_c, const Knobs &kn) {
     const int nrc = NUM_XCD / p.qgroups, qb_per = p.qblocks / p.qgroups, per_x = p.grid / NUM_XCD;
     // the select stage walks ranges x sublists sub-lists per query: 1 024 with its 256-thread form, 2 048 with the 1 024-thread
     // form large k uses anyway (rescore_cap > 512)
@@ -107,9 +107,9 @@ static MainPassChoice choose_main_pass(const Plan &p, int k, int64_t sample_a, i
 
     MainPassChoice best_choice = {sample_a, target, 0, 0};
     double best = 1e300;
-    for (int pass = 0; pass < 2; ++pass) {
-        const int64_t smp = pass == 0 ? sample_a : sample_b;
-        if (pass == 1 && smp == sample_a) break;
+    for (int pass = 0; pass < 3; ++pass) {
+        const int64_t smp = pass == 0 ? sample_a : (pass == 1 ? sample_b : sample_c);
+        if ((pass >= 1 && smp == sample_a) || (pass == 2 && smp == sample_b)) continue;
         const double fs = (double)smp / (double)p.tiles;
         const double smp_cost = sample_cost(smp);
         auto survivors = [&](double fa, double fb) -> double {   // fa, fb: corpus fractions of phases A and B1 (0 = absent)
@@ -201,8 +201,13 @@ static Plan make_plan_for(int64_t n_rows, int dim, int n_q, int k, int flags, in
     };
     if (p.fused) {
         p.qgroups = pick_qgroups(p.qblocks, dim, kn);
-        const int64_t sample_alt = (sample_div_forced || (flags & CCR_SEARCH_FORCE_FUSED)) ? sample : sample_for(2 * sample_div);
-        const MainPassChoice choice = choose_main_pass(p, k, sample, sample_alt, kn);
+        // the planner prices three sample sizes: 1/32 of the tiles, 1/64 (cheaper pass, twice the survivors of phase A) and 1/16
+        // (large k: phase A's survivors cost more than the second half of the sample)
+        const bool pinned = sample_div_forced || (flags & CCR_SEARCH_FORCE_FUSED);
+        const int64_t sample_alt = pinned ? sample : sample_for(2 * sample_div);
+        int64_t sample_big = pinned ? sample : sample_for(sample_div / 2);
+        if (sample_big * 4 > p.full_tiles) sample_big = sample;
+        const MainPassChoice choice = choose_main_pass(p, k, sample, sample_alt, sample_big, kn);
         sample = choice.sample;
         const int64_t R = choice.ranges;
         p.sample_tiles = (int)sample;
