@@ -1032,25 +1032,48 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
     const size_t stage_bytes = (size_t)compact * 8;
     // (only in the 1024-thread large-k variant: at k <= 256 the ~100 rows per query are re-read from L2 / Infinity Cache
     // quickly enough by the direct walk, and the slice barriers cost more than they save)
-    const int SB = THREADS < 1024 ? 0 : ((size_t)ncoll * 144 <= stage_bytes ? 128 : ((size_t)ncoll * 80 <= stage_bytes ? 64 : 0));
-    if (SB != 0 && ncoll <= 2 * THREADS) {
+    int SB = THREADS < 1024 ? 0 : ((size_t)ncoll * 144 <= stage_bytes ? 128 : ((size_t)ncoll * 80 <= stage_bytes ? 64 : 0));
+    constexpr int PRE = 8;                                               // 16-byte pieces a thread keeps in flight for the next slice
+    if (SB == 128 && ncoll * 8 > PRE * THREADS) SB = 64;
+    if (SB != 0 && ncoll <= 2 * THREADS && ncoll * (SB / 16) <= PRE * THREADS) {
         char *stage = reinterpret_cast<char *>(s_comp);
         const int stride = SB + 16;                 // +16: consecutive rows start 4 banks apart (conflict-free b128 reads)
-        const int lpr = SB / 16;                    // lanes per row and slice
+        const int lpr = SB / 16;                    // lanes per row and slice (THREADS % lpr == 0: a thread's pieces share one column)
         const int row_bytes = dim * 2;
         const char *Dbytes = reinterpret_cast<const char *>(D);
+        const int col = (tid % lpr) * 16;           // byte column of this thread's pieces inside a slice
+        // Software pipeline: the pieces of slice s + 1 are loaded into registers while slice s is consumed from the LDS, so the
+        // scattered row reads (the bulk of this stage: ~1.5 KB per re-scored row) overlap the fp64 chains instead of sitting
+        // between two barriers 24 times per query.
+        // (every piece is loaded unconditionally -- an unused slot reads row 0, a column past the row end re-reads column 0 --
+        // so that the prefetched values stay in registers; only the store into the LDS is conditional)
+        // piece j of this thread belongs to candidate (tid + j * THREADS) / lpr; only its row pointer is kept.  Eight named
+        // values, not an array: hipcc leaves a uint4[8] in scratch memory under the 128-register budget of 1 024 threads.
+#define CCR_PIECES(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+        const char *Dcol = Dbytes + col;
+        const int npiece = ncoll * lpr;
+#define CCR_DECL(j)                                                                                              \
+    const int idx##j = tid + j * THREADS;                                                                        \
+    const char *src##j = Dcol + (int64_t)(uint32_t)s_keys[idx##j < npiece ? idx##j / lpr : 0] * row_bytes;      \
+    uint4 pre##j = *reinterpret_cast<const uint4 *>(src##j);
+        CCR_PIECES(CCR_DECL)
+#undef CCR_DECL
         double acc[2] = {0.0, 0.0};
         for (int k0 = 0; k0 < row_bytes; k0 += SB) {
-            __syncthreads();                        // the previous slice has been consumed (first pass: s_keys/s_comp settled)
-            for (int idx = tid; idx < ncoll * lpr; idx += THREADS) {
-                const int r = idx / lpr, c = idx - r * lpr;
-                if (k0 + c * 16 < row_bytes) {
-                    const uint32_t row = (uint32_t)s_keys[r];
-                    *reinterpret_cast<uint4 *>(stage + (size_t)r * stride + c * 16) =
-                        *reinterpret_cast<const uint4 *>(Dbytes + (int64_t)row * row_bytes + k0 + c * 16);
-                }
-            }
+            __syncthreads();                        // the previous slice has been consumed (first pass: s_comp is free)
+            const bool col_in = k0 + col < row_bytes;
+#define CCR_PUT(j) \
+    if (col_in && idx##j < npiece) *reinterpret_cast<uint4 *>(stage + (idx##j / lpr) * stride + col) = pre##j;
+            CCR_PIECES(CCR_PUT)
+#undef CCR_PUT
             __syncthreads();
+            {   // next slice: in flight during the fp64 chains below
+                const int kn = (k0 + SB + col < row_bytes) ? k0 + SB : -col;
+#define CCR_GET(j) pre##j = *reinterpret_cast<const uint4 *>(src##j + kn);
+                CCR_PIECES(CCR_GET)
+#undef CCR_GET
+            }
+#undef CCR_PIECES
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int i = tid + j * THREADS;
