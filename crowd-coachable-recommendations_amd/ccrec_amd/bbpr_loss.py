@@ -67,3 +67,32 @@ class MultipleNrlStep:
         return multiple_nrl_loss(qid_emb, pos_emb, neg_emb)
 
     training_and_validation_step = __call__
+
+
+class BertMTStep(MultipleNrlStep):
+    """training_and_validation_step of _BertMT (src/ccrec/models/bert_mt.py:105-113): the fine-tune loss of the base step
+    weighted alpha / ft_cycles; the corpus-tuning (VAE) term is identically zero for contriever models there
+    ((1 - alpha) / ct_cycles * 0).  batch = (ijw, inputs) as the reference's CombinedLoader hands it over."""
+
+    def __init__(self, forward, i_to_ptr, j_to_ptr, user_to_negs, alpha=1.0, ct_cycles=1, ft_cycles=1):
+        super().__init__(forward, i_to_ptr, j_to_ptr, user_to_negs)
+        self.alpha, self.ct_cycles, self.ft_cycles = float(alpha), ct_cycles, ft_cycles
+
+    def __call__(self, batch, batch_idx=0):
+        ijw = batch[0] if isinstance(batch, (tuple, list)) else batch
+        ft_loss = super().__call__(ijw, batch_idx)
+        return (1 - self.alpha) / self.ct_cycles * 0.0 + self.alpha / self.ft_cycles * ft_loss.mean()
+
+    training_and_validation_step = __call__
+
+
+def grouped_adamw(named_parameters, lr, weight_decay):
+    """configure_optimizers of _BertMT (bert_mt.py:115-134): AdamW with weight decay on everything but biases and LayerNorm
+    parameters."""
+    no_decay = ("bias", "LayerNorm.bias", "LayerNorm.weight")
+    named = list(named_parameters)
+    groups = [
+        {"params": [p for n, p in named if not any(nd in n for nd in no_decay)], "weight_decay": weight_decay},
+        {"params": [p for n, p in named if any(nd in n for nd in no_decay)], "weight_decay": 0.0},
+    ]
+    return torch.optim.AdamW(groups, lr=lr, weight_decay=weight_decay)

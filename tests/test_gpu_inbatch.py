@@ -75,3 +75,31 @@ def test_training_step_mirror_vs_reference_golden(golden_dir, tag, B, sim):
     ref = g[f"{tag}_grad"]
     assert np.abs(E.grad.cpu().numpy() - ref).max() < 6e-2 * np.abs(ref).max()
     assert negs == {u: [B + u] for u in range(B)}          # round robin over a single negative leaves the list as it was
+
+
+def test_bert_mt_step_weighting_and_optimizer_groups():
+    """_BertMT.training_and_validation_step (bert_mt.py:105-113): alpha / ft_cycles times the multiple_nrl loss; one AdamW
+    step through the HIP loss moves the embedding table."""
+    import os
+    from ccrec_amd.bbpr_loss import BertMTStep, MultipleNrlStep, grouped_adamw
+    os.environ["CCREC_SIM_TYPE"] = "dot"
+    os.environ["CCREC_BBPR_INV_TEMPERATURE"] = "5"
+    torch.manual_seed(0)
+    table = torch.nn.Embedding(40, 64).cuda()
+    with torch.no_grad():
+        table.weight.mul_(0.2)
+    i_to_ptr = torch.arange(0, 20)
+    j_to_ptr = torch.arange(20, 40)
+    negs = lambda: {u: [(u + 3) % 20, (u + 7) % 20] for u in range(20)}   # noqa: E731
+    batch = torch.stack([torch.arange(16), (torch.arange(16) * 3) % 20, torch.ones(16)], 1).long()
+    fwd = lambda ptr: table(ptr.cuda())                                   # noqa: E731
+    base = MultipleNrlStep(fwd, i_to_ptr, j_to_ptr, negs())(batch)
+    mt = BertMTStep(fwd, i_to_ptr, j_to_ptr, negs(), alpha=0.25, ct_cycles=3, ft_cycles=2)((batch, None))
+    assert abs(float(mt) - 0.25 / 2 * float(base)) < 1e-6
+    opt = grouped_adamw(table.named_parameters(), lr=1e-2, weight_decay=0.01)
+    assert len(opt.param_groups) == 2 and opt.param_groups[1]["weight_decay"] == 0.0
+    before = table.weight.detach().clone()
+    opt.zero_grad()
+    mt.backward()
+    opt.step()
+    assert float((table.weight - before).abs().max()) > 0
