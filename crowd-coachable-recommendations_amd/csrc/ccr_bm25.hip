@@ -18,7 +18,8 @@
 
 namespace ccr {
 int launch_dense_select(const float *scores, int64_t n_rows, int k, const uint32_t *out_rows, int q_begin, int nq_chunk,
-                        const uint32_t *count_dev, int64_t id_offset, float *out_scores, int64_t *out_ids, hipStream_t s);
+                        const uint32_t *count_dev, int64_t id_offset, float *out_scores, int64_t *out_ids, hipStream_t s,
+                        bool aggregate);
 
 struct Bm25Round {       // one (query row of the batch, term) pair of a round
     int64_t begin, end;  // posting range
@@ -198,7 +199,7 @@ extern "C" int ccr_bm25_search(const ccr_bm25_index *ix, const int64_t *q_ptr_ho
         const int64_t n = (int64_t)m * ix->n_docs;
         hipLaunchKernelGGL(bm25_finish_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, (int64_t)1 << 30)), dim3(256), 0, s, acc, scores, n);   // one cell per thread: streams faster than a capped grid-stride loop
         CCR_LAUNCH_CHECK();
-        const int rc = launch_dense_select(scores, ix->n_docs, k, nullptr, q0, m, nullptr, 0, out_scores, out_ids, s);
+        const int rc = launch_dense_select(scores, ix->n_docs, k, nullptr, q0, m, nullptr, 0, out_scores, out_ids, s, false);
         if (rc != CCR_OK) return rc;
     }
     CCR_HIP_CHECK(hipStreamSynchronize(s));

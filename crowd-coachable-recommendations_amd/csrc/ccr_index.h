@@ -53,7 +53,8 @@ int launch_threshold_update(const uint2 *cand, const uint32_t *cnt, int nsub, in
 int launch_dense_scores(const uint16_t *D, int64_t n_rows, int dim, const uint16_t *Q, const uint32_t *qlist,
                         int q_begin, int nq_chunk, const uint32_t *count_dev, float *out, hipStream_t s);
 int launch_dense_select(const float *scores, int64_t n_rows, int k, const uint32_t *out_rows, int q_begin, int nq_chunk,
-                        const uint32_t *count_dev, int64_t id_offset, float *out_scores, int64_t *out_ids, hipStream_t s);
+                        const uint32_t *count_dev, int64_t id_offset, float *out_scores, int64_t *out_ids, hipStream_t s,
+                        bool aggregate = true);
 
 }  // namespace ccr
 

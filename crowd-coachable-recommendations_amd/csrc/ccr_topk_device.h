@@ -45,12 +45,34 @@ __device__ __forceinline__ void radix_pick_digit(const uint32_t *hist, int lane,
     }
 }
 
+// Histogram increment with wave-level aggregation (all 64 lanes of the wave must call; `active` masks the lane).
+// Scores of one row fall into a handful of the 256 top-byte bins, so plain LDS atomics from 64 lanes hit the same address and
+// serialise (2.7 M of them per pass over an NQ-sized row).  Up to three rounds: the first active lane's bin is broadcast, the
+// lanes that share it are counted with a ballot and ONE atomic adds the count; lanes still active afterwards (flat
+// distributions) fall back to their own atomic.
+__device__ __forceinline__ void hist_add_aggregated(uint32_t *hist, uint32_t bin, bool active) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(active);
+#pragma unroll 1
+    for (int r = 0; r < 3 && todo != 0ull; ++r) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t lb = (uint32_t)__shfl((int)bin, leader, 64);
+        const bool mine = active && bin == lb;
+        const unsigned long long same = __ballot(mine);
+        if (lane == leader) atomicAdd(&hist[lb], (uint32_t)__popcll(same));
+        if (mine) active = false;
+        todo &= ~same;
+    }
+    if (active) atomicAdd(&hist[bin], 1u);
+}
+
 // All threads of the block must call.  get(i) -> uint32 orderable key of item i (0 <= i < M) or
 // skip == true to ignore the slot.  On return (uniform across the block):
 //   kth      = key of the k-th largest item
 //   need_eq  = how many items equal to kth belong to the top-k (1 <= need_eq)
 // Requires the number of non-skipped items >= k.  s_hist: 256 uint32, s_ctl: 4 uint32 (LDS).
-template <class Get>
+// AGG: wave-aggregated histogram updates (long rows: M in the millions, skewed bins); the block size must be a multiple of 64.
+template <bool AGG = false, class Get>
 __device__ __forceinline__ void block_radix_select(Get get, int64_t M, int k, uint32_t *s_hist, uint32_t *s_ctl,
                                                    uint32_t &kth, int &need_eq) {
     const int tid = threadIdx.x;
@@ -60,10 +82,20 @@ __device__ __forceinline__ void block_radix_select(Get get, int64_t M, int k, ui
     for (int shift = 24; shift >= 0; shift -= 8) {
         for (int b = tid; b < 256; b += nt) s_hist[b] = 0;
         __syncthreads();
-        for (int64_t i = tid; i < M; i += nt) {
-            bool skip = false;
-            uint32_t o = get(i, skip);
-            if (!skip && (o & mask) == prefix) atomicAdd(&s_hist[(o >> shift) & 255u], 1u);
+        if (AGG) {
+            for (int64_t base = 0; base < M; base += nt) {   // every lane of a wave runs the same trips
+                const int64_t i = base + tid;
+                bool skip = false;
+                uint32_t o = 0;
+                if (i < M) o = get(i, skip);
+                hist_add_aggregated(s_hist, (o >> shift) & 255u, i < M && !skip && (o & mask) == prefix);
+            }
+        } else {
+            for (int64_t i = tid; i < M; i += nt) {
+                bool skip = false;
+                uint32_t o = get(i, skip);
+                if (!skip && (o & mask) == prefix) atomicAdd(&s_hist[(o >> shift) & 255u], 1u);
+            }
         }
         __syncthreads();
         if (tid < 64) radix_pick_digit(s_hist, tid, (uint32_t)remaining, s_ctl);
