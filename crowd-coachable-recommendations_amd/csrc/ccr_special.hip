@@ -467,9 +467,10 @@ extern "C" int ccr_search_sparse_prior(ccr_index *ix, const uint16_t *Q_bf16, in
     while (mp2_max < sp.max_len) mp2_max <<= 1;
     auto merge = [&](const float *ls, const int64_t *li, int k_in, const uint32_t *qmap, int n_blocks) -> int {
         const size_t lds = (((size_t)k_in * 12 + 15) & ~(size_t)15) + (size_t)mp2_max * 12;
-        if (lds > 48 * 1024)
-            CCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&apply_prior_kernel),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (lds > 48 * 1024) {   // 4 096-entry lists: 96 KiB; the opt-in is set once per device
+            const int rc_lds = ensure_dynamic_lds(reinterpret_cast<const void *>(&apply_prior_kernel), 100 * 1024);
+            if (rc_lds != CCR_OK) return rc_lds;
+        }
         hipLaunchKernelGGL(apply_prior_kernel, dim3(n_blocks), dim3(256), lds, s, ls, li, k_in, qmap, d_ptr, prior_idx, prior_val, Lp,
                            id_lo, id_hi, out_scores, out_ids, k, sp.kf, mp2_max);
         CCR_LAUNCH_CHECK();
