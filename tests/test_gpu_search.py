@@ -423,3 +423,32 @@ def test_non_finite_embeddings_do_not_fault_and_are_path_independent():
         finite = torch.isfinite(s_f[0])
         assert finite.sum() >= 7 and torch.all(s_f[0][finite][:-1] >= s_f[0][finite][1:])
 
+
+
+def test_generate_embeddings_contract(tmp_path, capsys):
+    """scripts/ms_marco_eval.py:123-152: ceil(num / bs) batches in index order, progress line when the step is a power of
+    two, total line, optional torch.save(name); an empty index list gives a [0, embedding_size] tensor."""
+    from ccrec_amd.ms_marco_eval import generate_embeddings
+    g = torch.Generator().manual_seed(1)
+    table = torch.randn(70, 768, generator=g)
+    seen = []
+
+    def embedding_func(rows):
+        seen.append(list(rows))
+        return table[torch.as_tensor(rows, dtype=torch.long)]
+
+    ids = [f"d{j}" for j in range(70)]
+    data = {ids[j]: j for j in range(70)}
+    name = str(tmp_path / "emb.pt")
+    out = generate_embeddings(ids, data, embedding_func, 16, name=name)
+    assert [len(b) for b in seen] == [16, 16, 16, 16, 6] and seen[1][0] == 16        # ceil(70 / 16) batches, index order
+    assert out.is_cuda and tuple(out.shape) == (70, 768) and torch.equal(out.cpu(), table)
+    assert torch.equal(torch.load(name).cpu(), table)
+    text = capsys.readouterr().out
+    assert "Processed 16 | 70" in text and "Processed 32 | 70" in text and "Processed 64 | 70" in text   # steps 1, 2, 4
+    assert "Processed 48" not in text and "Processed total 70" in text
+    packed = generate_embeddings(ids, data, embedding_func, 16, pack="cos")
+    assert packed.dtype == torch.bfloat16
+    assert np.array_equal(_bits(packed), orc.normalize_pack_bf16(table.numpy()))
+    empty = generate_embeddings([], data, embedding_func, 16, embedding_size=768)
+    assert tuple(empty.shape) == (0, 768)
