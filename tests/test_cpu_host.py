@@ -26,6 +26,33 @@ def test_header_symbols_are_exported():
     assert lib.ccr_last_error() is not None
 
 
+def test_header_is_plain_c_and_links_against_the_library(tmp_path):
+    """include/ccr_retrieval.h must be usable from C (the reference-side binding could be cgo / ctypes / a C extension): a C
+    translation unit that takes the address of every declared entry point compiles with gcc -std=c99 -pedantic and links
+    against the in-tree library; run without a GPU it reports the version and an error string (no compute call)."""
+    import subprocess
+    from ccrec_amd import _lib
+    header = open(os.path.join(ROOT, "include", "ccr_retrieval.h")).read()
+    names = sorted(set(re.findall(r"\b(ccr_[a-z0-9_]+)\s*\(", header)) - {"ccr_index", "ccr_search_stats"})
+    src = tmp_path / "abi.c"
+    src.write_text("#include <stdio.h>\n#include \"ccr_retrieval.h\"\n"
+                   "typedef void (*fn)(void);\n"
+                   "static fn table[] = {" + ", ".join(f"(fn){n}" for n in names) + "};\n"
+                   "int main(void) {\n"
+                   "    ccr_search_stats st; (void)st;\n"
+                   "    printf(\"%d %d %s|\\n\", (int)(sizeof(table) / sizeof(table[0])), ccr_version(), ccr_last_error());\n"
+                   "    return ccr_index_rows(NULL) == -1 ? 0 : 1;\n}\n")
+    exe = tmp_path / "abi"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    cmd = ["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+           "-L", libdir, "-lccr_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert run.returncode == 0, run.stderr
+    assert run.stdout.split()[0] == str(len(names)) and int(run.stdout.split()[1]) >= 100
+
+
 def test_library_is_in_tree_and_has_no_torch_dependency():
     from ccrec_amd import _lib
     assert _lib.LIB_PATH.startswith(PKG)
