@@ -15,7 +15,8 @@ Extra objects on the JSON line: `roofline` for the dominant kernel (main-pass GE
 events recorded by the library on the search stream), `cpu_baseline` (the oracle's
 reference-faithful CPU path timed on this host's cores on a bounded query sample, rank 0, N = 1) and, in the default
 N = 1 run, `secondary`: the same step at the north-star target shape (MS-MARCO scale 8,841,823 x 768, 6,980 queries,
-top-100, with its own CPU leg) and at k = 1001 (what ranking() asks for) -- short runs, never part of `value`.
+top-100, with its own CPU leg), at k = 1001 (what ranking() asks for) and the configs[4] in-batch-negative loss step -- short runs,
+never part of `value`.
 --data clustered: a non-iid corpus (1,024 Gaussian clusters, log-normal row norms, 3 % duplicate rows).
 """
 import argparse
@@ -238,6 +239,41 @@ class Workload:
         torch.cuda.empty_cache()
 
 
+def inbatch_side_run(dev, B=1024, d=768, iters=30):
+    """configs[4]: the in-batch-negative contrastive step (bbpr.py:205-212) at B = 1024, d = 768: forward + backward of the HIP loss
+    (ccr_inbatch_ce_fwd/bwd) next to the reference's torch formulation (mm, mm, cat, scale, CrossEntropyLoss + autograd) on this GPU."""
+    from ccrec_amd import ops
+    g = torch.Generator(device=dev).manual_seed(0)
+    q, p, n = (torch.randn(B, d, device=dev, generator=g) * d ** -0.5 for _ in range(3))
+
+    def ours():
+        a, b, c = (t.clone().requires_grad_(True) for t in (q, p, n))
+        loss = ops.inbatch_ce(a, b, c, 20.0)
+        loss.backward()
+        return loss
+
+    def ref():
+        a, b, c = (t.clone().requires_grad_(True) for t in (q, p, n))
+        scores = torch.cat([a @ b.T, a @ c.T], 1) * 20.0
+        loss = torch.nn.CrossEntropyLoss()(scores, torch.arange(B, device=dev))
+        loss.backward()
+        return loss
+
+    out = {"workload": f"configs[4]: in-batch-negative loss forward + backward, B = {B}, d = {d}, inv_temperature 20"}
+    for name, fn in (("hip_ms", ours), ("torch_fp32_ms", ref)):
+        for _ in range(5):
+            loss = fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            loss = fn()
+        torch.cuda.synchronize()
+        out[name] = round((time.perf_counter() - t0) / iters * 1e3, 4)
+        out[name.replace("_ms", "_loss")] = round(float(loss), 6)
+    out["steps_per_s"] = round(1e3 / out["hip_ms"], 1)
+    return out
+
+
 def roofline_obj(r, traffic=None, traffic_source=None):
     st = r["stats"]
     return {"bound": "mfma", "kernel": ("gemm_topk16_kernel<EPI_FILTER> (main pass, v_mfma_f32_16x16x32_bf16)" if st.get("sublists") == 8
@@ -351,6 +387,7 @@ def main():
             ms["recall_at_100_vs_cpu"] = cb["recall_at_k_of_gpu_vs_cpu"]
         sec["msmarco_scale"] = ms
         m.release()
+        sec["inbatch_b1024"] = inbatch_side_run(dev)
         out["secondary"] = sec
     if rank == 0:
         print(json.dumps(out), flush=True)
