@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--data", default="gaussian", choices=["gaussian", "clustered", "sorted"],
                     help="gaussian: iid N(0, 1/dim) rows (BASELINE.md); clustered: 1,024 clusters, log-normal norms, 3 %% duplicates; "
                          "sorted: the same with every cluster's rows CONTIGUOUS (a corpus in topical order)")
+    ap.add_argument("--sim", default="dot", choices=["dot", "cos"], help="cos: rows are L2-normalised by the pack kernel (CCREC_SIM_TYPE=cos)")
     ap.add_argument("--cpu-queries", type=int, default=64, help="query sample of the CPU baseline (0 = skip)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the MS-MARCO-scale and k = 1001 side runs")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU rehearsal of N > 1)")
@@ -142,9 +143,10 @@ def cpu_baseline(corpus_bf16, queries_bf16, nq_sample, k, gpu_ids):
 class Workload:
     """One configuration of the hot path on this rank: resident fp32 inputs, packed buffers, the step closure."""
 
-    def __init__(self, rows, queries, dim, k, data, dev, rank, world, backend):
+    def __init__(self, rows, queries, dim, k, data, dev, rank, world, backend, normalize=False):
         from ccrec_amd.dist import shard_bounds, TopkMessage
         self.rows, self.queries, self.dim, self.k, self.world, self.dev, self.backend = rows, queries, dim, k, world, dev, backend
+        self.normalize = normalize
         self.lo, self.hi = shard_bounds(rows, world, rank)
         # every rank generates the same global stream and keeps its rows: identical corpus for every N
         if world == 1:
@@ -172,9 +174,9 @@ class Workload:
     def step(self):
         from ccrec_amd import ops
         self.max_norm.zero_()
-        ops.pack_bf16(self.corpus_f32, out=self.shard, max_norm=self.max_norm)     # pack + max packed-row norm in one pass
+        ops.pack_bf16(self.corpus_f32, out=self.shard, max_norm=self.max_norm, normalize=self.normalize)   # pack + max packed-row norm in one pass
         index = ops.CorpusIndex(self.shard, global_row_offset=self.lo, max_norm=self.max_norm)
-        ops.pack_bf16(self.queries_f32, out=self.qpack)
+        ops.pack_bf16(self.queries_f32, out=self.qpack, normalize=self.normalize)
         if self.world > 1:
             # asynchronous search (no host round trip), then the all-gather on the communication stream; the exchange of the
             # PREVIOUS step is completed (wait + merge) behind this step's search, so its latency hides behind compute.
@@ -307,7 +309,7 @@ def main():
 
     from ccrec_amd import ops
 
-    w = Workload(args.rows, args.queries, args.dim, args.k, args.data, dev, rank, world, args.dist_backend)
+    w = Workload(args.rows, args.queries, args.dim, args.k, args.data, dev, rank, world, args.dist_backend, normalize=args.sim == "cos")
     log(f"rank {rank}: inputs resident, rows [{w.lo},{w.hi}), data={args.data}")
     r = w.run(args.steps, args.warmup, "main")
     st = r["stats"]
@@ -315,13 +317,13 @@ def main():
     # untimed extras: pack-kernel HBM rate
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    ops.pack_bf16(w.corpus_f32, out=w.shard, max_norm=w.max_norm)
+    ops.pack_bf16(w.corpus_f32, out=w.shard, max_norm=w.max_norm, normalize=w.normalize)
     e1.record()
     torch.cuda.synchronize()
     pack_ms = e0.elapsed_time(e1)
     pack_gbs = (w.hi - w.lo) * args.dim * 6 / (pack_ms * 1e-3) / 1e9
 
-    default_shape = (args.rows, args.queries, args.dim, args.k, args.data) == (N_ROWS, N_Q, DIM, TOP_K, "gaussian")
+    default_shape = (args.rows, args.queries, args.dim, args.k, args.data, args.sim) == (N_ROWS, N_Q, DIM, TOP_K, "gaussian", "dot")
     # HBM traffic of the dominant kernel cannot be read from inside the process (it needs rocprofv3 --pmc passes): the
     # figure below is the offline PMC measurement of THIS command committed under profiles/, labelled as such
     traffic, traffic_source = None, None
@@ -333,7 +335,7 @@ def main():
             traffic = None
 
     workload = ("configs[1]: NQ corpus top-100, corpus row-sharded over n_gpus" if default_shape else
-                f"custom shape (not the headline config): {args.rows:,} x {args.dim} corpus ({args.data}), {args.queries:,} queries, "
+                f"custom shape (not the headline config): {args.rows:,} x {args.dim} corpus ({args.data}, {args.sim}), {args.queries:,} queries, "
                 f"top-{args.k}, corpus row-sharded over n_gpus")
     out = {
         "metric": ("queries/sec, exhaustive inner-product top-100 retrieval (NQ-shaped 2,681,468 x 768 bf16 corpus)" if default_shape

@@ -34,12 +34,14 @@ def main():
     el = n * d
     t_pack = timeit(lambda: ops.pack_bf16(x, out=y16, max_norm=mx))
     t_plain = timeit(lambda: ops.pack_bf16(x, out=y16))
+    t_cos = timeit(lambda: ops.pack_bf16(x, out=y16, normalize=True, max_norm=mx))
     t_cast = timeit(lambda: y16.copy_(x))
     t_copy = timeit(lambda: y32.copy_(x))
     print(json.dumps({"rows": n, "dim": d,
                       "ccr_pack_maxnorm_GBps": round(el * 6 / t_pack / 1e9, 1), "ccr_pack_GBps": round(el * 6 / t_plain / 1e9, 1),
+                      "ccr_pack_normalize_maxnorm_GBps": round(el * 6 / t_cos / 1e9, 1),
                       "torch_cast_GBps": round(el * 6 / t_cast / 1e9, 1), "fp32_copy_GBps": round(el * 8 / t_copy / 1e9, 1),
-                      "ms": {"ccr_pack_maxnorm": round(t_pack * 1e3, 3), "ccr_pack": round(t_plain * 1e3, 3),
+                      "ms": {"ccr_pack_maxnorm": round(t_pack * 1e3, 3), "ccr_pack": round(t_plain * 1e3, 3), "ccr_pack_normalize": round(t_cos * 1e3, 3),
                              "torch_cast": round(t_cast * 1e3, 3), "fp32_copy": round(t_copy * 1e3, 3)}}))
 
 
