@@ -615,7 +615,9 @@ __global__ __launch_bounds__(256) void row_norms_bf16_kernel(const uint16_t *__r
         if (norms && lane == 0) norms[r] = n;
         wmax = fmaxf(wmax, n);
     }
-    if (max_bits && lane == 0) atomicMax(max_bits, __float_as_uint(wmax));  // non-negative floats order as uints
+    // non-negative floats order as uints; one look first: only a wave that would raise the maximum touches the atomic
+    if (max_bits && lane == 0 && __float_as_uint(wmax) > __hip_atomic_load(max_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(max_bits, __float_as_uint(wmax));
 }
 
 // thr[q] = (k-th largest group maximum) - delta[q].
