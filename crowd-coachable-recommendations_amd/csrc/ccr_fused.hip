@@ -595,7 +595,7 @@ __global__ __launch_bounds__(256) void row_norms_bf16_kernel(const uint16_t *__r
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    float wmax = 0.f;
+    uint32_t wbits = 0u;   // max norm as ordered bits: non-negative floats order as unsigned and a NaN (row with NaN) stays on top
     for (int64_t r = wave; r < rows; r += nwaves) {
         const uint16_t *x = X + r * dim;
         float s = 0.f;
@@ -613,11 +613,11 @@ __global__ __launch_bounds__(256) void row_norms_bf16_kernel(const uint16_t *__r
         for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
         const float n = sqrtf(s);
         if (norms && lane == 0) norms[r] = n;
-        wmax = fmaxf(wmax, n);
+        const uint32_t nb = __float_as_uint(n) & 0x7fffffffu;
+        wbits = nb > wbits ? nb : wbits;
     }
     // non-negative floats order as uints; one look first: only a wave that would raise the maximum touches the atomic
-    if (max_bits && lane == 0 && __float_as_uint(wmax) > __hip_atomic_load(max_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-        atomicMax(max_bits, __float_as_uint(wmax));
+    if (max_bits && lane == 0 && wbits > __hip_atomic_load(max_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_bits, wbits);
 }
 
 // thr[q] = (k-th largest group maximum) - delta[q].

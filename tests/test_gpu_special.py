@@ -273,6 +273,8 @@ def test_nan_row_with_norm_path_equals_dense():
     s0, i0 = ops.CorpusIndex(Db, max_norm=mx).search(Qb, k, 2)
     s1, i1 = ops.CorpusIndex(Db).search(Qb, k, 1)
     assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
+    s2, i2 = ops.CorpusIndex(Db).search(Qb, k, 2)                      # the index's own norm pass must keep the NaN too
+    assert torch.equal(i2, i1) and torch.equal(s2.view(torch.int32), s1.view(torch.int32))
 
 
 def test_colsum_bf16():
