@@ -465,3 +465,38 @@ def test_lazy_scores_slice_like_rime_lite_and_odd_widths_take_the_fused_path():
     Pc.sort_indices()
     ref_pi, _ = orc.sparse_prior_search(Ub, Vb, Pc.indptr, Pc.indices, Pc.data, k)
     assert np.array_equal(i1.cpu().numpy(), ref_pi)
+
+
+def test_empty_and_degenerate_inputs():
+    """Zero queries, one row, k == n_rows, empty block lists and an empty prior through every round-2 entry point."""
+    import os
+    from ccrec_amd import ops
+    from ccrec_amd.ms_marco_eval import ranking
+    Db, Qb = _rand_bits(500, 64, 1), _rand_bits(5, 64, 2)
+    index = ops.CorpusIndex(_bf16(Db))
+    empty_q = _bf16(Qb)[:0]
+    s, i = index.search(empty_q, 7)
+    assert tuple(s.shape) == (0, 7) and tuple(i.shape) == (0, 7)
+    s, i = index.search_blocked(empty_q, 7, np.zeros(1, np.int64), np.zeros(0, np.int64))
+    assert tuple(i.shape) == (0, 7)
+    f, i = index.search_sparse_prior(empty_q, 7, np.zeros(1, np.int64), np.zeros(0, np.int64), np.zeros(0))
+    assert tuple(f.shape) == (0, 7) and f.dtype == torch.float64
+    assert tuple(index.scores(empty_q).shape) == (0, 500)
+    # no blocked ids / no prior entries at all == the plain search (scores as fp64 for the prior form)
+    s0, i0 = index.search(_bf16(Qb), 500)                                # k == n_rows: the whole corpus, ranked
+    assert sorted(i0[0].tolist()) == list(range(500))
+    s1, i1 = index.search_blocked(_bf16(Qb), 500, np.zeros(6, np.int64), np.zeros(0, np.int64))
+    assert torch.equal(i0, i1) and torch.equal(s0, s1)
+    f2, i2 = index.search_sparse_prior(_bf16(Qb), 500, np.zeros(6, np.int64), np.zeros(0, np.int64), np.zeros(0))
+    assert torch.equal(i0, i2) and torch.equal(s0.double(), f2)
+    # a one-row corpus
+    one = ops.CorpusIndex(_bf16(Db[:1]))
+    s, i = one.search(_bf16(Qb), 1)
+    assert i.flatten().tolist() == [0] * 5
+    with pytest.raises(Exception, match="k="):
+        one.search(_bf16(Qb), 2)                                          # k > n_rows is an error, as documented
+    # ranking() with no queries: an empty profile (the corpus is still encoded, as the reference does)
+    os.environ["CCREC_SIM_TYPE"] = "dot"
+    table = torch.randn(20, 768)
+    prof = ranking({f"p{j}": j for j in range(20)}, {}, lambda rows: table[torch.as_tensor(rows, dtype=torch.long)], 8)
+    assert prof == {}
