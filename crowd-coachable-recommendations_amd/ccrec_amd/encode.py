@@ -153,5 +153,6 @@ def ranking_sharded(corpus, queries, encoder, block_dict=None, rank=0, world=1, 
         block = block_csr(lists, n)
     scores, ids = sharded_search(index, q_bf16, min(n, keep), group=group, block=block, n_total=n)
     scores_l, ids_l = scores.cpu().tolist(), ids.cpu().tolist()
-    profile = {qid: dict(zip([corpus_ids[j] for j in row_i], row_s)) for qid, row_i, row_s in zip(queries_ids, ids_l, scores_l)}
+    pid_of = corpus_ids.__getitem__
+    profile = {qid: dict(zip(map(pid_of, row_i), row_s)) for qid, row_i, row_s in zip(queries_ids, ids_l, scores_l)}
     return (profile, ids, scores) if with_tensors else profile
