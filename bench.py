@@ -178,17 +178,15 @@ class Workload:
         index = ops.CorpusIndex(self.shard, global_row_offset=self.lo, max_norm=self.max_norm)
         ops.pack_bf16(self.queries_f32, out=self.qpack, normalize=self.normalize)
         if self.world > 1:
-            # asynchronous search (no host round trip), then the all-gather on the communication stream; the exchange of the
-            # PREVIOUS step is completed (wait + merge) behind this step's search, so its latency hides behind compute.
+            # search (its one host synchronisation reads the flagged-query count, so the lists are FINAL before they are
+            # exchanged -- an exchange that had to be repeated on some ranks only would need every rank's agreement), then the
+            # all-gather on the communication stream; the exchange of the PREVIOUS step is completed (wait + merge) behind it,
+            # so its latency hides behind the next step's pack and search.
             msg = self.messages[self.nstep % 2]
             self.nstep += 1
-            index.search(self.qpack, self.k_local, out=(msg.scores, msg.ids), defer=True)
+            index.search(self.qpack, self.k_local, out=(msg.scores, msg.ids))
             work = msg.gather_async()
             self.drain()
-            index.finish()   # the synchronisation the results need anyway; reports flagged queries beyond the on-stream chunk
-            if index.last_stats()["n_fallback"] > 16:   # mass ties: the exchange ran ahead of the complete lists -- redo it
-                work.wait()
-                work = msg.gather_async()
             self.prev = (msg, work, index)
             self.index = index
         else:
