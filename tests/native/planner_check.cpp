@@ -1,0 +1,75 @@
+// Host-only check of the search planner (ccr::make_plan in libccr_hip.so): no GPU call.  Built and run by
+// tests/test_cpu_host.py::test_planner_invariants_on_cpu.  Prints one line per shape; exits non-zero on a violated invariant.
+#include <stdio.h>
+#include <string.h>
+
+#include "ccr_index.h"
+
+using namespace ccr;
+
+static int fail(const char *what, long long n, int d, int nq, int k) {
+    printf("FAIL %s at n=%lld dim=%d nq=%d k=%d\n", what, n, d, nq, k);
+    return 1;
+}
+
+int main() {
+    Knobs kn;
+    memset(&kn, 0, sizeof(kn));
+    kn.progressive = 1;
+    kn.max_phases = 3;
+    kn.mfma16 = -1;
+    kn.stagger = 1;
+    const long long rows[] = {300, 9862, 70000, 335184, 1105228, 2681468, 8841823, 6250000};
+    const int dims[] = {64, 768, 1024};
+    const int nqs[] = {1, 40, 300, 3452, 6980, 10000};
+    const int ks[] = {1, 10, 100, 300, 1001, 4096};
+    int bad = 0, fused = 0, total = 0;
+    for (long long n : rows)
+        for (int d : dims)
+            for (int nq : nqs)
+                for (int k : ks) {
+                    if (k > n) continue;
+                    const Plan p = make_plan(n, d, nq, k, CCR_SEARCH_DEFAULT, 256, kn);
+                    ++total;
+                    if (p.total == 0) bad += fail("empty workspace", n, d, nq, k);
+                    if (!p.fused) continue;
+                    ++fused;
+                    const int nrc = NUM_XCD / p.qgroups, qb_per = p.qblocks / p.qgroups, per_x = p.grid / NUM_XCD;
+                    const int items = p.ranges / nrc * qb_per;
+                    if (p.nq_pad % TILE_Q || p.nq_pad < nq || p.qblocks * TILE_Q != p.nq_pad) bad += fail("query padding", n, d, nq, k);
+                    if (p.qblocks % p.qgroups || NUM_XCD % p.qgroups) bad += fail("query groups", n, d, nq, k);
+                    if (p.ranges % NUM_XCD || p.ranges < NUM_XCD) bad += fail("ranges not a multiple of the XCD count", n, d, nq, k);
+                    if (p.sublists != (p.mfma16 ? 8 : 4)) bad += fail("sublists", n, d, nq, k);
+                    if (p.ranges * p.sublists > (p.rescore_cap > 512 ? 2048 : 1024)) bad += fail("too many sub-lists for the select stage", n, d, nq, k);
+                    if (p.item_a < 0 || p.item_b < 0 || (p.item_b && p.item_b <= p.item_a) || p.item_a > items || p.item_b > items)
+                        bad += fail("phase ends", n, d, nq, k);
+                    if (p.item_a && p.item_a % per_x) bad += fail("phase A is not whole rounds", n, d, nq, k);
+                    if (p.item_b && p.item_b % per_x) bad += fail("phase B is not whole rounds", n, d, nq, k);
+                    if (p.sample_tiles * GROUPS_PER_TILE < k) bad += fail("sample smaller than k groups", n, d, nq, k);
+                    if ((long long)p.sample_tiles * p.sample_stride > p.full_tiles + p.sample_stride) bad += fail("sample beyond the shard", n, d, nq, k);
+                    // candidate segments: ascending, capacities hold one whole tile per sub-list, area inside the workspace
+                    const CandLayout &L = p.cand;
+                    if (L.nseg < 1 || L.nseg > 3) bad += fail("segments", n, d, nq, k);
+                    long long end = 0;
+                    int prev = 0;
+                    for (int g = 0; g < L.nseg; ++g) {
+                        const int seg_end = g + 1 < L.nseg ? L.seg_end[g] : p.ranges;
+                        if (seg_end <= prev) bad += fail("segment order", n, d, nq, k);
+                        if (L.cap[g] < TILE_DOCS / p.sublists + 16 || L.cap[g] % 4) bad += fail("sub-list capacity", n, d, nq, k);
+                        if (L.base[g] < end) bad += fail("segments overlap", n, d, nq, k);
+                        end = L.base[g] + (long long)(seg_end - prev) * p.nq_pad * p.sublists * L.cap[g];
+                        prev = seg_end;
+                    }
+                    if (p.off_cand + (size_t)end * 8 > p.off_flag) bad += fail("candidate area overruns the flag area", n, d, nq, k);
+                    if (!(p.off_qnorm < p.off_thr && p.off_thr < p.off_gmax && p.off_gmax < p.off_cnt && p.off_cnt < p.off_cand &&
+                          p.off_cand < p.off_flag && p.off_flag < p.off_dense && p.off_dense < p.off_retry && p.off_retry < p.total))
+                        bad += fail("workspace layout order", n, d, nq, k);
+                    if ((n == 2681468 && d == 768 && nq == 3452 && (k == 100 || k == 1001)) || (n == 8841823 && d == 768 && nq == 6980 && k == 100) ||
+                        (n == 6250000 && d == 1024 && nq == 10000 && k == 1001))
+                        printf("n=%lld nq=%d k=%d: ranges %d x %d sub-lists, items/XCD-set %d = %.2f rounds, phases end at %d / %d, sample %d tiles, caps %d/%d/%d, "
+                               "workspace %.2f GB\n", n, nq, k, p.ranges, p.sublists, items, (double)items / per_x, p.item_a, p.item_b, p.sample_tiles,
+                               L.cap[0], L.cap[1], L.cap[2], (double)p.total / 1e9);
+                }
+    printf("%d plans (%d fused), %d violations\n", total, fused, bad);
+    return bad ? 1 : 0;
+}

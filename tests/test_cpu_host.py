@@ -53,6 +53,30 @@ def test_header_is_plain_c_and_links_against_the_library(tmp_path):
     assert run.stdout.split()[0] == str(len(names)) and int(run.stdout.split()[1]) >= 100
 
 
+def test_planner_invariants_on_cpu(tmp_path):
+    """The search planner is host code (ccr::make_plan in the library): tests/native/planner_check.cpp walks 800+ shapes --
+    every BASELINE config among them -- and checks range / phase / sample / candidate-segment / workspace-layout invariants
+    (phases are whole rounds of work items, capacities hold one whole tile, segments do not overlap ...).  No GPU call."""
+    import shutil
+    import subprocess
+    from ccrec_amd import _lib
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    exe = tmp_path / "planner_check"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    cmd = [hipcc, "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(PKG, "csrc"),
+           os.path.join(ROOT, "tests", "native", "planner_check.cpp"), "-o", str(exe), "-L", libdir, "-lccr_hip", f"-Wl,-rpath,{libdir}"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    run = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert run.returncode == 0, run.stdout[-2000:]
+    last = run.stdout.strip().splitlines()[-1]
+    assert last.endswith(", 0 violations") and int(last.split()[0]) > 500, last
+    nq_line = [ln for ln in run.stdout.splitlines() if ln.startswith("n=2681468 nq=3452 k=100:")][0]
+    assert "= 7.00 rounds" in nq_line                    # NQ: exactly seven full rounds of work items
+
+
 def test_library_is_in_tree_and_has_no_torch_dependency():
     from ccrec_amd import _lib
     assert _lib.LIB_PATH.startswith(PKG)
