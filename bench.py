@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--queries", type=int, default=N_Q)
     ap.add_argument("--dim", type=int, default=DIM)
     ap.add_argument("--k", type=int, default=TOP_K)
-    ap.add_argument("--data", default="gaussian", choices=["gaussian", "clustered", "sorted"],
+    ap.add_argument("--data", default="gaussian", choices=["gaussian", "clustered", "sorted", "outlier"],
                     help="gaussian: iid N(0, 1/dim) rows (BASELINE.md); clustered: 1,024 clusters, log-normal norms, 3 %% duplicates; "
                          "sorted: the same with every cluster's rows CONTIGUOUS (a corpus in topical order)")
     ap.add_argument("--sim", default="dot", choices=["dot", "cos"], help="cos: rows are L2-normalised by the pack kernel (CCREC_SIM_TYPE=cos)")
@@ -85,7 +85,9 @@ def host_threads():
 def gen_rows(n, dim, seed, device, data="gaussian", chunk=262144):
     """fp32 rows generated on device in chunks.  gaussian: N(0,1) / sqrt(dim).
     clustered / sorted: 1,024 cluster centres (seeded, shared by corpus and queries), row = 0.8 centre + 0.6 noise (unit scale),
-    times a log-normal norm (sigma 0.35); 3 % of the rows of a chunk are exact duplicates of other rows of that chunk."""
+    times a log-normal norm (sigma 0.35); 3 % of the rows of a chunk are exact duplicates of other rows of that chunk.
+    outlier: gaussian, with every 500,000th corpus row scaled by CCR_BENCH_OUTLIER (default 100): rows whose norm is far above the
+    rest (the filter margins scale with the LARGEST row norm, DESIGN 4.4 'known limit')."""
     g = torch.Generator(device=device).manual_seed(seed)
     out = torch.empty(n, dim, dtype=torch.float32, device=device)
     centres = None
@@ -108,6 +110,8 @@ def gen_rows(n, dim, seed, device, data="gaussian", chunk=262144):
                 src = torch.randint(0, m, (ndup,), generator=g, device=device)
                 x[dst] = x[src]
         out[lo:hi] = x
+    if data == "outlier" and seed == 1234:
+        out[::500_000] *= float(os.environ.get("CCR_BENCH_OUTLIER", "100"))
     return out
 
 
@@ -160,7 +164,7 @@ class Workload:
         self.shard = torch.empty(self.hi - self.lo, dim, dtype=torch.bfloat16, device=dev)
         self.qpack = torch.empty(queries, dim, dtype=torch.bfloat16, device=dev)
         self.k_local = min(k, self.hi - self.lo)
-        self.max_norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.norm_bounds = torch.empty(self.hi - self.lo, dtype=torch.float32, device=dev)   # norm bound per packed row (pack kernel)
         # N > 1: the search writes its top-k straight into the packed exchange message (one all-gather per step).  Two
         # messages: the all-gather of step i runs on the communication stream while step i + 1 packs and searches.
         self.messages = None
@@ -173,9 +177,8 @@ class Workload:
 
     def step(self):
         from ccrec_amd import ops
-        self.max_norm.zero_()
-        ops.pack_bf16(self.corpus_f32, out=self.shard, max_norm=self.max_norm, normalize=self.normalize)   # pack + max packed-row norm in one pass
-        index = ops.CorpusIndex(self.shard, global_row_offset=self.lo, max_norm=self.max_norm)
+        ops.pack_bf16(self.corpus_f32, out=self.shard, norm_bounds=self.norm_bounds, normalize=self.normalize)   # pack + norm bound of every packed row in one pass
+        index = ops.CorpusIndex(self.shard, global_row_offset=self.lo, norm_bounds=self.norm_bounds)
         ops.pack_bf16(self.queries_f32, out=self.qpack, normalize=self.normalize)
         if self.world > 1:
             # search (its one host synchronisation reads the flagged-query count, so the lists are FINAL before they are
@@ -315,7 +318,7 @@ def main():
     # untimed extras: pack-kernel HBM rate
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    ops.pack_bf16(w.corpus_f32, out=w.shard, max_norm=w.max_norm, normalize=w.normalize)
+    ops.pack_bf16(w.corpus_f32, out=w.shard, norm_bounds=w.norm_bounds, normalize=w.normalize)
     e1.record()
     torch.cuda.synchronize()
     pack_ms = e0.elapsed_time(e1)
@@ -341,7 +344,8 @@ def main():
         "value": round(r["qps"], 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(r["ms_per_step"], 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "bf16", "data": {"gaussian": "synthetic", "clustered": "synthetic (clustered, log-normal norms, 3% duplicates)",
-                                   "sorted": "synthetic (clustered in topical row order, log-normal norms, 3% duplicates)"}[args.data],
+                                   "sorted": "synthetic (clustered in topical row order, log-normal norms, 3% duplicates)",
+                                   "outlier": "synthetic (gaussian, every 500,000th corpus row scaled by CCR_BENCH_OUTLIER)"}[args.data],
         "config": {"workload": workload, "corpus_rows": args.rows,
                    "dim": args.dim, "queries": args.queries, "k": args.k,
                    "step": "pack corpus shard fp32->bf16 + index build + pack queries + fused MFMA score/top-k"

@@ -14,7 +14,7 @@ SCORES_CANONICAL, SCORES_MFMA = 0, 1
 
 EXPORTS = [
     "ccr_last_error", "ccr_version", "ccr_pack_bf16", "ccr_pack_bf16_ex", "ccr_meanpool_pack_bf16", "ccr_meanpool_pack_bf16_ex", "ccr_index_create",
-    "ccr_index_create_with_norm", "ccr_index_destroy",
+    "ccr_index_create_with_norms", "ccr_index_destroy",
     "ccr_index_rows", "ccr_index_dim", "ccr_search_workspace_bytes", "ccr_search", "ccr_search_last_stats",
     "ccr_merge_topk", "ccr_merge_topk_strided", "ccr_apply_block", "ccr_inbatch_ce_workspace_bytes", "ccr_inbatch_ce_fwd", "ccr_inbatch_ce_bwd", "ccr_inbatch_ce_bwd_dev", "ccr_rank_metrics",
     "ccr_search_finish", "ccr_scores", "ccr_search_blocked_workspace_bytes", "ccr_search_blocked",
@@ -53,7 +53,7 @@ def load():
     lib.ccr_version.restype = i32
     lib.ccr_pack_bf16.argtypes = [vp, vp, vp, i64, i32, i32, vp]
     lib.ccr_pack_bf16_ex.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp]
-    lib.ccr_index_create_with_norm.argtypes = [vp, i64, i32, i64, vp, vp, ctypes.POINTER(vp)]
+    lib.ccr_index_create_with_norms.argtypes = [vp, i64, i32, i64, vp, vp, ctypes.POINTER(vp)]
     lib.ccr_meanpool_pack_bf16.argtypes = [vp, i32, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.ccr_meanpool_pack_bf16_ex.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.ccr_index_create.argtypes = [vp, i64, i32, i64, vp, ctypes.POINTER(vp)]

@@ -85,9 +85,10 @@ class LengthSortedEncoder:
                 "attention_mask": torch.from_numpy(mask).to(device, non_blocking=True)}
 
     @torch.no_grad()
-    def encode(self, texts, sim="dot", out=None, row_offset=0, max_norm=None, out_f32=None):
+    def encode(self, texts, sim="dot", out=None, row_offset=0, norm_bounds=None, out_f32=None):
         """Encode `texts` into rows [row_offset, row_offset + len(texts)) of `out` (bf16 [>=N, dim] cuda; allocated if
-        None).  sim "cos" L2-normalises before rounding.  max_norm: see ops.pack_bf16.  out_f32: optional fp32
+        None).  sim "cos" L2-normalises before rounding.  norm_bounds: fp32 [>=N] tensor indexed like `out`'s rows, see
+        ops.pack_bf16.  out_f32: optional fp32
         [>=N, dim] tensor that also receives the un-rounded pooled rows (tests / the cls|mean_layer_norm consumers).
         Returns the bf16 tensor."""
         ops.require_gpu()
@@ -109,16 +110,16 @@ class LengthSortedEncoder:
                 out = torch.empty(n + row_offset, hidden.shape[-1], dtype=torch.bfloat16, device=hidden.device)
             rows = torch.as_tensor(np.asarray(idx, dtype=np.int64) + int(row_offset))
             ops.meanpool_pack(hidden, inputs["attention_mask"], normalize=(sim == "cos"), want_f32=False, out_bf16=out,
-                              out_f32=out_f32, dst_rows=rows, max_norm=max_norm)
+                              out_f32=out_f32, dst_rows=rows, norm_bounds=norm_bounds)
         if out is None:   # no texts
             out = torch.empty(row_offset, 0, dtype=torch.bfloat16, device=device)
         return out
 
 
-def encode_local_shard(encoder, corpus_ids, corpus, sim, rank, world, max_norm=None):
+def encode_local_shard(encoder, corpus_ids, corpus, sim, rank, world, norm_bounds=None):
     """This rank's contiguous block of the corpus (dist.shard_bounds) -> (bf16 shard [hi-lo, dim], lo, hi)."""
     lo, hi = shard_bounds(len(corpus_ids), world, rank)
-    shard = encoder.encode([corpus[c] for c in corpus_ids[lo:hi]], sim=sim, max_norm=max_norm)
+    shard = encoder.encode([corpus[c] for c in corpus_ids[lo:hi]], sim=sim, norm_bounds=norm_bounds)
     return shard, lo, hi
 
 
@@ -134,11 +135,13 @@ def ranking_sharded(corpus, queries, encoder, block_dict=None, rank=0, world=1, 
     sim = "cos" if os.environ["CCREC_SIM_TYPE"] == "cos" else "dot"
     keep = KEEP if keep is None else keep
     q_bf16 = encoder.encode([queries[q] for q in queries_ids], sim=sim)
-    max_norm = torch.zeros(1, dtype=torch.float32, device=q_bf16.device)
-    shard, lo, hi = encode_local_shard(encoder, corpus_ids, corpus, sim, rank, world, max_norm=max_norm)
+    lo0, hi0 = shard_bounds(len(corpus_ids), world, rank)
+    bounds = torch.empty(max(hi0 - lo0, 1), dtype=torch.float32, device=q_bf16.device)   # norm bound of every packed row
+    shard, lo, hi = encode_local_shard(encoder, corpus_ids, corpus, sim, rank, world, norm_bounds=bounds)
+    bounds = bounds if hi > lo else None
     if world == 1:
-        return Retriever(corpus_ids, shard, max_norm=max_norm).ranking_profile(queries_ids, q_bf16, block_dict, keep, with_tensors)
-    index = ops.CorpusIndex(shard, global_row_offset=lo, max_norm=max_norm)
+        return Retriever(corpus_ids, shard, norm_bounds=bounds).ranking_profile(queries_ids, q_bf16, block_dict, keep, with_tensors)
+    index = ops.CorpusIndex(shard, global_row_offset=lo, norm_bounds=bounds)
     n = len(corpus_ids)
     block = None
     if block_dict is not None:   # every rank passes the whole lists; a shard applies the ids that fall inside it

@@ -24,7 +24,7 @@ CANONICAL_COS_SIM_MACS = 4e9   # above this many multiply-adds cos_sim() switche
 
 
 def generate_embeddings(data_indices, data_dic, embedding_func, batch_size, embedding_size=768, name=None, pack=None,
-                        device=None, max_norm=None):
+                        device=None, norm_bounds=None):
     """scripts/ms_marco_eval.py:123-152.  Same batching, progress lines and return value (a [num, dim]
     tensor), but the result stays on the GPU.  pack=None -> fp32; pack="dot"/"cos" -> bf16 shard packed
     batch by batch (cos = L2-normalised first)."""
@@ -50,7 +50,8 @@ def generate_embeddings(data_indices, data_dic, embedding_func, batch_size, embe
             if pack is None:
                 out[lo:lo + emb.shape[0]] = emb
             else:
-                ops.pack_bf16(emb, normalize=(pack == "cos"), out=out[lo:lo + emb.shape[0]], max_norm=max_norm)
+                ops.pack_bf16(emb, normalize=(pack == "cos"), out=out[lo:lo + emb.shape[0]],
+                              norm_bounds=None if norm_bounds is None else norm_bounds[lo:lo + emb.shape[0]])
     torch.cuda.synchronize()
     print(f"Processed total {num} t={time.time() - tic:.1f}s")
     if out is None:
@@ -93,9 +94,9 @@ class Retriever:
 
     corpus_ids: list of passage ids in corpus row order; corpus_bf16: packed shard [N, dim]."""
 
-    def __init__(self, corpus_ids, corpus_bf16, global_row_offset=0, max_norm=None):
+    def __init__(self, corpus_ids, corpus_bf16, global_row_offset=0, norm_bounds=None):
         self.corpus_ids = list(corpus_ids)
-        self.index = ops.CorpusIndex(corpus_bf16, global_row_offset, max_norm=max_norm)
+        self.index = ops.CorpusIndex(corpus_bf16, global_row_offset, norm_bounds=norm_bounds)
         self._pos = None
 
     def _positions(self):
@@ -141,7 +142,8 @@ def ranking(corpus, queries, embedding_func, batch_size, block_dict=None):
     queries_ids, corpus_ids = list(queries.keys()), list(corpus.keys())
     sim = "cos" if os.environ["CCREC_SIM_TYPE"] == "cos" else "dot"
     queries_embeddings = generate_embeddings(queries_ids, queries, embedding_func, batch_size, pack=sim)
-    max_norm = torch.zeros(1, dtype=torch.float32, device="cuda")   # accumulated by the pack kernel, batch by batch
-    passage_embeddings = generate_embeddings(corpus_ids, corpus, embedding_func, batch_size, pack=sim, max_norm=max_norm)
-    retriever = Retriever(corpus_ids, passage_embeddings, max_norm=max_norm)
+    # the pack kernel leaves a norm bound per packed row, batch by batch: the index build then needs no pass over the shard
+    bounds = torch.empty(len(corpus_ids), dtype=torch.float32, device="cuda") if corpus_ids else None
+    passage_embeddings = generate_embeddings(corpus_ids, corpus, embedding_func, batch_size, pack=sim, norm_bounds=bounds)
+    retriever = Retriever(corpus_ids, passage_embeddings, norm_bounds=bounds)
     return retriever.ranking_profile(queries_ids, queries_embeddings, block_dict)

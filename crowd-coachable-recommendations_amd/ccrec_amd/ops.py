@@ -36,11 +36,17 @@ def _on(t):
     return torch.cuda.device(t.device)
 
 
-def pack_bf16(x, normalize=False, out=None, return_norms=False, max_norm=None):
+def _check_bounds(norm_bounds, rows):
+    assert norm_bounds.is_cuda and norm_bounds.dtype == torch.float32 and norm_bounds.is_contiguous()
+    assert norm_bounds.dim() == 1 and norm_bounds.numel() >= rows, "norm_bounds: one fp32 per (destination) row"
+
+
+def pack_bf16(x, normalize=False, out=None, return_norms=False, norm_bounds=None):
     """fp32 [rows, dim] (cuda) -> bf16 [rows, dim]; normalize=True applies x / max(||x||, 1e-12) first
     (the cos_sim rule, ms_marco_eval.py:160-161).  `out` may be a slice of a preallocated shard.
-    max_norm: optional 1-element fp32 cuda tensor (zero-initialised by the caller) that accumulates an upper
-    bound of the largest packed-row norm over all batches; hand it to CorpusIndex(max_norm=...)."""
+    norm_bounds: optional [rows] fp32 cuda tensor (the matching slice of a shard-sized one; no initialisation needed) that
+    receives an upper bound of every packed row's norm; hand the whole array to CorpusIndex(norm_bounds=...) and the
+    index build needs no pass over the shard (the search uses the bounds, per 256-row tile, in its filter margins)."""
     lib = require_gpu()
     assert x.is_cuda and x.dim() == 2, "pack_bf16 expects a 2-d cuda tensor"
     x = x.contiguous()
@@ -51,22 +57,22 @@ def pack_bf16(x, normalize=False, out=None, return_norms=False, max_norm=None):
         out = torch.empty(rows, dim, dtype=torch.bfloat16, device=x.device)
     assert out.is_contiguous() and out.dtype == torch.bfloat16 and tuple(out.shape) == (rows, dim)
     norms = torch.empty(rows, dtype=torch.float32, device=x.device) if return_norms else None
-    if max_norm is not None:
-        assert max_norm.is_cuda and max_norm.dtype == torch.float32 and max_norm.numel() == 1
+    if norm_bounds is not None:
+        _check_bounds(norm_bounds, rows)
     with _on(x):
-        _lib.check(lib.ccr_pack_bf16_ex(_ptr(x), _ptr(out), _ptr(norms), _ptr(max_norm), rows, dim, int(bool(normalize)),
+        _lib.check(lib.ccr_pack_bf16_ex(_ptr(x), _ptr(out), _ptr(norms), _ptr(norm_bounds), rows, dim, int(bool(normalize)),
                                         _stream(x)), "ccr_pack_bf16")
     return (out, norms) if return_norms else out
 
 
 def meanpool_pack(hidden, mask, normalize=False, want_f32=True, want_bf16=True, out_bf16=None, out_f32=None, dst_rows=None,
-                  max_norm=None):
+                  norm_bounds=None):
     """Fused masked mean pooling (item_tower.py:141-146) + bf16 pack of [B, L, dim] hidden states.
     Returns (pooled_f32 or None, packed_bf16 or None).
 
     out_bf16 / out_f32: write into these [rows, dim] tensors (e.g. the resident shard) instead of fresh [B, dim] ones;
     dst_rows: [B] int64 destination rows inside them (length-sorted batches scatter back to corpus order);
-    max_norm: 1-element fp32 cuda tensor accumulating a bound of the packed rows' norm (see pack_bf16)."""
+    norm_bounds: fp32 cuda tensor indexed like the destination rows: bound of each packed row's norm (see pack_bf16)."""
     lib = require_gpu()
     assert hidden.is_cuda and hidden.dim() == 3 and hidden.dtype in _DTYPES
     hidden = hidden.contiguous()
@@ -82,11 +88,11 @@ def meanpool_pack(hidden, mask, normalize=False, want_f32=True, want_bf16=True, 
     if dst_rows is not None:
         dst_rows = dst_rows.to(device=hidden.device, dtype=torch.int64).contiguous()
         assert dst_rows.numel() == B
-    if max_norm is not None:
-        assert max_norm.is_cuda and max_norm.dtype == torch.float32 and max_norm.numel() == 1
+    if norm_bounds is not None:
+        _check_bounds(norm_bounds, b16.shape[0] if (b16 is not None and dst_rows is not None) else B)
     with _on(hidden):
         _lib.check(lib.ccr_meanpool_pack_bf16_ex(_ptr(hidden), _DTYPES[hidden.dtype], _ptr(mask), _ptr(b16), _ptr(f32),
-                                                 _ptr(dst_rows), _ptr(max_norm), B, L, dim, int(bool(normalize)),
+                                                 _ptr(dst_rows), _ptr(norm_bounds), B, L, dim, int(bool(normalize)),
                                                  _stream(hidden)), "ccr_meanpool_pack_bf16")
     return f32, b16
 
@@ -125,9 +131,11 @@ class CorpusIndex:
 
     corpus_bf16: [n_rows, dim] bf16 cuda tensor (kept alive by this object; the C index borrows it).
     global_row_offset: id of row 0 in the whole corpus (row-sharded multi-GPU search).
+    norm_bounds: [n_rows] fp32 cuda tensor written by pack_bf16 / meanpool_pack(norm_bounds=...) for THESE rows (optional;
+    kept alive by this object and not to be rewritten while the index is in use).
     """
 
-    def __init__(self, corpus_bf16, global_row_offset=0, max_norm=None):
+    def __init__(self, corpus_bf16, global_row_offset=0, norm_bounds=None):
         self._lib = require_gpu()
         assert corpus_bf16.is_cuda and corpus_bf16.dtype == torch.bfloat16 and corpus_bf16.dim() == 2
         self.corpus = corpus_bf16.contiguous()
@@ -137,14 +145,15 @@ class CorpusIndex:
         self._ws = None
         self._ws_need = {}
         with _on(self.corpus):
-            if max_norm is None:
+            if norm_bounds is None:
                 _lib.check(self._lib.ccr_index_create(_ptr(self.corpus), self.n_rows, self.dim, self.offset,
                                                       _stream(self.corpus), ctypes.byref(self._h)), "ccr_index_create")
-            else:  # bound from ccr_pack_bf16_ex: no extra pass over the shard, no synchronisation
-                assert max_norm.is_cuda and max_norm.dtype == torch.float32 and max_norm.numel() == 1
-                _lib.check(self._lib.ccr_index_create_with_norm(_ptr(self.corpus), self.n_rows, self.dim, self.offset,
-                                                                _ptr(max_norm), _stream(self.corpus),
-                                                                ctypes.byref(self._h)), "ccr_index_create_with_norm")
+            else:  # row-norm bounds from ccr_pack_bf16_ex: no extra pass over the shard, no synchronisation
+                _check_bounds(norm_bounds, self.n_rows)
+                self._norm_bounds = norm_bounds   # borrowed by the C index, like the corpus
+                _lib.check(self._lib.ccr_index_create_with_norms(_ptr(self.corpus), self.n_rows, self.dim, self.offset,
+                                                                 _ptr(norm_bounds), _stream(self.corpus),
+                                                                 ctypes.byref(self._h)), "ccr_index_create_with_norms")
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None

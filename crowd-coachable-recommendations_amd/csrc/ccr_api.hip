@@ -357,7 +357,56 @@ extern "C" int ccr_version(void) { return 100; }
 
 extern "C" int ccr_index_destroy(ccr_index *ix);
 
-static int index_create_impl(const uint16_t *D_bf16, int64_t n_rows, int dim, int64_t global_row_offset, const float *max_norm,
+// Per-device cache of the indices' tile-norm arrays (4 B per 256 corpus rows): an index built per step gets the block the
+// previous one gave back instead of a hipMalloc / hipFree pair.
+namespace {
+struct CachedBlock {
+    void *p;
+    size_t bytes;
+};
+std::vector<CachedBlock> g_blocks[MAX_DEVICES];
+constexpr size_t BLOCK_CACHE_ENTRIES = 8;
+
+int block_take(int device, size_t bytes, void **out, size_t *got) {
+    CCR_REQUIRE(device >= 0 && device < MAX_DEVICES, "device ordinal %d out of range", device);
+    bytes = (bytes + 4095) / 4096 * 4096;
+    {
+        std::lock_guard<std::mutex> lock(g_slab_mutex);
+        auto &v = g_blocks[device];
+        for (size_t i = 0; i < v.size(); ++i)
+            if (v[i].bytes >= bytes && v[i].bytes <= 2 * bytes) {
+                *out = v[i].p;
+                *got = v[i].bytes;
+                v.erase(v.begin() + i);
+                return CCR_OK;
+            }
+    }
+    CCR_HIP_CHECK(hipMalloc(out, bytes));
+    *got = bytes;
+    return CCR_OK;
+}
+
+void block_give(int device, void *p, size_t bytes) {
+    if (!p) return;
+    void *drop = nullptr;
+    if (device >= 0 && device < MAX_DEVICES && bytes <= ((size_t)64 << 20)) {   // larger blocks are not worth pinning
+        std::lock_guard<std::mutex> lock(g_slab_mutex);
+        auto &v = g_blocks[device];
+        v.push_back({p, bytes});
+        if (v.size() > BLOCK_CACHE_ENTRIES) {   // oldest out
+            drop = v.front().p;
+            v.erase(v.begin());
+        }
+    } else {
+        drop = p;
+    }
+    if (drop) (void)hipFree(drop);
+}
+}  // namespace
+
+// row_bounds (device, n_rows floats, or null): upper bounds of the packed rows' norms as ccr_pack_bf16_ex wrote them (borrowed for
+// the life of the index: the select stage reads them per candidate); without them the index makes its own pass over the shard.
+static int index_create_impl(const uint16_t *D_bf16, int64_t n_rows, int dim, int64_t global_row_offset, const float *row_bounds,
                              void *stream, ccr_index **out) {
     CCR_REQUIRE(D_bf16 && out, "ccr_index_create: null pointer");
     CCR_REQUIRE(n_rows >= 1 && n_rows < ((int64_t)1 << 32), "ccr_index_create: n_rows=%lld out of range [1, 2^32)",
@@ -376,15 +425,26 @@ static int index_create_impl(const uint16_t *D_bf16, int64_t n_rows, int dim, in
     auto build = [&]() -> int {
         CCR_HIP_CHECK(hipGetDevice(&ix->device));
         CCR_HIP_CHECK(hipDeviceGetAttribute(&ix->num_cu, hipDeviceAttributeMultiprocessorCount, ix->device));
-        {
-            const int rc = slab_take(ix->device, &ix->dmax_bits);
+        int rc = slab_take(ix->device, &ix->dmax_bits);
+        if (rc != CCR_OK) return rc;
+        const int64_t tiles = (n_rows + TILE_DOCS - 1) / TILE_DOCS;
+        void *tn = nullptr;
+        rc = block_take(ix->device, (size_t)tiles * 4, &tn, &ix->tile_bytes);
+        if (rc != CCR_OK) return rc;
+        ix->tile_norm = (float *)tn;
+        uint32_t *tile_bits = reinterpret_cast<uint32_t *>(ix->tile_norm);   // non-negative floats: bit patterns order as unsigned
+        CCR_HIP_CHECK(hipMemsetAsync(ix->dmax_bits, 0, 4, s));
+        if (row_bounds) {   // no pass over the shard, no synchronisation
+            ix->row_norm = row_bounds;
+            rc = launch_tile_norms(row_bounds, n_rows, tile_bits, ix->dmax_bits, s);
             if (rc != CCR_OK) return rc;
-        }
-        if (max_norm) {
-            CCR_HIP_CHECK(hipMemcpyAsync(ix->dmax_bits, max_norm, 4, hipMemcpyDeviceToDevice, s));
         } else {
-            CCR_HIP_CHECK(hipMemsetAsync(ix->dmax_bits, 0, 4, s));
-            int rc = launch_row_norms_bf16(D_bf16, n_rows, dim, nullptr, ix->dmax_bits, s);
+            void *rn = nullptr;
+            rc = block_take(ix->device, (size_t)n_rows * 4, &rn, &ix->row_bytes);
+            if (rc != CCR_OK) return rc;
+            ix->row_norm = ix->row_norm_own = (float *)rn;
+            CCR_HIP_CHECK(hipMemsetAsync(tile_bits, 0, (size_t)tiles * 4, s));
+            rc = launch_row_norms_bf16(D_bf16, n_rows, dim, ix->row_norm_own, ix->dmax_bits, tile_bits, s);
             if (rc != CCR_OK) return rc;
             CCR_HIP_CHECK(hipStreamSynchronize(s));
         }
@@ -404,17 +464,19 @@ extern "C" int ccr_index_create(const uint16_t *D_bf16, int64_t n_rows, int dim,
     return index_create_impl(D_bf16, n_rows, dim, global_row_offset, nullptr, stream, out);
 }
 
-extern "C" int ccr_index_create_with_norm(const uint16_t *D_bf16, int64_t n_rows, int dim, int64_t global_row_offset,
-                                          const float *max_norm, void *stream, ccr_index **out) {
-    CCR_REQUIRE(max_norm, "ccr_index_create_with_norm: null max_norm");
-    return index_create_impl(D_bf16, n_rows, dim, global_row_offset, max_norm, stream, out);
+extern "C" int ccr_index_create_with_norms(const uint16_t *D_bf16, int64_t n_rows, int dim, int64_t global_row_offset,
+                                           const float *row_norm_bounds, void *stream, ccr_index **out) {
+    CCR_REQUIRE(row_norm_bounds, "ccr_index_create_with_norms: null row_norm_bounds");
+    return index_create_impl(D_bf16, n_rows, dim, global_row_offset, row_norm_bounds, stream, out);
 }
 
 extern "C" int ccr_index_destroy(ccr_index *ix) {
     if (!ix) return CCR_OK;
-    // a slot handed back may be rewritten by the next index's create on ITS stream; the caller destroys an index only
+    // a slot / block handed back may be rewritten by the next index's create on ITS stream; the caller destroys an index only
     // after the work that uses it has completed (the same contract as for the borrowed corpus)
     slab_give(ix->device, ix->dmax_bits);
+    block_give(ix->device, ix->tile_norm, ix->tile_bytes);
+    block_give(ix->device, ix->row_norm_own, ix->row_bytes);
     if (ix->have_events)
         for (int i = 0; i < 7; ++i)
             if (ix->ev[i]) (void)hipEventDestroy(ix->ev[i]);
@@ -459,20 +521,22 @@ static int dense_for_list(const ccr_index *ix, const uint16_t *Q, const uint32_t
 
 // The main pass: one launch per phase (work items [begin, end) of every XCD set), the thresholds re-tightened from the candidates
 // of the ranges completed so far between two launches when `retighten` is set.
-static int run_main_pass(const ccr_index *ix, const Plan &p, GemmArgs gm, uint2 *cand, uint32_t *cnt, float *thr, const float *delta,
+static int run_main_pass(const ccr_index *ix, const Plan &p, GemmArgs gm, uint2 *cand, uint32_t *cnt, float *thr, const float *cq,
                          int n_q, int k, bool retighten, hipStream_t s) {
     const int nrc = NUM_XCD / gm.qgroups, qb_per = gm.qblocks / gm.qgroups;
     const int items = p.ranges / nrc * qb_per;
     const int bounds[4] = {0, retighten ? p.item_a : 0, retighten ? p.item_b : 0, items};
     gm.cand = cand;
     gm.lay = p.cand;
+    gm.cq = cq;
+    gm.tile_norm = ix->tile_norm;
     int done = 0;
     for (int ph = 1; ph < 4; ++ph) {
         if (bounds[ph] <= done) continue;
         if (done > 0) {
             const int rl_full = done / qb_per, part = done % qb_per;   // complete range rows; blocks done of the started one
             const int rc = launch_threshold_update(cand, cnt, rl_full * nrc * p.sublists, part ? (rl_full + 1) * nrc * p.sublists : 0, part,
-                                                   qb_per, p.sublists, n_q, p.nq_pad, p.cand, k, delta, thr, s);
+                                                   qb_per, p.sublists, n_q, p.nq_pad, p.cand, k, cq, ix->tile_norm, thr, s);
             if (rc != CCR_OK) return rc;
         }
         gm.item_begin = done;
@@ -529,7 +593,7 @@ static int search_complete(ccr_index *ix) {
     const int n_q = pd.n_q, k = pd.k;
     uint32_t *flag_list = (uint32_t *)(ws + p.off_flag + 64);
     float *thr = (float *)(ws + p.off_thr);
-    float *delta = thr + p.nq_pad;
+    float *delta = thr + p.nq_pad;   // cq: margin coefficients gamma ||q|| (the per-tile margin is cq * tile norm)
     uint32_t *cnt = (uint32_t *)(ws + p.off_cnt);
     uint2 *cand = (uint2 *)(ws + p.off_cand);
     float *dense_scratch = (float *)(ws + p.off_dense);
@@ -563,10 +627,11 @@ static int search_complete(ccr_index *ix) {
     for (int round = 0; round < 3 && n_cur > 0 && nsub_all <= 2048; ++round) {
         // thresholds re-tightened from everything the previous attempt recorded (truncated lists included)
         if (round == 0) {
-            rc = launch_threshold_update(cand, cnt, nsub_all, 0, 0, 1, p.sublists, n_q, p.nq_pad, p.cand, k, delta, thr, s);
+            rc = launch_threshold_update(cand, cnt, nsub_all, 0, 0, 1, p.sublists, n_q, p.nq_pad, p.cand, k, delta, ix->tile_norm, thr, s);
             if (rc != CCR_OK) return rc;
         } else {
-            rc = launch_threshold_update(cand, cnt, nsub_all, 0, 0, 1, p.sublists, prev_n, prev_pad, prev_lay, k, delta2, thr2, s);
+            rc = launch_threshold_update(cand, cnt, nsub_all, 0, 0, 1, p.sublists, prev_n, prev_pad, prev_lay, k, delta2, ix->tile_norm, thr2,
+                                         s);
             if (rc != CCR_OK) return rc;
             rc = launch_scatter_thresholds(nxt, prev_n, thr2, thr, s);   // nxt still holds the previous round's list
             if (rc != CCR_OK) return rc;
@@ -600,6 +665,8 @@ static int search_complete(ccr_index *ix) {
         g.tile_stride = 1;
         g.ranges = p.ranges;
         g.thr = thr2;
+        g.cq = delta2;
+        g.tile_norm = ix->tile_norm;
         g.cnt = cnt;
         g.cand = cand;
         g.lay = lay2;
@@ -608,7 +675,7 @@ static int search_complete(ccr_index *ix) {
         rc = p.mfma16 ? launch_gemm16_filter(g, p.grid, s) : launch_gemm_filter(g, p.grid, s);
         if (rc != CCR_OK) return rc;
         rc = launch_select_rescore(cand, cnt, nsub_all, p.sublists, n_cur, pad2, lay2, k, p.rescore_cap, p.select_compact, ix->n_rows, delta2,
-                                   Q2, ix->D, ix->dim, ix->offset, pd.out_scores, pd.out_ids, flag2, flag2 + 16, nullptr, cur, s);
+                                   ix->row_norm, ix->dmax_bits, Q2, ix->D, ix->dim, ix->offset, pd.out_scores, pd.out_ids, flag2, flag2 + 16, nullptr, cur, s);
         if (rc != CCR_OK) return rc;
         ix->stats.n_retried += n_cur;
         uint32_t again = 0;
@@ -713,7 +780,7 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
 
     CCR_HIP_CHECK(hipMemsetAsync(flag_count, 0, 64, s));
     CCR_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)p.ranges * p.nq_pad * p.sublists * 4, s));  // ranges with no tiles write nothing
-    int rc = launch_row_norms_bf16(Q_bf16, n_q, ix->dim, qnorm, nullptr, s);
+    int rc = launch_row_norms_bf16(Q_bf16, n_q, ix->dim, qnorm, nullptr, nullptr, s);
     if (rc != CCR_OK) return rc;
 
     GemmArgs g;
@@ -726,7 +793,9 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
     g.nq_pad = p.nq_pad;
     g.qblocks = p.qblocks;
     g.qgroups = p.qgroups;
+#ifdef CCR_DIAGNOSTICS
     g.dbg = ix->knobs.gemm_dbg;
+#endif
     g.stagger = ix->knobs.stagger;
 
     // sample pass -> group maxima -> thresholds
@@ -742,7 +811,7 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
     if (rc != CCR_OK) return rc;
     CCR_HIP_CHECK(hipEventRecord(ix->ev[2], s));
     rc = launch_threshold(gmax, (int64_t)p.sample_tiles * GROUPS_PER_TILE, n_q, p.nq_pad, k, qnorm, ix->dmax_bits, ix->dim,
-                          thr, delta, s);
+                          ix->tile_norm, p.sample_stride, thr, delta, s);
     if (rc != CCR_OK) return rc;
 
     // main pass -> candidates
@@ -752,8 +821,12 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
     gm.ranges = p.ranges;
     gm.thr = thr;
     gm.cnt = cnt;
-    unsigned long long *stamps = nullptr;   // CCR_GEMM_DBG=16: in-kernel cycle stamps of the main pass (diagnostic build)
+    unsigned long long *stamps = nullptr;   // CCR_GEMM_DBG=16: in-kernel cycle stamps of the main pass (diagnostic build only)
+#ifdef CCR_DIAGNOSTICS
     const bool want_stamps = ix->knobs.gemm_dbg == 16;
+#else
+    const bool want_stamps = false;
+#endif
     if (want_stamps) {
         CCR_HIP_CHECK(hipMalloc((void **)&stamps, (size_t)p.grid * 64 * 8));
         CCR_HIP_CHECK(hipMemsetAsync(stamps, 0, (size_t)p.grid * 64 * 8, s));
@@ -784,7 +857,7 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
     }
 
     rc = launch_select_rescore(cand, cnt, p.ranges * p.sublists, p.sublists, n_q, p.nq_pad, p.cand, k, p.rescore_cap, p.select_compact, ix->n_rows, delta,
-                               Q_bf16, ix->D, ix->dim,
+                               ix->row_norm, ix->dmax_bits, Q_bf16, ix->D, ix->dim,
                                ix->offset, out_scores, out_ids, flag_count, flag_list, stat_cand, nullptr, s);
     if (rc != CCR_OK) return rc;
     CCR_HIP_CHECK(hipEventRecord(ix->ev[5], s));

@@ -110,7 +110,9 @@ struct GemmArgs {
     // items [item_begin, item_end) of every XCD set, so a phase can be EXACTLY whole rounds of items whatever the range count
     int item_begin, item_end;
     // EPI_FILTER
-    const float *thr;     // [nq_pad]
+    const float *thr;     // [nq_pad] tau_q: a lower bound of the query's k-th largest EXACT score
+    const float *cq;      // [nq_pad] margin coefficient gamma * ||q||: |mfma - exact| <= cq * ||d||
+    const float *tile_norm;   // [ceil(n_rows / TILE_DOCS)] bound of the row norms of each 256-row tile (the index's)
     uint2 *cand;          // candidate area {score bits, local row}; sub-list addresses and capacities from `lay`
     uint32_t *cnt;        // [ranges][nq_pad][sublists]
     CandLayout lay;

@@ -5,11 +5,11 @@
 //                              fragment to its maximum -> gmax[group][query]
 //   threshold    (threshold_kernel): tau_q = k-th largest group maximum (a lower bound of the k-th
 //                              largest score: k disjoint groups hold a score >= tau_q), minus the
-//                              MFMA error margin delta_q
+//                              MFMA error margins (cq * tile norm)
 //   main pass    (EPI_FILTER): score the whole shard; accumulators >= thr_q are appended to the
 //                              (range, query) candidate list (LDS counter, 8-byte records)
 //   select       (select_rescore_kernel): per query radix-select the k-th largest MFMA score among
-//                              the candidates, keep everything within delta_q of it, re-score those
+//                              the candidates, keep everything whose error interval reaches it, re-score those
 //                              canonically (fp64 ordered) and sort by (score desc, id asc).
 //
 // GEMM geometry (gfx950): 256 docs x 256 queries per workgroup tile, 512 threads = 8 waves as
@@ -28,6 +28,13 @@
 #include "ccr_topk_device.h"
 
 namespace ccr {
+
+// Wave-uniform 4-byte load through the scalar cache (lgkmcnt, not vmcnt), complete on return.
+__device__ __forceinline__ float load_uniform_f32(const float *p) {
+    float v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
 
 // =============================================================================================
 // GEMM + top-k filter kernel.  Ping-pong schedule: K is walked in 32-element sub-stages through a
@@ -116,7 +123,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
 
         // Each lane owns ONE (query, lane-half, wave-row) candidate sub-list per query column, so the
         // append counter is a plain register: no atomics anywhere in the filter.
-        float thr[2] = {0.f, 0.f};
+        float thr[2] = {0.f, 0.f}, cqv[2] = {0.f, 0.f};
         uint32_t ncand[2] = {0u, 0u};
         uint2 *clist[2] = {nullptr, nullptr};
         int cap = 0;
@@ -128,11 +135,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
             for (int qt = 0; qt < 2; ++qt) {
                 const int q = q0 + wq * 64 + qt * 32 + l31;
                 thr[qt] = (q < a.n_q) ? a.thr[q] : __builtin_nanf("");
+                cqv[qt] = (q < a.n_q) ? a.cq[q] : 0.f;
                 clist[qt] = a.cand + seg_base + (((int64_t)(r - seg_r0) * a.nq_pad + q) * 4 + wd * 2 + h) * cap;
             }
             // make hipcc wait for the threshold loads HERE, before any LDS-DMA is in flight: its own
             // wait at the first use inside the tile epilogue would be vmcnt(0) and drain the DMA ring
-            asm volatile("" : "+v"(thr[0]), "+v"(thr[1]));
+            asm volatile("" : "+v"(thr[0]), "+v"(thr[1]), "+v"(cqv[0]), "+v"(cqv[1]));
         }
         const uint16_t *qsrc[2];
 #pragma unroll
@@ -181,7 +189,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
         // ---- epilogue of a finished 256x256 tile (accumulators still live)
         // C layout of v_mfma_f32_32x32x16: lane -> query column (lane & 31); register e -> corpus row
         // (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) of the 32-row MFMA tile.
-        auto epilogue = [&](int64_t vt) {
+        auto epilogue = [&](int64_t vt, float nt) {   // nt: norm bound of the tile's rows (wave-uniform)
             const int64_t row_base = vt * a.tile_stride * TILE_DOCS + wd * 128 + 4 * h;
             const uint32_t row32 = (uint32_t)row_base;
             const int64_t left = a.n_rows - row_base;
@@ -208,7 +216,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
                     for (int dt = 0; dt < 4; ++dt)
                         a.gmax[(vt * GROUPS_PER_TILE + wd * 8 + dt * 2 + h) * a.nq_pad + q0 + ql] = mdt[dt];
                 } else if (EPI == EPI_FILTER) {
-                    const float t = thr[qt];
+                    // a row of this tile can reach tau_q only if mfma + cq * ||d|| >= tau_q, and ||d|| <= nt
+                    const float t = fmaf(-cqv[qt], nt, thr[qt]);
                     const float mall = fmaxf(fmaxf(mdt[0], mdt[1]), fmaxf(mdt[2], mdt[3]));
                     if (__ballot(mall >= t) != 0ull) {
 #pragma unroll
@@ -262,12 +271,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
         int64_t ct = 0;
         bool pending = false;
         int64_t pending_vt = 0;
+        float pending_nt = 0.f;
         if constexpr ((DBG & 16) != 0) tprev = stamp();
         for (int64_t u = 0; u < U; ++u) {
             // ================= mem phase
             CCR_STAMP(0)  // barrier B wait (+ loop overhead)
             if (pending) {
-                epilogue(pending_vt);
+                epilogue(pending_vt, pending_nt);
                 pending = false;
             }
             CCR_STAMP(1)  // tile epilogue
@@ -340,17 +350,22 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
                 // Tile finished.  The leading group filters it at the start of its next mem phase; the trailing
                 // group (one barrier interval behind) filters it right here, so that BOTH filters fall into the
                 // same interval instead of stalling the partner twice per tile.
+                // (the tile's norm bound: a SCALAR load + wait right here, behind the MFMAs just issued -- a vector load would
+                // sit in vmcnt among the LDS-DMA pieces and hipcc's own wait for it would drain the ring)
+                const int64_t vt_done = r + ct * a.ranges;
+                const float nt_done = EPI == EPI_FILTER ? load_uniform_f32(a.tile_norm + vt_done * a.tile_stride) : 0.f;
                 if (g1) {
-                    epilogue(r + ct * a.ranges);
+                    epilogue(vt_done, nt_done);
                 } else {
                     pending = true;
-                    pending_vt = r + ct * a.ranges;
+                    pending_vt = vt_done;
+                    pending_nt = nt_done;
                 }
                 ++ct;
             }
             CCR_BARRIER();
         }
-        if (pending) epilogue(pending_vt);
+        if (pending) epilogue(pending_vt, pending_nt);
         if (STAGGER && !g1) CCR_BARRIER();  // every wave executes the same number of barriers
 
         if (EPI == EPI_FILTER) {
@@ -418,7 +433,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
         if (ntile <= 0) continue;
         const int q0 = qb * TILE_Q;
 
-        float thr[4] = {0.f, 0.f, 0.f, 0.f};
+        float thr[4] = {0.f, 0.f, 0.f, 0.f}, cqv[4] = {0.f, 0.f, 0.f, 0.f};
         uint32_t ncand[4] = {0u, 0u, 0u, 0u};
         uint2 *clist[4] = {nullptr, nullptr, nullptr, nullptr};
         int cap = 0;
@@ -430,9 +445,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
             for (int qt = 0; qt < 4; ++qt) {
                 const int q = q0 + wq * 64 + qt * 16 + l15;
                 thr[qt] = (q < a.n_q) ? a.thr[q] : __builtin_nanf("");
+                cqv[qt] = (q < a.n_q) ? a.cq[q] : 0.f;
                 clist[qt] = a.cand + seg_base + (((int64_t)(r - seg_r0) * a.nq_pad + q) * 8 + wd * 4 + lq) * cap;
             }
-            asm volatile("" : "+v"(thr[0]), "+v"(thr[1]), "+v"(thr[2]), "+v"(thr[3]));
+            asm volatile("" : "+v"(thr[0]), "+v"(thr[1]), "+v"(thr[2]), "+v"(thr[3]), "+v"(cqv[0]), "+v"(cqv[1]), "+v"(cqv[2]), "+v"(cqv[3]));
         }
         const uint16_t *qsrc[2];
 #pragma unroll
@@ -473,7 +489,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
             }
         };
 
-        auto epilogue = [&](int64_t vt) {
+        auto epilogue = [&](int64_t vt, float nt) {   // nt: norm bound of the tile's rows (wave-uniform)
             const int64_t row_base = vt * a.tile_stride * TILE_DOCS + wd * 128 + 4 * lq;  // + dt*16 + e
 #pragma unroll
             for (int qt = 0; qt < 4; ++qt) {
@@ -482,7 +498,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
 #pragma unroll
                     for (int dt = 0; dt < 8; ++dt)
                         sub[dt] = fmaxf(fmaxf(acc[dt][qt][0], acc[dt][qt][1]), fmaxf(acc[dt][qt][2], acc[dt][qt][3]));
-                    const float t = thr[qt];
+                    const float t = fmaf(-cqv[qt], nt, thr[qt]);   // per-tile margin: mfma + cq * ||d|| >= tau_q with ||d|| <= nt
                     const float mall = fmaxf(fmaxf(fmaxf(sub[0], sub[1]), fmaxf(sub[2], sub[3])),
                                              fmaxf(fmaxf(sub[4], sub[5]), fmaxf(sub[6], sub[7])));
                     if (__ballot(mall >= t) != 0ull) {
@@ -530,9 +546,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
         int64_t ct = 0;
         bool pending = false;
         int64_t pending_vt = 0;
+        float pending_nt = 0.f;
         for (int64_t u = 0; u < U; ++u) {
             if (pending) {
-                epilogue(pending_vt);
+                epilogue(pending_vt, pending_nt);
                 pending = false;
             }
             if (u + 1 < U) {
@@ -566,17 +583,22 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
             }
             if (++cks == KS2) {
                 cks = 0;
+                // (the tile's norm bound: a SCALAR load + wait right here, behind the MFMAs just issued -- a vector load would
+                // sit in vmcnt among the LDS-DMA pieces and hipcc's own wait for it would drain the ring)
+                const int64_t vt_done = r + ct * a.ranges;
+                const float nt_done = EPI == EPI_FILTER ? load_uniform_f32(a.tile_norm + vt_done * a.tile_stride) : 0.f;
                 if (g1) {
-                    epilogue(r + ct * a.ranges);
+                    epilogue(vt_done, nt_done);
                 } else {
                     pending = true;
-                    pending_vt = r + ct * a.ranges;
+                    pending_vt = vt_done;
+                    pending_nt = nt_done;
                 }
                 ++ct;
             }
             CCR_BARRIER();
         }
-        if (pending) epilogue(pending_vt);
+        if (pending) epilogue(pending_vt, pending_nt);
         if (!g1) CCR_BARRIER();
 
         if (EPI == EPI_FILTER) {
@@ -589,45 +611,81 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
 }
 
 // ---------------------------------------------------------------------------------------------
-// bf16 row norms (fp32 accumulate; used only for error margins, inflated by the caller)
+// bf16 row norms (fp32 accumulate; used only for error margins, inflated by the caller).  With tile_bits (the index's own
+// pass over a shard it was given without norms) a wave takes 64 CONSECUTIVE rows at a time and max-accumulates their norms
+// into the word of their 256-row tile (four adds per tile); norms of non-negative floats order as unsigned bit patterns and a
+// NaN (row with a NaN) stays on top.
 __global__ __launch_bounds__(256) void row_norms_bf16_kernel(const uint16_t *__restrict__ X, int64_t rows, int dim,
-                                                            float *__restrict__ norms, uint32_t *__restrict__ max_bits) {
+                                                            float *__restrict__ norms, uint32_t *__restrict__ max_bits,
+                                                            uint32_t *__restrict__ tile_bits) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    uint32_t wbits = 0u;   // max norm as ordered bits: non-negative floats order as unsigned and a NaN (row with NaN) stays on top
-    for (int64_t r = wave; r < rows; r += nwaves) {
-        const uint16_t *x = X + r * dim;
-        float s = 0.f;
-        for (int c = lane * 8; c < dim; c += 64 * 8) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(x + c);
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    const int chunk = tile_bits ? 64 : 1;
+    uint32_t wbits = 0u;
+    for (int64_t r0 = wave * chunk; r0 < rows; r0 += nwaves * chunk) {
+        uint32_t cbits = 0u;
+        const int64_t r1 = r0 + chunk < rows ? r0 + chunk : rows;
+        for (int64_t r = r0; r < r1; ++r) {
+            const uint16_t *x = X + r * dim;
+            float s = 0.f;
+            for (int c = lane * 8; c < dim; c += 64 * 8) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(x + c);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
-                s = fmaf(lo, lo, s);
-                s = fmaf(hi, hi, s);
+                for (int e = 0; e < 4; ++e) {
+                    const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
+                    s = fmaf(lo, lo, s);
+                    s = fmaf(hi, hi, s);
+                }
             }
-        }
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-        const float n = sqrtf(s);
-        if (norms && lane == 0) norms[r] = n;
-        const uint32_t nb = __float_as_uint(n) & 0x7fffffffu;
-        wbits = nb > wbits ? nb : wbits;
+            for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+            const float n = sqrtf(s);
+            if (norms && lane == 0) norms[r] = n;
+            const uint32_t nb = __float_as_uint(n) & 0x7fffffffu;
+            cbits = nb > cbits ? nb : cbits;
+        }
+        if (tile_bits && lane == 0) atomicMax(tile_bits + r0 / TILE_DOCS, cbits);
+        wbits = cbits > wbits ? cbits : wbits;
     }
-    // non-negative floats order as uints; one look first: only a wave that would raise the maximum touches the atomic
+    // one look first: only a wave that would raise the maximum touches the atomic
     if (max_bits && lane == 0 && wbits > __hip_atomic_load(max_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_bits, wbits);
 }
 
-// thr[q] = (k-th largest group maximum) - delta[q].
+// tile_norm[t] = the largest of the row-norm bounds of rows [256 t, 256 t + 256) the pack kernels wrote; max_bits = the largest
+// of all (bit patterns: a NaN bound stays on top and poisons the thresholds -> dense path).  grid = tiles, block = 256.
+__global__ __launch_bounds__(256) void tile_norms_kernel(const float *__restrict__ row_bounds, int64_t rows,
+                                                        uint32_t *__restrict__ tile_bits, uint32_t *__restrict__ max_bits) {
+    __shared__ uint32_t s_w[4];
+    const int64_t r = (int64_t)blockIdx.x * TILE_DOCS + threadIdx.x;
+    uint32_t b = r < rows ? (__float_as_uint(row_bounds[r]) & 0x7fffffffu) : 0u;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint32_t o = __shfl_xor(b, off, 64);
+        b = o > b ? o : b;
+    }
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t m01 = s_w[0] > s_w[1] ? s_w[0] : s_w[1], m23 = s_w[2] > s_w[3] ? s_w[2] : s_w[3];
+        const uint32_t m = m01 > m23 ? m01 : m23;
+        tile_bits[blockIdx.x] = m;
+        if (m > __hip_atomic_load(max_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_bits, m);
+    }
+}
+
+// Sample thresholds.  A sampled 16-row group whose maximum MFMA score is m holds a row whose EXACT score is at least
+// m - cq * nt (cq = gamma * ||q||, nt = norm bound of the group's tile), so tau_q = the k-th largest of those lower bounds is
+// a lower bound of the query's k-th largest exact score: thr[q] = tau_q, cq[q] = the margin coefficient the later stages use.
 // One workgroup = 16 queries x 16 group phases: a gmax row is read as 64-byte segments (query-contiguous
 // layout), every query has its own 256-bin LDS histogram (no same-address atomics), 4 MSB-first passes.
 // grid = nq_pad / 16, block = 256.
 __global__ __launch_bounds__(256) void threshold_kernel(const float *__restrict__ gmax, int64_t n_groups, int n_q, int nq_pad,
                                                        int k, const float *__restrict__ qnorm,
                                                        const uint32_t *__restrict__ dmax_bits, float gamma,
-                                                       float *__restrict__ thr, float *__restrict__ delta) {
+                                                       const float *__restrict__ tile_norm, int64_t sample_stride,
+                                                       float *__restrict__ thr, float *__restrict__ cq) {
     __shared__ uint32_t s_hist[16][256];
     __shared__ uint32_t s_prefix[16], s_remaining[16];
     const int tid = threadIdx.x;
@@ -637,6 +695,11 @@ __global__ __launch_bounds__(256) void threshold_kernel(const float *__restrict_
         s_prefix[tid] = 0;
         s_remaining[tid] = (uint32_t)k;
     }
+    // |mfma - exact| <= gamma * ||q|| * ||d||; a non-finite row norm anywhere in the shard (NaN / Inf embeddings) poisons
+    // every threshold, so that all queries take the exact dense path
+    const float dmax = __uint_as_float(*dmax_bits);
+    const float c = (q < n_q) ? ((dmax < INFINITY) ? gamma * (qnorm[q] * 1.001f) * 1.001f : __builtin_nanf("")) : 0.f;
+    auto tile_of = [&](int64_t g) { return tile_norm[(g / GROUPS_PER_TILE) * sample_stride]; };
     uint32_t mask = 0;
     for (int shift = 24; shift >= 0; shift -= 8) {
         for (int b = tid; b < 16 * 256; b += 256) (&s_hist[0][0])[b] = 0;
@@ -645,17 +708,20 @@ __global__ __launch_bounds__(256) void threshold_kernel(const float *__restrict_
         // 4 independent loads in flight per thread (the loop is latency-bound otherwise)
         int64_t i = ph;
         for (; i + 240 < n_groups; i += 256) {   // 16 independent loads in flight per thread
-            float v[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = gmax[(i + 16 * j) * nq_pad + q];
+            float v[16], tn[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const uint32_t o = f32_orderable(v[j]);
+                v[j] = gmax[(i + 16 * j) * nq_pad + q];
+                tn[j] = tile_of(i + 16 * j);
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t o = f32_orderable(fmaf(-c, tn[j], v[j]));
                 if ((o & mask) == prefix) atomicAdd(&s_hist[ql][(o >> shift) & 255u], 1u);
             }
         }
         for (; i < n_groups; i += 16) {
-            const uint32_t o = f32_orderable(gmax[i * nq_pad + q]);
+            const uint32_t o = f32_orderable(fmaf(-c, tile_of(i), gmax[i * nq_pad + q]));
             if ((o & mask) == prefix) atomicAdd(&s_hist[ql][(o >> shift) & 255u], 1u);
         }
         __syncthreads();
@@ -702,25 +768,23 @@ __global__ __launch_bounds__(256) void threshold_kernel(const float *__restrict_
         const int qq = blockIdx.x * 16 + tid;
         if (qq < n_q) {
             const float tau = orderable_to_f32(s_prefix[tid]);
-            const float dmax = __uint_as_float(*dmax_bits);
-            // |mfma - exact| <= gamma * ||q|| * ||d|| for both the threshold rows and the candidate
-            const float dl = 2.f * gamma * (qnorm[qq] * 1.001f) * (dmax * 1.001f) + 1e-30f;
-            delta[qq] = dl;
-            thr[qq] = tau - dl;
+            cq[qq] = c;   // tid < 16: q == qq
+            thr[qq] = (c < INFINITY) ? tau : __builtin_nanf("");
         }
     }
 }
 
 
-// Progressive thresholds: after phase A of the main pass (ranges [0, ranges_a)), the k-th largest candidate
-// score found so far is a tighter valid lower bound of the k-th largest score (the candidates are real rows
-// with their real MFMA scores, whether or not a sub-list overflowed).  thr[q] = max(thr[q], kth - delta[q]).
+// Progressive thresholds: after phase A of the main pass (ranges [0, ranges_a)), the k-th largest LOWER BOUND
+// (mfma - cq * tile norm) among the candidates found so far is a tighter valid lower bound of the k-th largest exact score
+// (the candidates are real rows with their real MFMA scores, whether or not a sub-list overflowed).  thr[q] = max(thr[q], that).
 // grid = n_q, block = 256.
 __global__ __launch_bounds__(256) void threshold_update_kernel(const uint2 *__restrict__ cand, const uint32_t *__restrict__ cnt,
                                                               int nsub_full, int nsub_part, int part_blocks, int qb_per, int sp,
                                                               int nq_pad, const CandLayout lay, int k, int compact,
-                                                              const float *__restrict__ delta, float *__restrict__ thr) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_val[];   // [compact] orderable scores of the candidates found so far
+                                                              const float *__restrict__ cq, const float *__restrict__ tile_norm,
+                                                              float *__restrict__ thr) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_val[];   // [compact] orderable lower bounds of the candidates found so far
     __shared__ uint32_t s_hist[256];
     __shared__ uint32_t s_ctl[4];
     __shared__ uint32_t s_cnt[2048];
@@ -766,6 +830,7 @@ __global__ __launch_bounds__(256) void threshold_update_kernel(const uint2 *__re
         // that bound -- far fewer -- until they all fit, so the final bound is the k-th largest of EVERYTHING recorded (a
         // corpus in topical order leaves the good rows in a few sub-lists that a first-come subset would miss).
         const int maxc = (int)s_maxc;
+        const float c = cq[q];
         uint32_t keep = 0u;   // orderable bound: records below it are skipped
         for (int round = 0; round < 4; ++round) {
             __syncthreads();
@@ -774,7 +839,8 @@ __global__ __launch_bounds__(256) void threshold_update_kernel(const uint2 *__re
             for (int i = tid; i < nsub * maxc; i += blockDim.x) {
                 const int j = i / maxc, sl = i - j * maxc;
                 if ((uint32_t)sl < s_cnt[j]) {
-                    const uint32_t o = f32_orderable(__uint_as_float(cand[sub_base(j) + sl].x));
+                    const uint2 e = cand[sub_base(j) + sl];
+                    const uint32_t o = f32_orderable(fmaf(-c, tile_norm[e.y / TILE_DOCS], __uint_as_float(e.x)));
                     if (o >= keep) {
                         const uint32_t p = atomicAdd(&s_fill, 1u);
                         if (p < (uint32_t)compact) s_val[p] = o;
@@ -796,7 +862,7 @@ __global__ __launch_bounds__(256) void threshold_update_kernel(const uint2 *__re
         }
     }
     if (tid == 0) {
-        const float t1 = orderable_to_f32(kth) - delta[q];
+        const float t1 = orderable_to_f32(kth);
         if (t1 > thr[q]) thr[q] = t1;
     }
 }
@@ -835,7 +901,8 @@ __device__ __forceinline__ void sweep_sublists(int tid, int n_lists, int first, 
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__restrict__ cand, const uint32_t *__restrict__ cnt,
                                                             int ranges, int sp, int nq_pad, const CandLayout lay, int k, int rescore_cap, int compact,
-                                                            int64_t n_rows, const float *__restrict__ delta,
+                                                            int64_t n_rows, const float *__restrict__ cq,
+                                                            const float *__restrict__ row_norm, const uint32_t *__restrict__ dmax_bits,
                                                             const uint16_t *__restrict__ Q, const uint16_t *__restrict__ D,
                                                             int dim, int64_t id_offset, float *__restrict__ out_scores,
                                                             int64_t *__restrict__ out_ids, uint32_t *__restrict__ flag_count,
@@ -922,6 +989,14 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
     uint32_t kth = 0;
     int need_eq = 0;
     int n_lds = 0;   // candidates resident in s_comp
+    // Every candidate (mfma score m, row d) has its exact score inside [m - c ||d||, m + c ||d||] (c = gamma ||q||; the ROW's own
+    // norm bound here -- the main pass could only use its tile's -- so one huge row widens nobody else's interval).  The LDS
+    // records carry the LOWER bound; the k-th largest lower bound L is a lower bound of the k-th largest exact score, and only
+    // candidates whose UPPER bound reaches L can be in the result.
+    const float c = cq[q];
+    auto to_lower = [&](uint2 e) -> uint2 {
+        return make_uint2(__float_as_uint(fmaf(-c, row_norm[e.y], __uint_as_float(e.x))), e.y);
+    };
     if (!bad && s_total <= (uint32_t)compact) {
         // The sub-lists are sparse: one sweep over (sub-list, slot < longest list) gathers them into LDS at their
         // scanned offsets (independent loads, no atomics); the select then never touches global memory.
@@ -957,12 +1032,14 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
                                    [&](int j, int sl, uint2 e) { s_comp[s_off[j] + sl] = e; });
         __syncthreads();
         n_lds = (int)s_total;
+        for (int i = tid; i < n_lds; i += THREADS) s_comp[i] = to_lower(s_comp[i]);   // (a scattered 4-byte read per record)
+        __syncthreads();
     } else if (!bad && compact < k) {
         bad = dense_only = true;   // the LDS budget cannot even hold k records (huge dim * k): exact dense path
     } else if (!bad) {
-        // More candidates than the LDS holds.  The k-th largest score of ANY `compact` of them is a valid lower bound of
-        // the query's k-th largest, so: keep the first `compact` records that pass the current bound (none at first),
-        // and while more than that passed, tighten the bound to (k-th largest of the kept ones) - delta and sweep again.
+        // More candidates than the LDS holds.  The k-th largest lower bound of ANY `compact` of them is a valid lower bound of
+        // the query's k-th largest, so: keep the first `compact` records whose upper bound passes the current bound (none at
+        // first), and while more than that passed, tighten the bound to the k-th largest lower bound of the kept ones and sweep again.
         // Every sweep at least halves what passes (the kept ones are a random part of what passed); 4 sweeps cover
         // 16 x the LDS capacity, beyond that the exact dense path takes the query.
         float keep = -INFINITY;
@@ -973,9 +1050,10 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
             __syncthreads();
             sweep_sublists<THREADS, 8>(tid, ranges, 0, (int)s_maxc, s_cnt, at, [](int, int) { return true; },
                                        [&](int, int, uint2 e) {
-                                           if (__uint_as_float(e.x) >= keep) {
+                                           const float cn = c * row_norm[e.y];
+                                           if (__uint_as_float(e.x) + cn >= keep) {
                                                const uint32_t p = atomicAdd(&s_fill, 1u);
-                                               if (p < (uint32_t)compact) s_comp[p] = e;
+                                               if (p < (uint32_t)compact) s_comp[p] = make_uint2(__float_as_uint(__uint_as_float(e.x) - cn), e.y);
                                            }
                                        });
             __syncthreads();
@@ -990,7 +1068,7 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
                         return f32_orderable(__uint_as_float(s_comp[i].x));
                     },
                     compact, k, s_hist, s_ctl, kth0, eq0);
-                keep = orderable_to_f32(kth0) - delta[q];
+                keep = orderable_to_f32(kth0);
             }
         }
         if (fits)
@@ -1006,10 +1084,12 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
                 return f32_orderable(__uint_as_float(s_comp[i].x));
             },
             M, k, s_hist, s_ctl, kth, need_eq);
-        const float cut = orderable_to_f32(kth) - delta[q];
+        const float low = orderable_to_f32(kth);                                  // L: the k-th largest lower bound
+        const float loose = fmaf(-2.f * c, __uint_as_float(*dmax_bits), low);    // no row's upper bound is further above its lower one
         for (int i = tid; i < M; i += THREADS) {
             const uint2 e = s_comp[i];
-            if (__uint_as_float(e.x) >= cut) {
+            const float lb = __uint_as_float(e.x);
+            if (lb >= loose && fmaf(2.f * c, row_norm[e.y], lb) >= low) {
                 const uint32_t p = atomicAdd(&s_ncoll, 1u);
                 if (p < (uint32_t)coll_cap) s_keys[p] = (unsigned long long)e.y;  // local row for now
             }
@@ -1190,10 +1270,12 @@ static int launch_kernel(K kernel, size_t lds, const GemmArgs &a, int grid, hipS
 
 template <int EPI>
 static int launch_gemm(const GemmArgs &a, int grid, hipStream_t s) {
-    const int dbg = a.dbg;   // CCR_GEMM_DBG, read once at index creation: timing-only ablations of the main pass (WRONG results)
     const size_t lds = RING * (size_t)SUB_BYTES;
-    if (EPI == EPI_FILTER && dbg != 0) {
-        switch (dbg) {
+#ifdef CCR_DIAGNOSTICS
+    // Timing-only ablations of the main pass (CCR_GEMM_DBG, read once at index creation): they return WRONG results, so they exist
+    // only in a library built with -DCCR_DIAGNOSTICS (make DIAG=1); the shipped library has no such mode.
+    if (EPI == EPI_FILTER && a.dbg != 0) {
+        switch (a.dbg) {
             case 1: return launch_kernel(&gemm_topk_kernel<EPI, true, 1>, lds, a, grid, s);
             case 2: return launch_kernel(&gemm_topk_kernel<EPI, true, 2>, lds, a, grid, s);
             case 3: return launch_kernel(&gemm_topk_kernel<EPI, true, 3>, lds, a, grid, s);
@@ -1204,6 +1286,7 @@ static int launch_gemm(const GemmArgs &a, int grid, hipStream_t s) {
             default: break;   // unknown value: the production kernel
         }
     }
+#endif
     if (!a.stagger) return launch_kernel(&gemm_topk_kernel<EPI, false, 0>, lds, a, grid, s);   // CCR_GEMM_STAGGER=0 (A/B of the ping-pong)
     return launch_kernel(&gemm_topk_kernel<EPI, true, 0>, lds, a, grid, s);
 }
@@ -1218,25 +1301,36 @@ int launch_gemm16_store(const GemmArgs &a, int grid, hipStream_t s) {
 int launch_gemm_gmax(const GemmArgs &a, int grid, hipStream_t s) { return launch_gemm<EPI_GMAX>(a, grid, s); }
 int launch_gemm_store(const GemmArgs &a, int grid, hipStream_t s) { return launch_gemm<EPI_STORE>(a, grid, s); }
 
-int launch_row_norms_bf16(const uint16_t *X, int64_t rows, int dim, float *norms, uint32_t *max_bits, hipStream_t s) {
+int launch_row_norms_bf16(const uint16_t *X, int64_t rows, int dim, float *norms, uint32_t *max_bits, uint32_t *tile_bits,
+                          hipStream_t s) {
     if (rows <= 0) return CCR_OK;
-    int64_t blocks = (rows + 3) / 4;
+    int64_t blocks = tile_bits ? (rows + 255) / 256 : (rows + 3) / 4;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(row_norms_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, X, rows, dim, norms, max_bits);
+    hipLaunchKernelGGL(row_norms_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, X, rows, dim, norms, max_bits, tile_bits);
+    CCR_LAUNCH_CHECK();
+    return CCR_OK;
+}
+
+int launch_tile_norms(const float *row_bounds, int64_t rows, uint32_t *tile_bits, uint32_t *max_bits, hipStream_t s) {
+    if (rows <= 0) return CCR_OK;
+    hipLaunchKernelGGL(tile_norms_kernel, dim3((unsigned)((rows + TILE_DOCS - 1) / TILE_DOCS)), dim3(256), 0, s, row_bounds, rows,
+                       tile_bits, max_bits);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
 }
 
 int launch_threshold(const float *gmax, int64_t n_groups, int n_q, int nq_pad, int k, const float *qnorm,
-                     const uint32_t *dmax_bits, int dim, float *thr, float *delta, hipStream_t s) {
+                     const uint32_t *dmax_bits, int dim, const float *tile_norm, int64_t sample_stride, float *thr, float *cq,
+                     hipStream_t s) {
     hipLaunchKernelGGL(threshold_kernel, dim3(nq_pad / 16), dim3(256), 0, s, gmax, n_groups, n_q, nq_pad, k, qnorm, dmax_bits,
-                       mfma_gamma(dim), thr, delta);
+                       mfma_gamma(dim), tile_norm, sample_stride, thr, cq);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
 }
 
 int launch_threshold_update(const uint2 *cand, const uint32_t *cnt, int nsub, int nsub_part, int part_blocks, int qb_per, int sp, int n_q,
-                            int nq_pad, const CandLayout &lay, int k, const float *delta, float *thr, hipStream_t s) {
+                            int nq_pad, const CandLayout &lay, int k, const float *cq, const float *tile_norm, float *thr,
+                            hipStream_t s) {
     if (nsub_part < nsub) nsub_part = nsub;
     if (nsub_part > 2048) {
         set_error("threshold_update: %d sub-lists exceed 2048", nsub_part);
@@ -1251,7 +1345,7 @@ int launch_threshold_update(const uint2 *cand, const uint32_t *cnt, int nsub, in
         if (rc != CCR_OK) return rc;
     }
     hipLaunchKernelGGL(threshold_update_kernel, dim3(n_q), dim3(256), lds, s, cand, cnt, nsub, nsub_part, part_blocks, qb_per > 0 ? qb_per : 1, sp,
-                       nq_pad, lay, k, compact, delta, thr);
+                       nq_pad, lay, k, compact, cq, tile_norm, thr);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
 }
@@ -1295,7 +1389,8 @@ int launch_gather_queries(const uint16_t *Q, int dim, const uint32_t *list, int 
 }
 
 int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, int sp, int n_q, int nq_pad, const CandLayout &lay, int k,
-                          int rescore_cap, int compact, int64_t n_rows, const float *delta, const uint16_t *Q,
+                          int rescore_cap, int compact, int64_t n_rows, const float *cq, const float *row_norm,
+                          const uint32_t *dmax_bits, const uint16_t *Q,
                           const uint16_t *D, int dim, int64_t id_offset, float *out_scores, int64_t *out_ids,
                           uint32_t *flag_count, uint32_t *flag_list, unsigned long long *stat_cand, const uint32_t *out_rows,
                           hipStream_t s) {
@@ -1307,7 +1402,8 @@ int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, in
             if (rc != CCR_OK) return rc;
         }
         hipLaunchKernelGGL(kernel, dim3(n_q), dim3(threads), lds, s, cand, cnt, ranges, sp, nq_pad, lay, k, rescore_cap, compact,
-                           n_rows, delta, Q, D, dim, id_offset, out_scores, out_ids, flag_count, flag_list, stat_cand, out_rows);
+                           n_rows, cq, row_norm, dmax_bits, Q, D, dim, id_offset, out_scores, out_ids, flag_count, flag_list, stat_cand,
+                           out_rows);
         CCR_LAUNCH_CHECK();
         return CCR_OK;
     };

@@ -30,23 +30,29 @@ int launch_gemm_store(const GemmArgs &a, int grid, hipStream_t s);
 int launch_gemm16_filter(const GemmArgs &a, int grid, hipStream_t s);
 int launch_gemm16_store(const GemmArgs &a, int grid, hipStream_t s);
 int ensure_dynamic_lds(const void *kernel, size_t lds);   // per (kernel, device) opt-in to > 64 KiB of dynamic LDS
-int launch_row_norms_bf16(const uint16_t *X, int64_t rows, int dim, float *norms, uint32_t *max_bits, hipStream_t s);
+// tile_bits (optional): bit patterns of the largest row norm of every 256-row tile, max-accumulated (zeroed by the caller)
+int launch_row_norms_bf16(const uint16_t *X, int64_t rows, int dim, float *norms, uint32_t *max_bits, uint32_t *tile_bits,
+                          hipStream_t s);
+int launch_tile_norms(const float *row_bounds, int64_t rows, uint32_t *tile_bits, uint32_t *max_bits, hipStream_t s);
+// thr[q] = tau_q (lower bound of the k-th largest exact score), cq[q] = gamma ||q|| (margin per unit of row norm)
 int launch_threshold(const float *gmax, int64_t n_groups, int n_q, int nq_pad, int k, const float *qnorm,
-                     const uint32_t *dmax_bits, int dim, float *thr, float *delta, hipStream_t s);
+                     const uint32_t *dmax_bits, int dim, const float *tile_norm, int64_t sample_stride, float *thr, float *cq,
+                     hipStream_t s);
 int select_compact_entries(int dim, int ranges, int rescore_cap, int64_t want);
 int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, int sp, int n_q, int nq_pad, const CandLayout &lay, int k,
-                          int rescore_cap, int compact, int64_t n_rows, const float *delta, const uint16_t *Q,
-                          const uint16_t *D, int dim, int64_t id_offset, float *out_scores, int64_t *out_ids,
+                          int rescore_cap, int compact, int64_t n_rows, const float *cq, const float *row_norm,
+                          const uint32_t *dmax_bits, const uint16_t *Q, const uint16_t *D, int dim, int64_t id_offset, float *out_scores, int64_t *out_ids,
                           uint32_t *flag_count, uint32_t *flag_list, unsigned long long *stat_cand, const uint32_t *out_rows,
                           hipStream_t s);
 int launch_partition_flags(const uint32_t *flags, int begin, int n, uint32_t *retry_list, uint32_t *dense_list, uint32_t *counts,
                            hipStream_t s);
 int launch_scatter_thresholds(const uint32_t *list, int n, const float *thr2, float *thr, hipStream_t s);
-int launch_gather_queries(const uint16_t *Q, int dim, const uint32_t *list, int n, const float *thr, const float *delta, uint16_t *Q2,
-                          float *thr2, float *delta2, hipStream_t s);
+int launch_gather_queries(const uint16_t *Q, int dim, const uint32_t *list, int n, const float *thr, const float *cq, uint16_t *Q2,
+                          float *thr2, float *cq2, hipStream_t s);
 // nsub: sub-lists of the fully scored ranges; queries whose block position inside its XCD group is < part_blocks have nsub_part
 int launch_threshold_update(const uint2 *cand, const uint32_t *cnt, int nsub, int nsub_part, int part_blocks, int qb_per, int sp, int n_q,
-                            int nq_pad, const CandLayout &lay, int k, const float *delta, float *thr, hipStream_t s);
+                            int nq_pad, const CandLayout &lay, int k, const float *cq, const float *tile_norm, float *thr,
+                            hipStream_t s);
 // dense exact path.  qlist: query rows to score (nullptr: q_begin + qi); out_rows: destination rows of the select
 // (nullptr: q_begin + qi); count_dev (device, may be null): only the first *count_dev - q_begin entries of the list exist
 // (the on-stream fallback chunk of an asynchronous search -- the host does not know the count yet).
@@ -64,6 +70,11 @@ struct ccr_index {
     int dim;
     int64_t offset;
     uint32_t *dmax_bits;  // device: bits of the max row norm (a slot of the per-device slab)
+    float *tile_norm;     // device [ceil(n_rows / 256)]: bound of the row norms of each 256-row tile (per-device block cache)
+    size_t tile_bytes;
+    const float *row_norm;   // device [n_rows]: norm bound of every row -- the caller's array (borrowed) or the index's own pass
+    float *row_norm_own;     // the latter (per-device block cache), else null
+    size_t row_bytes;
     bool have_events;
     int num_cu;
     int device;

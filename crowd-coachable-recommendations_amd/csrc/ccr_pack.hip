@@ -54,19 +54,18 @@ __global__ void pack_bf16_tail_kernel(const float *__restrict__ src, __bf16 *__r
 }
 
 
-// ---------------------------------------------------------------- pack + max row norm of the PACKED rows
+// ---------------------------------------------------------------- pack + norm bound of every PACKED row
 // One wave per row, 8 consecutive floats per lane per step (two 16-B loads -> one 16-B store), fp32 sum of
-// squares of the bf16-ROUNDED values, wave reduce, one atomicMax per wave on the bit pattern
-// (non-negative floats order as unsigned).  The index uses the maximum only inside error margins.
+// squares of the bf16-ROUNDED values, wave reduce, one 4-byte store per row: bounds[r] >= ||packed row r|| (inflated by 2^-11
+// for the fp32 summation; a NaN / Inf row gives a NaN / Inf bound).  The index reduces the bounds to one per 256-row tile;
+// they are used only inside the filter's error margins.
 template <int ROWS>
-__global__ __launch_bounds__(256) void pack_rows_maxnorm_kernel(const float *__restrict__ src, __bf16 *__restrict__ dst,
-                                                               int64_t rows, int dim, uint32_t *__restrict__ max_bits) {
+__global__ __launch_bounds__(256) void pack_rows_bound_kernel(const float *__restrict__ src, __bf16 *__restrict__ dst,
+                                                             int64_t rows, int dim, float *__restrict__ bounds) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const int n8 = dim >> 3;
-    uint32_t wbits = 0u;   // max of the norms as ordered bit patterns: non-negative floats order as unsigned, and a NaN
-                           // (0x7fc00000 > +inf) stays on top, so a NaN row makes the maximum NaN (fmaxf would drop it)
     // ROWS rows per iteration: 2*ROWS 16-byte loads in flight per lane (pure HBM stream, read once -> nontemporal)
     for (int64_t r = ROWS * wave; r < rows; r += ROWS * nwaves) {
         float ss[ROWS];
@@ -99,22 +98,8 @@ __global__ __launch_bounds__(256) void pack_rows_maxnorm_kernel(const float *__r
             float t = ss[j];
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
-            const uint32_t nb = __float_as_uint(sqrtf(t)) & 0x7fffffffu;
-            wbits = nb > wbits ? nb : wbits;
+            if (lane == 0 && r + j < rows) bounds[r + j] = sqrtf(t) * 1.00048828125f;
         }
-    }
-    // Record-breaking norms are rare (~ln N of them): look first, the atomic only when this BLOCK would raise the maximum
-    // (one per block: the waves resident when the kernel starts all see the caller's zero and would otherwise queue up
-    // 8 K atomics on one address), and the stored value is inflated by 2^-11 so that near-equal maxima do not follow
-    // each other in -- it stays an upper bound, which is all the filter margin needs.
-    __shared__ uint32_t s_wmax[4];
-    if (lane == 0) s_wmax[threadIdx.x >> 6] = wbits;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t b01 = s_wmax[0] > s_wmax[1] ? s_wmax[0] : s_wmax[1], b23 = s_wmax[2] > s_wmax[3] ? s_wmax[2] : s_wmax[3];
-        const uint32_t bmax = b01 > b23 ? b01 : b23;
-        if (bmax > __hip_atomic_load(max_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMax(max_bits, bmax >= 0x7f800000u ? bmax : __float_as_uint(__uint_as_float(bmax) * 1.00048828125f));
     }
 }
 
@@ -139,12 +124,11 @@ __device__ __forceinline__ double wave_sumsq(const float *__restrict__ x, int di
 
 __global__ __launch_bounds__(256) void pack_rows_kernel(const float *__restrict__ src, __bf16 *__restrict__ dst,
                                                        float *__restrict__ norms, int64_t rows, int dim,
-                                                       int normalize, uint32_t *__restrict__ max_bits) {
+                                                       int normalize, float *__restrict__ bounds) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const int nchunk = dim >> 2;
-    uint32_t wbits = 0u;   // largest packed-row norm bound of this wave, as ordered bits (a NaN stays on top)
     for (int64_t r = wave; r < rows; r += nwaves) {
         const float *x = src + r * dim;
         const double ss = wave_sumsq(x, dim, lane);
@@ -162,13 +146,11 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float *__restrict_
             }
             y[c] = cvt4(v);
         }
-        // upper bound of the packed row's norm: bf16 rounding moves each element by at most 2^-8 relative
-        const uint32_t nb = __float_as_uint((float)((normalize ? nrm / den : nrm) * 1.004)) & 0x7fffffffu;
-        wbits = nb > wbits ? nb : wbits;
+        // upper bound of the packed row's norm: bf16 rounding moves each element by at most 2^-8 relative.  One plain store
+        // per row (round 2 first did an atomicMax per row on ONE word: 2.7 M atomics on a single address took 30 ms at the NQ
+        // shape -- the whole normalising pack ran at 0.4 TB/s)
+        if (bounds && lane == 0) bounds[r] = (float)((normalize ? nrm / den : nrm) * 1.004);
     }
-    // ONE look (and an atomic only when it would raise the maximum) per wave, not one atomic per row: 2.7 M atomics on a
-    // single address took 30 ms at the NQ shape -- the whole normalising pack ran at 0.4 TB/s
-    if (max_bits && lane == 0 && wbits > __hip_atomic_load(max_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_bits, wbits);
 }
 
 // ---------------------------------------------------------------- fused masked mean pooling + pack
@@ -200,7 +182,7 @@ __global__ __launch_bounds__(256) void meanpool_pack_kernel(const T *__restrict_
                                                            __bf16 *__restrict__ dst_bf16,
                                                            float *__restrict__ dst_f32, int L, int dim,
                                                            int normalize, const int64_t *__restrict__ dst_rows,
-                                                           uint32_t *__restrict__ max_bits) {
+                                                           float *__restrict__ bounds) {
     __shared__ double red[4];
     __shared__ float redf[4];
     const int b = blockIdx.x;
@@ -279,7 +261,7 @@ __global__ __launch_bounds__(256) void meanpool_pack_kernel(const T *__restrict_
             }
         }
     }
-    if (max_bits && dst_bf16) {
+    if (bounds && dst_bf16) {
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) pss += __shfl_xor(pss, off, 64);
         if ((tid & 63) == 0) redf[tid >> 6] = pss;
@@ -287,7 +269,7 @@ __global__ __launch_bounds__(256) void meanpool_pack_kernel(const T *__restrict_
         if (tid == 0) {
             float tot = 0.f;
             for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += redf[w];
-            atomicMax(max_bits, __float_as_uint(sqrtf(tot) * 1.0001f));   // non-negative floats order as uints
+            bounds[ob] = sqrtf(tot) * 1.0001f;   // norm bound of the packed row, at its destination row
         }
     }
 }
@@ -369,41 +351,31 @@ extern "C" int ccr_meanpool_bwd(const float *grad, const int64_t *mask, void *dh
     return CCR_OK;
 }
 
-extern "C" int ccr_pack_bf16_ex(const float *src, uint16_t *dst, float *norms, float *max_norm, int64_t rows, int dim,
+extern "C" int ccr_pack_bf16_ex(const float *src, uint16_t *dst, float *norms, float *row_norm_bounds, int64_t rows, int dim,
                                 int normalize, void *stream) {
     CCR_REQUIRE(src && dst, "ccr_pack_bf16: null pointer");
     CCR_REQUIRE(rows >= 0 && dim > 0, "ccr_pack_bf16: bad shape rows=%lld dim=%d", (long long)rows, dim);
     if (rows == 0) return CCR_OK;
     hipStream_t s = (hipStream_t)stream;
-    uint32_t *max_bits = reinterpret_cast<uint32_t *>(max_norm);
+    float *bounds = row_norm_bounds;
     if (!normalize && !norms) {
         CCR_REQUIRE(((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0), "ccr_pack_bf16: buffers must be 16-byte aligned");
-        if (max_bits) {
-            CCR_REQUIRE(dim % 8 == 0, "ccr_pack_bf16: max_norm needs dim %% 8 == 0 (dim=%d)", dim);
+        if (bounds) {
+            CCR_REQUIRE(dim % 8 == 0, "ccr_pack_bf16: row_norm_bounds needs dim %% 8 == 0 (dim=%d)", dim);
             static int rows_per = -1;
             if (rows_per < 0) {
                 const char *e = getenv("CCR_PACK_ROWS");
                 rows_per = e ? atoi(e) : 1;
             }
-            // A small seed launch first (256 rows): the blocks of the main launch then find a realistic maximum instead of
-            // the caller's zero, and only the few that exceed it touch the atomic (otherwise the ~2 K blocks resident at the
-            // start all queue up on that one address: ~40 us).
-            const int64_t seed = rows > 4096 ? 256 : 0;
-            for (int part = 0; part < 2; ++part) {
-                const int64_t r0 = part == 0 ? 0 : seed, r1 = part == 0 ? seed : rows;
-                if (r1 <= r0) continue;
-                const int64_t nr = r1 - r0;
-                int64_t blocks = (nr + 4 * rows_per - 1) / (4 * rows_per);
-                if (blocks > 131072) blocks = 131072;   // measured best at the NQ shape: 16 K - 128 K blocks, one row per wave and trip
-                const float *sp = src + r0 * dim;
-                __bf16 *dp = reinterpret_cast<__bf16 *>(dst) + r0 * dim;
-                if (rows_per == 1)
-                    hipLaunchKernelGGL(pack_rows_maxnorm_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, sp, dp, nr, dim, max_bits);
-                else if (rows_per == 2)
-                    hipLaunchKernelGGL(pack_rows_maxnorm_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, sp, dp, nr, dim, max_bits);
-                else
-                    hipLaunchKernelGGL(pack_rows_maxnorm_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, sp, dp, nr, dim, max_bits);
-            }
+            int64_t blocks = (rows + 4 * rows_per - 1) / (4 * rows_per);
+            if (blocks > 131072) blocks = 131072;   // measured best at the NQ shape: 16 K - 128 K blocks, one row per wave and trip
+            __bf16 *dp = reinterpret_cast<__bf16 *>(dst);
+            if (rows_per == 1)
+                hipLaunchKernelGGL(pack_rows_bound_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, src, dp, rows, dim, bounds);
+            else if (rows_per == 2)
+                hipLaunchKernelGGL(pack_rows_bound_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, src, dp, rows, dim, bounds);
+            else
+                hipLaunchKernelGGL(pack_rows_bound_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, src, dp, rows, dim, bounds);
             CCR_LAUNCH_CHECK();
             return CCR_OK;
         }
@@ -429,7 +401,7 @@ extern "C" int ccr_pack_bf16_ex(const float *src, uint16_t *dst, float *norms, f
     int64_t blocks = (rows + 3) / 4;
     if (blocks > 65536) blocks = 65536;   // short-lived waves (a few rows each) stream faster than a 2 048-block grid-stride loop
     hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, reinterpret_cast<__bf16 *>(dst),
-                       norms, rows, dim, normalize, max_bits);
+                       norms, rows, dim, normalize, bounds);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
 }
@@ -440,7 +412,7 @@ extern "C" int ccr_pack_bf16(const float *src, uint16_t *dst, float *norms, int6
 }
 
 extern "C" int ccr_meanpool_pack_bf16_ex(const void *hidden, int hidden_dtype, const int64_t *mask, uint16_t *dst_bf16,
-                                         float *dst_f32, const int64_t *dst_rows, float *max_norm, int B, int L, int dim,
+                                         float *dst_f32, const int64_t *dst_rows, float *row_norm_bounds, int B, int L, int dim,
                                          int normalize, void *stream) {
     CCR_REQUIRE(hidden && mask && (dst_bf16 || dst_f32), "ccr_meanpool_pack_bf16: null pointer");
     CCR_REQUIRE(B >= 0 && L > 0 && dim > 0 && dim % 4 == 0 && dim <= 4096,
@@ -450,7 +422,7 @@ extern "C" int ccr_meanpool_pack_bf16_ex(const void *hidden, int hidden_dtype, c
     int threads = ((dim / 4 + 63) / 64) * 64;
     if (threads > 256) threads = 256;
     __bf16 *db = reinterpret_cast<__bf16 *>(dst_bf16);
-    uint32_t *mb = reinterpret_cast<uint32_t *>(max_norm);
+    float *mb = row_norm_bounds;
     switch (hidden_dtype) {
         case CCR_DTYPE_F32:
             hipLaunchKernelGGL(meanpool_pack_kernel<float>, dim3(B), dim3(threads), 0, s, (const float *)hidden, mask, db,

@@ -82,10 +82,11 @@ int ccr_version(void);
  * dim % 4 == 0.  normalize: y = x / max(||x||, 1e-12), fixed reduction order (oracle/ccr_oracle.c).
  */
 int ccr_pack_bf16(const float *src, uint16_t *dst, float *norms, int64_t rows, int dim, int normalize, void *stream);
-/* Same, plus max_norm (device float, may be NULL): an upper bound of the largest L2 norm of the PACKED rows is
- * max-accumulated into it (zero it before the first batch; several batches may share it).  Passing it on to
- * ccr_index_create_with_norm saves the index build's own pass over the shard. */
-int ccr_pack_bf16_ex(const float *src, uint16_t *dst, float *norms, float *max_norm, int64_t rows, int dim, int normalize,
+/* Same, plus row_norm_bounds ([rows] device floats, may be NULL): entry r receives an upper bound of the L2 norm of the
+ * PACKED row r (one plain store per row: no initialisation needed, batches write disjoint slices of one shard-sized
+ * array).  Passing the array on to ccr_index_create_with_norms saves the index build's own pass over the shard; the
+ * index uses the bounds only inside its filter margins. */
+int ccr_pack_bf16_ex(const float *src, uint16_t *dst, float *norms, float *row_norm_bounds, int64_t rows, int dim, int normalize,
                      void *stream);
 
 /*
@@ -98,12 +99,13 @@ int ccr_meanpool_pack_bf16(const void *hidden, int hidden_dtype, const int64_t *
                            float *dst_f32, int B, int L, int dim, int normalize, void *stream);
 /* Same for length-sorted (variable-length) encoder batches that write straight into the resident shard:
  *   dst_rows [B] int64 or NULL: pooled row b goes to row dst_rows[b] of dst_bf16 / dst_f32 (NULL = row b);
- *   max_norm (device float) or NULL: max-accumulates a bound of the packed rows' L2 norm, as ccr_pack_bf16_ex.
+ *   row_norm_bounds (device floats, indexed like the destination rows) or NULL: a bound of each packed row's L2 norm,
+ *   as ccr_pack_bf16_ex.
  * The pooled value does not depend on L (masked positions are skipped, real tokens are summed in order), so a batch
  * padded to its own longest text gives the same bits as the reference's fixed max_length padding (item_tower.py:29,
  * tokenizer_kw) whenever the encoder's hidden states for the real tokens are the same. */
 int ccr_meanpool_pack_bf16_ex(const void *hidden, int hidden_dtype, const int64_t *mask, uint16_t *dst_bf16,
-                              float *dst_f32, const int64_t *dst_rows, float *max_norm, int B, int L, int dim,
+                              float *dst_f32, const int64_t *dst_rows, float *row_norm_bounds, int B, int L, int dim,
                               int normalize, void *stream);
 
 /* Backward of the pooling for the training forward (the reference's tower is called with gradients on in
@@ -116,14 +118,16 @@ int ccr_meanpool_bwd(const float *grad, const int64_t *mask, void *dhidden, int 
  * Build a search index over a resident bf16 corpus shard (borrowed pointer, no copy).
  * Replaces: the host-resident fp32 passage matrix of scripts/ms_marco_eval.py:199-201,208-210.
  *   global_row_offset: id of row 0 of this shard in the whole corpus (multi-GPU row sharding).
- * Synchronises `stream` once (computes the shard's max row norm for the filter margins).
+ * Synchronises `stream` once (one pass over the shard: the largest row norm of every 256-row tile, for the filter margins).
  */
 int ccr_index_create(const uint16_t *D_bf16, int64_t n_rows, int dim, int64_t global_row_offset, void *stream,
                      ccr_index **out);
-/* As ccr_index_create, but the caller supplies (device pointer) an upper bound of the shard's largest row norm
- * (from ccr_pack_bf16_ex): no pass over the corpus, no stream synchronisation. */
-int ccr_index_create_with_norm(const uint16_t *D_bf16, int64_t n_rows, int dim, int64_t global_row_offset,
-                               const float *max_norm, void *stream, ccr_index **out);
+/* As ccr_index_create, but the caller supplies (device pointer, [n_rows] floats) an upper bound of every row's norm
+ * (from ccr_pack_bf16_ex / ccr_meanpool_pack_bf16_ex): no pass over the corpus, no stream synchronisation.  The array is
+ * BORROWED like the corpus: it must stay valid and unchanged until the index is destroyed (the main pass uses the largest
+ * bound of each 256-row tile, the select stage each candidate row's own bound). */
+int ccr_index_create_with_norms(const uint16_t *D_bf16, int64_t n_rows, int dim, int64_t global_row_offset,
+                                const float *row_norm_bounds, void *stream, ccr_index **out);
 int ccr_index_destroy(ccr_index *index);
 int64_t ccr_index_rows(const ccr_index *index);
 int ccr_index_dim(const ccr_index *index);

@@ -99,23 +99,24 @@ def test_item_tower_mirror(golden_dir):
             tower(**inputs, output_step="nonsense")
 
 
-def test_pack_max_norm_and_index_with_norm():
-    """ccr_pack_bf16_ex accumulates an upper bound of the largest packed-row norm over batches; an index built
-    from it (no pass over the shard) must search identically."""
+def test_pack_norm_bounds_and_index_with_norms():
+    """ccr_pack_bf16_ex leaves an upper bound of every packed row's norm, batch by batch; an index built
+    from them (no pass over the shard) must search identically."""
     from ccrec_amd import ops
     g = torch.Generator().manual_seed(17)
     x = torch.randn(5000, 768, generator=g) * torch.rand(5000, 1, generator=g) * 3
     shard = torch.empty(5000, 768, dtype=torch.bfloat16, device="cuda")
-    mx = torch.zeros(1, device="cuda")
+    nb = torch.empty(5000, device="cuda")
     for lo in range(0, 5000, 1024):            # batch by batch, as generate_embeddings does
-        ops.pack_bf16(x[lo:lo + 1024].cuda(), out=shard[lo:lo + 1024], max_norm=mx)
+        ops.pack_bf16(x[lo:lo + 1024].cuda(), out=shard[lo:lo + 1024], norm_bounds=nb[lo:lo + 1024])
     assert torch.equal(shard.view(torch.int16), x.cuda().to(torch.bfloat16).view(torch.int16))
-    true_max = float(orc.row_norms_bf16(_bits(shard)).max())
-    assert true_max <= float(mx) <= true_max * 1.001
-    mxn = torch.zeros(1, device="cuda")
-    ops.pack_bf16(x.cuda(), normalize=True, max_norm=mxn)
-    assert 1.0 <= float(mxn) <= 1.01
+    true = orc.row_norms_bf16(_bits(shard)).astype(np.float64)
+    got = nb.cpu().numpy().astype(np.float64)
+    assert np.all(true <= got) and np.all(got <= true * 1.001)
+    nbn = torch.empty(5000, device="cuda")
+    ops.pack_bf16(x.cuda(), normalize=True, norm_bounds=nbn)
+    assert 1.0 <= float(nbn.min()) and float(nbn.max()) <= 1.01
     q = ops.pack_bf16(torch.randn(40, 768, generator=g).cuda())
     a = ops.CorpusIndex(shard).search(q, 50, 2)
-    b = ops.CorpusIndex(shard, max_norm=mx).search(q, 50, 2)
+    b = ops.CorpusIndex(shard, norm_bounds=nb).search(q, 50, 2)
     assert torch.equal(a[1], b[1]) and torch.equal(a[0], b[0])

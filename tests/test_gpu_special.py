@@ -259,18 +259,18 @@ def test_async_search_equals_sync_including_many_flagged_queries():
 
 
 def test_nan_row_with_norm_path_equals_dense():
-    """A NaN corpus row must make the pack kernel's max norm NaN (fmaxf would drop it): every path then agrees."""
+    """A NaN corpus row must leave a NaN norm bound (and the index a NaN maximum: fmaxf would drop it): every path then agrees."""
     from ccrec_amd import ops
     n, d, k = 40_000, 64, 20
     g = torch.Generator().manual_seed(4)
     D = torch.randn(n, d, generator=g) / 8
     D[12345, 7] = float("nan")
     Q = (torch.randn(16, d, generator=g) / 8).cuda()
-    mx = torch.zeros(1, device="cuda")
-    Db = ops.pack_bf16(D.cuda(), max_norm=mx)
-    assert torch.isnan(mx).item()
+    nb = torch.empty(n, device="cuda")
+    Db = ops.pack_bf16(D.cuda(), norm_bounds=nb)
+    assert torch.isnan(nb[12345]).item() and int(torch.isnan(nb).sum()) == 1
     Qb = ops.pack_bf16(Q)
-    s0, i0 = ops.CorpusIndex(Db, max_norm=mx).search(Qb, k, 2)
+    s0, i0 = ops.CorpusIndex(Db, norm_bounds=nb).search(Qb, k, 2)
     s1, i1 = ops.CorpusIndex(Db).search(Qb, k, 1)
     assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
     s2, i2 = ops.CorpusIndex(Db).search(Qb, k, 2)                      # the index's own norm pass must keep the NaN too
@@ -500,3 +500,32 @@ def test_empty_and_degenerate_inputs():
     table = torch.randn(20, 768)
     prof = ranking({f"p{j}": j for j in range(20)}, {}, lambda rows: table[torch.as_tensor(rows, dtype=torch.long)], 8)
     assert prof == {}
+
+
+@pytest.mark.parametrize("route", ["pack_bounds", "own_pass"])
+def test_norm_outlier_rows_keep_the_fused_path(route):
+    """The filter margins are per 256-row tile (cq * tile norm), not per shard: a few rows with norms 30x - 1000x the rest
+    must neither flood the candidate lists nor send queries to the dense path (one global max norm did: 7.5 s per NQ step at
+    100x), and the result stays the canonical one.  Both index builds: norm bounds from the pack kernel, the index's own pass."""
+    from ccrec_amd import ops
+    n, d, nq, k = 600_000, 768, 300, 100
+    g = torch.Generator(device="cuda").manual_seed(77)
+    D = torch.randn(n, d, generator=g, device="cuda") / d ** 0.5
+    D[1000] *= 100.0
+    D[300_000] *= 1000.0
+    D[450_000:450_050] *= 30.0
+    Q = torch.randn(nq, d, generator=g, device="cuda") / d ** 0.5
+    Q[7] *= 50.0                                  # a query norm outlier must only widen its own margin
+    nb = torch.empty(n, device="cuda") if route == "pack_bounds" else None
+    Db = ops.pack_bf16(D, norm_bounds=nb)
+    Qb = ops.pack_bf16(Q)
+    index = ops.CorpusIndex(Db, norm_bounds=nb)
+    s, i = index.search(Qb, k)
+    st = index.last_stats()
+    assert st["path"] == 1 and st["n_fallback"] == 0, st
+    assert st["n_candidates"] / nq < 60 * k, st    # the 1 052 outlier rows pass for every query, little else beyond the usual
+    s1, i1 = index.search(Qb, k, 1)
+    assert torch.equal(i, i1) and torch.equal(s.view(torch.int32), s1.view(torch.int32))
+    bits = lambda t: t.view(torch.int16).cpu().numpy().view(np.uint16)   # noqa: E731
+    ref_i, ref_s = orc.canonical_search(bits(Qb[:4]), bits(Db), k)
+    assert np.array_equal(i[:4].cpu().numpy(), ref_i) and np.array_equal(s[:4].cpu().numpy(), ref_s)

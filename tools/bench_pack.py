@@ -30,11 +30,11 @@ def main():
     x = torch.randn(n, d, device="cuda")
     y16 = torch.empty(n, d, dtype=torch.bfloat16, device="cuda")
     y32 = torch.empty_like(x)
-    mx = torch.zeros(1, device="cuda")
+    mx = torch.empty(n, device="cuda")   # norm bound per packed row
     el = n * d
-    t_pack = timeit(lambda: ops.pack_bf16(x, out=y16, max_norm=mx))
+    t_pack = timeit(lambda: ops.pack_bf16(x, out=y16, norm_bounds=mx))
     t_plain = timeit(lambda: ops.pack_bf16(x, out=y16))
-    t_cos = timeit(lambda: ops.pack_bf16(x, out=y16, normalize=True, max_norm=mx))
+    t_cos = timeit(lambda: ops.pack_bf16(x, out=y16, normalize=True, norm_bounds=mx))
     t_cast = timeit(lambda: y16.copy_(x))
     t_copy = timeit(lambda: y32.copy_(x))
     print(json.dumps({"rows": n, "dim": d,

@@ -19,9 +19,9 @@ src = gen_rows(rows, 768, 1234, dev)
 q = ops.pack_bf16(gen_rows(nq, 768, 4321, dev))
 shard = torch.empty(rows, 768, dtype=torch.bfloat16, device=dev)
 other = torch.empty_like(shard)
-mx = torch.zeros(1, device=dev)
-ops.pack_bf16(src, out=shard, max_norm=mx)
-index = ops.CorpusIndex(shard, max_norm=mx)
+mx = torch.empty(rows, device=dev)   # norm bound per packed row
+ops.pack_bf16(src, out=shard, norm_bounds=mx)
+index = ops.CorpusIndex(shard, norm_bounds=mx)
 side = torch.cuda.Stream()
 
 
@@ -40,18 +40,18 @@ def search_only():
 
 
 def pack_only():
-    ops.pack_bf16(src, out=other, max_norm=mx)
+    ops.pack_bf16(src, out=other, norm_bounds=mx)
 
 
 def both_serial():
-    ops.pack_bf16(src, out=other, max_norm=mx)
+    ops.pack_bf16(src, out=other, norm_bounds=mx)
     index.search(q, 100)
 
 
 def both_overlapped():
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        ops.pack_bf16(src, out=other, max_norm=mx)
+        ops.pack_bf16(src, out=other, norm_bounds=mx)
     index.search(q, 100, defer=True)
     torch.cuda.current_stream().wait_stream(side)
     index.finish()
@@ -61,7 +61,7 @@ def both_overlapped_search_first():
     index.search(q, 100, defer=True)
     side.wait_stream(torch.cuda.current_stream()) if False else None
     with torch.cuda.stream(side):
-        ops.pack_bf16(src, out=other, max_norm=mx)
+        ops.pack_bf16(src, out=other, norm_bounds=mx)
     torch.cuda.current_stream().wait_stream(side)
     index.finish()
 
