@@ -18,20 +18,26 @@ def _case(seed):
     k = int(min(n, rs.choice([1, rs.randint(2, 30), rs.randint(30, 300), rs.randint(300, 1300)])))
     off = int(rs.choice([0, 7, 1 << 33]))
     quant = bool(rs.rand() < 0.3)
-    return n, nq, d, k, off, quant
+    wild = bool(rs.rand() < 0.35)   # rows / queries with norms up to 1000x the rest (the filter margins are per tile / per row)
+    return n, nq, d, k, off, quant, wild
 
 
 @pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("CCR_FUZZ_SEEDS", "24")))))   # soak: CCR_FUZZ_SEEDS=400
 def test_random_shapes_all_paths_agree(seed):
     from ccrec_amd import ops
-    n, nq, d, k, off, quant = _case(seed)
+    n, nq, d, k, off, quant, wild = _case(seed)
     g = torch.Generator().manual_seed(seed)
     D = torch.randn(n, d, generator=g) / d ** 0.5
     Q = torch.randn(nq, d, generator=g) / d ** 0.5
     if quant:   # coarse grid -> many exactly equal scores
         D, Q = torch.round(D * 8) / 8, torch.round(Q * 8) / 8
-    Db, Qb = ops.pack_bf16(D.cuda()), ops.pack_bf16(Q.cuda())
-    index = ops.CorpusIndex(Db, global_row_offset=off)
+    if wild:
+        rows = torch.randint(0, n, (max(1, n // 5000),), generator=g)
+        D[rows] *= 10.0 ** (3.0 * torch.rand(rows.numel(), 1, generator=g))
+        Q[torch.randint(0, nq, (1,), generator=g)] *= 64.0
+    nb = torch.empty(n, device="cuda") if seed % 2 else None   # odd seeds: the pack kernel's norm bounds; even: the index's own pass
+    Db, Qb = ops.pack_bf16(D.cuda(), norm_bounds=nb), ops.pack_bf16(Q.cuda())
+    index = ops.CorpusIndex(Db, global_row_offset=off, norm_bounds=nb)
     s0, i0 = index.search(Qb, k, 0)
     st0 = index.last_stats()
     s1, i1 = index.search(Qb, k, 1)
