@@ -246,6 +246,12 @@ def test_async_search_equals_sync_including_many_flagged_queries():
     ref_i, ref_s = orc.canonical_search(Qt[:3], Dt, k)
     assert np.array_equal(i2.cpu().numpy()[:3], ref_i) and np.array_equal(s2.cpu().numpy()[:3].view(np.uint32), ref_s.view(np.uint32))
     assert torch.equal(i2[0].expand_as(i2), i2)
+    # synchronous form, 100 flagged queries: the dense path scores them in chunks of >= 64 inside the (free) candidate area
+    Qh = _bf16(np.concatenate([Qt, Qb[:30], Qt, Qt[:20]]))
+    s4, i4 = index.search(Qh, k, 2)
+    assert index.last_stats()["n_dense"] == 100
+    s5, i5 = index.search(Qh, k, 1)
+    assert torch.equal(i4, i5) and torch.equal(s4.view(torch.int32), s5.view(torch.int32))
     # exactly the on-stream chunk: a handful of flagged queries are complete WITHOUT finish() having re-done anything
     Qm = np.concatenate([Qb[:100], Qt[:5]])
     s3, i3 = index.search(_bf16(Qm), k, 2, defer=True)
