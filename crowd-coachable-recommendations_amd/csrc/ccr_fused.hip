@@ -653,10 +653,11 @@ __global__ __launch_bounds__(256) void row_norms_bf16_kernel(const uint16_t *__r
     if (max_bits && lane == 0 && wbits > __hip_atomic_load(max_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_bits, wbits);
 }
 
-// tile_norm[t] = the largest of the row-norm bounds of rows [256 t, 256 t + 256) the pack kernels wrote; max_bits = the largest
-// of all (bit patterns: a NaN bound stays on top and poisons the thresholds -> dense path).  grid = tiles, block = 256.
+// tile_norm[t] = the largest of the row-norm bounds of rows [256 t, 256 t + 256) the pack kernels wrote (bit patterns: a NaN
+// bound stays on top).  grid = tiles, block = 256.  No shared maximum here: the ~2 K blocks resident at the start would all
+// see the initial zero and queue their atomics on one address (measured: 38 us for this kernel instead of 4).
 __global__ __launch_bounds__(256) void tile_norms_kernel(const float *__restrict__ row_bounds, int64_t rows,
-                                                        uint32_t *__restrict__ tile_bits, uint32_t *__restrict__ max_bits) {
+                                                        uint32_t *__restrict__ tile_bits) {
     __shared__ uint32_t s_w[4];
     const int64_t r = (int64_t)blockIdx.x * TILE_DOCS + threadIdx.x;
     uint32_t b = r < rows ? (__float_as_uint(row_bounds[r]) & 0x7fffffffu) : 0u;
@@ -669,9 +670,30 @@ __global__ __launch_bounds__(256) void tile_norms_kernel(const float *__restrict
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t m01 = s_w[0] > s_w[1] ? s_w[0] : s_w[1], m23 = s_w[2] > s_w[3] ? s_w[2] : s_w[3];
-        const uint32_t m = m01 > m23 ? m01 : m23;
-        tile_bits[blockIdx.x] = m;
-        if (m > __hip_atomic_load(max_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_bits, m);
+        tile_bits[blockIdx.x] = m01 > m23 ? m01 : m23;
+    }
+}
+
+// max_bits = the largest tile bound (a NaN / Inf poisons the thresholds -> dense path).  One workgroup of 1 024 threads.
+__global__ __launch_bounds__(1024) void max_tile_norm_kernel(const uint32_t *__restrict__ tile_bits, int64_t tiles,
+                                                            uint32_t *__restrict__ max_bits) {
+    __shared__ uint32_t s_w[16];
+    uint32_t b = 0u;
+    for (int64_t t = threadIdx.x; t < tiles; t += 1024) {
+        const uint32_t v = tile_bits[t];
+        b = v > b ? v : b;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint32_t o = __shfl_xor(b, off, 64);
+        b = o > b ? o : b;
+    }
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t m = 0u;
+        for (int w = 0; w < 16; ++w) m = s_w[w] > m ? s_w[w] : m;
+        *max_bits = m;
     }
 }
 
@@ -1313,8 +1335,9 @@ int launch_row_norms_bf16(const uint16_t *X, int64_t rows, int dim, float *norms
 
 int launch_tile_norms(const float *row_bounds, int64_t rows, uint32_t *tile_bits, uint32_t *max_bits, hipStream_t s) {
     if (rows <= 0) return CCR_OK;
-    hipLaunchKernelGGL(tile_norms_kernel, dim3((unsigned)((rows + TILE_DOCS - 1) / TILE_DOCS)), dim3(256), 0, s, row_bounds, rows,
-                       tile_bits, max_bits);
+    const int64_t tiles = (rows + TILE_DOCS - 1) / TILE_DOCS;
+    hipLaunchKernelGGL(tile_norms_kernel, dim3((unsigned)tiles), dim3(256), 0, s, row_bounds, rows, tile_bits);
+    hipLaunchKernelGGL(max_tile_norm_kernel, dim3(1), dim3(1024), 0, s, tile_bits, tiles, max_bits);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
 }
