@@ -292,6 +292,9 @@ def phases_obj(st):
 
 
 def main():
+    if int(os.environ.get("CCR_BENCH_WATCHDOG", "0")) > 0:   # tests: a hung rank dumps every thread's stack and exits
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["CCR_BENCH_WATCHDOG"]), exit=True)
     args = parse()
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))

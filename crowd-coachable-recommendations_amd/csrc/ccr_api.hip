@@ -286,7 +286,7 @@ static Plan make_plan_for(int64_t n_rows, int dim, int n_q, int k, int flags, in
         p.dense_rows_per_chunk = FALLBACK_ROWS;
         p.off_dense = take((size_t)FALLBACK_ROWS * n_rows * 4);
         // retry pass of flagged queries: compact query rows, thresholds + margins, the two lists, counts, second flag area
-        p.off_retry = take((size_t)p.nq_pad * dim * 2 + (size_t)p.nq_pad * 8 + (size_t)n_q * 12 + 64 + 64 + (size_t)n_q * 4 + 256 * 8);
+        p.off_retry = take((size_t)p.nq_pad * dim * 2 + (size_t)p.nq_pad * 8 + (size_t)n_q * 16 + 64 + 64 + (size_t)n_q * 4 + 256 * 10);
     } else {
         int64_t rows = (int64_t)(DENSE_SCRATCH_TARGET / ((size_t)n_rows * 4));
         rows = std::min<int64_t>(std::max<int64_t>(rows, 1), n_q);
@@ -612,115 +612,138 @@ static int search_complete(ccr_index *ix) {
     uint32_t *counts = (uint32_t *)carve(64);
     uint32_t *flag2 = (uint32_t *)carve(64 + (size_t)n_q * 4);
 
-    uint32_t *list_b = (uint32_t *)carve((size_t)n_q * 4);   // second retry list (the rounds ping-pong between the two)
+    uint32_t *list_b = (uint32_t *)carve((size_t)n_q * 4);   // the rounds of a group ping-pong between these two lists
+    uint32_t *list_c = (uint32_t *)carve((size_t)n_q * 4);
     int rc = launch_partition_flags(flag_list, begin, (int)host.nflag, retry_list, dense_list, counts, s);
     if (rc != CCR_OK) return rc;
     uint32_t hc[2] = {0, 0};
     CCR_HIP_CHECK(hipMemcpyAsync(hc, counts, 8, hipMemcpyDeviceToHost, s));
     CCR_HIP_CHECK(hipStreamSynchronize(s));
-    int n_cur = (int)hc[0], n_dense = (int)hc[1];
-    uint32_t *cur = retry_list, *nxt = list_b;
+    const int n_retry = (int)hc[0];
+    int n_dense = (int)hc[1];
+    int n_again = 0;   // queries the retry could not finish (they join the dense list)
     const int64_t area_recs = (int64_t)((p.off_flag - p.off_cand) / 8);   // records the candidate area holds
     const int nsub_all = p.ranges * p.sublists;
-    CandLayout prev_lay = p.cand;
-    int prev_n = n_q, prev_pad = p.nq_pad;
-    for (int round = 0; round < 3 && n_cur > 0 && nsub_all <= 2048; ++round) {
-        // thresholds re-tightened from everything the previous attempt recorded (truncated lists included)
-        if (round == 0) {
-            rc = launch_threshold_update(cand, cnt, nsub_all, 0, 0, 1, p.sublists, n_q, p.nq_pad, p.cand, k, delta, ix->tile_norm, thr, s);
-            if (rc != CCR_OK) return rc;
-        } else {
-            rc = launch_threshold_update(cand, cnt, nsub_all, 0, 0, 1, p.sublists, prev_n, prev_pad, prev_lay, k, delta2, ix->tile_norm, thr2,
-                                         s);
-            if (rc != CCR_OK) return rc;
-            rc = launch_scatter_thresholds(nxt, prev_n, thr2, thr, s);   // nxt still holds the previous round's list
-            if (rc != CCR_OK) return rc;
+    auto to_dense = [&](const uint32_t *list, int n) -> int {
+        CCR_HIP_CHECK(hipMemcpyAsync(dense_list + n_dense, list, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+        n_dense += n;
+        n_again += n;
+        return CCR_OK;
+    };
+    if (n_retry > 0 && nsub_all > 2048) {
+        rc = to_dense(retry_list, n_retry);
+        if (rc != CCR_OK) return rc;
+    } else if (n_retry > 0) {
+        // thresholds re-tightened from everything the first attempt recorded (truncated lists included) -- for every flagged
+        // query at once, before the candidate area is reused
+        rc = launch_threshold_update(cand, cnt, nsub_all, 0, 0, 1, p.sublists, n_q, p.nq_pad, p.cand, k, delta, ix->tile_norm, thr, s);
+        if (rc != CCR_OK) return rc;
+        // The flagged queries are retried in GROUPS that get the whole candidate area to themselves: the fewer queries share
+        // it, the larger every sub-list.  A group is as large as still leaves four times the first attempt's capacity (when
+        // most of a batch is flagged -- the lists were flooded, not unlucky -- one group per query block: about one corpus
+        // pass of ONE block per 256 queries instead of 0.65 ms of fp64 scoring per query).
+        const int64_t want_cap = std::min<int64_t>(8192, 4 * (int64_t)p.cap);
+        int64_t group = area_recs / ((int64_t)nsub_all * want_cap) / TILE_Q * TILE_Q;
+        group = std::max<int64_t>(TILE_Q, std::min<int64_t>(group, round_up(n_retry, TILE_Q)));
+        for (int g0 = 0; g0 < n_retry; g0 += (int)group) {
+            const uint32_t *cur = retry_list + g0;
+            int n_cur = std::min<int>((int)group, n_retry - g0);
+            const uint32_t *prev_list = nullptr;
+            CandLayout prev_lay = p.cand;
+            int prev_n = 0, prev_pad = 0;
+            for (int round = 0; round < 3 && n_cur > 0; ++round) {
+                if (round > 0) {   // re-tighten from the previous round's (truncated) lists of this group
+                    rc = launch_threshold_update(cand, cnt, nsub_all, 0, 0, 1, p.sublists, prev_n, prev_pad, prev_lay, k, delta2, ix->tile_norm,
+                                                 thr2, s);
+                    if (rc != CCR_OK) return rc;
+                    rc = launch_scatter_thresholds(prev_list, prev_n, thr2, thr, s);
+                    if (rc != CCR_OK) return rc;
+                }
+                rc = launch_gather_queries(pd.Q, ix->dim, cur, n_cur, thr, delta, Q2, thr2, delta2, s);
+                if (rc != CCR_OK) return rc;
+                const int pad2 = (int)round_up(n_cur, TILE_Q);
+                int64_t cap2 = area_recs / ((int64_t)nsub_all * pad2);
+                cap2 = std::min<int64_t>(8192, cap2 / 4 * 4);
+                if (cap2 < 16) break;
+                CandLayout lay2;
+                memset(&lay2, 0, sizeof(lay2));
+                lay2.nseg = 1;
+                lay2.seg_end[0] = lay2.seg_end[1] = lay2.seg_end[2] = INT32_MAX;
+                lay2.cap[0] = lay2.cap[1] = lay2.cap[2] = (int)cap2;
+                CCR_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)nsub_all * pad2 * 4, s));
+                CCR_HIP_CHECK(hipMemsetAsync(flag2, 0, 64, s));
+                GemmArgs g;
+                memset(&g, 0, sizeof(g));
+                g.D = ix->D;
+                g.n_rows = ix->n_rows;
+                g.dim = ix->dim;
+                g.Q = Q2;
+                g.n_q = n_cur;
+                g.nq_pad = pad2;
+                g.qblocks = pad2 / TILE_Q;
+                g.qgroups = pick_qgroups(g.qblocks, ix->dim, ix->knobs);
+                g.stagger = ix->knobs.stagger;
+                g.n_vt = p.tiles;
+                g.tile_stride = 1;
+                g.ranges = p.ranges;
+                g.thr = thr2;
+                g.cq = delta2;
+                g.tile_norm = ix->tile_norm;
+                g.cnt = cnt;
+                g.cand = cand;
+                g.lay = lay2;
+                g.item_begin = 0;
+                g.item_end = INT32_MAX;
+                rc = p.mfma16 ? launch_gemm16_filter(g, p.grid, s) : launch_gemm_filter(g, p.grid, s);
+                if (rc != CCR_OK) return rc;
+                rc = launch_select_rescore(cand, cnt, nsub_all, p.sublists, n_cur, pad2, lay2, k, p.rescore_cap, p.select_compact, ix->n_rows,
+                                           delta2, ix->row_norm, ix->dmax_bits, Q2, ix->D, ix->dim, ix->offset, pd.out_scores, pd.out_ids, flag2,
+                                           flag2 + 16, nullptr, cur, s);
+                if (rc != CCR_OK) return rc;
+                ix->stats.n_retried += n_cur;
+                uint32_t again = 0;
+                CCR_HIP_CHECK(hipMemcpyAsync(&again, flag2, 4, hipMemcpyDeviceToHost, s));
+                CCR_HIP_CHECK(hipStreamSynchronize(s));
+                prev_list = cur;
+                prev_lay = lay2;
+                prev_n = n_cur;
+                prev_pad = pad2;
+                if (again == 0) {
+                    n_cur = 0;
+                    break;
+                }
+                uint32_t *next = (cur == list_b) ? list_c : list_b;
+                rc = launch_partition_flags(flag2 + 16, 0, (int)again, next, dense_list + n_dense, counts, s);
+                if (rc != CCR_OK) return rc;
+                CCR_HIP_CHECK(hipMemcpyAsync(hc, counts, 8, hipMemcpyDeviceToHost, s));
+                CCR_HIP_CHECK(hipStreamSynchronize(s));
+                n_dense += (int)hc[1];
+                cur = next;
+                n_cur = (int)hc[0];
+                if (n_cur >= prev_n) break;   // no progress (every retried query overflowed again): the dense path takes them
+            }
+            if (n_cur > 0) {   // still flagged after the rounds of this group
+                rc = to_dense(cur, n_cur);
+                if (rc != CCR_OK) return rc;
+            }
         }
-        rc = launch_gather_queries(pd.Q, ix->dim, cur, n_cur, thr, delta, Q2, thr2, delta2, s);
-        if (rc != CCR_OK) return rc;
-        // the flagged queries alone: fewer queries share the candidate area, so every sub-list gets a larger capacity
-        const int pad2 = (int)round_up(n_cur, TILE_Q);
-        int64_t cap2 = area_recs / ((int64_t)nsub_all * pad2);
-        cap2 = std::min<int64_t>(8192, cap2 / 4 * 4);
-        if (cap2 < 16) break;
-        CandLayout lay2;
-        memset(&lay2, 0, sizeof(lay2));
-        lay2.nseg = 1;
-        lay2.seg_end[0] = lay2.seg_end[1] = lay2.seg_end[2] = INT32_MAX;
-        lay2.cap[0] = lay2.cap[1] = lay2.cap[2] = (int)cap2;
-        CCR_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)nsub_all * pad2 * 4, s));
-        CCR_HIP_CHECK(hipMemsetAsync(flag2, 0, 64, s));
-        GemmArgs g;
-        memset(&g, 0, sizeof(g));
-        g.D = ix->D;
-        g.n_rows = ix->n_rows;
-        g.dim = ix->dim;
-        g.Q = Q2;
-        g.n_q = n_cur;
-        g.nq_pad = pad2;
-        g.qblocks = pad2 / TILE_Q;
-        g.qgroups = pick_qgroups(g.qblocks, ix->dim, ix->knobs);
-        g.stagger = ix->knobs.stagger;
-        g.n_vt = p.tiles;
-        g.tile_stride = 1;
-        g.ranges = p.ranges;
-        g.thr = thr2;
-        g.cq = delta2;
-        g.tile_norm = ix->tile_norm;
-        g.cnt = cnt;
-        g.cand = cand;
-        g.lay = lay2;
-        g.item_begin = 0;
-        g.item_end = INT32_MAX;
-        rc = p.mfma16 ? launch_gemm16_filter(g, p.grid, s) : launch_gemm_filter(g, p.grid, s);
-        if (rc != CCR_OK) return rc;
-        rc = launch_select_rescore(cand, cnt, nsub_all, p.sublists, n_cur, pad2, lay2, k, p.rescore_cap, p.select_compact, ix->n_rows, delta2,
-                                   ix->row_norm, ix->dmax_bits, Q2, ix->D, ix->dim, ix->offset, pd.out_scores, pd.out_ids, flag2, flag2 + 16, nullptr, cur, s);
-        if (rc != CCR_OK) return rc;
-        ix->stats.n_retried += n_cur;
-        uint32_t again = 0;
-        CCR_HIP_CHECK(hipMemcpyAsync(&again, flag2, 4, hipMemcpyDeviceToHost, s));
-        CCR_HIP_CHECK(hipStreamSynchronize(s));
-        prev_lay = lay2;
-        prev_n = n_cur;
-        prev_pad = pad2;
-        std::swap(cur, nxt);   // nxt = this round's list (needed by the next scatter), cur = buffer for the next list
-        if (again == 0) {
-            n_cur = 0;
-            break;
-        }
-        rc = launch_partition_flags(flag2 + 16, 0, (int)again, cur, dense_list + n_dense, counts, s);
-        if (rc != CCR_OK) return rc;
-        CCR_HIP_CHECK(hipMemcpyAsync(hc, counts, 8, hipMemcpyDeviceToHost, s));
-        CCR_HIP_CHECK(hipStreamSynchronize(s));
-        n_dense += (int)hc[1];
-        if ((int)hc[0] >= prev_n) {   // no progress (every retried query overflowed again): the dense path takes them
-            n_cur = (int)hc[0];
-            break;
-        }
-        n_cur = (int)hc[0];
     }
-    int n_again = 0;
     // Many queries for the dense path: its 64 x 64 score tiles are a quarter full with the 16 reserved rows (2.2 instead of
     // 0.65 ms per NQ query), and the candidate area is free by now -- score 64 (or more) queries per chunk in there.
     int64_t chunk = p.dense_rows_per_chunk;
     {
         const int64_t fit = (int64_t)((p.off_flag - p.off_cand) / ((size_t)ix->n_rows * 4)) / 64 * 64;
-        if (std::max(n_cur, n_dense) > chunk && fit >= 64) {
+        if (n_dense > chunk && fit >= 64) {
             chunk = std::min<int64_t>(fit, 256);
             dense_scratch = (float *)cand;
         }
-    }
-    if (n_cur > 0) {   // still flagged after the retry rounds (or no retry possible)
-        rc = dense_for_list(ix, pd.Q, cur, 0, n_cur, k, dense_scratch, chunk, pd.out_scores, pd.out_ids, s);
-        if (rc != CCR_OK) return rc;
-        n_again = n_cur;
     }
     if (n_dense > 0) {
         rc = dense_for_list(ix, pd.Q, dense_list, 0, n_dense, k, dense_scratch, chunk, pd.out_scores, pd.out_ids, s);
         if (rc != CCR_OK) return rc;
     }
-    ix->stats.n_dense += n_again + n_dense;
+    ix->stats.n_dense += n_dense;   // (n_again of them after a retry)
+    (void)n_again;
     CCR_HIP_CHECK(hipEventRecord(ix->ev[6], s));
     CCR_HIP_CHECK(hipStreamSynchronize(s));
     CCR_HIP_CHECK(hipEventElapsedTime(&ix->stats.ms_fallback, ix->ev[5], ix->ev[6]));

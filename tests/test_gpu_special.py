@@ -535,3 +535,63 @@ def test_norm_outlier_rows_keep_the_fused_path(route):
     bits = lambda t: t.view(torch.int16).cpu().numpy().view(np.uint16)   # noqa: E731
     ref_i, ref_s = orc.canonical_search(bits(Qb[:4]), bits(Db), k)
     assert np.array_equal(i[:4].cpu().numpy(), ref_i) and np.array_equal(s[:4].cpu().numpy(), ref_s)
+
+
+def test_cancelling_components_margins_are_rigorous():
+    """Rows whose large components cancel exactly in the canonical (fp64) score but not in the MFMA's fp32 accumulation: +M at
+    element 0 and -M at element 100 (different MFMA K blocks), every query with q[0] == q[100].  The MFMA score of such a row is
+    off by ~ulp(M) -- far more than the spacing of the top scores -- so the MFMA order is wrong around them; the per-tile /
+    per-row margins must still deliver the canonical result on the fused path (no query may need the dense path)."""
+    from ccrec_amd import ops
+    n, d, nq, k = 120_000, 128, 64, 10
+    g = torch.Generator().manual_seed(9)
+    D = torch.randn(n, d, generator=g) / d ** 0.5
+    Q = torch.randn(nq, d, generator=g) / d ** 0.5
+    Q[:, 0] = Q[:, 100] = 0.5
+    rows = torch.randint(0, n, (6,), generator=g)      # (dozens of such rows flood the lists of a corpus this small: every query
+    for j, r in enumerate(rows.tolist()):             #  is then retried and ends on the dense path -- exact as well, but not the point)
+        m = float(2 ** (8 + 2 * j))                  # M = 256 ... 262144
+        D[r, 0], D[r, 100] = m, -m
+        D[r, 1:100] *= 3.0                            # lift some of them into the top-k region
+    Db, Qb = ops.pack_bf16(D.cuda()), ops.pack_bf16(Q.cuda())
+    bits = lambda t: t.view(torch.int16).cpu().numpy().view(np.uint16)   # noqa: E731
+    # the premise: MFMA scores of the cancelling rows are visibly wrong
+    index = ops.CorpusIndex(Db)
+    mf = index.scores(Qb[:4], mode="mfma")[:, rows.cuda()].cpu().double()
+    ex = index.scores(Qb[:4], mode="canonical")[:, rows.cuda()].cpu().double()
+    assert float((mf - ex).abs().max()) > 1e-3
+    for flag in (0, 2):
+        s, i = index.search(Qb, k, flag)
+        st = index.last_stats()
+        assert st["path"] == 1 and st["n_dense"] == 0, st
+        s1, i1 = index.search(Qb, k, 1)
+        assert torch.equal(i, i1) and torch.equal(s.view(torch.int32), s1.view(torch.int32))
+    ref_i, ref_s = orc.canonical_search(bits(Qb[:8]), bits(Db), k)
+    assert np.array_equal(i[:8].cpu().numpy(), ref_i) and np.array_equal(s[:8].cpu().numpy(), ref_s)
+    assert len(set(ref_i.ravel().tolist()) & set(rows.tolist())) > 0   # cancelling rows do appear in the top-k
+
+
+def test_flooded_lists_are_retried_in_groups():
+    """150 of the 2,344 tiles pass the filter completely for EVERY query (each holds a row whose norm is 10^5 x the rest, so
+    the tile's margin is wider than any score; 38,400 survivors per query): sub-lists of the first attempt overflow for all
+    1,024 queries, all are flagged.  The retry must not hand them to the dense path: it takes them in groups of a few query blocks, each with the whole
+    candidate area, and finishes every query on the fused path -- bit-exact."""
+    from ccrec_amd import ops
+    n, d, nq, k = 600_000, 128, 1024, 50
+    g = torch.Generator(device="cuda").manual_seed(31)
+    D = torch.randn(n, d, generator=g, device="cuda") / d ** 0.5
+    Q = torch.randn(nq, d, generator=g, device="cuda") / d ** 0.5
+    Q[:, 0] = Q[:, 100] = 0.5
+    rows = torch.arange(150, device="cuda") * 4_000 + 77
+    D[rows, 0], D[rows, 100] = 65536.0, -65536.0        # exact cancellation in the canonical score, a huge norm
+    Db, Qb = ops.pack_bf16(D), ops.pack_bf16(Q)
+    index = ops.CorpusIndex(Db)
+    s, i = index.search(Qb, k)
+    st = index.last_stats()
+    assert st["path"] == 1 and st["n_fallback"] > nq // 2 and st["n_retried"] >= st["n_fallback"] and st["n_dense"] == 0, st
+    pick = torch.arange(0, nq, 37, device="cuda")
+    s1, i1 = index.search(Qb[pick], k, 1)
+    assert torch.equal(i[pick], i1) and torch.equal(s[pick].view(torch.int32), s1.view(torch.int32))
+    bits = lambda t: t.view(torch.int16).cpu().numpy().view(np.uint16)   # noqa: E731
+    ref_i, ref_s = orc.canonical_search(bits(Qb[:4]), bits(Db), k)
+    assert np.array_equal(i[:4].cpu().numpy(), ref_i) and np.array_equal(s[:4].cpu().numpy(), ref_s)
