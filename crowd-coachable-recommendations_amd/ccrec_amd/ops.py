@@ -126,6 +126,9 @@ def meanpool(hidden, mask):
     return _MeanPool.apply(hidden, mask)
 
 
+MAX_QUERIES_PER_SEARCH = 16384   # larger batches are searched in pieces (last_stats() then describes the last piece)
+
+
 class CorpusIndex:
     """A resident bf16 corpus shard + its search state (ccr_index).  Build once per AL step, query many.
 
@@ -187,6 +190,12 @@ class CorpusIndex:
             assert scores.dtype == torch.float32 and ids.dtype == torch.int64 and scores.device == q.device == ids.device
         if n_q == 0:
             return scores, ids
+        if n_q > MAX_QUERIES_PER_SEARCH:   # the workspace grows with the query count (~0.4 MB per query at k = 100): bounded batches
+            assert not defer, "a deferred search takes at most MAX_QUERIES_PER_SEARCH queries"
+            for lo in range(0, n_q, MAX_QUERIES_PER_SEARCH):
+                hi = min(n_q, lo + MAX_QUERIES_PER_SEARCH)
+                self.search(q[lo:hi], k, flags, out=(scores[lo:hi], ids[lo:hi]))
+            return scores, ids
         ws = self._workspace(n_q, k)
         if defer:
             flags = int(flags) | _lib.SEARCH_ASYNC
@@ -228,6 +237,13 @@ class CorpusIndex:
         ids = torch.empty(n_q, k, dtype=torch.int64, device=q.device)
         if n_q == 0:
             return scores, ids
+        if n_q > MAX_QUERIES_PER_SEARCH:
+            for lo in range(0, n_q, MAX_QUERIES_PER_SEARCH):
+                hi = min(n_q, lo + MAX_QUERIES_PER_SEARCH)
+                a, b = int(ptr[lo]), int(ptr[hi])
+                s_part, i_part = self.search_blocked(q[lo:hi], k, ptr[lo:hi + 1] - a, idx[a:b], flags)
+                scores[lo:hi], ids[lo:hi] = s_part, i_part
+            return scores, ids
         pp = ctypes.c_void_p(ptr.data_ptr())
         need = int(self._lib.ccr_search_blocked_workspace_bytes(self._h, n_q, k, pp))
         if need == 0:
@@ -248,6 +264,13 @@ class CorpusIndex:
         scores = torch.empty(n_q, k, dtype=torch.float64, device=q.device)
         ids = torch.empty(n_q, k, dtype=torch.int64, device=q.device)
         if n_q == 0:
+            return scores, ids
+        if n_q > MAX_QUERIES_PER_SEARCH:
+            for lo in range(0, n_q, MAX_QUERIES_PER_SEARCH):
+                hi = min(n_q, lo + MAX_QUERIES_PER_SEARCH)
+                a, b = int(ptr[lo]), int(ptr[hi])
+                s_part, i_part = self.search_sparse_prior(q[lo:hi], k, ptr[lo:hi + 1] - a, idx[a:b], val[a:b], flags)
+                scores[lo:hi], ids[lo:hi] = s_part, i_part
             return scores, ids
         pp = ctypes.c_void_p(ptr.data_ptr())
         need = int(self._lib.ccr_search_sparse_prior_workspace_bytes(self._h, n_q, k, pp))

@@ -595,3 +595,24 @@ def test_flooded_lists_are_retried_in_groups():
     bits = lambda t: t.view(torch.int16).cpu().numpy().view(np.uint16)   # noqa: E731
     ref_i, ref_s = orc.canonical_search(bits(Qb[:4]), bits(Db), k)
     assert np.array_equal(i[:4].cpu().numpy(), ref_i) and np.array_equal(s[:4].cpu().numpy(), ref_s)
+
+
+def test_large_query_batches_are_searched_in_pieces(monkeypatch):
+    """ops.CorpusIndex bounds the queries per ccr_search call (the workspace grows with the query count): a batch above the
+    limit must give the same rows as one call, for the plain, blocked and sparse-prior searches."""
+    from ccrec_amd import ops
+    n, d, nq, k = 30_000, 64, 700, 12
+    Db, Qb = _bf16(_rand_bits(n, d, 3)), _bf16(_rand_bits(nq, d, 4))
+    index = ops.CorpusIndex(Db, global_row_offset=100)
+    rs = np.random.RandomState(1)
+    lens = rs.randint(0, 6, nq)
+    ptr = np.concatenate([[0], np.cumsum(lens)])
+    idx = np.concatenate([np.sort(rs.choice(n, m, replace=False)) + 100 for m in lens]).astype(np.int64)
+    val = rs.randn(idx.size)
+    whole = (index.search(Qb, k), index.search_blocked(Qb, k, ptr, idx), index.search_sparse_prior(Qb, k, ptr, idx, val))
+    monkeypatch.setattr(ops, "MAX_QUERIES_PER_SEARCH", 256)
+    parts = (index.search(Qb, k), index.search_blocked(Qb, k, ptr, idx), index.search_sparse_prior(Qb, k, ptr, idx, val))
+    for (s0, i0), (s1, i1) in zip(whole, parts):
+        assert torch.equal(i0, i1) and torch.equal(s0, s1)
+    with pytest.raises(AssertionError):
+        index.search(Qb, k, defer=True)
