@@ -283,6 +283,8 @@ static Plan make_plan_for(int64_t n_rows, int dim, int n_q, int k, int flags, in
         p.off_cnt = take((size_t)p.ranges * p.nq_pad * p.sublists * 4);
         p.off_cand = take((size_t)recs * 8);
         p.off_flag = take(64 + (size_t)n_q * 4);
+        // the k best lower bounds per query between two re-tightenings (three-phase plans only)
+        p.off_top = take(p.item_b ? ((size_t)p.nq_pad + (size_t)n_q * k) * 4 : 0);
         p.dense_rows_per_chunk = FALLBACK_ROWS;
         p.off_dense = take((size_t)FALLBACK_ROWS * n_rows * 4);
         // retry pass of flagged queries: compact query rows, thresholds + margins, the two lists, counts, second flag area
@@ -522,7 +524,7 @@ static int dense_for_list(const ccr_index *ix, const uint16_t *Q, const uint32_t
 // The main pass: one launch per phase (work items [begin, end) of every XCD set), the thresholds re-tightened from the candidates
 // of the ranges completed so far between two launches when `retighten` is set.
 static int run_main_pass(const ccr_index *ix, const Plan &p, GemmArgs gm, uint2 *cand, uint32_t *cnt, float *thr, const float *cq,
-                         int n_q, int k, bool retighten, hipStream_t s) {
+                         uint32_t *top, int n_q, int k, bool retighten, hipStream_t s) {
     const int nrc = NUM_XCD / gm.qgroups, qb_per = gm.qblocks / gm.qgroups;
     const int items = p.ranges / nrc * qb_per;
     const int bounds[4] = {0, retighten ? p.item_a : 0, retighten ? p.item_b : 0, items};
@@ -530,14 +532,21 @@ static int run_main_pass(const ccr_index *ix, const Plan &p, GemmArgs gm, uint2 
     gm.lay = p.cand;
     gm.cq = cq;
     gm.tile_norm = ix->tile_norm;
-    int done = 0;
+    int done = 0, updates = 0;
+    int prev_full = 0, prev_part = 0, prev_blocks = 0;
     for (int ph = 1; ph < 4; ++ph) {
         if (bounds[ph] <= done) continue;
         if (done > 0) {
             const int rl_full = done / qb_per, part = done % qb_per;   // complete range rows; blocks done of the started one
-            const int rc = launch_threshold_update(cand, cnt, rl_full * nrc * p.sublists, part ? (rl_full + 1) * nrc * p.sublists : 0, part,
-                                                   qb_per, p.sublists, n_q, p.nq_pad, p.cand, k, cq, ix->tile_norm, thr, s);
+            const int full = rl_full * nrc * p.sublists, partial = part ? (rl_full + 1) * nrc * p.sublists : 0;
+            const bool more = bounds[ph] < items && ph < 3;   // another re-tightening follows this phase
+            const int rc = launch_threshold_update(cand, cnt, full, partial, part, prev_full, prev_part, prev_blocks, qb_per, p.sublists, n_q,
+                                                   p.nq_pad, p.cand, k, cq, ix->tile_norm, top, updates > 0, more, thr, s);
             if (rc != CCR_OK) return rc;
+            prev_full = full;
+            prev_part = partial;
+            prev_blocks = part;
+            ++updates;
         }
         gm.item_begin = done;
         gm.item_end = bounds[ph];
@@ -636,7 +645,8 @@ static int search_complete(ccr_index *ix) {
     } else if (n_retry > 0) {
         // thresholds re-tightened from everything the first attempt recorded (truncated lists included) -- for every flagged
         // query at once, before the candidate area is reused
-        rc = launch_threshold_update(cand, cnt, nsub_all, 0, 0, 1, p.sublists, n_q, p.nq_pad, p.cand, k, delta, ix->tile_norm, thr, s);
+        rc = launch_threshold_update(cand, cnt, nsub_all, 0, 0, 0, 0, 0, 1, p.sublists, n_q, p.nq_pad, p.cand, k, delta, ix->tile_norm, nullptr, false,
+                                     false, thr, s);
         if (rc != CCR_OK) return rc;
         // The flagged queries are retried in GROUPS that get the whole candidate area to themselves: the fewer queries share
         // it, the larger every sub-list.  A group is as large as still leaves four times the first attempt's capacity (when
@@ -653,8 +663,8 @@ static int search_complete(ccr_index *ix) {
             int prev_n = 0, prev_pad = 0;
             for (int round = 0; round < 3 && n_cur > 0; ++round) {
                 if (round > 0) {   // re-tighten from the previous round's (truncated) lists of this group
-                    rc = launch_threshold_update(cand, cnt, nsub_all, 0, 0, 1, p.sublists, prev_n, prev_pad, prev_lay, k, delta2, ix->tile_norm,
-                                                 thr2, s);
+                    rc = launch_threshold_update(cand, cnt, nsub_all, 0, 0, 0, 0, 0, 1, p.sublists, prev_n, prev_pad, prev_lay, k, delta2, ix->tile_norm,
+                                                 nullptr, false, false, thr2, s);
                     if (rc != CCR_OK) return rc;
                     rc = launch_scatter_thresholds(prev_list, prev_n, thr2, thr, s);
                     if (rc != CCR_OK) return rc;
@@ -866,7 +876,7 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
         gm.store = reinterpret_cast<float *>(stamps);
     }
     CCR_HIP_CHECK(hipEventRecord(ix->ev[3], s));
-    rc = run_main_pass(ix, p, gm, cand, cnt, thr, delta, n_q, k, true, s);
+    rc = run_main_pass(ix, p, gm, cand, cnt, thr, delta, p.item_b ? (uint32_t *)(ws + p.off_top) : nullptr, n_q, k, true, s);
     if (rc != CCR_OK) return rc;
     CCR_HIP_CHECK(hipEventRecord(ix->ev[4], s));
     if (want_stamps) {

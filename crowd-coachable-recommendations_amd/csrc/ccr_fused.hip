@@ -721,6 +721,8 @@ __global__ __launch_bounds__(256) void threshold_kernel(const float *__restrict_
     // every threshold, so that all queries take the exact dense path
     const float dmax = __uint_as_float(*dmax_bits);
     const float c = (q < n_q) ? ((dmax < INFINITY) ? gamma * (qnorm[q] * 1.001f) * 1.001f : __builtin_nanf("")) : 0.f;
+    // norm bound of the sampled tile of group g (plain vector loads: staging them in LDS, or scalar loads of the wave-uniform
+    // index, both made this kernel slower -- 84 vs 70 us at NQ: they share lgkmcnt with the histogram's LDS atomics)
     auto tile_of = [&](int64_t g) { return tile_norm[(g / GROUPS_PER_TILE) * sample_stride]; };
     uint32_t mask = 0;
     for (int shift = 24; shift >= 0; shift -= 8) {
@@ -797,98 +799,6 @@ __global__ __launch_bounds__(256) void threshold_kernel(const float *__restrict_
 }
 
 
-// Progressive thresholds: after phase A of the main pass (ranges [0, ranges_a)), the k-th largest LOWER BOUND
-// (mfma - cq * tile norm) among the candidates found so far is a tighter valid lower bound of the k-th largest exact score
-// (the candidates are real rows with their real MFMA scores, whether or not a sub-list overflowed).  thr[q] = max(thr[q], that).
-// grid = n_q, block = 256.
-__global__ __launch_bounds__(256) void threshold_update_kernel(const uint2 *__restrict__ cand, const uint32_t *__restrict__ cnt,
-                                                              int nsub_full, int nsub_part, int part_blocks, int qb_per, int sp,
-                                                              int nq_pad, const CandLayout lay, int k, int compact,
-                                                              const float *__restrict__ cq, const float *__restrict__ tile_norm,
-                                                              float *__restrict__ thr) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_val[];   // [compact] orderable lower bounds of the candidates found so far
-    __shared__ uint32_t s_hist[256];
-    __shared__ uint32_t s_ctl[4];
-    __shared__ uint32_t s_cnt[2048];
-    __shared__ uint32_t s_total, s_maxc, s_fill;
-    const int tid = threadIdx.x;
-    const int q = blockIdx.x;
-    // sub-lists complete so far: those of the fully scored ranges, plus one more row of ranges for the queries whose block
-    // (position inside its XCD group) was already scored in the partially finished one
-    const int nsub = ((q / TILE_Q) % qb_per) < part_blocks ? nsub_part : nsub_full;
-    if (tid == 0) {
-        s_total = 0;
-        s_maxc = 0;
-        s_fill = 0;
-    }
-    __syncthreads();
-    uint32_t my = 0, mymax = 0;
-    for (int j = tid; j < nsub; j += blockDim.x) {
-        uint32_t c = cnt[((int64_t)(j / sp) * nq_pad + q) * sp + (j % sp)];
-        int cap;
-        (void)cand_sublist(lay, j / sp, q, j % sp, nq_pad, sp, cap);
-        if (c > (uint32_t)cap) c = (uint32_t)cap;
-        s_cnt[j] = c;
-        my += c;
-        mymax = c > mymax ? c : mymax;
-    }
-    if (my) {
-        atomicAdd(&s_total, my);
-        atomicMax(&s_maxc, mymax);
-    }
-    __syncthreads();
-    if (s_total < (uint32_t)k) return;  // not enough rows seen yet: keep the sample threshold
-    auto sub_base = [&](int j) -> int64_t {
-        int cap;
-        return cand_sublist(lay, j / sp, q, j % sp, nq_pad, sp, cap);
-    };
-    uint32_t kth = 0;
-    int need_eq;
-    {
-        // The sub-lists are sparse: one sweep over (sub-list, slot < longest list) with independent loads gathers the
-        // scores into LDS, the four radix passes then never touch global memory.  If more candidates exist than the LDS
-        // holds, the first `compact` the sweep meets give a first bound (the k-th largest score of ANY k or more real rows
-        // is a valid lower bound of the query's k-th largest score); the sweep is then repeated over the records at or above
-        // that bound -- far fewer -- until they all fit, so the final bound is the k-th largest of EVERYTHING recorded (a
-        // corpus in topical order leaves the good rows in a few sub-lists that a first-come subset would miss).
-        const int maxc = (int)s_maxc;
-        const float c = cq[q];
-        uint32_t keep = 0u;   // orderable bound: records below it are skipped
-        for (int round = 0; round < 4; ++round) {
-            __syncthreads();
-            if (tid == 0) s_fill = 0;
-            __syncthreads();
-            for (int i = tid; i < nsub * maxc; i += blockDim.x) {
-                const int j = i / maxc, sl = i - j * maxc;
-                if ((uint32_t)sl < s_cnt[j]) {
-                    const uint2 e = cand[sub_base(j) + sl];
-                    const uint32_t o = f32_orderable(fmaf(-c, tile_norm[e.y / TILE_DOCS], __uint_as_float(e.x)));
-                    if (o >= keep) {
-                        const uint32_t p = atomicAdd(&s_fill, 1u);
-                        if (p < (uint32_t)compact) s_val[p] = o;
-                    }
-                }
-            }
-            __syncthreads();
-            const uint32_t filled = s_fill;
-            const int M = (int)(filled < (uint32_t)compact ? filled : (uint32_t)compact);
-            if (M < k) break;   // (ties at the bound cut off by the LDS size: keep the bound of the previous round)
-            block_radix_select(
-                [&](int64_t i, bool &skip) -> uint32_t {
-                    (void)skip;
-                    return s_val[i];
-                },
-                (int64_t)M, k, s_hist, s_ctl, kth, need_eq);
-            if (filled <= (uint32_t)compact || kth <= keep) break;   // everything at or above the bound was seen / no progress
-            keep = kth;
-        }
-    }
-    if (tid == 0) {
-        const float t1 = orderable_to_f32(kth);
-        if (t1 > thr[q]) thr[q] = t1;
-    }
-}
-
 // Visit every record (sub-list j, slot sl) with first <= sl < count[j]: the (sub-list, slot) rectangle is padded to a
 // power of two per sub-list, BATCH independent 8-byte loads are issued before the first record is consumed.
 template <int THREADS, int BATCH, class At, class Want, class Put>
@@ -915,6 +825,133 @@ __device__ __forceinline__ void sweep_sublists(int tid, int n_lists, int first, 
 #pragma unroll
         for (int u = 0; u < BATCH; ++u)
             if (jj[u] >= 0) put(jj[u], ss[u], e[u]);
+    }
+}
+
+// Progressive thresholds: after a phase of the main pass the k-th largest LOWER BOUND (mfma - cq * tile norm) among the
+// candidates found so far is a tighter valid lower bound of the k-th largest exact score (the candidates are real rows with
+// their real MFMA scores, whether or not a sub-list overflowed).  thr[q] = max(thr[q], that).
+// The candidate lists are one or two 128-byte lines per sub-list scattered over the shard-sized candidate area: reading them
+// is what this kernel costs (measured at NQ: 1.4 TB/s of line traffic, 52 us for the 160 sub-lists per query after phase A,
+// 138-185 us for the 448 after phase B1).  So the second re-tightening does not read phase A's lists again: the first one
+// leaves the k best lower bounds of every query in `top` (k contiguous values), the second merges them with the sub-lists
+// completed since.
+// grid = n_q, block = 256.  top: [nq_pad] valid counts, then [n_q][k] values (may be null when top_in == top_out == 0).
+__global__ __launch_bounds__(256) void threshold_update_kernel(const uint2 *__restrict__ cand, const uint32_t *__restrict__ cnt,
+                                                              int nsub_full, int nsub_part, int part_blocks, int prev_full,
+                                                              int prev_part, int prev_blocks, int qb_per, int sp, int nq_pad,
+                                                              const CandLayout lay, int k, int compact,
+                                                              const float *__restrict__ cq, const float *__restrict__ tile_norm,
+                                                              uint32_t *__restrict__ top, int top_in, int top_out,
+                                                              float *__restrict__ thr) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_val[];   // [compact] orderable lower bounds of the candidates found so far
+    __shared__ uint32_t s_hist[256];
+    __shared__ uint32_t s_ctl[4];
+    __shared__ uint32_t s_cnt[2048];
+    __shared__ uint32_t s_total, s_maxc, s_fill, s_eq;
+    const int tid = threadIdx.x;
+    const int q = blockIdx.x;
+    // sub-lists complete so far: those of the fully scored ranges, plus one more row of ranges for the queries whose block
+    // (position inside its XCD group) was already scored in the partially finished one
+    const int qpos = (q / TILE_Q) % qb_per;
+    const int nsub = qpos < part_blocks ? nsub_part : nsub_full;
+    uint32_t *top_n = top;
+    uint32_t *top_v = top ? top + nq_pad + (int64_t)q * k : nullptr;
+    const bool have_prev = top_in && top_n[q] == (uint32_t)k;
+    const int j0 = have_prev ? (qpos < prev_blocks ? prev_part : prev_full) : 0;   // lists the previous update already covered
+    if (tid == 0) {
+        s_total = have_prev ? (uint32_t)k : 0u;
+        s_maxc = 0;
+        s_fill = 0;
+    }
+    __syncthreads();
+    uint32_t my = 0, mymax = 0;
+    for (int j = j0 + tid; j < nsub; j += blockDim.x) {
+        uint32_t c = cnt[((int64_t)(j / sp) * nq_pad + q) * sp + (j % sp)];
+        int cap;
+        (void)cand_sublist(lay, j / sp, q, j % sp, nq_pad, sp, cap);
+        if (c > (uint32_t)cap) c = (uint32_t)cap;
+        s_cnt[j - j0] = c;
+        my += c;
+        mymax = c > mymax ? c : mymax;
+    }
+    if (my) {
+        atomicAdd(&s_total, my);
+        atomicMax(&s_maxc, mymax);
+    }
+    __syncthreads();
+    if (s_total < (uint32_t)k) {   // not enough rows seen yet: keep the sample threshold
+        if (top_out && tid == 0) top_n[q] = 0u;
+        return;
+    }
+    auto sub_base = [&](int j) -> int64_t {
+        int cap;
+        return cand_sublist(lay, (j0 + j) / sp, q, (j0 + j) % sp, nq_pad, sp, cap);
+    };
+    uint32_t kth = 0;
+    int need_eq = 0, M = 0;
+    bool selected = false;   // s_val[0, M) is the set kth was selected from
+    {
+        // The sub-lists are sparse: one sweep over (sub-list, slot < longest list) with independent loads gathers the
+        // scores into LDS, the four radix passes then never touch global memory.  If more candidates exist than the LDS
+        // holds, the first `compact` the sweep meets give a first bound (the k-th largest score of ANY k or more real rows
+        // is a valid lower bound of the query's k-th largest score); the sweep is then repeated over the records at or above
+        // that bound -- far fewer -- until they all fit, so the final bound is the k-th largest of EVERYTHING recorded (a
+        // corpus in topical order leaves the good rows in a few sub-lists that a first-come subset would miss).
+        const int maxc = (int)s_maxc;
+        const float c = cq[q];
+        uint32_t keep = 0u;   // orderable bound: records below it are skipped
+        auto append = [&](uint32_t o) {
+            if (o >= keep) {
+                const uint32_t p = atomicAdd(&s_fill, 1u);
+                if (p < (uint32_t)compact) s_val[p] = o;
+            }
+        };
+        for (int round = 0; round < 4; ++round) {
+            __syncthreads();
+            if (tid == 0) s_fill = 0;
+            __syncthreads();
+            selected = false;
+            if (have_prev)
+                for (int i = tid; i < k; i += blockDim.x) append(top_v[i]);
+            sweep_sublists<256, 8>(
+                tid, nsub - j0, 0, maxc, s_cnt, [&](int j, int sl) -> uint2 { return cand[sub_base(j) + sl]; },
+                [](int, int) { return true; },
+                [&](int, int, uint2 e) { append(f32_orderable(fmaf(-c, tile_norm[e.y / TILE_DOCS], __uint_as_float(e.x)))); });
+            __syncthreads();
+            const uint32_t filled = s_fill;
+            M = (int)(filled < (uint32_t)compact ? filled : (uint32_t)compact);
+            if (M < k) break;   // (ties at the bound cut off by the LDS size: keep the bound of the previous round)
+            block_radix_select(
+                [&](int64_t i, bool &skip) -> uint32_t {
+                    (void)skip;
+                    return s_val[i];
+                },
+                (int64_t)M, k, s_hist, s_ctl, kth, need_eq);
+            selected = true;
+            if (filled <= (uint32_t)compact || kth <= keep) break;   // everything at or above the bound was seen / no progress
+            keep = kth;
+        }
+    }
+    if (top_out) {   // the k best lower bounds seen so far, for the next re-tightening (any order)
+        if (!selected) {
+            if (tid == 0) top_n[q] = 0u;
+        } else {
+            __syncthreads();
+            if (tid == 0) s_fill = s_eq = 0u;
+            __syncthreads();
+            for (int i = tid; i < M; i += blockDim.x) {
+                const uint32_t v = s_val[i];
+                bool take = v > kth;
+                if (v == kth) take = atomicAdd(&s_eq, 1u) < (uint32_t)need_eq;
+                if (take) top_v[atomicAdd(&s_fill, 1u)] = v;
+            }
+            if (tid == 0) top_n[q] = (uint32_t)k;
+        }
+    }
+    if (tid == 0) {
+        const float t1 = orderable_to_f32(kth);
+        if (t1 > thr[q]) thr[q] = t1;
     }
 }
 
@@ -1016,9 +1053,7 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
     // records carry the LOWER bound; the k-th largest lower bound L is a lower bound of the k-th largest exact score, and only
     // candidates whose UPPER bound reaches L can be in the result.
     const float c = cq[q];
-    auto to_lower = [&](uint2 e) -> uint2 {
-        return make_uint2(__float_as_uint(fmaf(-c, row_norm[e.y], __uint_as_float(e.x))), e.y);
-    };
+
     if (!bad && s_total <= (uint32_t)compact) {
         // The sub-lists are sparse: one sweep over (sub-list, slot < longest list) gathers them into LDS at their
         // scanned offsets (independent loads, no atomics); the select then never touches global memory.
@@ -1054,7 +1089,21 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
                                    [&](int j, int sl, uint2 e) { s_comp[s_off[j] + sl] = e; });
         __syncthreads();
         n_lds = (int)s_total;
-        for (int i = tid; i < n_lds; i += THREADS) s_comp[i] = to_lower(s_comp[i]);   // (a scattered 4-byte read per record)
+        for (int i0 = tid; i0 < n_lds; i0 += 4 * THREADS) {   // a scattered 4-byte read per record: four in flight per thread
+            uint2 e[4];
+            float rn[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * THREADS;
+                e[u] = s_comp[i < n_lds ? i : i0];
+                rn[u] = row_norm[e[u].y];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * THREADS;
+                if (i < n_lds) s_comp[i] = make_uint2(__float_as_uint(fmaf(-c, rn[u], __uint_as_float(e[u].x))), e[u].y);
+            }
+        }
         __syncthreads();
     } else if (!bad && compact < k) {
         bad = dense_only = true;   // the LDS budget cannot even hold k records (huge dim * k): exact dense path
@@ -1351,14 +1400,16 @@ int launch_threshold(const float *gmax, int64_t n_groups, int n_q, int nq_pad, i
     return CCR_OK;
 }
 
-int launch_threshold_update(const uint2 *cand, const uint32_t *cnt, int nsub, int nsub_part, int part_blocks, int qb_per, int sp, int n_q,
-                            int nq_pad, const CandLayout &lay, int k, const float *cq, const float *tile_norm, float *thr,
-                            hipStream_t s) {
+int launch_threshold_update(const uint2 *cand, const uint32_t *cnt, int nsub, int nsub_part, int part_blocks, int prev_nsub, int prev_part,
+                            int prev_blocks, int qb_per, int sp, int n_q, int nq_pad, const CandLayout &lay, int k, const float *cq,
+                            const float *tile_norm, uint32_t *top, bool top_in, bool top_out, float *thr, hipStream_t s) {
     if (nsub_part < nsub) nsub_part = nsub;
+    if (prev_part < prev_nsub) prev_part = prev_nsub;
     if (nsub_part > 2048) {
         set_error("threshold_update: %d sub-lists exceed 2048", nsub_part);
         return CCR_ERR_INVALID;
     }
+    if (!top) top_in = top_out = false;
     // LDS score buffer: comfortably more than k (the bound tightens with the number of rows seen), 16 KiB at least
     int compact = std::max(4096, 8 * pow2_ceil(k));
     if (compact > 32768) compact = 32768;
@@ -1367,8 +1418,9 @@ int launch_threshold_update(const uint2 *cand, const uint32_t *cnt, int nsub, in
         const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&threshold_update_kernel), 128 * 1024);
         if (rc != CCR_OK) return rc;
     }
-    hipLaunchKernelGGL(threshold_update_kernel, dim3(n_q), dim3(256), lds, s, cand, cnt, nsub, nsub_part, part_blocks, qb_per > 0 ? qb_per : 1, sp,
-                       nq_pad, lay, k, compact, cq, tile_norm, thr);
+    hipLaunchKernelGGL(threshold_update_kernel, dim3(n_q), dim3(256), lds, s, cand, cnt, nsub, nsub_part, part_blocks, prev_nsub, prev_part,
+                       prev_blocks, qb_per > 0 ? qb_per : 1, sp, nq_pad, lay, k, compact, cq, tile_norm, top, top_in ? 1 : 0, top_out ? 1 : 0,
+                       thr);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
 }

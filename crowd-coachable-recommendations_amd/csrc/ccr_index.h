@@ -49,10 +49,12 @@ int launch_partition_flags(const uint32_t *flags, int begin, int n, uint32_t *re
 int launch_scatter_thresholds(const uint32_t *list, int n, const float *thr2, float *thr, hipStream_t s);
 int launch_gather_queries(const uint16_t *Q, int dim, const uint32_t *list, int n, const float *thr, const float *cq, uint16_t *Q2,
                           float *thr2, float *cq2, hipStream_t s);
-// nsub: sub-lists of the fully scored ranges; queries whose block position inside its XCD group is < part_blocks have nsub_part
-int launch_threshold_update(const uint2 *cand, const uint32_t *cnt, int nsub, int nsub_part, int part_blocks, int qb_per, int sp, int n_q,
-                            int nq_pad, const CandLayout &lay, int k, const float *cq, const float *tile_norm, float *thr,
-                            hipStream_t s);
+// nsub: sub-lists of the fully scored ranges; queries whose block position inside its XCD group is < part_blocks have nsub_part.
+// prev_*: the same at the previous re-tightening of this search (top_in: its k best lower bounds per query are in `top` and only
+// the sub-lists completed since are read); top_out: leave the k best for the next one.  top: [nq_pad + n_q * k] u32 or null.
+int launch_threshold_update(const uint2 *cand, const uint32_t *cnt, int nsub, int nsub_part, int part_blocks, int prev_nsub, int prev_part,
+                            int prev_blocks, int qb_per, int sp, int n_q, int nq_pad, const CandLayout &lay, int k, const float *cq,
+                            const float *tile_norm, uint32_t *top, bool top_in, bool top_out, float *thr, hipStream_t s);
 // dense exact path.  qlist: query rows to score (nullptr: q_begin + qi); out_rows: destination rows of the select
 // (nullptr: q_begin + qi); count_dev (device, may be null): only the first *count_dev - q_begin entries of the list exist
 // (the on-stream fallback chunk of an asynchronous search -- the host does not know the count yet).
