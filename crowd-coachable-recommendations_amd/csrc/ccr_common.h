@@ -48,7 +48,10 @@ constexpr int NUM_XCD = 8;
 
 // Candidate storage of the main pass.  The ranges of one launch (phase) form a segment with its own sub-list capacity:
 // the later phases run under re-tightened thresholds and need far fewer slots per sub-list than phase A.
-// Sub-list (range r, query q, part s) of segment g starts at record base[g] + (((r - begin(g)) * nq_pad + q) * sp + s) * cap[g].
+// The sp sub-lists of one (range r, query q) share a CELL of sp * cap[g] records at base[g] + ((r - begin(g)) * nq_pad + q) * sp * cap[g],
+// stored SLOT-MAJOR: record `slot` of sub-list (part) s sits at cell + slot * sp + s.  Lists hold one or two records on
+// average, so a cell's records fill its first one or two 128-byte lines instead of one line per sub-list -- the readers
+// (threshold update, select) are bound by the number of scattered lines they touch, not by bytes.
 struct CandLayout {
     int nseg;
     int seg_end[3];     // exclusive end range of each segment (ascending; unused entries = INT_MAX)
@@ -62,11 +65,12 @@ __host__ __device__ __forceinline__ void cand_segment(const CandLayout &L, int r
     cap = L.cap[g];
     base = L.base[g];
 }
+// first record (slot 0) of sub-list (r, q, s); slot sl is sp * sl records further
 __host__ __device__ __forceinline__ long long cand_sublist(const CandLayout &L, int r, int q, int s, int nq_pad, int sp, int &cap) {
     const int g = (r >= L.seg_end[0] ? 1 : 0) + (r >= L.seg_end[1] ? 1 : 0);
     const int r0 = g ? L.seg_end[g - 1] : 0;
     cap = L.cap[g];
-    return L.base[g] + ((((long long)(r - r0) * nq_pad + q) * sp + s) * (long long)cap);
+    return L.base[g] + (((long long)(r - r0) * nq_pad + q) * sp) * (long long)cap + s;
 }
 
 struct Plan {

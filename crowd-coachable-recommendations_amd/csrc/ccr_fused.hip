@@ -136,7 +136,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
                 const int q = q0 + wq * 64 + qt * 32 + l31;
                 thr[qt] = (q < a.n_q) ? a.thr[q] : __builtin_nanf("");
                 cqv[qt] = (q < a.n_q) ? a.cq[q] : 0.f;
-                clist[qt] = a.cand + seg_base + (((int64_t)(r - seg_r0) * a.nq_pad + q) * 4 + wd * 2 + h) * cap;
+                clist[qt] = a.cand + seg_base + ((int64_t)(r - seg_r0) * a.nq_pad + q) * 4 * cap + (wd * 2 + h);   // slot-major cell
             }
             // make hipcc wait for the threshold loads HERE, before any LDS-DMA is in flight: its own
             // wait at the first use inside the tile epilogue would be vmcnt(0) and drain the DMA ring
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
                                         const uint32_t off = (uint32_t)(dt * 32 + 8 * g + e2);
                                         if (v >= t && off < rows_left) {
                                             if (ncand[qt] < (uint32_t)cap)
-                                                clist[qt][ncand[qt]] = make_uint2(__float_as_uint(v), row32 + off);
+                                                clist[qt][ncand[qt] * 4] = make_uint2(__float_as_uint(v), row32 + off);
                                             ++ncand[qt];
                                         }
                                     }
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
                 const int q = q0 + wq * 64 + qt * 16 + l15;
                 thr[qt] = (q < a.n_q) ? a.thr[q] : __builtin_nanf("");
                 cqv[qt] = (q < a.n_q) ? a.cq[q] : 0.f;
-                clist[qt] = a.cand + seg_base + (((int64_t)(r - seg_r0) * a.nq_pad + q) * 8 + wd * 4 + lq) * cap;
+                clist[qt] = a.cand + seg_base + ((int64_t)(r - seg_r0) * a.nq_pad + q) * 8 * cap + (wd * 4 + lq);   // slot-major cell
             }
             asm volatile("" : "+v"(thr[0]), "+v"(thr[1]), "+v"(thr[2]), "+v"(thr[3]), "+v"(cqv[0]), "+v"(cqv[1]), "+v"(cqv[2]), "+v"(cqv[3]));
         }
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
                                     const int64_t doc = row_base + dt * 16 + e;
                                     if (v >= t && doc < a.n_rows) {
                                         if (ncand[qt] < (uint32_t)cap)
-                                            clist[qt][ncand[qt]] = make_uint2(__float_as_uint(v), (uint32_t)doc);
+                                            clist[qt][ncand[qt] * 8] = make_uint2(__float_as_uint(v), (uint32_t)doc);
                                         ++ncand[qt];
                                     }
                                 }
@@ -915,7 +915,7 @@ __global__ __launch_bounds__(256) void threshold_update_kernel(const uint2 *__re
             if (have_prev)
                 for (int i = tid; i < k; i += blockDim.x) append(top_v[i]);
             sweep_sublists<256, 8>(
-                tid, nsub - j0, 0, maxc, s_cnt, [&](int j, int sl) -> uint2 { return cand[sub_base(j) + sl]; },
+                tid, nsub - j0, 0, maxc, s_cnt, [&](int j, int sl) -> uint2 { return cand[sub_base(j) + (int64_t)sl * sp]; },
                 [](int, int) { return true; },
                 [&](int, int, uint2 e) { append(f32_orderable(fmaf(-c, tile_norm[e.y / TILE_DOCS], __uint_as_float(e.x)))); });
             __syncthreads();
@@ -1043,7 +1043,7 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
         int cap;
         return cand_sublist(lay, j / sp, q, j % sp, nq_pad, sp, cap);
     };
-    auto at = [&](int j, int sl) -> uint2 { return cand[sub_base(j) + sl]; };
+    auto at = [&](int j, int sl) -> uint2 { return cand[sub_base(j) + (int64_t)sl * sp]; };
     const int coll_cap = rescore_cap;
     uint32_t kth = 0;
     int need_eq = 0;
@@ -1057,35 +1057,37 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
     if (!bad && s_total <= (uint32_t)compact) {
         // The sub-lists are sparse: one sweep over (sub-list, slot < longest list) gathers them into LDS at their
         // scanned offsets (independent loads, no atomics); the select then never touches global memory.
-        // (1) every thread takes the first 8 records of each of its sub-lists with four unconditional 16-byte loads
-        //     (cap >= 16, so the read stays inside the sub-list), all in flight together;
-        // (2) only lists longer than that are swept: (sub-list, slot 8 + s), s < W = pow2 >= longest - 8.
-        constexpr int MAXPER = 4;   // ranges <= 1024 sub-lists, THREADS >= 256
+        // (1) the first FIRST slots of every cell -- whole 16-byte pairs (slot, parts 2p and 2p + 1), contiguous and
+        //     independent of the counts: a cell's slots 0..3 are its first one (sp = 4) or two (sp = 8) lines (issuing these
+        //     loads at kernel start, ahead of the count scan, was measured: 398 -> 488 us, the 32 live registers cost more);
+        // (2) only lists longer than that are swept: (sub-list, slot FIRST + s), s < W = pow2 >= longest - FIRST.
+        constexpr int FIRST = 4, MAXL = 8;   // ranges * FIRST / 2 <= MAXL * THREADS (ranges <= 1024 sub-lists at 256 threads)
         {
-            uint4 v[MAXPER][4];
+            const int per_cell = FIRST * sp / 2;               // 16-byte pairs per cell
+            const int nload = (ranges / sp) * per_cell;
+            uint4 v[MAXL];
 #pragma unroll
-            for (int t = 0; t < MAXPER; ++t) {
-                const int j = tid * per + t;
-                if (t < per && j < ranges) {
-                    const uint4 *src = reinterpret_cast<const uint4 *>(cand + sub_base(j));
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) v[t][w] = src[w];
+            for (int t = 0; t < MAXL; ++t) {
+                const int x = tid + t * THREADS;
+                if (x < nload) {
+                    const int cell = x / per_cell, w = x - cell * per_cell;
+                    int cap;
+                    v[t] = *reinterpret_cast<const uint4 *>(cand + cand_sublist(lay, cell, q, 0, nq_pad, sp, cap) + 2 * w);
                 }
             }
 #pragma unroll
-            for (int t = 0; t < MAXPER; ++t) {
-                const int j = tid * per + t;
-                if (t < per && j < ranges) {
-                    const uint32_t c = s_cnt[j], o = s_off[j];
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        if (2u * w < c) s_comp[o + 2 * w] = make_uint2(v[t][w].x, v[t][w].y);
-                        if (2u * w + 1 < c) s_comp[o + 2 * w + 1] = make_uint2(v[t][w].z, v[t][w].w);
-                    }
+            for (int t = 0; t < MAXL; ++t) {
+                const int x = tid + t * THREADS;
+                if (x < nload) {
+                    const int cell = x / per_cell, w = x - cell * per_cell;
+                    const int slot = (2 * w) / sp, part = (2 * w) % sp;
+                    const int j = cell * sp + part;
+                    if ((uint32_t)slot < s_cnt[j]) s_comp[s_off[j] + slot] = make_uint2(v[t].x, v[t].y);
+                    if ((uint32_t)slot < s_cnt[j + 1]) s_comp[s_off[j + 1] + slot] = make_uint2(v[t].z, v[t].w);
                 }
             }
         }
-        sweep_sublists<THREADS, 8>(tid, ranges, 8, (int)s_maxc, s_cnt, at, [](int, int) { return true; },
+        sweep_sublists<THREADS, 8>(tid, ranges, FIRST, (int)s_maxc, s_cnt, at, [](int, int) { return true; },
                                    [&](int j, int sl, uint2 e) { s_comp[s_off[j] + sl] = e; });
         __syncthreads();
         n_lds = (int)s_total;
@@ -1183,9 +1185,10 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
     // lanes fetch one row's slice (whole 64/128-byte segments, all loads of a slice in flight), then every thread runs
     // the fp64 chain of its own row(s) over the slice from LDS.  Element order inside a row is unchanged.
     const size_t stage_bytes = (size_t)compact * 8;
-    // (only in the 1024-thread large-k variant: at k <= 256 the ~100 rows per query are re-read from L2 / Infinity Cache
-    // quickly enough by the direct walk, and the slice barriers cost more than they save)
-    int SB = THREADS < 1024 ? 0 : ((size_t)ncoll * 144 <= stage_bytes ? 128 : ((size_t)ncoll * 80 <= stage_bytes ? 64 : 0));
+    // (both variants: before the slices were software-pipelined the barriers cost the 256-thread form more than they saved;
+    // with the pipeline the NQ select goes 405 -> 308 us -- its re-score 228 -> 130 us -- and a 1/8 shard, whose rows sit in the
+    // Infinity Cache, is unchanged)
+    int SB = (size_t)ncoll * 144 <= stage_bytes ? 128 : ((size_t)ncoll * 80 <= stage_bytes ? 64 : 0);
     constexpr int PRE = 8;                                               // 16-byte pieces a thread keeps in flight for the next slice
     if (SB == 128 && ncoll * 8 > PRE * THREADS) SB = 64;
     if (SB != 0 && ncoll <= 2 * THREADS && ncoll * (SB / 16) <= PRE * THREADS) {
