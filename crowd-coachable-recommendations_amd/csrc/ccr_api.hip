@@ -707,7 +707,7 @@ static int search_complete(ccr_index *ix) {
                 rc = p.mfma16 ? launch_gemm16_filter(g, p.grid, s) : launch_gemm_filter(g, p.grid, s);
                 if (rc != CCR_OK) return rc;
                 rc = launch_select_rescore(cand, cnt, nsub_all, p.sublists, n_cur, pad2, lay2, k, p.rescore_cap, p.select_compact, ix->n_rows,
-                                           delta2, ix->row_norm, ix->dmax_bits, Q2, ix->D, ix->dim, ix->offset, pd.out_scores, pd.out_ids, flag2,
+                                           delta2, ix->tile_norm, ix->row_norm, ix->dmax_bits, Q2, ix->D, ix->dim, ix->offset, pd.out_scores, pd.out_ids, flag2,
                                            flag2 + 16, nullptr, cur, s);
                 if (rc != CCR_OK) return rc;
                 ix->stats.n_retried += n_cur;
@@ -900,7 +900,7 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
     }
 
     rc = launch_select_rescore(cand, cnt, p.ranges * p.sublists, p.sublists, n_q, p.nq_pad, p.cand, k, p.rescore_cap, p.select_compact, ix->n_rows, delta,
-                               ix->row_norm, ix->dmax_bits, Q_bf16, ix->D, ix->dim,
+                               ix->tile_norm, ix->row_norm, ix->dmax_bits, Q_bf16, ix->D, ix->dim,
                                ix->offset, out_scores, out_ids, flag_count, flag_list, stat_cand, nullptr, s);
     if (rc != CCR_OK) return rc;
     CCR_HIP_CHECK(hipEventRecord(ix->ev[5], s));

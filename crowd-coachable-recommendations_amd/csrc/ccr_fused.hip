@@ -961,7 +961,8 @@ template <int THREADS>
 __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__restrict__ cand, const uint32_t *__restrict__ cnt,
                                                             int ranges, int sp, int nq_pad, const CandLayout lay, int k, int rescore_cap, int compact,
                                                             int64_t n_rows, const float *__restrict__ cq,
-                                                            const float *__restrict__ row_norm, const uint32_t *__restrict__ dmax_bits,
+                                                            const float *__restrict__ tile_norm, const float *__restrict__ row_norm,
+                                                            const uint32_t *__restrict__ dmax_bits,
                                                             const uint16_t *__restrict__ Q, const uint16_t *__restrict__ D,
                                                             int dim, int64_t id_offset, float *__restrict__ out_scores,
                                                             int64_t *__restrict__ out_ids, uint32_t *__restrict__ flag_count,
@@ -1048,11 +1049,12 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
     uint32_t kth = 0;
     int need_eq = 0;
     int n_lds = 0;   // candidates resident in s_comp
-    // Every candidate (mfma score m, row d) has its exact score inside [m - c ||d||, m + c ||d||] (c = gamma ||q||; the ROW's own
-    // norm bound here -- the main pass could only use its tile's -- so one huge row widens nobody else's interval).  The LDS
-    // records carry the LOWER bound; the k-th largest lower bound L is a lower bound of the k-th largest exact score, and only
-    // candidates whose UPPER bound reaches L can be in the result.
+    // Every candidate (mfma score m, row d of tile t) has its exact score inside [m - c ||d||, m + c ||d||] (c = gamma ||q||), and
+    // ||d|| <= nt.  The LDS records carry the lower bound m - c nt; the k-th largest of them, L, is a lower bound of the k-th
+    // largest exact score, and only candidates whose UPPER bound m + c ||d|| -- the ROW's own norm here, so one huge row widens
+    // nobody else's interval -- reaches L can be in the result.
     const float c = cq[q];
+    bool row_lb = false;   // the records' lower bounds use the row's own norm (the rare overflow sweep) instead of its tile's
 
     if (!bad && s_total <= (uint32_t)compact) {
         // The sub-lists are sparse: one sweep over (sub-list, slot < longest list) gathers them into LDS at their
@@ -1061,7 +1063,8 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
         //     independent of the counts: a cell's slots 0..3 are its first one (sp = 4) or two (sp = 8) lines (issuing these
         //     loads at kernel start, ahead of the count scan, was measured: 398 -> 488 us, the 32 live registers cost more);
         // (2) only lists longer than that are swept: (sub-list, slot FIRST + s), s < W = pow2 >= longest - FIRST.
-        constexpr int FIRST = 4, MAXL = 8;   // ranges * FIRST / 2 <= MAXL * THREADS (ranges <= 1024 sub-lists at 256 threads)
+        // (large k -- the 1 024-thread form -- has lists of three to six records: eight unconditional slots there)
+        constexpr int FIRST = THREADS >= 1024 ? 8 : 4, MAXL = 8;   // ranges * FIRST / 2 <= MAXL * THREADS (1 024 / 2 048 sub-lists)
         {
             const int per_cell = FIRST * sp / 2;               // 16-byte pairs per cell
             const int nload = (ranges / sp) * per_cell;
@@ -1091,14 +1094,14 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
                                    [&](int j, int sl, uint2 e) { s_comp[s_off[j] + sl] = e; });
         __syncthreads();
         n_lds = (int)s_total;
-        for (int i0 = tid; i0 < n_lds; i0 += 4 * THREADS) {   // a scattered 4-byte read per record: four in flight per thread
+        for (int i0 = tid; i0 < n_lds; i0 += 4 * THREADS) {   // lower bounds with the TILE's norm (a 42-KB table: cache hits)
             uint2 e[4];
             float rn[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int i = i0 + u * THREADS;
                 e[u] = s_comp[i < n_lds ? i : i0];
-                rn[u] = row_norm[e[u].y];
+                rn[u] = tile_norm[e[u].y / TILE_DOCS];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -1117,12 +1120,15 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
         // 16 x the LDS capacity, beyond that the exact dense path takes the query.
         float keep = -INFINITY;
         bool fits = false;
+        row_lb = true;
         for (int round = 0; round < 4 && !fits; ++round) {
             __syncthreads();   // everybody is done with s_comp / s_fill of the previous round
             if (tid == 0) s_fill = 0u;
             __syncthreads();
             sweep_sublists<THREADS, 8>(tid, ranges, 0, (int)s_maxc, s_cnt, at, [](int, int) { return true; },
                                        [&](int, int, uint2 e) {
+                                           // (the ROW's own norm on both sides here: records of a tile that holds one huge row
+                                           // would otherwise pass every sweep and contribute nothing to the bound)
                                            const float cn = c * row_norm[e.y];
                                            if (__uint_as_float(e.x) + cn >= keep) {
                                                const uint32_t p = atomicAdd(&s_fill, 1u);
@@ -1162,7 +1168,9 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
         for (int i = tid; i < M; i += THREADS) {
             const uint2 e = s_comp[i];
             const float lb = __uint_as_float(e.x);
-            if (lb >= loose && fmaf(2.f * c, row_norm[e.y], lb) >= low) {
+            // (the row's own norm only here, for the few records near the cut: 4-byte reads scattered over an n_rows table --
+            // taken for every record they cost the k = 1001 select +0.25 ms)
+            if (lb >= loose && fmaf(c, row_norm[e.y], fmaf(c, row_lb ? row_norm[e.y] : tile_norm[e.y / TILE_DOCS], lb)) >= low) {
                 const uint32_t p = atomicAdd(&s_ncoll, 1u);
                 if (p < (uint32_t)coll_cap) s_keys[p] = (unsigned long long)e.y;  // local row for now
             }
@@ -1467,7 +1475,7 @@ int launch_gather_queries(const uint16_t *Q, int dim, const uint32_t *list, int 
 }
 
 int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, int sp, int n_q, int nq_pad, const CandLayout &lay, int k,
-                          int rescore_cap, int compact, int64_t n_rows, const float *cq, const float *row_norm,
+                          int rescore_cap, int compact, int64_t n_rows, const float *cq, const float *tile_norm, const float *row_norm,
                           const uint32_t *dmax_bits, const uint16_t *Q,
                           const uint16_t *D, int dim, int64_t id_offset, float *out_scores, int64_t *out_ids,
                           uint32_t *flag_count, uint32_t *flag_list, unsigned long long *stat_cand, const uint32_t *out_rows,
@@ -1480,7 +1488,7 @@ int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, in
             if (rc != CCR_OK) return rc;
         }
         hipLaunchKernelGGL(kernel, dim3(n_q), dim3(threads), lds, s, cand, cnt, ranges, sp, nq_pad, lay, k, rescore_cap, compact,
-                           n_rows, cq, row_norm, dmax_bits, Q, D, dim, id_offset, out_scores, out_ids, flag_count, flag_list, stat_cand,
+                           n_rows, cq, tile_norm, row_norm, dmax_bits, Q, D, dim, id_offset, out_scores, out_ids, flag_count, flag_list, stat_cand,
                            out_rows);
         CCR_LAUNCH_CHECK();
         return CCR_OK;

@@ -40,7 +40,7 @@ int launch_threshold(const float *gmax, int64_t n_groups, int n_q, int nq_pad, i
                      hipStream_t s);
 int select_compact_entries(int dim, int ranges, int rescore_cap, int64_t want);
 int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, int sp, int n_q, int nq_pad, const CandLayout &lay, int k,
-                          int rescore_cap, int compact, int64_t n_rows, const float *cq, const float *row_norm,
+                          int rescore_cap, int compact, int64_t n_rows, const float *cq, const float *tile_norm, const float *row_norm,
                           const uint32_t *dmax_bits, const uint16_t *Q, const uint16_t *D, int dim, int64_t id_offset, float *out_scores, int64_t *out_ids,
                           uint32_t *flag_count, uint32_t *flag_list, unsigned long long *stat_cand, const uint32_t *out_rows,
                           hipStream_t s);
