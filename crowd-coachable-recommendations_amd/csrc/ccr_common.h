@@ -123,7 +123,8 @@ struct GemmArgs {
     // EPI_GMAX
     float *gmax;          // [n_vt * 16][nq_pad]
     // EPI_STORE (debug)
-    float *store;         // [n_q][n_rows]
+    float *store;         // [n_q][store_pitch]
+    int64_t store_pitch;  // floats per stored query row (0: n_rows); a multiple of 4 lets a lane store its 4 consecutive rows as 16 bytes
     int dbg;              // timing-only ablations (CCR_GEMM_DBG; results are WRONG when non-zero)
     int stagger;          // 32x32x16 kernel: 1 = the two wave groups run one barrier interval apart (production), 0 = in phase
 };

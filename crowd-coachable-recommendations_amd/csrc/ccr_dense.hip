@@ -193,4 +193,116 @@ int launch_dense_select(const float *scores, int64_t n_rows, int k, const uint32
     return CCR_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Exact top-k from MFMA score rows + error margins (the fast form of this file's path for inner-product scores).
+// scores: [chunk][pitch] fp32 MFMA scores (EPI_STORE of the fused kernel) of the chunk's queries against ALL rows.  Row j of
+// tile t = j / 256 has its canonical score inside [m_j - c nt, m_j + c ||d_j||] (c = gamma ||q||), so: L = the
+// k-th largest m_j - c nt is a lower bound of the k-th largest canonical score; every row whose upper bound reaches L is
+// re-scored canonically (fp64 ordered) and the k best of those, by (score desc, row asc), are the exact result.  A query
+// with more than `cap` such rows (mass ties) or non-finite margins is flagged for the fp64 path.
+// grid = chunk, block = 1024, dyn LDS = dim * 2 (query row) + cap * 8 (keys).
+__global__ __launch_bounds__(1024) void margin_select_kernel(const float *__restrict__ scores, int64_t pitch, int64_t n_rows, int k, int dim,
+                                                            const uint16_t *__restrict__ Q, const uint16_t *__restrict__ D,
+                                                            const float *__restrict__ tile_norm, const float *__restrict__ row_norm,
+                                                            const uint32_t *__restrict__ dmax_bits, float gamma, int cap,
+                                                            const uint32_t *__restrict__ out_rows, int q_begin, int64_t id_offset,
+                                                            float *__restrict__ out_scores, int64_t *__restrict__ out_ids,
+                                                            uint32_t *__restrict__ flag_count, uint32_t *__restrict__ flag_list) {
+    extern __shared__ __attribute__((aligned(16))) char sm_ms[];
+    uint16_t *s_q = reinterpret_cast<uint16_t *>(sm_ms);
+    unsigned long long *s_keys = reinterpret_cast<unsigned long long *>(sm_ms + (((size_t)dim * 2 + 15) & ~(size_t)15));
+    __shared__ uint32_t s_hist[256];
+    __shared__ uint32_t s_ctl[4];
+    __shared__ float s_red[16];
+    __shared__ uint32_t s_n;
+    const int tid = threadIdx.x;
+    const int qi = blockIdx.x;
+    const float *row = scores + (int64_t)qi * pitch;
+    const uint16_t *qrow = Q + (int64_t)qi * dim;   // the chunk's query rows are contiguous (gathered by the caller if need be)
+    const int64_t orow = out_rows ? (int64_t)(out_rows[qi] & ~FLAG_DENSE) : (int64_t)(q_begin + qi);
+
+    float ss = 0.f;
+    for (int c = tid; c < dim / 8; c += blockDim.x) {
+        const uint4 v = reinterpret_cast<const uint4 *>(qrow)[c];
+        reinterpret_cast<uint4 *>(s_q)[c] = v;
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
+            ss = fmaf(lo, lo, ss);
+            ss = fmaf(hi, hi, ss);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    if ((tid & 63) == 0) s_red[tid >> 6] = ss;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    float tot = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += s_red[w];
+    const float c = gamma * (sqrtf(tot) * 1.001f) * 1.001f;
+    const float dmax = __uint_as_float(*dmax_bits);
+    auto give_up = [&]() {
+        if (tid == 0) flag_list[atomicAdd(flag_count, 1u)] = (uint32_t)orow | FLAG_DENSE;
+    };
+    if (!(dmax < INFINITY) || !(c < INFINITY)) {   // NaN / Inf embeddings: the fp64 path ranks them by its own rule
+        give_up();
+        return;
+    }
+    uint32_t kth;
+    int need_eq;
+    block_radix_select<true>(
+        [&](int64_t i, bool &skip) -> uint32_t {
+            (void)skip;
+            return f32_orderable(fmaf(-c, tile_norm[i / TILE_DOCS], row[i]));
+        },
+        n_rows, k, s_hist, s_ctl, kth, need_eq);
+    const float low = orderable_to_f32(kth);
+    for (int64_t i = tid; i < n_rows; i += blockDim.x) {
+        const float m = row[i];
+        // the tile's bound first (a coherent table lookup); the row's own norm only for the few that pass it
+        if (fmaf(c, tile_norm[i / TILE_DOCS], m) >= low && fmaf(c, row_norm[i], m) >= low) {
+            const uint32_t p = atomicAdd(&s_n, 1u);
+            if (p < (uint32_t)cap) s_keys[p] = (unsigned long long)i;
+        }
+    }
+    __syncthreads();
+    const int n = (int)s_n;
+    if (n > cap || n < k) {   // (n < k cannot happen with finite margins: the k rows that define L pass their own test)
+        give_up();
+        return;
+    }
+    const int np2 = pow2_ceil(n);
+    for (int i = tid; i < np2; i += blockDim.x) {
+        unsigned long long key = 0ull;
+        if (i < n) {
+            const uint32_t r = (uint32_t)s_keys[i];
+            key = make_key(canonical_dot(s_q, D + (int64_t)r * dim, dim), r);
+        }
+        s_keys[i] = key;
+    }
+    block_bitonic_sort_desc(s_keys, np2);
+    for (int i = tid; i < k; i += blockDim.x) {
+        const unsigned long long key = s_keys[i];
+        out_scores[orow * k + i] = key_score(key);
+        out_ids[orow * k + i] = id_offset + (int64_t)key_idx(key);
+    }
+}
+
+constexpr int MARGIN_SELECT_CAP = 8192;   // rows re-scored per query at most (64 KiB of keys)
+
+int launch_margin_select(const float *scores, int64_t pitch, int64_t n_rows, int k, int dim, const uint16_t *Q, const uint16_t *D,
+                         const float *tile_norm, const float *row_norm, const uint32_t *dmax_bits, const uint32_t *out_rows, int q_begin,
+                         int nq_chunk, int64_t id_offset, float *out_scores, int64_t *out_ids, uint32_t *flag_count, uint32_t *flag_list,
+                         hipStream_t s) {
+    const size_t lds = (((size_t)dim * 2 + 15) & ~(size_t)15) + (size_t)MARGIN_SELECT_CAP * 8;
+    const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&margin_select_kernel), 96 * 1024);
+    if (rc != CCR_OK) return rc;
+    hipLaunchKernelGGL(margin_select_kernel, dim3(nq_chunk), dim3(1024), lds, s, scores, pitch, n_rows, k, dim, Q, D, tile_norm, row_norm,
+                       dmax_bits, mfma_gamma(dim), MARGIN_SELECT_CAP, out_rows, q_begin, id_offset, out_scores, out_ids, flag_count, flag_list);
+    CCR_LAUNCH_CHECK();
+    return CCR_OK;
+}
+
 }  // namespace ccr

@@ -244,13 +244,24 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
                     }
                 } else {  // EPI_STORE
                     const int q = q0 + wq * 64 + qt * 32 + l31;
+                    const int64_t pitch = a.store_pitch ? a.store_pitch : a.n_rows;
+                    if (q < a.n_q) {
+                        float *dst = a.store + (int64_t)q * pitch;
 #pragma unroll
-                    for (int dt = 0; dt < 4; ++dt)
+                        for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            const int64_t doc = row_base + dt * 32 + (e & 3) + 8 * (e >> 2);
-                            if (q < a.n_q && doc < a.n_rows) a.store[(int64_t)q * a.n_rows + doc] = acc[dt][qt][e];
-                        }
+                            for (int g = 0; g < 4; ++g) {   // registers 4g .. 4g+3 are four consecutive corpus rows
+                                const int64_t doc = row_base + dt * 32 + 8 * g;
+                                if ((pitch & 3) == 0 && doc + 3 < a.n_rows) {
+                                    *reinterpret_cast<float4 *>(dst + doc) = make_float4(acc[dt][qt][4 * g], acc[dt][qt][4 * g + 1],
+                                                                                         acc[dt][qt][4 * g + 2], acc[dt][qt][4 * g + 3]);
+                                } else {
+#pragma unroll
+                                    for (int e2 = 0; e2 < 4; ++e2)
+                                        if (doc + e2 < a.n_rows) dst[doc + e2] = acc[dt][qt][4 * g + e2];
+                                }
+                            }
+                    }
                 }
             }
         };
@@ -520,13 +531,22 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
                     }
                 } else {  // EPI_STORE
                     const int q = q0 + wq * 64 + qt * 16 + l15;
+                    const int64_t pitch = a.store_pitch ? a.store_pitch : a.n_rows;
+                    if (q < a.n_q) {
+                        float *dst = a.store + (int64_t)q * pitch;
 #pragma unroll
-                    for (int dt = 0; dt < 8; ++dt)
+                        for (int dt = 0; dt < 8; ++dt) {   // the four registers of a tile are four consecutive corpus rows
+                            const int64_t doc = row_base + dt * 16;
+                            if ((pitch & 3) == 0 && doc + 3 < a.n_rows) {
+                                *reinterpret_cast<float4 *>(dst + doc) =
+                                    make_float4(acc[dt][qt][0], acc[dt][qt][1], acc[dt][qt][2], acc[dt][qt][3]);
+                            } else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int64_t doc = row_base + dt * 16 + e;
-                            if (q < a.n_q && doc < a.n_rows) a.store[(int64_t)q * a.n_rows + doc] = acc[dt][qt][e];
+                                for (int e = 0; e < 4; ++e)
+                                    if (doc + e < a.n_rows) dst[doc + e] = acc[dt][qt][e];
+                            }
                         }
+                    }
                 }
             }
         };

@@ -64,6 +64,13 @@ int launch_dense_select(const float *scores, int64_t n_rows, int k, const uint32
                         const uint32_t *count_dev, int64_t id_offset, float *out_scores, int64_t *out_ids, hipStream_t s,
                         bool aggregate = true);
 
+// Exact top-k from MFMA score rows [nq_chunk][pitch] + error margins (ccr_dense.hip); the chunk's query rows are contiguous at Q.
+// Queries it cannot finish (more than 8 192 rows inside the margin, non-finite margins) are appended to flag_list with FLAG_DENSE.
+int launch_margin_select(const float *scores, int64_t pitch, int64_t n_rows, int k, int dim, const uint16_t *Q, const uint16_t *D,
+                         const float *tile_norm, const float *row_norm, const uint32_t *dmax_bits, const uint32_t *out_rows, int q_begin,
+                         int nq_chunk, int64_t id_offset, float *out_scores, int64_t *out_ids, uint32_t *flag_count, uint32_t *flag_list,
+                         hipStream_t s);
+
 }  // namespace ccr
 
 struct ccr_index {
