@@ -616,3 +616,45 @@ def test_large_query_batches_are_searched_in_pieces(monkeypatch):
         assert torch.equal(i0, i1) and torch.equal(s0, s1)
     with pytest.raises(AssertionError):
         index.search(Qb, k, defer=True)
+
+
+def test_margin_path_small_corpus_and_flagged_queries():
+    """The margin path (MFMA score rows + margin select + canonical re-score) behind the default search of a corpus too small for
+    the sampled thresholds and behind the flagged queries of a fused search: bit-identical to the fp64 path (flag 1), ties of
+    hundreds of rows included; more than 8,192 rows inside the margin fall through to the fp64 path."""
+    from ccrec_amd import ops
+    rs = np.random.RandomState(5)
+    # (a) small corpus, default search = margin path; 700 identical rows sit in every query's top-k region
+    Db = _rand_bits(2_000, 64, 11)
+    Db[100:800] = Db[100]
+    Qb = _rand_bits(300, 64, 12)
+    Qb[:40] = Db[100]
+    index = ops.CorpusIndex(_bf16(Db), global_row_offset=1 << 35)
+    for k in (1, 50, 900):
+        s0, i0 = index.search(_bf16(Qb), k)
+        st = index.last_stats()
+        assert st["path"] == 0 and st["n_dense"] == 0, st
+        s1, i1 = index.search(_bf16(Qb), k, 1)
+        assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
+    ref_i, ref_s = orc.canonical_search(Qb[:5], Db, 50)
+    s0, i0 = index.search(_bf16(Qb[:5]), 50)
+    assert np.array_equal(i0.cpu().numpy() - (1 << 35), ref_i) and np.array_equal(s0.cpu().numpy().view(np.uint32), ref_s.view(np.uint32))
+    # (b) every row identical: 20,000 rows inside the margin > 8,192 -> the fp64 path finishes the query
+    Dc = np.tile(_rand_bits(1, 64, 13), (20_000, 1))
+    index = ops.CorpusIndex(_bf16(Dc))
+    s0, i0 = index.search(_bf16(Qb[:9]), 30)
+    assert index.last_stats()["n_dense"] == 9
+    assert torch.equal(i0, torch.arange(30, device="cuda").expand(9, 30))
+    # (c) a fused search whose flagged queries (400 rows tied at the cut > rescore_cap) finish on the margin path
+    n = 300_000
+    g = torch.Generator(device="cuda").manual_seed(3)
+    D = ops.pack_bf16(torch.randn(n, 128, generator=g, device="cuda") / 128 ** 0.5)
+    D[5000:5400] = D[5000]
+    Q = ops.pack_bf16(torch.randn(600, 128, generator=g, device="cuda") / 128 ** 0.5)
+    Q[17:23] = D[5000]
+    index = ops.CorpusIndex(D)
+    s0, i0 = index.search(Q, 100)
+    st = index.last_stats()
+    assert st["path"] == 1 and st["n_fallback"] == 6 and st["n_dense"] == 6, st
+    s1, i1 = index.search(Q[10:30], 100, 1)
+    assert torch.equal(i0[10:30], i1) and torch.equal(s0[10:30].view(torch.int32), s1.view(torch.int32))
