@@ -526,7 +526,7 @@ static int dense_for_list(const ccr_index *ix, const uint16_t *Q, const uint32_t
 // out_rows[i] (or q_begin + i).  Queries the margin select cannot finish are appended to flag_list (flag_count is NOT reset here).
 static bool margin_path_ok(const ccr_index *ix, int k) { return ix->dim % TILE_K == 0 && k <= MAX_K; }
 
-static int margin_for_rows(const ccr_index *ix, const uint16_t *Qc, const uint32_t *out_rows, int q_begin, int n, int k, float *scratch,
+static int margin_for_rows(const ccr_index *ix, const uint16_t *Qc, const float *hint, const uint32_t *out_rows, int q_begin, int n, int k, float *scratch,
                            size_t scratch_bytes, float *out_scores, int64_t *out_ids, uint32_t *flag_count, uint32_t *flag_list,
                            hipStream_t s) {
     const int64_t pitch = round_up(ix->n_rows, 4);
@@ -557,7 +557,7 @@ static int margin_for_rows(const ccr_index *ix, const uint16_t *Qc, const uint32
         int rc = (ix->knobs.mfma16 >= 0 ? ix->knobs.mfma16 : CCR_MFMA16_DEFAULT) ? launch_gemm16_store(g, grid, s) : launch_gemm_store(g, grid, s);
         if (rc != CCR_OK) return rc;
         rc = launch_margin_select(scratch, pitch, ix->n_rows, k, ix->dim, g.Q, ix->D, ix->tile_norm, ix->row_norm, ix->dmax_bits,
-                                  out_rows ? out_rows + lo : nullptr, q_begin + lo, m, ix->offset, out_scores, out_ids, flag_count, flag_list, s);
+                                  hint ? hint + lo : nullptr, out_rows ? out_rows + lo : nullptr, q_begin + lo, m, ix->offset, out_scores, out_ids, flag_count, flag_list, s);
         if (rc != CCR_OK) return rc;
     }
     return CCR_OK;
@@ -804,7 +804,8 @@ static int search_complete(ccr_index *ix) {
             const int m = std::min(p.nq_pad, n_dense - lo);
             rc = launch_gather_queries(pd.Q, ix->dim, dense_list + lo, m, thr, delta, Q2, thr2, delta2, s);
             if (rc != CCR_OK) return rc;
-            rc = margin_for_rows(ix, Q2, dense_list + lo, 0, m, k, scr, room, pd.out_scores, pd.out_ids, flag2, flag2 + 16, s);
+            // (thr2: the gathered thresholds of these queries -- valid lower bounds of their k-th largest scores)
+            rc = margin_for_rows(ix, Q2, thr2, dense_list + lo, 0, m, k, scr, room, pd.out_scores, pd.out_ids, flag2, flag2 + 16, s);
             if (rc != CCR_OK) return rc;
         }
         uint32_t left = 0;
@@ -872,7 +873,7 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
             // MFMA score rows + margin select; what it cannot finish (mass ties, non-finite embeddings) takes the fp64 path
             uint32_t *fc = (uint32_t *)(ws + p.off_flag), *fl = (uint32_t *)(ws + p.off_flag + 64);
             CCR_HIP_CHECK(hipMemsetAsync(fc, 0, 64, s));
-            rc0 = margin_for_rows(ix, Q_bf16, nullptr, 0, n_q, k, dense_scratch, (size_t)p.dense_rows_per_chunk * (ix->n_rows + 3) * 4,
+            rc0 = margin_for_rows(ix, Q_bf16, nullptr, nullptr, 0, n_q, k, dense_scratch, (size_t)p.dense_rows_per_chunk * (ix->n_rows + 3) * 4,
                                   out_scores, out_ids, fc, fl, s);
             if (rc0 != CCR_OK) return rc0;
             uint32_t nf = 0;

@@ -206,6 +206,7 @@ __global__ __launch_bounds__(1024) void margin_select_kernel(const float *__rest
                                                             const uint16_t *__restrict__ Q, const uint16_t *__restrict__ D,
                                                             const float *__restrict__ tile_norm, const float *__restrict__ row_norm,
                                                             const uint32_t *__restrict__ dmax_bits, float gamma, int cap,
+                                                            const float *__restrict__ hint,
                                                             const uint32_t *__restrict__ out_rows, int q_begin, int64_t id_offset,
                                                             float *__restrict__ out_scores, int64_t *__restrict__ out_ids,
                                                             uint32_t *__restrict__ flag_count, uint32_t *__restrict__ flag_list) {
@@ -252,22 +253,69 @@ __global__ __launch_bounds__(1024) void margin_select_kernel(const float *__rest
     }
     uint32_t kth;
     int need_eq;
-    block_radix_select<true>(
-        [&](int64_t i, bool &skip) -> uint32_t {
-            (void)skip;
-            return f32_orderable(fmaf(-c, tile_norm[i / TILE_DOCS], row[i]));
-        },
-        n_rows, k, s_hist, s_ctl, kth, need_eq);
-    const float low = orderable_to_f32(kth);
-    for (int64_t i = tid; i < n_rows; i += blockDim.x) {
-        const float m = row[i];
-        // the tile's bound first (a coherent table lookup); the row's own norm only for the few that pass it
-        if (fmaf(c, tile_norm[i / TILE_DOCS], m) >= low && fmaf(c, row_norm[i], m) >= low) {
-            const uint32_t p = atomicAdd(&s_n, 1u);
-            if (p < (uint32_t)cap) s_keys[p] = (unsigned long long)i;
+    bool done = false;
+    // With a valid lower bound tau of the k-th largest score (the fused search's threshold of a flagged query) ONE scan of the
+    // row is enough: the rows whose upper bound reaches tau are collected (their lower bounds with them), L is selected among
+    // those in LDS and the list is cut down to the rows that reach L.  Without a hint, or if that list overflows: four radix
+    // passes + one collecting scan over the row.
+    const float tau = hint ? hint[qi] : -INFINITY;
+    if (tau > -INFINITY) {
+        for (int64_t i = tid; i < n_rows; i += blockDim.x) {
+            const float m = row[i], cn = c * tile_norm[i / TILE_DOCS];
+            if (m + cn >= tau) {
+                const uint32_t p = atomicAdd(&s_n, 1u);
+                if (p < (uint32_t)cap) s_keys[p] = ((unsigned long long)f32_orderable(m - cn) << 32) | (unsigned long long)i;
+            }
+        }
+        __syncthreads();
+        const int n0 = (int)s_n;
+        __syncthreads();
+        if (n0 >= k && n0 <= cap) {
+            block_radix_select<false>(
+                [&](int64_t i, bool &skip) -> uint32_t {
+                    (void)skip;
+                    return (uint32_t)(s_keys[i] >> 32);
+                },
+                (int64_t)n0, k, s_hist, s_ctl, kth, need_eq);
+            const float low = orderable_to_f32(kth);
+            // cut the list down to the rows whose own upper bound reaches L (in place: survivors are re-appended at the front
+            // after everybody has read its entries)
+            unsigned long long mine[8];
+            int nm = 0;
+            for (int i = tid; i < n0; i += blockDim.x) {
+                const unsigned long long e = s_keys[i];
+                const uint32_t r = (uint32_t)e;
+                if (fmaf(c, row_norm[r], row[r]) >= low && nm < 8) mine[nm++] = (unsigned long long)r;
+            }
+            __syncthreads();
+            if (tid == 0) s_n = 0;
+            __syncthreads();
+            for (int j = 0; j < nm; ++j) s_keys[atomicAdd(&s_n, 1u)] = mine[j];
+            __syncthreads();
+            done = true;
+        } else {
+            if (tid == 0) s_n = 0;
+            __syncthreads();
         }
     }
-    __syncthreads();
+    if (!done) {
+        block_radix_select<true>(
+            [&](int64_t i, bool &skip) -> uint32_t {
+                (void)skip;
+                return f32_orderable(fmaf(-c, tile_norm[i / TILE_DOCS], row[i]));
+            },
+            n_rows, k, s_hist, s_ctl, kth, need_eq);
+        const float low = orderable_to_f32(kth);
+        for (int64_t i = tid; i < n_rows; i += blockDim.x) {
+            const float m = row[i];
+            // the tile's bound first (a coherent table lookup); the row's own norm only for the few that pass it
+            if (fmaf(c, tile_norm[i / TILE_DOCS], m) >= low && fmaf(c, row_norm[i], m) >= low) {
+                const uint32_t p = atomicAdd(&s_n, 1u);
+                if (p < (uint32_t)cap) s_keys[p] = (unsigned long long)i;
+            }
+        }
+        __syncthreads();
+    }
     const int n = (int)s_n;
     if (n > cap || n < k) {   // (n < k cannot happen with finite margins: the k rows that define L pass their own test)
         give_up();
@@ -293,14 +341,14 @@ __global__ __launch_bounds__(1024) void margin_select_kernel(const float *__rest
 constexpr int MARGIN_SELECT_CAP = 8192;   // rows re-scored per query at most (64 KiB of keys)
 
 int launch_margin_select(const float *scores, int64_t pitch, int64_t n_rows, int k, int dim, const uint16_t *Q, const uint16_t *D,
-                         const float *tile_norm, const float *row_norm, const uint32_t *dmax_bits, const uint32_t *out_rows, int q_begin,
+                         const float *tile_norm, const float *row_norm, const uint32_t *dmax_bits, const float *hint, const uint32_t *out_rows, int q_begin,
                          int nq_chunk, int64_t id_offset, float *out_scores, int64_t *out_ids, uint32_t *flag_count, uint32_t *flag_list,
                          hipStream_t s) {
     const size_t lds = (((size_t)dim * 2 + 15) & ~(size_t)15) + (size_t)MARGIN_SELECT_CAP * 8;
     const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&margin_select_kernel), 96 * 1024);
     if (rc != CCR_OK) return rc;
     hipLaunchKernelGGL(margin_select_kernel, dim3(nq_chunk), dim3(1024), lds, s, scores, pitch, n_rows, k, dim, Q, D, tile_norm, row_norm,
-                       dmax_bits, mfma_gamma(dim), MARGIN_SELECT_CAP, out_rows, q_begin, id_offset, out_scores, out_ids, flag_count, flag_list);
+                       dmax_bits, mfma_gamma(dim), MARGIN_SELECT_CAP, hint, out_rows, q_begin, id_offset, out_scores, out_ids, flag_count, flag_list);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
 }

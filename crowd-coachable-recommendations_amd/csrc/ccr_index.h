@@ -65,10 +65,11 @@ int launch_dense_select(const float *scores, int64_t n_rows, int k, const uint32
                         bool aggregate = true);
 
 // Exact top-k from MFMA score rows [nq_chunk][pitch] + error margins (ccr_dense.hip); the chunk's query rows are contiguous at Q.
+// hint (per chunk query, or null): a valid lower bound of its k-th largest score -- one scan of the row instead of five.
 // Queries it cannot finish (more than 8 192 rows inside the margin, non-finite margins) are appended to flag_list with FLAG_DENSE.
 int launch_margin_select(const float *scores, int64_t pitch, int64_t n_rows, int k, int dim, const uint16_t *Q, const uint16_t *D,
-                         const float *tile_norm, const float *row_norm, const uint32_t *dmax_bits, const uint32_t *out_rows, int q_begin,
-                         int nq_chunk, int64_t id_offset, float *out_scores, int64_t *out_ids, uint32_t *flag_count, uint32_t *flag_list,
+                         const float *tile_norm, const float *row_norm, const uint32_t *dmax_bits, const float *hint, const uint32_t *out_rows,
+                         int q_begin, int nq_chunk, int64_t id_offset, float *out_scores, int64_t *out_ids, uint32_t *flag_count, uint32_t *flag_list,
                          hipStream_t s);
 
 }  // namespace ccr
