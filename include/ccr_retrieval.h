@@ -39,7 +39,8 @@ extern "C" {
 
 /* ccr_search flags */
 #define CCR_SEARCH_DEFAULT 0
-#define CCR_SEARCH_FORCE_DENSE 1   /* exact brute-force path for every query (tests, tiny corpora) */
+#define CCR_SEARCH_FORCE_DENSE 1   /* fp64 brute-force path for every query (tests; the default path of a tiny corpus scores on the matrix
+                                      cores and re-scores only the rows inside the error margin in fp64 -- same result) */
 #define CCR_SEARCH_FORCE_FUSED 2   /* MFMA fused path even where the planner would pick dense */
 #define CCR_SEARCH_ASYNC 4         /* do not synchronise: results complete on `stream` once ccr_search_finish() has run */
 
@@ -66,7 +67,8 @@ typedef struct ccr_search_stats {
     float ms_fallback;         /* retry pass + dense path for flagged queries (0 if none) */
     float ms_total;
     int32_t n_retried;         /* flagged queries re-done by the fused retry pass (thresholds re-tightened from their own lists) */
-    int32_t n_dense;           /* flagged queries that took the exact dense path (mass ties, flagged again, on-stream chunk) */
+    int32_t n_dense;           /* flagged queries finished by an exact whole-row path (margin select or fp64: mass ties, flagged again,
+                                  on-stream chunk); path 0: queries the margin select left to the fp64 path */
 } ccr_search_stats;
 
 const char *ccr_last_error(void);
