@@ -93,6 +93,9 @@ static MainPassChoice choose_main_pass(const Plan &p, int k, int64_t sample_a, i
     // the select stage walks ranges x sublists sub-lists per query: 1 024 with its 256-thread form, 2 048 with the 1 024-thread
     // form large k uses anyway (rescore_cap > 512)
     int64_t max_lists = p.rescore_cap > 512 ? 2048 : 1024;
+    // one or two query blocks: 128 ranges x 8 sub-lists would leave half of the workgroups without a work item (n_q = 1: main pass
+    // 1.34 ms instead of 0.7) -- the select stage's wide form walks 2 048 sub-lists, and its cost does not matter for so few queries
+    if ((max_lists / p.sublists) * p.qblocks < p.grid) max_lists = 2048;
     if (kn.max_lists >= 64 && kn.max_lists < max_lists) max_lists = kn.max_lists;
     const int64_t r_hi = std::min<int64_t>(max_lists / p.sublists, round_up(std::max<int64_t>(1, p.tiles / 8), NUM_XCD));
     const int64_t target = std::min<int64_t>(r_hi, round_up(std::max<int64_t>(NUM_XCD, (int64_t)p.grid * 6 / p.qblocks), NUM_XCD));
@@ -101,8 +104,10 @@ static MainPassChoice choose_main_pass(const Plan &p, int k, int64_t sample_a, i
     const double qscale = (double)p.nq_pad / 3584.0;
     const double select_per_range = 0.1 * qscale, hit_w = 0.014 * qscale, phase_w = 3.0;
     // 0.11 ms = 4.9 units of threshold kernel for 328 sample tiles x 3 584 queries
+    // (the threshold kernel's time follows the number of sampled groups, not the number of queries, below ~3 500 queries: it runs
+    // nq_pad / 16 workgroups of four latency-bound passes -- 0.21 ms for 655 sample tiles at n_q = 1)
     auto sample_cost = [&](int64_t smp) -> double {
-        return (double)((smp * p.qblocks + p.grid - 1) / p.grid) + 0.015 * (double)smp * qscale;
+        return (double)((smp * p.qblocks + p.grid - 1) / p.grid) + 0.015 * (double)smp * std::max(1.0, qscale);
     };
 
     MainPassChoice best_choice = {sample_a, target, 0, 0};

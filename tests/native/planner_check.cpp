@@ -40,7 +40,11 @@ int main() {
                     if (p.qblocks % p.qgroups || NUM_XCD % p.qgroups) bad += fail("query groups", n, d, nq, k);
                     if (p.ranges % NUM_XCD || p.ranges < NUM_XCD) bad += fail("ranges not a multiple of the XCD count", n, d, nq, k);
                     if (p.sublists != (p.mfma16 ? 8 : 4)) bad += fail("sublists", n, d, nq, k);
-                    if (p.ranges * p.sublists > (p.rescore_cap > 512 ? 2048 : 1024)) bad += fail("too many sub-lists for the select stage", n, d, nq, k);
+                    // 2 048 sub-lists is what the select stage's wide form and the threshold update walk; above 1 024 only at large k or
+                    // when one or two query blocks would otherwise leave workgroups without a work item
+                    if (p.ranges * p.sublists > 2048) bad += fail("too many sub-lists for the select stage", n, d, nq, k);
+                    if (p.ranges * p.sublists > 1024 && p.rescore_cap <= 512 && (1024 / p.sublists) * p.qblocks >= p.grid)
+                        bad += fail("more than 1 024 sub-lists without need", n, d, nq, k);
                     if (p.item_a < 0 || p.item_b < 0 || (p.item_b && p.item_b <= p.item_a) || p.item_a > items || p.item_b > items)
                         bad += fail("phase ends", n, d, nq, k);
                     if (p.item_a && p.item_a % per_x) bad += fail("phase A is not whole rounds", n, d, nq, k);
