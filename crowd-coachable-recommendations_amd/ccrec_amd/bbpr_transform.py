@@ -92,7 +92,7 @@ class LowRankScore:
     def as_tensor(self, device=None):
         """Dense scores (this materialises n_users x n_items fp32): canonical fp64-ordered values for small problems,
         the MFMA tile kernel (same bf16 rows, fp32 accumulation) above 4e9 multiply-adds."""
-        big = self.shape[0] * self.shape[1] * self.user.shape[1] > 4e9 and self.user.shape[1] % 64 == 0
+        big = self.shape[0] * self.shape[1] * self.user.shape[1] > 4e9 and self.user.shape[1] % 32 == 0
         s = self.index().scores(self.user, "mfma" if big else "canonical")
         return s if device is None else s.to(device)
 

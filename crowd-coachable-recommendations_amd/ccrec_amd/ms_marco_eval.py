@@ -75,7 +75,7 @@ def cos_sim(a: torch.Tensor, b: torch.Tensor):
     b_n = ops.pack_bf16(b.cuda().float(), normalize=True)
     # small matrices: the canonical fp64-ordered scores (bit-identical to the oracle); large ones: the MFMA tile kernel
     # (fp32 accumulation of the same bf16 rows, within 1e-6 of the canonical value) -- the fp64 path is VALU-bound
-    big = a_n.shape[0] * b_n.shape[0] * a_n.shape[1] > CANONICAL_COS_SIM_MACS and a_n.shape[1] % 64 == 0
+    big = a_n.shape[0] * b_n.shape[0] * a_n.shape[1] > CANONICAL_COS_SIM_MACS and a_n.shape[1] % 32 == 0
     return ops.CorpusIndex(b_n).scores(a_n, "mfma" if big else "canonical")
 
 

@@ -290,7 +290,7 @@ class CorpusIndex:
 
     def scores(self, queries_bf16, mode="canonical"):
         """Dense score matrix [n_q, n_rows] fp32 (ccr_scores).  mode "canonical": the fp64-ordered values the ranking
-        reports; "mfma": the same bf16 rows through the MFMA tile kernel (fp32 accumulation; dim % 64 == 0)."""
+        reports; "mfma": the same bf16 rows through the MFMA tile kernel (fp32 accumulation; dim % 32 == 0)."""
         q = queries_bf16.contiguous()
         assert q.is_cuda and q.dtype == torch.bfloat16 and q.dim() == 2 and q.shape[1] == self.dim
         out = torch.empty(q.shape[0], self.n_rows, dtype=torch.float32, device=q.device)

@@ -1022,7 +1022,7 @@ extern "C" int ccr_scores(const ccr_index *ix, const uint16_t *Q_bf16, int n_q, 
     if (mode == CCR_SCORES_CANONICAL)
         return launch_dense_scores(ix->D, ix->n_rows, ix->dim, Q_bf16, nullptr, 0, n_q, nullptr, out, (hipStream_t)stream);
     CCR_REQUIRE(mode == CCR_SCORES_MFMA, "ccr_scores: unknown mode %d", mode);
-    CCR_REQUIRE(ix->dim % TILE_K == 0, "ccr_scores: CCR_SCORES_MFMA needs dim %% 64 == 0 (dim=%d)", ix->dim);
+    CCR_REQUIRE(ix->dim % TILE_K == 0, "ccr_scores: CCR_SCORES_MFMA needs dim %% 32 == 0 (dim=%d)", ix->dim);
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.D = ix->D;

@@ -39,7 +39,7 @@ void set_error(const char *fmt, ...);
 // ---- geometry of the fused MFMA path (one definition for kernels and planner)
 constexpr int TILE_DOCS = 256;      // corpus rows per GEMM tile
 constexpr int TILE_Q = 256;         // queries per GEMM tile
-constexpr int TILE_K = 64;          // K step (bf16 elements) = 128 B per row
+constexpr int TILE_K = 32;          // K granularity of the fused kernels (one LDS sub-stage = 32 bf16 = 64 B per row): dim % 32 == 0
 constexpr int GEMM_THREADS = 512;   // 8 waves: 2 (doc halves) x 4 (query quarters)
 constexpr int GROUPS_PER_TILE = 16; // group maxima per (sample tile, query): 2 wave rows x 4 MFMA tiles x 2 lane halves
 constexpr int MAX_K = 4096;

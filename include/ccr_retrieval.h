@@ -161,7 +161,7 @@ int ccr_search_last_stats(const ccr_index *index, ccr_search_stats *stats /* hos
  * Dense score matrix of n_q queries against the shard: out [n_q][n_rows] fp32.
  * Replaces: cos_sim / the chunked `Q @ chunk^T` of scripts/ms_marco_eval.py:155-162,212-215 and
  * src/ccrec/models/bbpr.py:485-492,536-540 when a caller really wants the matrix (small problems; the ranking path
- * never materialises it).  mode: CCR_SCORES_CANONICAL or CCR_SCORES_MFMA (dim % 64 == 0).
+ * never materialises it).  mode: CCR_SCORES_CANONICAL or CCR_SCORES_MFMA (dim % 32 == 0).
  */
 int ccr_scores(const ccr_index *index, const uint16_t *Q_bf16, int n_q, int mode, float *out, void *stream);
 
