@@ -339,6 +339,7 @@ __global__ __launch_bounds__(1024) void margin_select_kernel(const float *__rest
 }
 
 constexpr int MARGIN_SELECT_CAP = 8192;   // rows re-scored per query at most (64 KiB of keys)
+static_assert(MARGIN_SELECT_CAP <= 8 * 1024, "margin_select_kernel: a thread keeps at most 8 list entries while the list is rebuilt in place");
 
 int launch_margin_select(const float *scores, int64_t pitch, int64_t n_rows, int k, int dim, const uint16_t *Q, const uint16_t *D,
                          const float *tile_norm, const float *row_norm, const uint32_t *dmax_bits, const float *hint, const uint32_t *out_rows, int q_begin,
