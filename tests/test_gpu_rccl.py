@@ -73,7 +73,8 @@ def test_topk_message_through_rccl_world1():
         dist.destroy_process_group()
 
 
-def test_bench_two_ranks_rehearsal_in_a_fresh_process(tmp_path):
+@pytest.mark.parametrize("world,rows", [(2, 200000), (3, 200003)])   # 200003 rows over 3 ranks: uneven shards (as NQ over 8)
+def test_bench_two_ranks_rehearsal_in_a_fresh_process(tmp_path, world, rows):
     """The N > 1 branch of bench.py exactly as the driver launches it (`python -m torch.distributed.run ... bench.py
     --gpus 2`), rehearsed on this one GPU: both ranks share cuda:0 and exchange over gloo.  The JSON line must parse and
     the merged ids must equal the 1-rank run's (the corpus is the same global stream, row-sharded)."""
@@ -81,7 +82,7 @@ def test_bench_two_ranks_rehearsal_in_a_fresh_process(tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    common = ["--steps", "2", "--warmup", "1", "--rows", "200000", "--queries", "300", "--cpu-queries", "0", "--no-secondary"]
+    common = ["--steps", "2", "--warmup", "1", "--rows", str(rows), "--queries", "300", "--cpu-queries", "0", "--no-secondary"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CCR_BENCH_WATCHDOG="150")   # a hung rank dumps its stacks and exits
     try:
         one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dump-ids", str(tmp_path / "one.pt")] + common,
@@ -90,8 +91,8 @@ def test_bench_two_ranks_rehearsal_in_a_fresh_process(tmp_path):
         pytest.skip(f"1-rank child did not finish in 240 s on this box: {(e.stderr or b'')[-1500:]}")
     assert one.returncode == 0, one.stderr[-4000:]
     try:
-        two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                              "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2",
+        two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+                              "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(world),
                               "--dist-backend", "gloo", "--same-device", "--dump-ids", str(tmp_path / "two.pt")] + common,
                              capture_output=True, text=True, timeout=240, env=env)
     except subprocess.TimeoutExpired as e:
@@ -100,8 +101,8 @@ def test_bench_two_ranks_rehearsal_in_a_fresh_process(tmp_path):
     lines = [ln for ln in two.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, two.stdout[-2000:]                  # rank 0 prints ONE JSON line
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["scaling"] == "strong" and rec["value"] > 0
-    assert rec["config"]["parallelism"] == "row-shard x2" and rec["cpu_baseline"] is None
+    assert rec["n_gpus"] == world and rec["steps"] == 2 and rec["scaling"] == "strong" and rec["value"] > 0
+    assert rec["config"]["parallelism"] == f"row-shard x{world}" and rec["cpu_baseline"] is None
     assert rec["roofline"]["bound"] == "mfma" and rec["search_stats"]["n_fallback"] == 0
     a, b = torch.load(tmp_path / "one.pt"), torch.load(tmp_path / "two.pt")
     assert a.shape == (300, 100) and torch.equal(a, b)
