@@ -82,26 +82,34 @@ def host_threads():
     return max(1, int(forced)) if forced else max(1, n)
 
 
-def gen_rows(n, dim, seed, device, data="gaussian", chunk=262144):
-    """fp32 rows generated on device in chunks.  gaussian: N(0,1) / sqrt(dim).
+def gen_rows(n, dim, seed, device, data="gaussian", chunk=262144, lo=0, hi=None):
+    """Rows [lo, hi) of the n-row fp32 matrix `seed` names, generated on device chunk by chunk.  Chunk c (global rows
+    [c chunk, (c + 1) chunk)) is drawn from its OWN generator state (seed, c), so a rank of an N-way row sharding generates
+    only the chunks that overlap its shard and still holds exactly the rows the single-GPU run holds: the corpus is the
+    same for every N, and no rank ever materialises more than its shard plus one chunk.
+    gaussian: N(0,1) / sqrt(dim).
     clustered / sorted: 1,024 cluster centres (seeded, shared by corpus and queries), row = 0.8 centre + 0.6 noise (unit scale),
     times a log-normal norm (sigma 0.35); 3 % of the rows of a chunk are exact duplicates of other rows of that chunk.
     outlier: gaussian, with every 500,000th corpus row scaled by CCR_BENCH_OUTLIER (default 100): rows whose norm is far above the
     rest (the filter margins scale with the LARGEST row norm, DESIGN 4.4 'known limit')."""
-    g = torch.Generator(device=device).manual_seed(seed)
-    out = torch.empty(n, dim, dtype=torch.float32, device=device)
+    hi = n if hi is None else hi
+    assert 0 <= lo <= hi <= n
+    g = torch.Generator(device=device)
+    out = torch.empty(hi - lo, dim, dtype=torch.float32, device=device)
     centres = None
     if data in ("clustered", "sorted"):
         gc = torch.Generator(device=device).manual_seed(777)
         centres = torch.randn(1024, dim, generator=gc, device=device) * dim ** -0.5
-    for lo in range(0, n, chunk):
-        hi = min(n, lo + chunk)
-        m = hi - lo
+    for c in range(lo // chunk, (hi + chunk - 1) // chunk if hi > lo else 0):
+        c_lo = c * chunk
+        c_hi = min(n, c_lo + chunk)
+        m = c_hi - c_lo
+        g.manual_seed(seed * 1_000_003 + c)
         x = torch.randn(m, dim, generator=g, device=device) * dim ** -0.5
         if centres is not None:
             cid = torch.randint(0, 1024, (m,), generator=g, device=device)
             if data == "sorted" and seed == 1234:   # corpus rows in topical order: cluster c owns rows [c n / 1024, (c + 1) n / 1024)
-                cid = (torch.arange(lo, hi, device=device, dtype=torch.int64) * 1024 // n).clamp_(max=1023)
+                cid = (torch.arange(c_lo, c_hi, device=device, dtype=torch.int64) * 1024 // n).clamp_(max=1023)
             x = 0.8 * centres[cid] + 0.6 * x
             x *= torch.exp(0.35 * torch.randn(m, 1, generator=g, device=device))
             ndup = int(0.03 * m)
@@ -109,9 +117,12 @@ def gen_rows(n, dim, seed, device, data="gaussian", chunk=262144):
                 dst = torch.randint(0, m, (ndup,), generator=g, device=device)
                 src = torch.randint(0, m, (ndup,), generator=g, device=device)
                 x[dst] = x[src]
-        out[lo:hi] = x
-    if data == "outlier" and seed == 1234:
-        out[::500_000] *= float(os.environ.get("CCR_BENCH_OUTLIER", "100"))
+        if data == "outlier" and seed == 1234:
+            first = (c_lo + 499_999) // 500_000 * 500_000   # global rows 0, 500 000, ... inside this chunk
+            if first < c_hi:
+                x[first - c_lo::500_000] *= float(os.environ.get("CCR_BENCH_OUTLIER", "100"))
+        a, b = max(lo, c_lo), min(hi, c_hi)
+        out[a - lo:b - lo] = x[a - c_lo:b - c_lo]
     return out
 
 
@@ -145,66 +156,68 @@ def cpu_baseline(corpus_bf16, queries_bf16, nq_sample, k, gpu_ids):
 
 
 class Workload:
-    """One configuration of the hot path on this rank: resident fp32 inputs, packed buffers, the step closure."""
+    """One configuration of the hot path on this rank: resident fp32 inputs, packed buffers, the step closure.
+
+    Steps are PIPELINED on the host: step i enqueues pack + index + asynchronous search (+ the all-gather behind it on RCCL's
+    stream), then completes step i - 1 (ccr_search_finish waits for THAT search's own event; the exchange's headers arrive in
+    pinned memory from a side stream; the merge is enqueued) -- so the GPU never waits for the host between two steps, and the
+    exchange of step i - 1 overlaps the pack and search of step i.  Packed shard, query pack, norm bounds and exchange message
+    are double-buffered: a step that had to re-do flagged queries after the fact still finds its operands."""
 
     def __init__(self, rows, queries, dim, k, data, dev, rank, world, backend, normalize=False):
-        from ccrec_amd.dist import shard_bounds, TopkMessage
+        from ccrec_amd.dist import shard_bounds, ShardMessage
         self.rows, self.queries, self.dim, self.k, self.world, self.dev, self.backend = rows, queries, dim, k, world, dev, backend
         self.normalize = normalize
         self.lo, self.hi = shard_bounds(rows, world, rank)
-        # every rank generates the same global stream and keeps its rows: identical corpus for every N
-        if world == 1:
-            self.corpus_f32 = gen_rows(rows, dim, 1234, dev, data)
-        else:
-            full = gen_rows(rows, dim, 1234, dev, data)
-            self.corpus_f32 = full[self.lo:self.hi].clone()
-            del full
-            torch.cuda.empty_cache()
+        # a rank generates only its own rows of the global corpus (per-chunk generator states): identical corpus for every N
+        self.corpus_f32 = gen_rows(rows, dim, 1234, dev, data, lo=self.lo, hi=self.hi)
         self.queries_f32 = gen_rows(queries, dim, 4321, dev, data)
-        self.shard = torch.empty(self.hi - self.lo, dim, dtype=torch.bfloat16, device=dev)
-        self.qpack = torch.empty(queries, dim, dtype=torch.bfloat16, device=dev)
-        self.k_local = min(k, self.hi - self.lo)
-        self.norm_bounds = torch.empty(self.hi - self.lo, dtype=torch.float32, device=dev)   # norm bound per packed row (pack kernel)
-        # N > 1: the search writes its top-k straight into the packed exchange message (one all-gather per step).  Two
-        # messages: the all-gather of step i runs on the communication stream while step i + 1 packs and searches.
-        self.messages = None
-        self.prev = None   # (message, work handle, index) of the step whose exchange is still in flight
-        self.nstep = 0
+        n_local = self.hi - self.lo
+        self.k_local = min(k, n_local)
         if world > 1:
             assert self.k_local == k, "shard smaller than k"
-            self.messages = [TopkMessage(queries, k, dev, world) for _ in range(2)]
+        self.slots = [{"shard": torch.empty(n_local, dim, dtype=torch.bfloat16, device=dev),
+                       "qpack": torch.empty(queries, dim, dtype=torch.bfloat16, device=dev),
+                       "bounds": torch.empty(n_local, dtype=torch.float32, device=dev),   # norm bound per packed row (pack kernel)
+                       "message": ShardMessage(queries, k, dev, world) if world > 1 else None} for _ in range(2)]
+        self.shard, self.qpack = self.slots[0]["shard"], self.slots[0]["qpack"]
+        self.prev = None        # the step whose search / exchange is still in flight
+        self.nstep = 0
+        self.done_stats = []    # last_stats() of every completed step
+        self.repeats = 0        # exchanges that had to be repeated (some rank flagged more queries than its search re-did on the stream)
         self.index = self.scores = self.ids = None
 
     def step(self):
         from ccrec_amd import ops
-        ops.pack_bf16(self.corpus_f32, out=self.shard, norm_bounds=self.norm_bounds, normalize=self.normalize)   # pack + norm bound of every packed row in one pass
-        index = ops.CorpusIndex(self.shard, global_row_offset=self.lo, norm_bounds=self.norm_bounds)
-        ops.pack_bf16(self.queries_f32, out=self.qpack, normalize=self.normalize)
+        from ccrec_amd.dist import submit_sharded_search
+        b = self.slots[self.nstep % 2]
+        self.nstep += 1
+        ops.pack_bf16(self.corpus_f32, out=b["shard"], norm_bounds=b["bounds"], normalize=self.normalize)   # pack + norm bound of every packed row in one pass
+        index = ops.CorpusIndex(b["shard"], global_row_offset=self.lo, norm_bounds=b["bounds"])
+        ops.pack_bf16(self.queries_f32, out=b["qpack"], normalize=self.normalize)
         if self.world > 1:
-            # search (its one host synchronisation reads the flagged-query count, so the lists are FINAL before they are
-            # exchanged -- an exchange that had to be repeated on some ranks only would need every rank's agreement), then the
-            # all-gather on the communication stream; the exchange of the PREVIOUS step is completed (wait + merge) behind it,
-            # so its latency hides behind the next step's pack and search.
-            msg = self.messages[self.nstep % 2]
-            self.nstep += 1
-            index.search(self.qpack, self.k_local, out=(msg.scores, msg.ids))
-            work = msg.gather_async()
-            self.drain()
-            self.prev = (msg, work, index)
-            self.index = index
+            # asynchronous search straight into the packed message, all-gather behind it on the communication stream
+            cur = (index, submit_sharded_search(index, b["qpack"], self.k_local, message=b["message"]), None, None)
         else:
-            s, i = index.search(self.qpack, self.k_local)
-            self.index, self.scores, self.ids = index, s, i
+            s, i = index.search(b["qpack"], self.k_local, defer=True)
+            cur = (index, None, s, i)
+        self.drain()
+        self.prev = cur
+        self.shard, self.qpack = b["shard"], b["qpack"]
 
     def drain(self):
-        """Complete the exchange still in flight: wait for its all-gather, merge the gathered per-shard lists."""
-        from ccrec_amd import ops
+        """Complete the step still in flight: finish its search (its own event), merge the gathered per-shard lists."""
         if self.prev is None:
             return
-        msg, work, _ = self.prev
-        work.wait()
-        self.scores, self.ids = ops.merge_topk(msg.all_scores, msg.all_ids)
+        index, exchange, s, i = self.prev
         self.prev = None
+        if exchange is not None:
+            s, i = exchange.result()
+            self.repeats += int(exchange.repeated)
+        else:
+            index.finish()
+        self.index, self.scores, self.ids = index, s, i
+        self.done_stats.append(index.last_stats())
 
     def fence(self):
         self.drain()
@@ -215,19 +228,24 @@ class Workload:
     def run(self, steps, warmup, tag):
         for _ in range(warmup):
             self.step()
-            log(f"{tag}: warmup step", self.index.last_stats())
         self.fence()
+        if self.done_stats:
+            log(f"{tag}: warmup step", self.done_stats[-1])
+        self.done_stats, self.repeats = [], 0
         t0 = time.perf_counter()
-        stats = []
         for _ in range(steps):
             self.step()
-            stats.append(self.index.last_stats())
         self.fence()
         elapsed = time.perf_counter() - t0
-        t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        stats = self.done_stats
+        per_rank = [elapsed]
         if self.world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+            every = [torch.zeros_like(t) for _ in range(self.world)]
+            dist.all_gather(every, t)
+            per_rank = [float(x.item()) for x in every]
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+            elapsed = float(t.item())
         ms_per_step = elapsed / steps * 1e3
         log(f"{tag}: timed {steps} steps: {ms_per_step:.3f} ms/step")
         st = stats[-1]
@@ -235,10 +253,12 @@ class Workload:
         flops = 2.0 * self.queries * (self.hi - self.lo) * self.dim
         achieved = flops / (avg_main * 1e-3) / 1e12 if avg_main > 0 else 0.0
         return {"qps": self.queries * steps / elapsed, "ms_per_step": ms_per_step, "stats": st, "avg_main": avg_main, "flops": flops,
-                "achieved_tflops": achieved, "n_fallback_max": max(m["n_fallback"] for m in stats)}
+                "achieved_tflops": achieved, "n_fallback_max": max(m["n_fallback"] for m in stats),
+                "rank_ms_per_step": [e / steps * 1e3 for e in per_rank], "exchange_repeats": self.repeats}
 
     def release(self):
-        self.corpus_f32 = self.queries_f32 = self.shard = self.qpack = self.index = self.scores = self.ids = self.messages = self.prev = None
+        self.drain()
+        self.corpus_f32 = self.queries_f32 = self.shard = self.qpack = self.index = self.scores = self.ids = self.slots = None
         torch.cuda.empty_cache()
 
 
@@ -278,12 +298,15 @@ def inbatch_side_run(dev, B=1024, d=768, iters=30):
 
 
 def roofline_obj(r, traffic=None, traffic_source=None):
+    """`achieved` = algorithmic flops of one step's main pass (2 n_q n_rows dim: every launch of the pass covers its share of the
+    corpus, together exactly once) / the main pass's duration per step from the library's HIP events on the search stream."""
     st = r["stats"]
     return {"bound": "mfma", "kernel": ("gemm_topk16_kernel<EPI_FILTER> (main pass, v_mfma_f32_16x16x32_bf16)" if st.get("sublists") == 8
                                         else "gemm_topk_kernel<EPI_FILTER> (main pass, v_mfma_f32_32x32x16_bf16)"),
             "achieved": round(r["achieved_tflops"], 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(r["achieved_tflops"] / MFMA_PEAK_TFLOPS, 4), "flops_per_launch": r["flops"],
-            "avg_launch_ms": round(r["avg_main"], 4), "traffic": traffic, "traffic_source": traffic_source}
+            "frac": round(r["achieved_tflops"] / MFMA_PEAK_TFLOPS, 4), "flops_per_step": r["flops"],
+            "main_pass_ms_per_step": round(r["avg_main"], 4), "launches_per_step": st.get("main_launches"),
+            "traffic": traffic, "traffic_source": traffic_source}
 
 
 def phases_obj(st):
@@ -291,15 +314,61 @@ def phases_obj(st):
             "select_rescore": round(st["ms_select"], 3), "fallback": round(st["ms_fallback"], 3), "search_total": round(st["ms_total"], 3)}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD `python -m torch.distributed.run` (one
+    process per GPU, RCCL rendezvous on 127.0.0.1), relay rank 0's JSON line and the ranks' stderr, return the child's exit
+    code.  Called before this process has made any GPU call (importing torch makes none), and the child is a child process,
+    not an exec."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    log("launching", " ".join(cmd))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    for line in proc.stdout:   # rank 0 prints ONE JSON line; anything else on stdout goes to stderr
+        if line.startswith("{"):
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(line)
+    return proc.wait()
+
+
+def install_watchdog():
+    """Tests (CCR_BENCH_WATCHDOG = seconds): a rank that is still running then dumps every thread's Python stack and exits;
+    SIGUSR1 dumps the stacks at any time (the parent test sends it before it kills a child that overran its time limit).
+    CCR_BENCH_WATCHDOG_DIR: the dumps go to <dir>/stacks.rank<R>.txt instead of stderr, so they survive a killed pipe."""
+    secs = int(os.environ.get("CCR_BENCH_WATCHDOG", "0"))
+    if secs <= 0:
+        return
+    import faulthandler
+    import signal
+    out = sys.stderr
+    d = os.environ.get("CCR_BENCH_WATCHDOG_DIR")
+    if d:
+        out = open(os.path.join(d, f"stacks.rank{os.environ.get('RANK', '0')}.txt"), "w")
+    faulthandler.enable(file=out, all_threads=True)
+    faulthandler.register(signal.SIGUSR1, file=out, all_threads=True)
+    faulthandler.dump_traceback_later(secs, exit=True, file=out)
+
+
 def main():
-    if int(os.environ.get("CCR_BENCH_WATCHDOG", "0")) > 0:   # tests: a hung rank dumps every thread's stack and exits
-        import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ["CCR_BENCH_WATCHDOG"]), exit=True)
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))   # plain `python bench.py --gpus N`: this process never touches a GPU
+    install_watchdog()
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if world != args.gpus:
+        log(f"--gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus {args.gpus}` (it launches its own ranks) "
+            f"or through `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}`")
+        sys.exit(2)
     if args.same_device:
         local = 0
     torch.cuda.set_device(local)
@@ -321,7 +390,7 @@ def main():
     # untimed extras: pack-kernel HBM rate
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    ops.pack_bf16(w.corpus_f32, out=w.shard, norm_bounds=w.norm_bounds, normalize=w.normalize)
+    ops.pack_bf16(w.corpus_f32, out=w.slots[0]["shard"], norm_bounds=w.slots[0]["bounds"], normalize=w.normalize)
     e1.record()
     torch.cuda.synchronize()
     pack_ms = e0.elapsed_time(e1)
@@ -351,8 +420,9 @@ def main():
                                    "outlier": "synthetic (gaussian, every 500,000th corpus row scaled by CCR_BENCH_OUTLIER)"}[args.data],
         "config": {"workload": workload, "corpus_rows": args.rows,
                    "dim": args.dim, "queries": args.queries, "k": args.k,
-                   "step": "pack corpus shard fp32->bf16 + index build + pack queries + fused MFMA score/top-k"
-                           + (" + RCCL all-gather + merge (the exchange of step i overlaps the pack and search of step i + 1)" if world > 1 else ""),
+                   "step": "pack corpus shard fp32->bf16 + index build + pack queries + fused MFMA score/top-k (asynchronous: the host enqueues "
+                           "step i + 1 before it completes step i)"
+                           + (" + RCCL all-gather of the packed shard message + merge (the exchange of step i overlaps the pack and search of step i + 1)" if world > 1 else ""),
                    "parallelism": f"row-shard x{world}"},
         "roofline": roofline_obj(r, traffic, traffic_source),
         "phases_ms": dict(phases_obj(st), corpus_pack=round(pack_ms, 3)),
@@ -361,6 +431,15 @@ def main():
         "search_stats": dict({k_: st[k_] for k_ in ("path", "n_fallback", "sample_tiles", "ranges", "sublists", "cap", "n_candidates")},
                              candidates_per_query=round(st["n_candidates"] / max(1, args.queries), 1), n_fallback_max=r["n_fallback_max"]),
     }
+    if world > 1:
+        from ccrec_amd.ops import shard_message_bytes
+        msg = shard_message_bytes(args.queries, args.k)
+        out["exchange"] = {"n_ranks_seen": dist.get_world_size(), "backend": dist.get_backend(),
+                           "collective": "one all_gather_into_tensor of the packed shard message per step (header + fp32 scores + u32 local rows)",
+                           "message_bytes_per_rank": msg, "gathered_bytes_per_rank_per_step": msg * world,
+                           "repeated_exchanges": r["exchange_repeats"],
+                           "rank_ms_per_step_min": round(min(r["rank_ms_per_step"]), 3),
+                           "rank_ms_per_step_max": round(max(r["rank_ms_per_step"]), 3)}
     if args.dump_ids and rank == 0:
         torch.save(w.ids.cpu(), args.dump_ids)
     if rank == 0 and world == 1 and args.cpu_queries > 0:

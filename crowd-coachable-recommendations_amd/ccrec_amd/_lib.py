@@ -19,8 +19,17 @@ EXPORTS = [
     "ccr_merge_topk", "ccr_merge_topk_strided", "ccr_apply_block", "ccr_inbatch_ce_workspace_bytes", "ccr_inbatch_ce_fwd", "ccr_inbatch_ce_bwd", "ccr_inbatch_ce_bwd_dev", "ccr_rank_metrics",
     "ccr_search_finish", "ccr_scores", "ccr_search_blocked_workspace_bytes", "ccr_search_blocked",
     "ccr_search_sparse_prior_workspace_bytes", "ccr_search_sparse_prior", "ccr_colsum_bf16", "ccr_meanpool_bwd", "ccr_bm25_index_create", "ccr_bm25_index_destroy", "ccr_bm25_search_workspace_bytes",
-    "ccr_bm25_search",
+    "ccr_bm25_search", "ccr_shard_message_bytes", "ccr_search_shard", "ccr_shard_message_fill", "ccr_merge_shard_messages",
 ]
+
+SHARD_HEADER_BYTES = 32
+SHARD_MAGIC = 0x4D524343
+
+
+class ShardHeader(ctypes.Structure):
+    """ccr_shard_header (include/ccr_retrieval.h)."""
+    _fields_ = [("magic", ctypes.c_uint32), ("n_flagged", ctypes.c_uint32), ("k_valid", ctypes.c_uint32),
+                ("n_covered", ctypes.c_uint32), ("row_offset", ctypes.c_int64), ("n_rows", ctypes.c_int64)]
 
 
 class SearchStats(ctypes.Structure):
@@ -28,7 +37,8 @@ class SearchStats(ctypes.Structure):
                 ("ranges", ctypes.c_int32), ("cap", ctypes.c_int32), ("sublists", ctypes.c_int32),
                 ("n_candidates", ctypes.c_int64), ("ms_sample", ctypes.c_float), ("ms_threshold", ctypes.c_float),
                 ("ms_main", ctypes.c_float), ("ms_select", ctypes.c_float), ("ms_fallback", ctypes.c_float),
-                ("ms_total", ctypes.c_float), ("n_retried", ctypes.c_int32), ("n_dense", ctypes.c_int32)]
+                ("ms_total", ctypes.c_float), ("n_retried", ctypes.c_int32), ("n_dense", ctypes.c_int32),
+                ("main_launches", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class CcrError(RuntimeError):
@@ -89,6 +99,11 @@ def load():
     lib.ccr_bm25_search_workspace_bytes.argtypes = [vp, i32, i32]
     lib.ccr_bm25_search_workspace_bytes.restype = sz
     lib.ccr_bm25_search.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp, sz, vp]
+    lib.ccr_shard_message_bytes.argtypes = [i32, i32]
+    lib.ccr_shard_message_bytes.restype = sz
+    lib.ccr_search_shard.argtypes = [vp, vp, i32, i32, vp, vp, sz, i32, vp]
+    lib.ccr_shard_message_fill.argtypes = [vp, i32, i32, i32, vp, vp, i64, i64, vp]
+    lib.ccr_merge_shard_messages.argtypes = [vp, i64, i32, i32, i32, vp, vp, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is ctypes.c_int and name not in ("ccr_version", "ccr_index_dim"):

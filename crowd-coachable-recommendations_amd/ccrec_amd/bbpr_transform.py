@@ -105,14 +105,21 @@ class LowRankScore:
 
     def __add__(self, other):
         """+ a sparse prior (scipy.sparse, or an object carrying one in .c like rime_lite's LazySparseMatrix)."""
-        if other is None:
+        if other is None or _is_scalar_zero(other):   # rime_lite's datasets start with prior_score = 0 (dataset/base.py:217)
             return self
         c = other.c if hasattr(other, "c") else other
-        if not sps.issparse(c):
-            return NotImplemented
-        return LowRankPlusSparse(self, c)
+        if sps.issparse(c):
+            return LowRankPlusSparse(self, c)
+        if isinstance(c, (np.ndarray, torch.Tensor)) and tuple(c.shape) == tuple(self.shape):
+            # a dense addend: the sum is dense (the reference's ElementWiseExpression would materialise it as well)
+            return self.as_tensor() + torch.as_tensor(c, device=self.user.device)
+        return NotImplemented
 
     __radd__ = __add__
+
+
+def _is_scalar_zero(x):
+    return isinstance(x, (int, float, np.integer, np.floating)) and x == 0
 
 
 class LowRankPlusSparse:
@@ -138,10 +145,14 @@ class LowRankPlusSparse:
         return LowRankPlusSparse(self.low.T, self.prior.T.tocsr())
 
     def __add__(self, other):
+        if other is None or _is_scalar_zero(other):
+            return self
         c = other.c if hasattr(other, "c") else other
-        if not sps.issparse(c):
-            return NotImplemented
-        return LowRankPlusSparse(self.low, self.prior + sps.csr_matrix(c, dtype=np.float64))
+        if sps.issparse(c):
+            return LowRankPlusSparse(self.low, self.prior + sps.csr_matrix(c, dtype=np.float64))
+        if isinstance(c, (np.ndarray, torch.Tensor)) and tuple(c.shape) == tuple(self.shape):
+            return self.as_tensor() + torch.as_tensor(c, device=self.low.user.device)
+        return NotImplemented
 
     __radd__ = __add__
 

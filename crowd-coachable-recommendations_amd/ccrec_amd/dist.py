@@ -1,13 +1,25 @@
 """Multi-GPU search: one process per GPU, corpus row-sharded, queries replicated, per-shard fused
-top-k, then ONE exchange step -- a single all-gather of the packed [Q,k] (score, id) message over RCCL/xGMI --
-and a merge on every rank.  (The reference scores on GPU 0 only: SURVEY 2a/8e.)
+top-k, then ONE exchange step -- a single all-gather of the packed shard message over RCCL/xGMI --
+and a merge on every rank.  (The reference scores on GPU 0 only: SURVEY 2a/8e, scripts/ms_marco_eval.py:205-218.)
 
-shard_bounds() gives contiguous row blocks; ids are global (local row + global_row_offset), and
-scores are canonical (shard-independent), so the merged result is identical to a single-GPU search."""
+shard_bounds() gives contiguous row blocks; the message carries u32 LOCAL rows + the shard's row offset in its header
+(8 bytes per entry on the wire), scores are canonical (shard-independent), so the merged result is identical to a
+single-GPU search.
+
+No host round trip before the collective: the per-shard search is asynchronous (CCR_SEARCH_ASYNC) and leaves the number of
+queries it flagged in the message HEADER, on the stream.  After the all-gather every rank holds every rank's header, so all
+ranks take the same branch: lists final (the usual case: nothing flagged, or at most the 16 queries the search re-does on
+the stream by itself) -> merge; otherwise every rank completes its search (ccr_search_finish: a no-op where nothing was
+flagged) and ALL ranks repeat the all-gather -- the second collective is matched by construction."""
+import ctypes
+
 import torch
 import torch.distributed as dist
 
-from . import ops
+from . import _lib, ops
+
+HEADER_WORDS = _lib.SHARD_HEADER_BYTES // 4   # the header as int32 words: magic, n_flagged, k_valid, n_covered, row_offset (2), n_rows (2)
+PAD_ID = torch.iinfo(torch.int64).max           # padding slot (r, p) carries id PAD_ID - (r k + p): distinct, above every real id
 
 
 def shard_bounds(n_rows, world_size, rank):
@@ -17,82 +29,185 @@ def shard_bounds(n_rows, world_size, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-class TopkMessage:
-    """One rank's packed exchange message {scores [n_q,k] fp32 | ids [n_q,k] int64} and the gathered copy of all
-    ranks' messages: ONE all_gather_into_tensor moves both arrays (xGMI collectives are latency-bound at this size).
-    `scores` / `ids` are views of the send buffer (search writes them directly); after gather(), `all_scores` /
-    `all_ids` are rank-strided [R, n_q, k] views of the receive buffer, merged in place by ops.merge_topk."""
+class ShardMessage:
+    """One rank's packed exchange message (include/ccr_retrieval.h: ccr_shard_header | scores [n_q,k] fp32 | rows [n_q,k] u32
+    local) and the gathered copy of all ranks' messages: ONE all_gather_into_tensor moves everything (xGMI collectives are
+    latency-bound at this size).  `send` is what ccr_search_shard / ccr_shard_message_fill write; after gather(), `recv` holds
+    the R messages back to back for ccr_merge_shard_messages."""
 
     def __init__(self, n_q, k, device, world):
         self.n_q, self.k, self.world = int(n_q), int(k), int(world)
         n = self.n_q * self.k
-        self.ids_at = (n * 4 + 15) // 16 * 16            # byte offset of the id block (int64-aligned)
-        self.nbytes = (self.ids_at + n * 8 + 15) // 16 * 16
+        self.rows_at = (_lib.SHARD_HEADER_BYTES + n * 4 + 15) // 16 * 16
+        self.nbytes = ops.shard_message_bytes(self.n_q, self.k)
         self.send = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
-        self.recv = torch.empty(self.world * self.nbytes, dtype=torch.uint8, device=device)
-        self.scores = self.send[:n * 4].view(torch.float32).view(self.n_q, self.k)
-        self.ids = self.send[self.ids_at:self.ids_at + n * 8].view(torch.int64).view(self.n_q, self.k)
+        self.recv = torch.zeros(self.world * self.nbytes, dtype=torch.uint8, device=device)
+        hb = _lib.SHARD_HEADER_BYTES
+        self.header = self.send[:hb].view(torch.int32)
+        self.scores = self.send[hb:hb + n * 4].view(torch.float32).view(self.n_q, self.k)
+        self.rows = self.send[self.rows_at:self.rows_at + n * 4].view(torch.int32).view(self.n_q, self.k)   # u32 bit patterns
         per_rank = self.recv.view(self.world, self.nbytes)
-        self.all_scores = per_rank[:, :n * 4].view(torch.float32).view(self.world, self.n_q, self.k)
-        self.all_ids = per_rank[:, self.ids_at:self.ids_at + n * 8].view(torch.int64).view(self.world, self.n_q, self.k)
+        self.all_headers = per_rank[:, :hb].view(torch.int32)                                                  # [R, 8]
+        self.all_scores = per_rank[:, hb:hb + n * 4].view(torch.float32).view(self.world, self.n_q, self.k)
+        self.all_rows = per_rank[:, self.rows_at:self.rows_at + n * 4].view(torch.int32).view(self.world, self.n_q, self.k)
+        self.is_cuda = self.send.is_cuda
+        # headers land here (pinned) from a side stream, so reading them never waits for work enqueued after the collective
+        self.headers_host = torch.empty(self.world, HEADER_WORDS, dtype=torch.int32)
+        if self.is_cuda:
+            self.headers_host = self.headers_host.pin_memory()
 
+    # ---- writing
+    def fill(self, scores, ids, row_offset, n_rows):
+        """Ordinary results ([n_q, k_valid] scores, int64 GLOBAL ids, k_valid <= k) -> the send buffer.  Device tensors go
+        through ccr_shard_message_fill; host tensors (the gloo tests' CPU stand-in for an index) are laid out here."""
+        k_valid = scores.shape[1]
+        assert scores.shape[0] == self.n_q and k_valid <= self.k
+        if self.is_cuda:
+            ops.shard_message_fill(self.send, self.n_q, self.k, scores, ids, row_offset, n_rows)
+            return
+        hdr = _lib.ShardHeader(_lib.SHARD_MAGIC, 0, k_valid, 0, int(row_offset), int(n_rows))
+        self.header.copy_(torch.frombuffer(bytearray(bytes(hdr)), dtype=torch.int32))
+        self.scores.zero_()
+        self.rows.zero_()
+        local = ids.to(torch.int64) - int(row_offset)
+        assert k_valid == 0 or (int(local.min()) >= 0 and int(local.max()) < 2 ** 32), "ids outside the shard's row range"
+        self.scores[:, :k_valid] = scores
+        self.rows[:, :k_valid] = ((local + 2 ** 31) % 2 ** 32 - 2 ** 31).to(torch.int32)   # u32 bit patterns
+
+    # ---- exchange
     def gather(self, group=None):
         dist.all_gather_into_tensor(self.recv, self.send, group=group)
-        return self.all_scores, self.all_ids
 
     def gather_async(self, group=None):
-        """Start the all-gather on the communication stream and return its work handle: kernels enqueued afterwards on
-        the compute stream (the next step's pack and search) overlap with it; call work.wait() before merging
-        `all_scores` / `all_ids`.  The message must not be rewritten before that wait (double-buffer it)."""
+        """Start the all-gather on the communication stream and return its work handle: kernels enqueued afterwards on the
+        compute stream (the next step's pack and search) overlap with it.  The message must not be rewritten before the
+        exchange has been completed (double-buffer it)."""
         return dist.all_gather_into_tensor(self.recv, self.send, group=group, async_op=True)
 
+    # ---- reading
+    @staticmethod
+    def parse_headers(words):
+        """[R, 8] int32 host tensor -> list of dicts."""
+        out = []
+        for row in words.tolist():
+            raw = (ctypes.c_int32 * HEADER_WORDS)(*row)
+            h = _lib.ShardHeader.from_buffer_copy(raw)
+            assert h.magic == _lib.SHARD_MAGIC, f"not a shard message (magic {h.magic:#x})"
+            out.append({f: getattr(h, f) for f, _ in _lib.ShardHeader._fields_})
+        return out
 
-def all_gather_topk(scores, ids, group=None, message=None):
-    """[Q,k] per rank -> rank-strided ([R,Q,k], [R,Q,k]) views on every rank, one collective.
-    message: a reusable TopkMessage; when `scores` / `ids` already ARE its views nothing is copied."""
+    def decoded(self):
+        """The gathered messages as ([R, n_q, k] fp32 scores, [R, n_q, k] int64 global ids), padding slots as the merge kernel
+        sees them: (-inf, PAD_ID - (r k + p)).  Host-side view for tests and for merge hooks; the product path merges the
+        packed bytes directly (merge())."""
+        hdrs = self.parse_headers(self.all_headers.cpu())
+        scores = self.all_scores.clone()
+        ids = self.all_rows.to(torch.int64).bitwise_and(0xFFFFFFFF)
+        slot = torch.arange(self.k, dtype=torch.int64, device=ids.device)
+        for r, h in enumerate(hdrs):
+            ids[r] += h["row_offset"]
+            if h["k_valid"] < self.k:
+                scores[r, :, h["k_valid"]:] = -float("inf")
+                ids[r, :, h["k_valid"]:] = (PAD_ID - (r * self.k + slot))[h["k_valid"]:]
+        return scores, ids
+
+    def merge(self, merge_fn=None):
+        """Global ([n_q, k] fp32, [n_q, k] int64) from the gathered messages.  merge_fn: test hook taking decoded()."""
+        if merge_fn is not None:
+            return merge_fn(*self.decoded())
+        return ops.merge_shard_messages(self.recv, self.world, self.n_q, self.k)
+
+
+class ShardExchange:
+    """One exchange in flight: submit() starts it behind the (asynchronous) search, result() completes it.  Between the two the
+    caller may enqueue the next step's pack and search: nothing in here waits for work enqueued after the collective."""
+
+    def __init__(self, message, index=None, group=None, merge_fn=None):
+        self.message, self.index, self.group, self.merge_fn = message, index, group, merge_fn
+        self.work = self.event = None
+        self.repeated = False
+        self.headers = None
+
+    def submit(self):
+        m = self.message
+        self.work = m.gather_async(self.group)
+        if m.is_cuda and dist.get_backend(self.group) == "nccl":
+            # a side stream waits for the collective and copies the R headers to pinned memory; result() waits for THAT event
+            side = _side_stream(m.send.device)
+            with torch.cuda.stream(side):
+                self.work.wait()
+                m.headers_host.copy_(m.all_headers, non_blocking=True)
+                self.event = torch.cuda.Event()
+                self.event.record(side)
+        return self
+
+    def result(self):
+        m = self.message
+        if self.event is not None:
+            self.event.synchronize()                              # the collective + the header copy, nothing later
+            torch.cuda.current_stream(m.send.device).wait_event(self.event)   # the merge reads `recv` behind the collective
+            words = m.headers_host
+        else:
+            self.work.wait()
+            words = m.all_headers.cpu()
+        self.headers = m.parse_headers(words)
+        if self.index is not None and getattr(self.index, "_deferred", None) is not None:
+            self.index.finish()    # its own event is long complete: fills last_stats(); re-does flagged queries beyond the on-stream chunk
+        if any(h["n_flagged"] > h["n_covered"] for h in self.headers):
+            # some rank's lists were not final when they were exchanged.  Every rank sees the same headers, so every rank is
+            # here: the flagged ranks have completed their lists in finish() above, all ranks repeat the collective.
+            self.repeated = True
+            m.header[1:2].zero_()
+            m.gather(self.group)
+        return m.merge(self.merge_fn)
+
+
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = torch.device(device).index
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
+def submit_sharded_search(index, queries_bf16, k, group=None, message=None, merge_fn=None):
+    """Asynchronous per-shard search straight into a packed message + the all-gather behind it -> ShardExchange (call
+    .result() for the merged lists).  Needs k <= index.n_rows (sharded_search handles tiny shards)."""
     world = dist.get_world_size(group)
-    n_q, k = scores.shape
-    m = message if message is not None else TopkMessage(n_q, k, scores.device, world)
-    assert (m.n_q, m.k, m.world) == (n_q, k, world)
-    if scores.data_ptr() != m.scores.data_ptr():
-        m.scores.copy_(scores)
-    if ids.data_ptr() != m.ids.data_ptr():
-        m.ids.copy_(ids)
-    return m.gather(group)
-
-
-def merge_gathered(gs, gi, merge_fn=None):
-    """Merge gathered per-shard lists.  merge_fn defaults to the HIP kernel (ops.merge_topk)."""
-    return (merge_fn or ops.merge_topk)(gs, gi)
+    if message is None:
+        message = ShardMessage(queries_bf16.shape[0], k, queries_bf16.device, world)
+    assert (message.n_q, message.k, message.world) == (queries_bf16.shape[0], k, world)
+    index.search_shard(queries_bf16, k, message.send, defer=True)
+    return ShardExchange(message, index, group, merge_fn).submit()
 
 
 def sharded_search(index, queries_bf16, k, group=None, merge_fn=None, search_fn=None, message=None, block=None, n_total=None):
     """index: this rank's CorpusIndex (built with global_row_offset = its shard's first row).
-    message: optional reusable TopkMessage(n_q, k, device, world) -- the search then writes straight into it.
+    message: optional reusable ShardMessage(n_q, k, device, world) -- the search then writes straight into it.
     block: (ptr, idx) CSR of per-query blocked GLOBAL row ids (the same on every rank; each shard applies its own part).
-    n_total: rows of the whole corpus; k is clamped to it (a corpus smaller than k cannot fill k ranks)."""
+    n_total: rows of the whole corpus; k is clamped to it (a corpus smaller than k cannot fill k ranks).
+    search_fn / merge_fn: test hooks (CPU stand-ins for the per-shard search and the merge)."""
     if n_total is not None:
         k = min(k, int(n_total))
     k_local = min(k, index.n_rows)
     multi = dist.is_initialized() and dist.get_world_size(group) > 1
+    if not multi:
+        if block is not None and search_fn is None:
+            return index.search_blocked(queries_bf16, k_local, block[0], block[1])
+        return (search_fn or index.search)(queries_bf16, k_local)
+    world = dist.get_world_size(group)
+    if block is None and search_fn is None and k_local == k:   # the kernel writes the exchange message itself, no host round trip
+        return submit_sharded_search(index, queries_bf16, k, group, message, merge_fn).result()
+    # blocked lists, tiny shards (k_local < k: the message pads with (-inf, distinct ids), so every output slot is written even
+    # when the whole corpus holds fewer than k rows -- pass n_total to clamp k instead) and test hooks: ordinary results -> message
     if block is not None and search_fn is None:
         scores, ids = index.search_blocked(queries_bf16, k_local, block[0], block[1])
-    elif multi and search_fn is None and k_local == k:   # the kernel writes the exchange message itself
-        if message is None:
-            message = TopkMessage(queries_bf16.shape[0], k, queries_bf16.device, dist.get_world_size(group))
-        scores, ids = index.search(queries_bf16, k, out=(message.scores, message.ids))
     else:
         scores, ids = (search_fn or index.search)(queries_bf16, k_local)
-    if not multi:
-        return scores, ids
-    if k_local < k:
-        # tiny shard: pad so that every rank gathers the same shape.  Pads score -inf and carry DISTINCT ids (per rank and
-        # slot), so the merge's rank-by-counting stays a permutation and every output slot is written even when the whole
-        # corpus holds fewer than k rows (the tail is then (-inf, pad id) -- pass n_total to clamp k instead).
-        pad = k - k_local
-        rank = dist.get_rank(group)
-        scores = torch.cat([scores, torch.full((scores.shape[0], pad), -float("inf"), device=scores.device)], 1)
-        pad_ids = torch.iinfo(torch.int64).max - (rank * k + torch.arange(pad, dtype=torch.int64, device=ids.device))
-        ids = torch.cat([ids, pad_ids.expand(ids.shape[0], pad)], 1)
-    gs, gi = all_gather_topk(scores, ids, group, message)
-    return merge_gathered(gs, gi, merge_fn)
+    if message is None:
+        message = ShardMessage(scores.shape[0], k, scores.device, world)
+    lo = index.offset
+    message.fill(scores, ids, lo, index.n_rows)
+    return ShardExchange(message, None, group, merge_fn).submit().result()

@@ -147,6 +147,7 @@ class CorpusIndex:
         self._h = ctypes.c_void_p()
         self._ws = None
         self._ws_need = {}
+        self._deferred = None
         with _on(self.corpus):
             if norm_bounds is None:
                 _lib.check(self._lib.ccr_index_create(_ptr(self.corpus), self.n_rows, self.dim, self.offset,
@@ -161,16 +162,25 @@ class CorpusIndex:
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:
+            # a deferred search nobody finished: ccr_index_destroy waits for that search's own event before the index's
+            # arrays go back to the block cache (the workspace tensor is released after this call returns)
             self._lib.ccr_index_destroy(h)
+
+    def _grow_ws(self, need):
+        """The workspace, at least `need` bytes.  A deferred search still owns the current one: complete it before the
+        tensor is replaced (or handed to another search)."""
+        if getattr(self, "_deferred", None) is not None:
+            self.finish()
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.corpus.device)
+        return self._ws
 
     def _workspace(self, n_q, k):
         need = self._ws_need.get((n_q, k))
         if need is None:   # the planner runs three times in there: once per (n_q, k) is enough
             need = self._ws_need[(n_q, k)] = int(self._lib.ccr_search_workspace_bytes(self._h, n_q, k))
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = None
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.corpus.device)
-        return self._ws
+        return self._grow_ws(need)
 
     def search(self, queries_bf16, k, flags=_lib.SEARCH_DEFAULT, out=None, defer=False):
         """-> (scores [n_q, k] fp32, ids [n_q, k] int64 global), canonical order.
@@ -206,10 +216,31 @@ class CorpusIndex:
         return scores, ids
 
     def finish(self):
-        """Complete a deferred search: synchronises its stream, re-does flagged queries beyond the on-stream chunk."""
+        """Complete a deferred search: waits for THAT search's stream work (its own event -- not for work enqueued after it),
+        fills last_stats(), and re-does flagged queries beyond the on-stream chunk (only then does it synchronise the stream)."""
         with _on(self.corpus):
             _lib.check(self._lib.ccr_search_finish(self._h), "ccr_search_finish")
         self._deferred = None
+
+    def search_shard(self, queries_bf16, k, message, defer=False, flags=_lib.SEARCH_DEFAULT):
+        """ccr_search_shard: the search writes the packed shard message (header | scores | u32 local rows) that ONE all-gather
+        moves (dist.ShardMessage.send).  `message`: uint8 cuda tensor of ccr_shard_message_bytes(n_q, k).  defer=True: no host
+        synchronisation; the header's n_flagged is written on the stream, finish() completes the search."""
+        q = queries_bf16
+        assert q.is_cuda and q.dtype == torch.bfloat16 and q.dim() == 2 and q.shape[1] == self.dim
+        q = q.contiguous()
+        n_q = q.shape[0]
+        assert 0 < n_q <= MAX_QUERIES_PER_SEARCH and 1 <= k <= self.n_rows
+        assert message.is_cuda and message.dtype == torch.uint8 and message.is_contiguous() and message.device == q.device
+        assert message.numel() >= shard_message_bytes(n_q, k)
+        ws = self._workspace(n_q, k)
+        if defer:
+            flags = int(flags) | _lib.SEARCH_ASYNC
+            self._deferred = (q, message)
+        with _on(q):
+            _lib.check(self._lib.ccr_search_shard(self._h, _ptr(q), n_q, k, _ptr(message), _ptr(ws), ws.numel(), int(flags),
+                                                  _stream(q)), "ccr_search_shard")
+        return message
 
     def _special_args(self, queries_bf16, ptr, idx):
         q = queries_bf16
@@ -222,10 +253,7 @@ class CorpusIndex:
         return q, ptr, idx
 
     def _special_ws(self, need):
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = None
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.corpus.device)
-        return self._ws
+        return self._grow_ws(need)
 
     def search_blocked(self, queries_bf16, k, block_ptr, block_idx, flags=_lib.SEARCH_DEFAULT):
         """Search with per-query blocked GLOBAL ids (CSR: block_ptr [n_q + 1] on the host, block_idx ascending and unique
@@ -321,6 +349,40 @@ def merge_topk(scores, ids):
     with _on(scores):
         _lib.check(lib.ccr_merge_topk_strided(_ptr(scores), _ptr(ids), scores.stride(0), ids.stride(0), R, n_q, k, _ptr(os_),
                                               _ptr(oi), _stream(scores)), "ccr_merge_topk")
+    return os_, oi
+
+
+def shard_message_bytes(n_q, k):
+    """Bytes of one packed shard message (ccr_shard_message_bytes): 32-byte header | fp32 scores | u32 local rows."""
+    rows_at = (_lib.SHARD_HEADER_BYTES + n_q * k * 4 + 15) // 16 * 16
+    return (rows_at + n_q * k * 4 + 15) // 16 * 16
+
+
+def shard_message_fill(message, n_q, k, scores, ids, row_offset, n_rows):
+    """Ordinary results ([n_q, k_valid] fp32 scores, int64 GLOBAL ids; k_valid <= k) -> packed shard message."""
+    lib = require_gpu()
+    k_valid = scores.shape[1] if scores is not None and scores.dim() == 2 else 0
+    assert message.is_cuda and message.dtype == torch.uint8 and message.numel() >= shard_message_bytes(n_q, k)
+    if k_valid:
+        scores, ids = scores.contiguous(), ids.contiguous()
+        assert scores.dtype == torch.float32 and ids.dtype == torch.int64 and scores.shape == ids.shape == (n_q, k_valid)
+    with _on(message):
+        _lib.check(lib.ccr_shard_message_fill(_ptr(message), n_q, k, k_valid, _ptr(scores) if k_valid else None,
+                                              _ptr(ids) if k_valid else None, int(row_offset), int(n_rows), _stream(message)),
+                   "ccr_shard_message_fill")
+    return message
+
+
+def merge_shard_messages(gathered, world, n_q, k):
+    """R gathered shard messages (uint8 [R * stride]) -> global ([n_q, k] fp32, [n_q, k] int64 global ids)."""
+    lib = require_gpu()
+    assert gathered.is_cuda and gathered.dtype == torch.uint8 and gathered.is_contiguous() and gathered.numel() % world == 0
+    stride = gathered.numel() // world
+    os_ = torch.empty(n_q, k, dtype=torch.float32, device=gathered.device)
+    oi = torch.empty(n_q, k, dtype=torch.int64, device=gathered.device)
+    with _on(gathered):
+        _lib.check(lib.ccr_merge_shard_messages(_ptr(gathered), stride, world, n_q, k, _ptr(os_), _ptr(oi), _stream(gathered)),
+                   "ccr_merge_shard_messages")
     return os_, oi
 
 

@@ -329,17 +329,25 @@ namespace {
 constexpr int SLAB_SLOTS = 1024, SLAB_SLOT_BYTES = 256, MAX_DEVICES = 64;
 struct Slab {
     char *base = nullptr;
+    char *host = nullptr;   // pinned host twin (one 64-byte line per slot): where an asynchronous search leaves its flag count
     std::vector<int> free_slots;
 };
+constexpr int SLAB_HOST_BYTES = 64;
 std::mutex g_slab_mutex;
 Slab g_slabs[MAX_DEVICES];
 
-int slab_take(int device, uint32_t **out) {
+int slab_take(int device, uint32_t **out, volatile uint32_t **host_out) {
     std::lock_guard<std::mutex> lock(g_slab_mutex);
     CCR_REQUIRE(device >= 0 && device < MAX_DEVICES, "device ordinal %d out of range", device);
     Slab &sl = g_slabs[device];
     if (!sl.base) {
         CCR_HIP_CHECK(hipMalloc((void **)&sl.base, (size_t)SLAB_SLOTS * SLAB_SLOT_BYTES));
+        if (hipHostMalloc((void **)&sl.host, (size_t)SLAB_SLOTS * SLAB_HOST_BYTES, hipHostMallocDefault) != hipSuccess) {
+            (void)hipFree(sl.base);
+            sl.base = nullptr;
+            set_error("ccr_index_create: hipHostMalloc of the pinned flag lines failed");
+            return CCR_ERR_HIP;
+        }
         for (int i = SLAB_SLOTS - 1; i >= 0; --i) sl.free_slots.push_back(i);
     }
     if (sl.free_slots.empty()) {
@@ -347,6 +355,7 @@ int slab_take(int device, uint32_t **out) {
         return CCR_ERR_INVALID;
     }
     *out = reinterpret_cast<uint32_t *>(sl.base + (size_t)sl.free_slots.back() * SLAB_SLOT_BYTES);
+    *host_out = reinterpret_cast<volatile uint32_t *>(sl.host + (size_t)sl.free_slots.back() * SLAB_HOST_BYTES);
     sl.free_slots.pop_back();
     return CCR_OK;
 }
@@ -426,13 +435,13 @@ static int index_create_impl(const uint16_t *D_bf16, int64_t n_rows, int dim, in
     ix->D = D_bf16;
     ix->n_rows = n_rows;
     ix->dim = dim;
-    ix->offset = global_row_offset;
+    ix->offset = ix->id_out = global_row_offset;
     ix->knobs = read_knobs();
     // on any failure below the partially built index is released before returning
     auto build = [&]() -> int {
         CCR_HIP_CHECK(hipGetDevice(&ix->device));
         CCR_HIP_CHECK(hipDeviceGetAttribute(&ix->num_cu, hipDeviceAttributeMultiprocessorCount, ix->device));
-        int rc = slab_take(ix->device, &ix->dmax_bits);
+        int rc = slab_take(ix->device, &ix->dmax_bits, &ix->host_flags);
         if (rc != CCR_OK) return rc;
         const int64_t tiles = (n_rows + TILE_DOCS - 1) / TILE_DOCS;
         void *tn = nullptr;
@@ -479,13 +488,17 @@ extern "C" int ccr_index_create_with_norms(const uint16_t *D_bf16, int64_t n_row
 
 extern "C" int ccr_index_destroy(ccr_index *ix) {
     if (!ix) return CCR_OK;
+    // an asynchronous search the caller never finished: its kernels still read the index's arrays -- wait for THAT search (not
+    // for the stream) before the blocks go back to the cache; queries it flagged beyond the on-stream chunk stay un-redone
+    if (ix->pending.active && ix->have_events) (void)hipEventSynchronize(ix->ev[7]);
+    ix->pending.active = false;
     // a slot / block handed back may be rewritten by the next index's create on ITS stream; the caller destroys an index only
     // after the work that uses it has completed (the same contract as for the borrowed corpus)
     slab_give(ix->device, ix->dmax_bits);
     block_give(ix->device, ix->tile_norm, ix->tile_bytes);
     block_give(ix->device, ix->row_norm_own, ix->row_bytes);
     if (ix->have_events)
-        for (int i = 0; i < 7; ++i)
+        for (int i = 0; i < 8; ++i)
             if (ix->ev[i]) (void)hipEventDestroy(ix->ev[i]);
     delete ix;
     return CCR_OK;
@@ -519,7 +532,7 @@ static int dense_for_list(const ccr_index *ix, const uint16_t *Q, const uint32_t
         int rc = launch_dense_scores(ix->D, ix->n_rows, ix->dim, Q, d_qlist ? d_qlist + lo : nullptr, q_begin + lo, m, nullptr,
                                      scratch, s);
         if (rc != CCR_OK) return rc;
-        rc = launch_dense_select(scratch, ix->n_rows, k, d_qlist ? d_qlist + lo : nullptr, q_begin + lo, m, nullptr, ix->offset,
+        rc = launch_dense_select(scratch, ix->n_rows, k, d_qlist ? d_qlist + lo : nullptr, q_begin + lo, m, nullptr, ix->id_out,
                                  out_scores, out_ids, s);
         if (rc != CCR_OK) return rc;
     }
@@ -562,7 +575,7 @@ static int margin_for_rows(const ccr_index *ix, const uint16_t *Qc, const float 
         int rc = (ix->knobs.mfma16 >= 0 ? ix->knobs.mfma16 : CCR_MFMA16_DEFAULT) ? launch_gemm16_store(g, grid, s) : launch_gemm_store(g, grid, s);
         if (rc != CCR_OK) return rc;
         rc = launch_margin_select(scratch, pitch, ix->n_rows, k, ix->dim, g.Q, ix->D, ix->tile_norm, ix->row_norm, ix->dmax_bits,
-                                  hint ? hint + lo : nullptr, out_rows ? out_rows + lo : nullptr, q_begin + lo, m, ix->offset, out_scores, out_ids, flag_count, flag_list, s);
+                                  hint ? hint + lo : nullptr, out_rows ? out_rows + lo : nullptr, q_begin + lo, m, ix->id_out, out_scores, out_ids, flag_count, flag_list, s);
         if (rc != CCR_OK) return rc;
     }
     return CCR_OK;
@@ -623,8 +636,16 @@ static int search_complete(ccr_index *ix) {
         uint32_t nflag, pad;
         unsigned long long ncand;
     } host;
-    CCR_HIP_CHECK(hipMemcpyAsync(&host, ws + p.off_flag, sizeof(host), hipMemcpyDeviceToHost, s));
-    CCR_HIP_CHECK(hipStreamSynchronize(s));
+    if (was_async) {
+        // the search itself copied its flag line to pinned host memory and recorded ev[7] behind it: wait for THAT event, not for
+        // the stream -- work enqueued after the search (the next step's pack and search, the exchange) is not waited for
+        CCR_HIP_CHECK(hipEventSynchronize(ix->ev[7]));
+        host.nflag = ix->host_flags[0];
+        host.ncand = *reinterpret_cast<volatile unsigned long long *>(ix->host_flags + 2);
+    } else {
+        CCR_HIP_CHECK(hipMemcpyAsync(&host, ws + p.off_flag, sizeof(host), hipMemcpyDeviceToHost, s));
+        CCR_HIP_CHECK(hipStreamSynchronize(s));
+    }
     {
         float a = 0, b = 0;
         CCR_HIP_CHECK(hipEventElapsedTime(&ix->stats.ms_sample, ix->ev[1], ix->ev[2]));
@@ -641,6 +662,7 @@ static int search_complete(ccr_index *ix) {
     ix->stats.ranges = p.ranges;
     ix->stats.cap = p.cap;
     ix->stats.sublists = p.sublists;
+    ix->stats.main_launches = 1 + (p.item_a ? 1 : 0) + (p.item_b ? 1 : 0);
     ix->stats.n_candidates = (int64_t)host.ncand;
     const int begin = was_async ? std::min<int>(FALLBACK_ROWS, (int)host.nflag) : 0;   // the on-stream chunk took these
     ix->stats.n_dense = begin;
@@ -754,7 +776,7 @@ static int search_complete(ccr_index *ix) {
                 rc = p.mfma16 ? launch_gemm16_filter(g, p.grid, s) : launch_gemm_filter(g, p.grid, s);
                 if (rc != CCR_OK) return rc;
                 rc = launch_select_rescore(cand, cnt, nsub_all, p.sublists, n_cur, pad2, lay2, k, p.rescore_cap, p.select_compact, ix->n_rows,
-                                           delta2, ix->tile_norm, ix->row_norm, ix->dmax_bits, Q2, ix->D, ix->dim, ix->offset, pd.out_scores, pd.out_ids, flag2,
+                                           delta2, ix->tile_norm, ix->row_norm, ix->dmax_bits, Q2, ix->D, ix->dim, ix->id_out, pd.out_scores, pd.out_ids, flag2,
                                            flag2 + 16, nullptr, cur, s);
                 if (rc != CCR_OK) return rc;
                 ix->stats.n_retried += n_cur;
@@ -839,8 +861,10 @@ extern "C" int ccr_search_finish(ccr_index *ix) {
     return search_complete(ix);
 }
 
-extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k, float *out_scores, int64_t *out_ids,
-                          void *workspace, size_t ws_bytes, int flags, void *stream) {
+// id_out: what the result ids are (ix->offset: int64 global ids; ID_LOCAL_U32: u32 local rows of a shard message).
+// flagged_out (device, may be null; zero on entry): an ASYNCHRONOUS search leaves the select stage's flag count there, on the stream.
+static int search_impl(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k, float *out_scores, int64_t *out_ids, int64_t id_out,
+                       uint32_t *flagged_out, void *workspace, size_t ws_bytes, int flags, void *stream) {
     CCR_REQUIRE(ix && Q_bf16 && out_scores && out_ids, "ccr_search: null pointer");
     CCR_REQUIRE(n_q >= 0, "ccr_search: n_q=%d", n_q);
     CCR_REQUIRE(k >= 1 && k <= MAX_K && (int64_t)k <= ix->n_rows, "ccr_search: k=%d must be in [1, min(n_rows=%lld, %d)]", k,
@@ -850,6 +874,7 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
     memset(&ix->stats, 0, sizeof(ix->stats));
     if (n_q == 0) return CCR_OK;
     hipStream_t s = (hipStream_t)stream;
+    ix->id_out = id_out;
     const bool async = (flags & CCR_SEARCH_ASYNC) != 0;
     const int plan_flags = flags & ~CCR_SEARCH_ASYNC;
     if (!(ix->plan_nq == n_q && ix->plan_k == k && ix->plan_flags == plan_flags)) {
@@ -867,7 +892,7 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
     float *dense_scratch = (float *)(ws + p.off_dense);
 
     if (!ix->have_events) {   // phase-boundary events of the statistics, created on first use
-        for (int i = 0; i < 7; ++i) CCR_HIP_CHECK(hipEventCreate(&ix->ev[i]));
+        for (int i = 0; i < 8; ++i) CCR_HIP_CHECK(hipEventCreate(&ix->ev[i]));
         ix->have_events = true;
     }
     CCR_HIP_CHECK(hipEventRecord(ix->ev[0], s));
@@ -988,7 +1013,7 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
 
     rc = launch_select_rescore(cand, cnt, p.ranges * p.sublists, p.sublists, n_q, p.nq_pad, p.cand, k, p.rescore_cap, p.select_compact, ix->n_rows, delta,
                                ix->tile_norm, ix->row_norm, ix->dmax_bits, Q_bf16, ix->D, ix->dim,
-                               ix->offset, out_scores, out_ids, flag_count, flag_list, stat_cand, nullptr, s);
+                               ix->id_out, out_scores, out_ids, flag_count, flag_list, stat_cand, nullptr, s);
     if (rc != CCR_OK) return rc;
     CCR_HIP_CHECK(hipEventRecord(ix->ev[5], s));
 
@@ -1005,14 +1030,54 @@ extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k,
         // ccr_search_finish() covers the rest -- more than that many flagged queries means mass ties or adversarial data.
         rc = launch_dense_scores(ix->D, ix->n_rows, ix->dim, Q_bf16, flag_list, 0, FALLBACK_ROWS, flag_count, dense_scratch, s);
         if (rc != CCR_OK) return rc;
-        rc = launch_dense_select(dense_scratch, ix->n_rows, k, flag_list, 0, FALLBACK_ROWS, flag_count, ix->offset, out_scores,
+        rc = launch_dense_select(dense_scratch, ix->n_rows, k, flag_list, 0, FALLBACK_ROWS, flag_count, ix->id_out, out_scores,
                                  out_ids, s);
         if (rc != CCR_OK) return rc;
+        // the shard message's header learns the count on the stream: the exchange can be enqueued without the host knowing it
+        if (flagged_out) CCR_HIP_CHECK(hipMemcpyAsync(flagged_out, flag_count, 4, hipMemcpyDeviceToDevice, s));
+        CCR_HIP_CHECK(hipMemcpyAsync((void *)ix->host_flags, flag_count, 16, hipMemcpyDeviceToHost, s));   // pinned: stays asynchronous
+        CCR_HIP_CHECK(hipEventRecord(ix->ev[7], s));
         ix->pending.active = true;
         return CCR_OK;
     }
     ix->pending.active = false;
-    return search_complete(ix);
+    return search_complete(ix);   // (synchronous form: every flagged query has been re-done, the header's zero stands)
+}
+
+extern "C" int ccr_search(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k, float *out_scores, int64_t *out_ids,
+                          void *workspace, size_t ws_bytes, int flags, void *stream) {
+    CCR_REQUIRE(ix, "ccr_search: null index");
+    return search_impl(ix, Q_bf16, n_q, k, out_scores, out_ids, ix->offset, nullptr, workspace, ws_bytes, flags, stream);
+}
+
+// ------------------------------------------------------------------ packed shard message (row-sharded multi-GPU search)
+static inline size_t shard_rows_at(int n_q, int k) { return (sizeof(ccr_shard_header) + (size_t)n_q * k * 4 + 15) / 16 * 16; }
+
+extern "C" size_t ccr_shard_message_bytes(int n_q, int k) {
+    if (n_q < 0 || k < 1) return 0;
+    return (shard_rows_at(n_q, k) + (size_t)n_q * k * 4 + 15) / 16 * 16;
+}
+
+extern "C" int ccr_search_shard(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k, void *message, void *workspace, size_t ws_bytes,
+                                int flags, void *stream) {
+    CCR_REQUIRE(ix && message, "ccr_search_shard: null pointer");
+    CCR_REQUIRE((uintptr_t)message % 16 == 0, "ccr_search_shard: message must be 16-byte aligned");
+    CCR_REQUIRE(n_q >= 0 && k >= 1, "ccr_search_shard: bad shape n_q=%d k=%d", n_q, k);
+    hipStream_t s = (hipStream_t)stream;
+    ccr_shard_header h;
+    memset(&h, 0, sizeof(h));
+    h.magic = CCR_SHARD_MAGIC;
+    h.k_valid = (uint32_t)k;
+    h.n_covered = (flags & CCR_SEARCH_ASYNC) ? (uint32_t)FALLBACK_ROWS : 0u;
+    h.row_offset = ix->offset;
+    h.n_rows = ix->n_rows;
+    int rc = launch_shard_header(h, message, s);   // by value through a kernel: no host buffer, no synchronisation
+    if (rc != CCR_OK) return rc;
+    if (n_q == 0) return CCR_OK;
+    char *m = (char *)message;
+    uint32_t *flagged = reinterpret_cast<uint32_t *>(m + offsetof(ccr_shard_header, n_flagged));
+    return search_impl(ix, Q_bf16, n_q, k, reinterpret_cast<float *>(m + sizeof(ccr_shard_header)),
+                       reinterpret_cast<int64_t *>(m + shard_rows_at(n_q, k)), ID_LOCAL_U32, flagged, workspace, ws_bytes, flags, stream);
 }
 
 // ------------------------------------------------------------------ dense score matrix

@@ -142,6 +142,16 @@ __device__ __forceinline__ float orderable_to_f32(uint32_t u) {
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
 }
 
+// Result ids are written as int64 global ids (row + id_offset) or, for a packed shard message (ccr_search_shard), as the u32 LOCAL row:
+// the exchange then moves 8 instead of 12 bytes per entry and the merge adds the shard's row offset from the message header.
+constexpr int64_t ID_LOCAL_U32 = INT64_MIN;
+__device__ __forceinline__ void store_id(int64_t *out_ids, int64_t pos, int64_t id_offset, uint32_t row) {
+    if (id_offset == ID_LOCAL_U32)
+        reinterpret_cast<uint32_t *>(out_ids)[pos] = row;
+    else
+        out_ids[pos] = id_offset + (int64_t)row;
+}
+
 // worst-case |mfma fp32 score - exact| <= gamma(dim) * ||q|| * ||d||  (any summation order, each
 // fp32 add within 2^-23 relative: see DESIGN.md "filter margins")
 __host__ __device__ __forceinline__ float mfma_gamma(int dim) { return (float)dim * 1.1920929e-7f * 1.02f; }

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void dense_select_kernel(const float *__restri
     for (int i = tid; i < k; i += blockDim.x) {
         const unsigned long long key = s_keys[i];
         out_scores[orow * k + i] = key_score(key);
-        out_ids[orow * k + i] = id_offset + (int64_t)key_idx(key);
+        store_id(out_ids, orow * k + i, id_offset, key_idx(key));
     }
 }
 
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(1024) void margin_select_kernel(const float *__rest
     for (int i = tid; i < k; i += blockDim.x) {
         const unsigned long long key = s_keys[i];
         out_scores[orow * k + i] = key_score(key);
-        out_ids[orow * k + i] = id_offset + (int64_t)key_idx(key);
+        store_id(out_ids, orow * k + i, id_offset, key_idx(key));
     }
 }
 

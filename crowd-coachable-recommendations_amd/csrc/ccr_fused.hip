@@ -1234,7 +1234,10 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
         // piece j of this thread belongs to candidate (tid + j * THREADS) / lpr; only its row pointer is kept.  Eight named
         // values, not an array: hipcc leaves a uint4[8] in scratch memory under the 128-register budget of 1 024 threads.
 #define CCR_PIECES(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
-        const char *Dcol = Dbytes + col;
+        // address column: a column past the row end (dim = 32 under a 128-byte slice) reads column 0 -- the FIRST load too, not only
+        // the refills below: the last corpus row may end exactly at the end of the caller's allocation
+        const int acol = col < row_bytes ? col : 0;
+        const char *Dcol = Dbytes + acol;
         const int npiece = ncoll * lpr;
 #define CCR_DECL(j)                                                                                              \
     const int idx##j = tid + j * THREADS;                                                                        \
@@ -1252,7 +1255,7 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
 #undef CCR_PUT
             __syncthreads();
             {   // next slice: in flight during the fp64 chains below
-                const int kn = (k0 + SB + col < row_bytes) ? k0 + SB : -col;
+                const int kn = (k0 + SB + col < row_bytes) ? k0 + SB : -acol;
 #define CCR_GET(j) pre##j = *reinterpret_cast<const uint4 *>(src##j + kn);
                 CCR_PIECES(CCR_GET)
 #undef CCR_GET
@@ -1300,7 +1303,7 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
     for (int i = tid; i < k; i += blockDim.x) {
         const unsigned long long key = s_keys[i];
         out_scores[orow * k + i] = key_score(key);
-        out_ids[orow * k + i] = id_offset + (int64_t)key_idx(key);
+        store_id(out_ids, orow * k + i, id_offset, key_idx(key));
     }
 }
 

@@ -29,6 +29,7 @@ int launch_gemm_gmax(const GemmArgs &a, int grid, hipStream_t s);
 int launch_gemm_store(const GemmArgs &a, int grid, hipStream_t s);
 int launch_gemm16_filter(const GemmArgs &a, int grid, hipStream_t s);
 int launch_gemm16_store(const GemmArgs &a, int grid, hipStream_t s);
+int launch_shard_header(const ccr_shard_header &h, void *message, hipStream_t s);   // ccr_merge.hip: the 32-byte header, by value
 int ensure_dynamic_lds(const void *kernel, size_t lds);   // per (kernel, device) opt-in to > 64 KiB of dynamic LDS
 // tile_bits (optional): bit patterns of the largest row norm of every 256-row tile, max-accumulated (zeroed by the caller)
 int launch_row_norms_bf16(const uint16_t *X, int64_t rows, int dim, float *norms, uint32_t *max_bits, uint32_t *tile_bits,
@@ -79,6 +80,7 @@ struct ccr_index {
     int64_t n_rows;
     int dim;
     int64_t offset;
+    int64_t id_out;       // what the running search writes as ids: `offset` (int64 global ids) or ID_LOCAL_U32 (u32 local rows of a shard message)
     uint32_t *dmax_bits;  // device: bits of the max row norm (a slot of the per-device slab)
     float *tile_norm;     // device [ceil(n_rows / 256)]: bound of the row norms of each 256-row tile (per-device block cache)
     size_t tile_bytes;
@@ -89,7 +91,8 @@ struct ccr_index {
     int num_cu;
     int device;
     ccr::Knobs knobs;
-    hipEvent_t ev[7];     // phase boundaries of the last search
+    hipEvent_t ev[8];     // phase boundaries of the last search; ev[7]: end of an asynchronous search's stream work (flag line copied)
+    volatile uint32_t *host_flags;   // pinned host line {flag count, -, candidate count (8 B)} of the per-device slab
     ccr::Plan plan;       // plan of the last search and its key (the planner simulates item assignments: ~25 us)
     int plan_nq, plan_k, plan_flags;
     ccr_search_stats stats;

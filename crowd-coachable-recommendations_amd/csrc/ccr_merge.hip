@@ -1,5 +1,7 @@
 // ccr_merge.hip -- shard merge after the RCCL all-gather (the block_dict post-filter lives in ccr_special.hip).
-#include "ccr_common.h"
+#include <string.h>
+
+#include "ccr_index.h"
 
 namespace ccr {
 
@@ -86,9 +88,175 @@ __global__ __launch_bounds__(1024) void merge_topk_lds_kernel(const float *__res
     }
 }
 
+// ---- packed shard messages (include/ccr_retrieval.h: header | scores [n_q][k] fp32 | rows [n_q][k] u32 local)
+__host__ __device__ __forceinline__ size_t shard_rows_at(int n_q, int k) { return (sizeof(ccr_shard_header) + (size_t)n_q * k * 4 + 15) / 16 * 16; }
+
+__global__ void shard_header_kernel(ccr_shard_header h, ccr_shard_header *dst) { *dst = h; }
+
+int launch_shard_header(const ccr_shard_header &h, void *message, hipStream_t s) {
+    hipLaunchKernelGGL(shard_header_kernel, dim3(1), dim3(1), 0, s, h, reinterpret_cast<ccr_shard_header *>(message));
+    CCR_LAUNCH_CHECK();
+    return CCR_OK;
+}
+
+// entry (r, q, p) of the gathered messages as (score, global id); padding slots are (-inf, a distinct id above every real one)
+struct ShardSrc {
+    const char *base;
+    int64_t stride;
+    size_t rows_at;
+    int k;
+};
+__device__ __forceinline__ void shard_entry(const ShardSrc &m, int r, int q, int p, float &s, int64_t &id) {
+    const char *msg = m.base + (int64_t)r * m.stride;
+    const ccr_shard_header *h = reinterpret_cast<const ccr_shard_header *>(msg);
+    if (p < (int)h->k_valid) {
+        s = reinterpret_cast<const float *>(msg + sizeof(ccr_shard_header))[(int64_t)q * m.k + p];
+        id = h->row_offset + (int64_t) reinterpret_cast<const uint32_t *>(msg + m.rows_at)[(int64_t)q * m.k + p];
+    } else {
+        s = -INFINITY;
+        id = INT64_MAX - ((int64_t)r * m.k + p);
+    }
+}
+
+// one workgroup per query, the R lists staged in LDS (R * k * 12 bytes), rank by counting as above
+__global__ __launch_bounds__(1024) void merge_messages_lds_kernel(ShardSrc m, int R, float *__restrict__ out_scores,
+                                                                int64_t *__restrict__ out_ids) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    const int k = m.k, n = R * k;
+    int64_t *s_id = reinterpret_cast<int64_t *>(sm);
+    float *s_sc = reinterpret_cast<float *>(sm + (size_t)n * 8);
+    const int q = blockIdx.x;
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        const int r = e / k, p = e - r * k;
+        shard_entry(m, r, q, p, s_sc[e], s_id[e]);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        const int r = e / k, p = e - r * k;
+        const float s = s_sc[e];
+        const int64_t id = s_id[e];
+        int rank = p;
+        for (int o = 0; o < R && rank < k; ++o) {
+            if (o == r) continue;
+            const float *os = s_sc + o * k;
+            const int64_t *oi = s_id + o * k;
+            int lo = 0, hi = k;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const float so = os[mid];
+                if (so > s || (so == s && oi[mid] < id))
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            rank += lo;
+        }
+        if (rank < k) {
+            out_scores[(int64_t)q * k + rank] = s;
+            out_ids[(int64_t)q * k + rank] = id;
+        }
+    }
+}
+
+// lists too long for the LDS: every probe decodes its entry from the messages.  grid = (ceil(R*k/256), n_q)
+__global__ __launch_bounds__(256) void merge_messages_kernel(ShardSrc m, int R, int n_q, float *__restrict__ out_scores,
+                                                           int64_t *__restrict__ out_ids) {
+    const int k = m.k, q = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= R * k || q >= n_q) return;
+    const int r = e / k, p = e - r * k;
+    float s;
+    int64_t id;
+    shard_entry(m, r, q, p, s, id);
+    int rank = p;
+    for (int o = 0; o < R && rank < k; ++o) {
+        if (o == r) continue;
+        int lo = 0, hi = k;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            float so;
+            int64_t io;
+            shard_entry(m, o, q, mid, so, io);
+            if (precedes(so, io, s, id))
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        rank += lo;
+    }
+    if (rank < k) {
+        out_scores[(int64_t)q * k + rank] = s;
+        out_ids[(int64_t)q * k + rank] = id;
+    }
+}
+
+// message from ordinary results: scores [n_q][k_valid], ids int64 global -> u32 local rows; slots [k_valid, k) zeroed
+__global__ __launch_bounds__(256) void shard_fill_kernel(char *msg, size_t rows_at, int n_q, int k, int k_valid, const float *__restrict__ scores,
+                                                        const int64_t *__restrict__ ids, int64_t row_offset) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)n_q * k) return;
+    const int q = (int)(e / k), p = (int)(e - (int64_t)q * k);
+    float s = 0.0f;
+    uint32_t row = 0u;
+    if (p < k_valid) {
+        s = scores[(int64_t)q * k_valid + p];
+        row = (uint32_t)(ids[(int64_t)q * k_valid + p] - row_offset);
+    }
+    reinterpret_cast<float *>(msg + sizeof(ccr_shard_header))[e] = s;
+    reinterpret_cast<uint32_t *>(msg + rows_at)[e] = row;
+}
+
 }  // namespace ccr
 
 using namespace ccr;
+
+extern "C" int ccr_shard_message_fill(void *message, int n_q, int k, int k_valid, const float *scores, const int64_t *ids, int64_t row_offset,
+                                      int64_t n_rows, void *stream) {
+    CCR_REQUIRE(message && (uintptr_t)message % 16 == 0, "ccr_shard_message_fill: message must be a 16-byte aligned device pointer");
+    CCR_REQUIRE(n_q >= 0 && k >= 1 && k <= MAX_K && k_valid >= 0 && k_valid <= k, "ccr_shard_message_fill: bad shape n_q=%d k=%d k_valid=%d", n_q, k,
+                k_valid);
+    CCR_REQUIRE(n_q == 0 || k_valid == 0 || (scores && ids), "ccr_shard_message_fill: null results");
+    ccr_shard_header h;
+    memset(&h, 0, sizeof(h));
+    h.magic = CCR_SHARD_MAGIC;
+    h.k_valid = (uint32_t)k_valid;
+    h.row_offset = row_offset;
+    h.n_rows = n_rows;
+    int rc = launch_shard_header(h, message, (hipStream_t)stream);
+    if (rc != CCR_OK || n_q == 0) return rc;
+    const int64_t n = (int64_t)n_q * k;
+    hipLaunchKernelGGL(shard_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (char *)message,
+                       shard_rows_at(n_q, k), n_q, k, k_valid, scores, ids, row_offset);
+    CCR_LAUNCH_CHECK();
+    return CCR_OK;
+}
+
+extern "C" int ccr_merge_shard_messages(const void *messages, int64_t message_stride_bytes, int R, int n_q, int k, float *out_scores,
+                                        int64_t *out_ids, void *stream) {
+    CCR_REQUIRE(messages && out_scores && out_ids, "ccr_merge_shard_messages: null pointer");
+    CCR_REQUIRE(R >= 1 && R <= 64 && n_q >= 0 && k >= 1 && k <= MAX_K, "ccr_merge_shard_messages: bad shape R=%d n_q=%d k=%d", R, n_q, k);
+    const size_t rows_at = shard_rows_at(n_q, k);
+    CCR_REQUIRE((uintptr_t)messages % 16 == 0 && message_stride_bytes % 16 == 0 &&
+                    (size_t)message_stride_bytes >= rows_at + (size_t)n_q * k * 4,
+                "ccr_merge_shard_messages: message stride %lld shorter than one message or not 16-byte aligned", (long long)message_stride_bytes);
+    if (n_q == 0) return CCR_OK;
+    ShardSrc m = {reinterpret_cast<const char *>(messages), message_stride_bytes, rows_at, k};
+    const size_t lds = (size_t)R * k * 12;
+    if (lds <= 96 * 1024) {
+        if (lds > 48 * 1024) {
+            const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&merge_messages_lds_kernel), 96 * 1024);
+            if (rc != CCR_OK) return rc;
+        }
+        const int threads = R * k >= 2048 ? 1024 : 256;
+        hipLaunchKernelGGL(merge_messages_lds_kernel, dim3((unsigned)n_q), dim3(threads), lds, (hipStream_t)stream, m, R, out_scores, out_ids);
+        CCR_LAUNCH_CHECK();
+        return CCR_OK;
+    }
+    dim3 grid((unsigned)((R * k + 255) / 256), (unsigned)n_q);
+    hipLaunchKernelGGL(merge_messages_kernel, grid, dim3(256), 0, (hipStream_t)stream, m, R, n_q, out_scores, out_ids);
+    CCR_LAUNCH_CHECK();
+    return CCR_OK;
+}
 
 extern "C" int ccr_merge_topk_strided(const float *scores, const int64_t *ids, int64_t score_rank_stride, int64_t id_rank_stride,
                                       int R, int n_q, int k, float *out_scores, int64_t *out_ids, void *stream) {

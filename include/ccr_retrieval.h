@@ -69,6 +69,8 @@ typedef struct ccr_search_stats {
     int32_t n_retried;         /* flagged queries re-done by the fused retry pass (thresholds re-tightened from their own lists) */
     int32_t n_dense;           /* flagged queries finished by an exact whole-row path (margin select or fp64: mass ties, flagged again,
                                   on-stream chunk); path 0: queries the margin select left to the fp64 path */
+    int32_t main_launches;     /* launches of the main-pass kernel in this search (phases: thresholds are re-tightened between them) */
+    int32_t reserved;
 } ccr_search_stats;
 
 const char *ccr_last_error(void);
@@ -215,6 +217,41 @@ int ccr_merge_topk(const float *scores, const int64_t *ids, int R, int n_q, int 
  * message {scores [n_q][k] fp32 | ids [n_q][k] int64} leaves behind: a single collective instead of two. */
 int ccr_merge_topk_strided(const float *scores, const int64_t *ids, int64_t score_rank_stride, int64_t id_rank_stride,
                            int R, int n_q, int k, float *out_scores, int64_t *out_ids, void *stream);
+
+/*
+ * Packed per-shard result message of a row-sharded search: ONE all-gather (RCCL) moves it, one kernel merges the gathered copies.
+ * New (the reference scores on one GPU only, scripts/ms_marco_eval.py:205-218); what it replaces there is the per-row
+ * sort + keep-1001 of :228-230 for a corpus split over the GPUs of a node.
+ *   layout: 32-byte ccr_shard_header | scores [n_q][k] fp32 | pad to 16 B | rows [n_q][k] u32 LOCAL row of this shard | pad to 16 B
+ *   8 bytes per entry on the wire (12 with int64 global ids); the merge adds header.row_offset.
+ * ccr_search_shard == ccr_search writing that message.  With CCR_SEARCH_ASYNC the call does not synchronise and the header's
+ * n_flagged is written ON THE STREAM (the select stage's flag count): after the all-gather every rank reads every rank's
+ * {n_flagged, n_covered} and all ranks take the same branch -- lists are final iff n_flagged <= n_covered on every rank, otherwise
+ * the flagged ranks call ccr_search_finish and the exchange is repeated by ALL ranks (a matched second collective).
+ * 1 <= k <= min(n_rows, 4096); a shard smaller than k searches k_valid = n_rows entries and fills the message with
+ * ccr_shard_message_fill instead.
+ */
+#define CCR_SHARD_MAGIC 0x4d524343u /* "CCRM" */
+typedef struct ccr_shard_header {
+    uint32_t magic;
+    uint32_t n_flagged;   /* queries flagged by the shard's asynchronous search (0 after a synchronous one) */
+    uint32_t k_valid;     /* entries of every list that are real rows; slots [k_valid, k) are padding */
+    uint32_t n_covered;   /* flagged queries the search completed on the stream by itself (CCR_SEARCH_ASYNC: 16) */
+    int64_t row_offset;   /* global id of the shard's row 0 */
+    int64_t n_rows;       /* rows of the shard */
+} ccr_shard_header;
+size_t ccr_shard_message_bytes(int n_q, int k);
+int ccr_search_shard(ccr_index *index, const uint16_t *Q_bf16, int n_q, int k, void *message, void *workspace, size_t ws_bytes,
+                     int flags, void *stream);
+/* Build a message from ordinary results (blocked searches, shards smaller than k):
+ *   scores [n_q][k_valid] fp32, ids [n_q][k_valid] int64 GLOBAL ids inside [row_offset, row_offset + n_rows), k_valid <= k. */
+int ccr_shard_message_fill(void *message, int n_q, int k, int k_valid, const float *scores, const int64_t *ids, int64_t row_offset,
+                           int64_t n_rows, void *stream);
+/* Merge R gathered messages (message r at messages + r * message_stride_bytes) into the global top-k: out_scores [n_q][k] fp32,
+ * out_ids [n_q][k] int64 global ids, order rule as everywhere.  Padding slots rank last (score -inf, distinct ids above 2^62), so
+ * every output slot is written even when the whole corpus holds fewer than k rows.  k <= 4096, R <= 64. */
+int ccr_merge_shard_messages(const void *messages, int64_t message_stride_bytes, int R, int n_q, int k, float *out_scores,
+                             int64_t *out_ids, void *stream);
 
 /*
  * Apply per-query blocked ids to an over-fetched result list.

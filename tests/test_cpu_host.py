@@ -1,6 +1,7 @@
 """CPU-side checks: the C-ABI library loads and exports every symbol include/ccr_retrieval.h declares
 (no compute calls without a GPU), the host mirror keeps the reference's config/error behaviour, and the
 multi-process exchange path (all-gather of per-shard top-k + merge) is correct under gloo, world_size 2."""
+import ctypes
 import os
 import re
 import socket
@@ -161,6 +162,7 @@ def _worker(rank, world, port, n, nq, k, out_dir):
 
     class Shard:  # CPU stand-in for a CorpusIndex: the oracle scores the local rows
         n_rows = hi - lo
+        offset = lo
 
     def search_fn(q, kk):
         ids, sc = orc.canonical_search(Qb, Db[lo:hi], kk)
@@ -218,23 +220,97 @@ def test_plan_batches_covers_every_text_once_under_the_budget():
     assert plan_batches([], 4096) == [] and plan_batches([9000], 4096)[0][1] == 9000
 
 
-def test_topk_message_layout_on_cpu():
-    """The packed exchange message {scores | ids}: views alias one byte buffer, the id block is 16-byte aligned, and
-    the gathered per-rank views are rank-strided (what ccr_merge_topk_strided consumes)."""
-    from ccrec_amd.dist import TopkMessage
-    m = TopkMessage(7, 5, "cpu", 3)            # 7 * 5 * 4 = 140 bytes of scores: the id block starts at 144
-    assert m.ids_at == 144 and m.nbytes == 144 + 7 * 5 * 8 + 8 and m.nbytes % 16 == 0
-    m.scores.fill_(1.5)
-    m.ids.copy_(torch.arange(35).view(7, 5) + (1 << 40))
-    assert m.send[:140].view(torch.float32).eq(1.5).all() and m.send[140:144].eq(0).all()
-    assert m.send[144:144 + 280].view(torch.int64)[34] == (1 << 40) + 34
+def test_shard_message_layout_on_cpu():
+    """The packed exchange message {32-byte header | fp32 scores | u32 local rows} (include/ccr_retrieval.h): the views alias
+    one byte buffer, blocks are 16-byte aligned, the size matches ccr_shard_message_bytes, padding slots decode to
+    (-inf, distinct ids above every real id)."""
+    from ccrec_amd import _lib, ops
+    from ccrec_amd.dist import ShardMessage, PAD_ID
+    m = ShardMessage(7, 5, "cpu", 3)           # 7 * 5 * 4 = 140 bytes of scores after the 32-byte header: rows start at 176
+    assert m.rows_at == 176 and m.nbytes == 176 + 140 + 4 and m.nbytes % 16 == 0 == m.rows_at % 16
+    assert m.nbytes == ops.shard_message_bytes(7, 5) and ctypes.sizeof(_lib.ShardHeader) == _lib.SHARD_HEADER_BYTES == 32
+    sc = torch.arange(21, dtype=torch.float32).view(7, 3)
+    ids = torch.arange(21).view(7, 3) + (1 << 40) + (1 << 31)       # local rows at and above 2^31: u32, not i32
+    m.fill(sc, ids, row_offset=1 << 40, n_rows=1 << 32)            # k_valid = 3 of k = 5
+    h = ShardMessage.parse_headers(m.header.view(1, 8))[0]
+    assert h == {"magic": _lib.SHARD_MAGIC, "n_flagged": 0, "k_valid": 3, "n_covered": 0, "row_offset": 1 << 40, "n_rows": 1 << 32}
+    assert m.send[32:172].view(torch.float32).view(7, 5)[:, :3].equal(sc) and m.send[172:176].eq(0).all()
     for r in range(3):
         m.recv.view(3, -1)[r].copy_(m.send)
-        m.recv.view(3, -1)[r][:4].view(torch.float32).fill_(float(r))
-    assert m.all_scores.shape == (3, 7, 5) and m.all_ids.shape == (3, 7, 5)
-    assert m.all_scores.stride() == (m.nbytes // 4, 5, 1) and m.all_ids.stride() == (m.nbytes // 8, 5, 1)
-    assert [float(m.all_scores[r, 0, 0]) for r in range(3)] == [0.0, 1.0, 2.0] and int(m.all_ids[2, 6, 4]) == (1 << 40) + 34
+    gs, gi = m.decoded()
+    assert gs.shape == (3, 7, 5) and gi.shape == (3, 7, 5)
+    for r in range(3):
+        assert gi[r, :, :3].equal(ids) and gs[r, :, :3].equal(sc) and bool(torch.isinf(gs[r, :, 3:]).all())
+        assert gi[r, 0, 3] == PAD_ID - (r * 5 + 3) and gi[r, 6, 4] == PAD_ID - (r * 5 + 4)
+    assert len(set(gi[:, 0, 3:].flatten().tolist())) == 6
 
+
+def _flag_worker(rank, world, port, out_dir):
+    """The asynchronous exchange when exactly ONE rank's lists are not final at the first all-gather: its header says so, every
+    rank reads every header, every rank repeats the collective (a matched second all-gather), the merged lists are exact."""
+    import torch.distributed as dist
+    sys.path[:0] = [ROOT, PKG]
+    from ccrec_amd.dist import shard_bounds, submit_sharded_search, ShardMessage
+    from ccrec_amd import _lib
+    from oracle import oracle as orc
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    n, nq, k = 900, 40, 30
+    g = torch.Generator().manual_seed(5)
+    Db = orc.pack_bf16((torch.randn(n, 64, generator=g) / 8).numpy())
+    Qb = orc.pack_bf16((torch.randn(nq, 64, generator=g) / 8).numpy())
+    lo, hi = shard_bounds(n, world, rank)
+    ids, sc = orc.canonical_search(Qb, Db[lo:hi], k)
+    flagged_rank = world - 1
+
+    class FakeIndex:   # CPU stand-in for CorpusIndex.search_shard(defer=True) / finish()
+        n_rows, offset, _deferred, finished = hi - lo, lo, None, 0
+
+        def search_shard(self, q, kk, send, defer=False):
+            msg = self.msg
+            msg.fill(torch.from_numpy(sc), torch.from_numpy(ids + lo), lo, hi - lo)
+            if rank == flagged_rank:           # 20 queries flagged, 16 covered on the stream: rows of 4 queries are not final yet
+                msg.scores[:4] = 0.0
+                msg.rows[:4] = 0
+                msg.header[1], msg.header[3] = 20, 16
+            else:
+                msg.header[3] = 16
+            self._deferred = (q, send)
+
+        def finish(self):
+            self.finished += 1
+            self._deferred = None
+            if rank == flagged_rank:
+                self.msg.scores[:4] = torch.from_numpy(sc[:4])
+                self.msg.rows[:4] = torch.from_numpy(ids[:4].astype(np.int32))
+
+    def merge_fn(gs, gi):
+        s, i = orc.merge_topk(gs.numpy(), gi.numpy())
+        return torch.from_numpy(s), torch.from_numpy(i)
+
+    ok = True
+    for flag_it in (True, False):
+        ix = FakeIndex()
+        ix.msg = ShardMessage(nq, k, "cpu", world)
+        if not flag_it:
+            flagged_rank = -1
+        ex = submit_sharded_search(ix, torch.zeros(nq, 64), k, message=ix.msg, merge_fn=merge_fn)
+        s, i = ex.result()
+        ref_i, ref_s = orc.canonical_search(Qb, Db, k)
+        ok = ok and np.array_equal(i.numpy(), ref_i) and np.array_equal(s.numpy(), ref_s)
+        ok = ok and ex.repeated == flag_it and ix.finished == 1
+        ok = ok and [h["n_flagged"] for h in ex.headers] == [20 if (flag_it and r == world - 1) else 0 for r in range(world)]
+    open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if ok else "MISMATCH")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_exchange_repeats_on_every_rank_when_one_rank_flags(tmp_path, world):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_flag_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert open(tmp_path / f"rank{r}.txt").read() == "ok"
 
 def test_committed_bench_line_has_the_contract_fields():
     """The bench line committed under profiles/ (a real MI355X run of `python bench.py`) carries every field the driver reads."""

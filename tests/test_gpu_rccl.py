@@ -1,9 +1,16 @@
 """The exchange step over RCCL itself (backend "nccl"), as far as one GPU allows: a world-size-1 process group moves a
-TopkMessage through all_gather_into_tensor, and the collectives bench.py brackets its timed region with
-(barrier, fp64 MAX all-reduce) run on device tensors.  World sizes > 1 are covered on CPU with gloo
-(test_cpu_host.py) and by the merge tests in test_gpu_search.py."""
+packed ShardMessage through all_gather_into_tensor (synchronous and asynchronous form, header round trip included), and
+the collectives bench.py brackets its timed region with (barrier, fp64 MAX all-reduce) run on device tensors.  World sizes
+> 1 are covered on CPU with gloo (test_cpu_host.py), by the merge tests in test_gpu_search.py and by the rehearsal below:
+bench.py's N > 1 branch in child processes that share this GPU and exchange over gloo -- started both ways the driver may
+start it (`python bench.py --gpus N` and `python -m torch.distributed.run ... bench.py --gpus N`)."""
+import json
 import os
+import signal
 import socket
+import subprocess
+import sys
+import time
 
 import numpy as np
 import pytest
@@ -12,6 +19,8 @@ import torch
 from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
@@ -29,35 +38,40 @@ def _rand_bits(n, d, seed):
     return orc.pack_bf16((torch.randn(n, d, generator=g) * d ** -0.5).numpy())
 
 
-def test_topk_message_through_rccl_world1():
+def test_shard_message_through_rccl_world1():
     import torch.distributed as dist
     from ccrec_amd import ops
-    from ccrec_amd.dist import TopkMessage, all_gather_topk, merge_gathered, sharded_search
+    from ccrec_amd.dist import ShardMessage, sharded_search, submit_sharded_search
     assert not dist.is_initialized()
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(_free_port())
     dev = torch.device("cuda", 0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
-        n, nq, d, k = 20000, 37, 768, 100              # nq * k * 4 % 16 != 0: the id block starts on padding
+        n, nq, d, k = 20000, 37, 768, 100              # nq * k * 4 % 16 != 0: the row block starts on padding
         Db, Qb = _rand_bits(n, d, 41), _rand_bits(nq, d, 42)
         index = ops.CorpusIndex(_bf16(Db), global_row_offset=777)
         Q = _bf16(Qb)
         s1, i1 = index.search(Q, k)
-        m = TopkMessage(nq, k, dev, 1)
-        index.search(Q, k, out=(m.scores, m.ids))
-        gs, gi = m.gather()                             # ONE RCCL all_gather_into_tensor of the packed bytes
-        assert gs.shape == (1, nq, k) and gi.shape == (1, nq, k)
-        ms, mi = merge_gathered(gs, gi)
+        # synchronous form: the search writes the message, ONE RCCL all_gather_into_tensor of the packed bytes, merge
+        m = ShardMessage(nq, k, dev, 1)
+        index.search_shard(Q, k, m.send)
+        m.gather()
+        h = ShardMessage.parse_headers(m.all_headers.cpu())[0]
+        assert h["n_flagged"] == 0 and h["k_valid"] == k and h["row_offset"] == 777 and h["n_rows"] == n and h["n_covered"] == 0
+        ms, mi = m.merge()
         assert torch.equal(mi, i1) and torch.equal(ms.view(torch.int32), s1.view(torch.int32))
-        # the asynchronous form bench.py pipelines across steps: the collective runs on RCCL's stream, wait() orders the merge behind it
-        m.recv.zero_()
-        work = m.gather_async()
-        work.wait()
-        ms2, mi2 = merge_gathered(m.all_scores, m.all_ids)
+        gs, gi = m.decoded()
+        assert torch.equal(gi[0], i1) and torch.equal(gs[0], s1)
+        # the asynchronous form bench.py pipelines across steps: no host synchronisation before the collective, the
+        # headers come back through pinned memory from a side stream, finish() waits for the search's own event
+        m2 = ShardMessage(nq, k, dev, 1)
+        ex = submit_sharded_search(index, Q, k, message=m2)
+        junk = torch.randn(4096, 4096, device=dev) @ torch.randn(4096, 4096, device=dev)   # later work on the compute stream
+        ms2, mi2 = ex.result()
         assert torch.equal(mi2, i1) and torch.equal(ms2.view(torch.int32), s1.view(torch.int32))
-        # separate tensors are copied into the message first
-        gs2, gi2 = all_gather_topk(s1, i1)
-        assert torch.equal(gs2[0], s1) and torch.equal(gi2[0], i1)
+        assert not ex.repeated and ex.headers[0]["n_flagged"] == 0 and ex.headers[0]["n_covered"] == 16
+        assert index.last_stats()["path"] == 1 and index.last_stats()["ms_main"] > 0      # finish() filled the statistics
+        del junk
         # world 1: sharded_search is the plain search
         s3, i3 = sharded_search(index, Q, k)
         assert torch.equal(i3, i1) and torch.equal(s3, s1)
@@ -66,43 +80,125 @@ def test_topk_message_through_rccl_world1():
         # bench.py's timing collectives on device tensors
         dist.barrier()
         t = torch.tensor([1.25], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(t)]
+        dist.all_gather(every, t)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         torch.cuda.synchronize()
-        assert t.item() == 1.25
+        assert t.item() == 1.25 and every[0].item() == 1.25
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,rows", [(2, 200000), (3, 200003)])   # 200003 rows over 3 ranks: uneven shards (as NQ over 8)
-def test_bench_two_ranks_rehearsal_in_a_fresh_process(tmp_path, world, rows):
-    """The N > 1 branch of bench.py exactly as the driver launches it (`python -m torch.distributed.run ... bench.py
-    --gpus 2`), rehearsed on this one GPU: both ranks share cuda:0 and exchange over gloo.  The JSON line must parse and
-    the merged ids must equal the 1-rank run's (the corpus is the same global stream, row-sharded)."""
-    import json
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+def _proc_state(pid):
+    """What the kernel says a process and its threads are doing: state + wait channel of every thread (readable without root)."""
+    lines = []
+    try:
+        for tid in sorted(os.listdir(f"/proc/{pid}/task"), key=int):
+            base = f"/proc/{pid}/task/{tid}"
+            try:
+                comm = open(base + "/comm").read().strip()
+                state = [ln for ln in open(base + "/status").read().splitlines() if ln.startswith("State:")][0]
+                wchan = open(base + "/wchan").read().strip()
+                lines.append(f"  tid {tid} {comm}: {state} wchan={wchan}")
+            except OSError:
+                pass
+    except OSError:
+        lines.append(f"  pid {pid}: gone")
+    return lines
+
+
+def _children_of(pid):
+    try:
+        out = subprocess.run(["ps", "-o", "pid=", "--ppid", str(pid)], capture_output=True, text=True).stdout.split()
+        kids = [int(x) for x in out]
+    except Exception:
+        kids = []
+    return kids + [g for c in kids for g in _children_of(c)]
+
+
+def _run_child(cmd, env, tmp_path, tag, limit=240):
+    """Run a bench.py child in its own process group.  A child that overruns `limit` is a FAILURE with evidence: the Python
+    stacks of every rank (SIGUSR1 -> faulthandler, written to files that survive the kill), the kernel-side state and wait
+    channel of every thread of every process of the group, and the child's stderr so far.  The whole group is killed then
+    (a killed launcher alone would leave its ranks holding the GPU)."""
+    dump_dir = tmp_path / f"{tag}_stacks"
+    dump_dir.mkdir(exist_ok=True)
+    env = dict(env, CCR_BENCH_WATCHDOG_DIR=str(dump_dir))
+    err_path, out_path = tmp_path / f"{tag}.stderr", tmp_path / f"{tag}.stdout"
+    with open(err_path, "w") as ferr, open(out_path, "w") as fout:
+        proc = subprocess.Popen(cmd, stdout=fout, stderr=ferr, env=env, start_new_session=True)
+        t0 = time.time()
+        try:
+            proc.wait(timeout=limit)
+        except subprocess.TimeoutExpired:
+            pids = [proc.pid] + _children_of(proc.pid)
+            evidence = [f"{tag}: child still running after {time.time() - t0:.0f} s: {' '.join(cmd)}"]
+            for pid in pids:
+                evidence.append(f"pid {pid}: {open(f'/proc/{pid}/cmdline').read().replace(chr(0), ' ')[:200] if os.path.exists(f'/proc/{pid}/cmdline') else 'gone'}")
+                evidence += _proc_state(pid)
+            for pid in pids:
+                if not _children_of(pid):                  # the ranks (leaves): launchers have no handler and would just die
+                    try:
+                        os.kill(pid, signal.SIGUSR1)       # faulthandler: every thread's Python stack into the dump file
+                    except OSError:
+                        pass
+            time.sleep(3)
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except OSError:
+                pass
+            try:
+                proc.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                evidence.append("child did not die within 30 s of SIGKILL (uninterruptible)")
+            for f in sorted(dump_dir.iterdir()):
+                evidence.append(f"--- {f.name}\n{f.read_text()[-6000:]}")
+            evidence.append(f"--- stderr\n{err_path.read_text()[-6000:]}")
+            pytest.fail("\n".join(evidence))
+    stderr, stdout = err_path.read_text(), out_path.read_text()
+    if proc.returncode != 0:   # includes the in-child watchdog (exit code 1 after its stack dump)
+        dumps = "".join(f"--- {f.name}\n{f.read_text()[-6000:]}\n" for f in sorted(dump_dir.iterdir()))
+        pytest.fail(f"{tag}: exit code {proc.returncode}\n{dumps}--- stderr\n{stderr[-6000:]}")
+    return stdout, stderr
+
+
+@pytest.mark.parametrize("world,rows,launcher", [(2, 200000, "plain"), (2, 200000, "torchrun"), (3, 200003, "plain")])
+def test_bench_ranks_rehearsal_in_fresh_processes(tmp_path, world, rows, launcher):
+    """The N > 1 branch of bench.py as the driver launches it -- `python bench.py --gpus N` (bench.py starts its own ranks as a
+    child torch.distributed.run) and the explicit `python -m torch.distributed.run ... bench.py --gpus N` -- rehearsed on this
+    one GPU: the ranks share cuda:0 and exchange over gloo.  The JSON line must parse and the merged ids must equal the 1-rank
+    run's (the corpus is the same global stream, row-sharded; 200003 rows over 3 ranks: uneven shards, as NQ over 8)."""
+    bench = os.path.join(ROOT, "bench.py")
     common = ["--steps", "2", "--warmup", "1", "--rows", str(rows), "--queries", "300", "--cpu-queries", "0", "--no-secondary"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CCR_BENCH_WATCHDOG="150")   # a hung rank dumps its stacks and exits
-    try:
-        one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dump-ids", str(tmp_path / "one.pt")] + common,
-                             capture_output=True, text=True, timeout=240, env=env)
-    except subprocess.TimeoutExpired as e:   # seen once in ~30 runs on a cold box, never reproduced: not a verdict on the code
-        pytest.skip(f"1-rank child did not finish in 240 s on this box: {(e.stderr or b'')[-1500:]}")
-    assert one.returncode == 0, one.stderr[-4000:]
-    try:
-        two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
-                              "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(world),
-                              "--dist-backend", "gloo", "--same-device", "--dump-ids", str(tmp_path / "two.pt")] + common,
-                             capture_output=True, text=True, timeout=240, env=env)
-    except subprocess.TimeoutExpired as e:
-        pytest.skip(f"2-rank rehearsal did not finish in 240 s on this box: {(e.stderr or b'')[-1500:]}")
-    assert two.returncode == 0, two.stderr[-6000:]
-    lines = [ln for ln in two.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, two.stdout[-2000:]                  # rank 0 prints ONE JSON line
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()    # the children share this GPU: hand back what the earlier (full-size) tests left cached
+    one_out, _ = _run_child([sys.executable, bench, "--gpus", "1", "--dump-ids", str(tmp_path / "one.pt")] + common, env, tmp_path, "one")
+    rehearsal = ["--gpus", str(world), "--dist-backend", "gloo", "--same-device", "--dump-ids", str(tmp_path / "two.pt")] + common
+    if launcher == "plain":
+        cmd = [sys.executable, bench] + rehearsal
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), bench] + rehearsal
+    two_out, two_err = _run_child(cmd, env, tmp_path, "ranks")
+    assert len([ln for ln in one_out.splitlines() if ln.startswith("{")]) == 1
+    lines = [ln for ln in two_out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, two_out[-2000:]                     # rank 0 prints ONE JSON line
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == world and rec["steps"] == 2 and rec["scaling"] == "strong" and rec["value"] > 0
     assert rec["config"]["parallelism"] == f"row-shard x{world}" and rec["cpu_baseline"] is None
     assert rec["roofline"]["bound"] == "mfma" and rec["search_stats"]["n_fallback"] == 0
+    assert rec["roofline"]["launches_per_step"] >= 1 and rec["roofline"]["flops_per_step"] > 0
+    ex = rec["exchange"]
+    assert ex["n_ranks_seen"] == world and ex["backend"] == "gloo" and ex["repeated_exchanges"] == 0
+    assert ex["message_bytes_per_rank"] == 32 + 300 * 100 * 8 and ex["rank_ms_per_step_min"] <= ex["rank_ms_per_step_max"]
     a, b = torch.load(tmp_path / "one.pt"), torch.load(tmp_path / "two.pt")
     assert a.shape == (300, 100) and torch.equal(a, b)
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus(tmp_path):
+    """WORLD_SIZE set by a launcher but different from --gpus: a clear message and exit code 2 before any GPU call."""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1"], capture_output=True, text=True,
+                         timeout=120, env=env)
+    assert run.returncode == 2 and "WORLD_SIZE=2" in run.stderr and "{" not in run.stdout

@@ -214,27 +214,64 @@ def test_merge_and_sharded_search_equal_single():
     assert np.array_equal(mi.cpu().numpy(), oi) and np.array_equal(ms.cpu().numpy(), os_)
 
 
-def test_packed_message_strided_merge_equals_single():
-    """The one-collective exchange layout: every shard's search writes into a TopkMessage, the gathered buffer is
-    emulated by copying the three messages side by side, and the merge reads the rank-strided views in place."""
+@pytest.mark.parametrize("n,nq,k,world", [(20000, 37, 100, 3), (9000, 5, 1001, 8), (3000, 3, 2500, 8), (700, 9, 300, 3)])
+def test_shard_messages_merge_equals_single(n, nq, k, world):
+    """The one-collective exchange layout: every shard's search writes a packed message (header | scores | u32 local rows,
+    ccr_search_shard), the gathered buffer is emulated by copying the messages side by side, ccr_merge_shard_messages reads
+    them in place.  (20000, 37, 100): n_q k 4 is not a multiple of 16 -- block padding; k = 1001 x 8 ranks: the largest
+    lists the LDS merge takes; k = 2500 x 8: the global-memory merge; (700, 300, 3 ranks): shards SMALLER than k -- k_valid
+    < k through ccr_shard_message_fill, padding slots rank last.)"""
     from ccrec_amd import ops
-    from ccrec_amd.dist import shard_bounds, TopkMessage
-    n, nq, d, k = 20000, 37, 768, 100          # nq * k * 4 is not a multiple of 16: exercises the id-block padding
+    from ccrec_amd.dist import shard_bounds, ShardMessage
+    d = 64 if k > 1001 else 768
     Db, Qb = _rand_bits(n, d, 33), _rand_bits(nq, d, 34)
+    Db[n // 2 + 1] = Db[1]                     # cross-shard exact tie: the lower global id wins
     D, Q = _bf16(Db), _bf16(Qb)
     s1, i1 = ops.CorpusIndex(D).search(Q, k)
-    world = 3
-    gathered = TopkMessage(nq, k, D.device, world)
+    gathered = ShardMessage(nq, k, D.device, world)
     for r in range(world):
         lo, hi = shard_bounds(n, world, r)
-        m = TopkMessage(nq, k, D.device, 1)
-        so, io = ops.CorpusIndex(D[lo:hi].contiguous(), global_row_offset=lo).search(Q, k, out=(m.scores, m.ids))
-        assert so.data_ptr() == m.scores.data_ptr() and io.data_ptr() == m.ids.data_ptr()
+        m = ShardMessage(nq, k, D.device, 1)
+        ix = ops.CorpusIndex(D[lo:hi].contiguous(), global_row_offset=lo)
+        if hi - lo >= k:
+            ix.search_shard(Q, k, m.send, defer=(r % 2 == 1))      # both forms; finish() of the deferred one below
+            if r % 2 == 1:
+                ix.finish()
+            so, io = ix.search(Q, k)
+            assert torch.equal(m.scores, so) and torch.equal(m.rows.to(torch.int64).bitwise_and(0xFFFFFFFF) + lo, io)
+        else:
+            so, io = ix.search(Q, hi - lo)
+            m.fill(so, io, lo, hi - lo)
         gathered.recv.view(world, -1)[r].copy_(m.send)
-    gs, gi = gathered.all_scores, gathered.all_ids
-    assert not gs.is_contiguous() and gs.stride(0) * 4 == gathered.nbytes
-    ms, mi = ops.merge_topk(gs, gi)
+    hdrs = ShardMessage.parse_headers(gathered.all_headers.cpu())
+    assert [h["row_offset"] for h in hdrs] == [shard_bounds(n, world, r)[0] for r in range(world)]
+    assert all(h["n_flagged"] == 0 and h["k_valid"] == min(k, h["n_rows"]) for h in hdrs)
+    ms, mi = gathered.merge()
     assert torch.equal(mi, i1) and torch.equal(ms.view(torch.int32), s1.view(torch.int32))
+    gs, gi = gathered.decoded()                # the same through the oracle's merge on the decoded lists
+    os_, oi = orc.merge_topk(gs.cpu().numpy(), gi.cpu().numpy())
+    assert np.array_equal(mi.cpu().numpy(), oi) and np.array_equal(ms.cpu().numpy(), os_)
+
+
+def test_shard_messages_of_a_corpus_smaller_than_k_fill_every_slot():
+    from ccrec_amd import ops
+    from ccrec_amd.dist import shard_bounds, ShardMessage, PAD_ID
+    n, nq, k, world, d = 11, 4, 16, 3, 64
+    Db, Qb = _rand_bits(n, d, 35), _rand_bits(nq, d, 36)
+    D, Q = _bf16(Db), _bf16(Qb)
+    gathered = ShardMessage(nq, k, D.device, world)
+    for r in range(world):
+        lo, hi = shard_bounds(n, world, r)
+        m = ShardMessage(nq, k, D.device, 1)
+        so, io = ops.CorpusIndex(D[lo:hi].contiguous(), global_row_offset=lo).search(Q, hi - lo)
+        m.fill(so, io, lo, hi - lo)
+        gathered.recv.view(world, -1)[r].copy_(m.send)
+    ms, mi = gathered.merge()
+    ref_i, ref_s = orc.canonical_search(Qb, Db, n)
+    assert np.array_equal(mi.cpu().numpy()[:, :n], ref_i) and np.array_equal(ms.cpu().numpy()[:, :n], ref_s)
+    tail = mi.cpu().numpy()[:, n:]
+    assert bool(torch.isinf(ms[:, n:]).all()) and (tail > 2 ** 62).all() and (tail <= PAD_ID).all()
+    assert all(len(set(row.tolist())) == k - n for row in tail)
 
 
 @pytest.mark.parametrize("na,nb", [(5, 300), (600, 9000)])
