@@ -179,6 +179,7 @@ class Workload:
         self.slots = [{"shard": torch.empty(n_local, dim, dtype=torch.bfloat16, device=dev),
                        "qpack": torch.empty(queries, dim, dtype=torch.bfloat16, device=dev),
                        "bounds": torch.empty(n_local, dtype=torch.float32, device=dev),   # norm bound per packed row (pack kernel)
+                       "ws": None,   # search workspace, handed from the slot's previous index to its next one
                        "message": ShardMessage(queries, k, dev, world) if world > 1 else None} for _ in range(2)]
         self.shard, self.qpack = self.slots[0]["shard"], self.slots[0]["qpack"]
         self.prev = None        # the step whose search / exchange is still in flight
@@ -193,7 +194,7 @@ class Workload:
         b = self.slots[self.nstep % 2]
         self.nstep += 1
         ops.pack_bf16(self.corpus_f32, out=b["shard"], norm_bounds=b["bounds"], normalize=self.normalize)   # pack + norm bound of every packed row in one pass
-        index = ops.CorpusIndex(b["shard"], global_row_offset=self.lo, norm_bounds=b["bounds"])
+        index = ops.CorpusIndex(b["shard"], global_row_offset=self.lo, norm_bounds=b["bounds"], workspace=b["ws"])
         ops.pack_bf16(self.queries_f32, out=b["qpack"], normalize=self.normalize)
         if self.world > 1:
             # asynchronous search straight into the packed message, all-gather behind it on the communication stream
@@ -201,6 +202,7 @@ class Workload:
         else:
             s, i = index.search(b["qpack"], self.k_local, defer=True)
             cur = (index, None, s, i)
+        b["ws"] = index.workspace     # the slot's previous index was completed a step ago (drain below completes the other slot's)
         self.drain()
         self.prev = cur
         self.shard, self.qpack = b["shard"], b["qpack"]

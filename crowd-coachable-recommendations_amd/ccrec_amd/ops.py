@@ -136,16 +136,20 @@ class CorpusIndex:
     global_row_offset: id of row 0 in the whole corpus (row-sharded multi-GPU search).
     norm_bounds: [n_rows] fp32 cuda tensor written by pack_bf16 / meanpool_pack(norm_bounds=...) for THESE rows (optional;
     kept alive by this object and not to be rewritten while the index is in use).
+    workspace: optional uint8 cuda tensor to search in (not to be shared by two indices that are in use at the same time).
     """
 
-    def __init__(self, corpus_bf16, global_row_offset=0, norm_bounds=None):
+    def __init__(self, corpus_bf16, global_row_offset=0, norm_bounds=None, workspace=None):
         self._lib = require_gpu()
         assert corpus_bf16.is_cuda and corpus_bf16.dtype == torch.bfloat16 and corpus_bf16.dim() == 2
         self.corpus = corpus_bf16.contiguous()
         self.n_rows, self.dim = self.corpus.shape
         self.offset = int(global_row_offset)
         self._h = ctypes.c_void_p()
-        self._ws = None
+        # workspace: a uint8 cuda tensor to adopt (e.g. the previous step's `index.workspace`: an index built per step then
+        # allocates nothing in steady state); replaced by a larger one when a search needs more
+        assert workspace is None or (workspace.is_cuda and workspace.dtype == torch.uint8 and workspace.device == corpus_bf16.device)
+        self._ws = workspace
         self._ws_need = {}
         self._deferred = None
         with _on(self.corpus):
@@ -165,6 +169,10 @@ class CorpusIndex:
             # a deferred search nobody finished: ccr_index_destroy waits for that search's own event before the index's
             # arrays go back to the block cache (the workspace tensor is released after this call returns)
             self._lib.ccr_index_destroy(h)
+
+    @property
+    def workspace(self):
+        return self._ws
 
     def _grow_ws(self, need):
         """The workspace, at least `need` bytes.  A deferred search still owns the current one: complete it before the
