@@ -11,31 +11,35 @@ import os
 
 import torch
 
-from . import evaluation
+from . import evaluation, ranking_profile
 from .al_request import build_requests
 from .bm25 import ranking_bm25
 from .encode import LengthSortedEncoder, ranking_sharded
 
 
 def run_rank_step(tower, tokenizer, corpus, queries, qrels, step_qids, step, results_dir, ranking_profile_bm25=None,
-                  block_dict=None, landing_image=None, n_repeats=3, repeat_seed=42, encoder_kw=None, autocast=True):
+                  block_dict=None, landing_image=None, n_repeats=3, repeat_seed=42, encoder_kw=None, autocast=True,
+                  compat_profile=False):
     """-> {"ranking_profile", "mrr", "requests"}; files are written to results_dir/data_iteration_{step}/."""
     work = os.path.join(results_dir, f"data_iteration_{step}")
     os.makedirs(work, exist_ok=True)
     path = os.path.join(work, "ranking_profile.pt")
+    corpus_ids = list(corpus)
+    # the qrels in corpus-row space do not depend on the search: prepared BEFORE it, so that nothing of O(corpus) Python work
+    # sits between the search and the request builder
+    wanted = {p for rel_q in qrels.values() for p in rel_q}
+    pos = {pid: i for i, pid in enumerate(corpus_ids) if pid in wanted}
     ids = None
-    if os.path.isfile(path):                                   # al_0_rank.py:115-118: resume from the saved profile
-        profile = torch.load(path)
+    fresh = not os.path.isfile(path)
+    if not fresh:                                              # al_0_rank.py:115-118: resume from the saved profile
+        profile = ranking_profile.load(path)                   # (the tensor form or the reference's nested dict)
     else:
         encoder = LengthSortedEncoder(tower, tokenizer, **(encoder_kw or {}))
         with torch.autocast("cuda", enabled=bool(autocast)):
-            profile, ids, _ = ranking_sharded(corpus, queries, encoder, block_dict=block_dict, with_tensors=True)
-        torch.save(profile, path)
-    corpus_ids = list(corpus)
+            profile, ids, _ = ranking_sharded(corpus, queries, encoder, block_dict=block_dict, with_tensors=True, lazy=True)
     qids = list(profile)
-    if ids is None:     # resumed: rebuild the id tensor from the dicts (the fresh path keeps the search's own tensor)
+    if ids is None:     # resumed: the id tensor comes back from the file (the fresh path keeps the search's own tensor)
         qids, ids, _ = evaluation.profile_to_tensors(profile, corpus_ids)
-    pos = {pid: i for i, pid in enumerate(corpus_ids)}
     rel = [[pos[p] for p in qrels.get(q, {}) if p in pos] for q in qids]
     kmax = ids.shape[1]
     mrr = evaluation.rank_metrics(ids.cuda(), rel, tuple(k for k in (1, 5, 10, 100) if k <= kmax))
@@ -45,4 +49,6 @@ def run_rank_step(tower, tokenizer, corpus, queries, qrels, step_qids, step, res
         ranking_profile_bm25 = ranking_bm25(corpus, queries)
     requests = build_requests(profile, ranking_profile_bm25, step_qids, corpus, queries, step, n_repeats=n_repeats,
                               repeat_seed=repeat_seed, landing_image=landing_image, out_dir=work)
+    if fresh:   # the tensor form (loads under torch.load's weights_only default); save(path, compat=True) writes the nested dict
+        profile.save(path, compat=compat_profile)
     return {"ranking_profile": profile, "mrr": mrr, "requests": requests}

@@ -123,12 +123,13 @@ def encode_local_shard(encoder, corpus_ids, corpus, sim, rank, world, norm_bound
     return shard, lo, hi
 
 
-def ranking_sharded(corpus, queries, encoder, block_dict=None, rank=0, world=1, group=None, keep=None, with_tensors=False):
+def ranking_sharded(corpus, queries, encoder, block_dict=None, rank=0, world=1, group=None, keep=None, with_tensors=False, lazy=False):
     """Multi-GPU form of ms_marco_eval.ranking (scripts/ms_marco_eval.py:189-235): every rank encodes and indexes its
     own corpus rows, all ranks encode the (small) query set, per-shard fused top-k, one all-gather, merge.
     Returns the same rank-ordered {qid: {pid: score}} on every rank.  block_dict: each shard scores its own blocked rows
     -1e6 (ccr_search_blocked, lists of any length) before the exchange, so the merged list is the reference's.
-    with_tensors: return (profile, row ids [Q, keep] int64, scores [Q, keep]) -- the device tensors behind the dicts."""
+    with_tensors: return (profile, row ids [Q, keep] int64, scores [Q, keep]) -- the device tensors behind the dicts.
+    lazy: the profile is a ranking_profile.RankingProfile over those tensors (inner dicts built when a query is read)."""
     from .ms_marco_eval import KEEP, Retriever
     from .dist import sharded_search
     queries_ids, corpus_ids = list(queries.keys()), list(corpus.keys())
@@ -140,7 +141,7 @@ def ranking_sharded(corpus, queries, encoder, block_dict=None, rank=0, world=1, 
     shard, lo, hi = encode_local_shard(encoder, corpus_ids, corpus, sim, rank, world, norm_bounds=bounds)
     bounds = bounds if hi > lo else None
     if world == 1:
-        return Retriever(corpus_ids, shard, norm_bounds=bounds).ranking_profile(queries_ids, q_bf16, block_dict, keep, with_tensors)
+        return Retriever(corpus_ids, shard, norm_bounds=bounds).ranking_profile(queries_ids, q_bf16, block_dict, keep, with_tensors, lazy)
     index = ops.CorpusIndex(shard, global_row_offset=lo, norm_bounds=bounds)
     n = len(corpus_ids)
     block = None
@@ -155,7 +156,8 @@ def ranking_sharded(corpus, queries, encoder, block_dict=None, rank=0, world=1, 
             lists.append(rows)
         block = block_csr(lists, n)
     scores, ids = sharded_search(index, q_bf16, min(n, keep), group=group, block=block, n_total=n)
-    scores_l, ids_l = scores.cpu().tolist(), ids.cpu().tolist()
-    pid_of = corpus_ids.__getitem__
-    profile = {qid: dict(zip(map(pid_of, row_i), row_s)) for qid, row_i, row_s in zip(queries_ids, ids_l, scores_l)}
+    from .ranking_profile import RankingProfile
+    profile = RankingProfile(queries_ids, corpus_ids, ids, scores)
+    if not lazy:
+        profile = profile.to_dict()
     return (profile, ids, scores) if with_tensors else profile

@@ -42,13 +42,11 @@ def rank_metrics(ids, qrel_lists, k_values=(1, 5, 10, 100)):
     return out
 
 
-def profile_to_tensors(ranking_profile, corpus_ids):
-    """{qid: {pid: score}} (rank-ordered) -> (query ids, ids [Q,k] int64, scores [Q,k] fp32) on the host."""
-    pos = {pid: i for i, pid in enumerate(corpus_ids)}
-    qids = list(ranking_profile)
-    ids = torch.tensor([[pos[p] for p in ranking_profile[q]] for q in qids], dtype=torch.int64)
-    scores = torch.tensor([list(ranking_profile[q].values()) for q in qids], dtype=torch.float32)
-    return qids, ids, scores
+def profile_to_tensors(ranking_profile, corpus_ids, positions=None):
+    """{qid: {pid: score}} (rank-ordered; a nested dict or a lazy RankingProfile) -> (query ids, ids [Q,k] int64 into
+    corpus_ids, scores [Q,k] fp32) on the host.  positions: {pid: row}, if the caller has it already."""
+    from .ranking_profile import as_tensors
+    return as_tensors(ranking_profile, corpus_ids, positions)
 
 
 def tensors_to_profile(qids, corpus_ids, ids, scores):

@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .ranking_profile import RankingProfile
 
 KEEP = 1001  # ms_marco_eval.py:230
 CANONICAL_COS_SIM_MACS = 4e9   # above this many multiply-adds cos_sim() switches from the fp64 to the MFMA score kernel
@@ -115,9 +116,17 @@ class Retriever:
         ptr, idx = block_csr(block_lists, n)
         return self.index.search_blocked(queries_bf16, k, ptr, idx + self.index.offset)
 
-    def ranking_profile(self, queries_ids, queries_bf16, block_dict=None, keep=KEEP, with_tensors=False):
-        """{qid: {pid: score}} in rank order.  with_tensors: also return the device tensors it was built from,
-        (row ids [Q, keep] int64 into corpus_ids, scores [Q, keep]) -- evaluation.rank_metrics takes them as they are."""
+    def corpus_id_array(self):
+        """Corpus ids as a numpy object array (ids of any hashable type): a row of search results becomes its pids by ONE take."""
+        if self._cid_arr is None:
+            self._cid_arr = np.fromiter(self.corpus_ids, dtype=object, count=len(self.corpus_ids))
+        return self._cid_arr
+
+    def ranking_profile(self, queries_ids, queries_bf16, block_dict=None, keep=KEEP, with_tensors=False, lazy=False):
+        """{qid: {pid: score}} in rank order.  lazy=True: a ranking_profile.RankingProfile over the search's tensors (same
+        Mapping behaviour, inner dicts built when a query is read) instead of Q x keep Python pairs.
+        with_tensors: also return the device tensors it was built from, (row ids [Q, keep] int64 into corpus_ids,
+        scores [Q, keep]) -- evaluation.rank_metrics takes them as they are."""
         block_lists = None
         if block_dict is not None:
             print("using block_dict")
@@ -129,21 +138,19 @@ class Retriever:
                 block_lists.append(rows)
         scores_t, ids_t = self.search(queries_bf16, keep, block_lists)
         ids_t = ids_t - self.index.offset
-        # 3.5 M (pid, score) pairs at the NQ shape: the rows of ids are turned into pid objects by ONE numpy take on an object array
-        # (0.25 s; a Python-level lookup per element was 0.5 s) and the inner dicts are built by dict(zip()) from whole rows
-        # (0.9 s: CPython's floor for that many inserts) -- 1.3 s instead of 1.7 s per NQ-sized profile
-        if self._cid_arr is None:
-            self._cid_arr = np.fromiter(self.corpus_ids, dtype=object, count=len(self.corpus_ids))   # (ids of any hashable type)
-        keys = self._cid_arr[ids_t.cpu().numpy()]
-        scores = scores_t.cpu().tolist()
-        profile = {qid: dict(zip(row_k, row_s)) for qid, row_k, row_s in zip(queries_ids, keys, scores)}
+        profile = RankingProfile(queries_ids, self.corpus_id_array(), ids_t, scores_t)
+        if not lazy:
+            # the reference's nested dict: 3.5 M (pid, score) pairs at the NQ shape -- one numpy take on the object array for the
+            # pids, dict(zip()) from whole rows (1.3 s per NQ-sized profile: CPython's floor for that many inserts)
+            profile = profile.to_dict()
         return (profile, ids_t, scores_t) if with_tensors else profile
 
 
-def ranking(corpus, queries, embedding_func, batch_size, block_dict=None):
+def ranking(corpus, queries, embedding_func, batch_size, block_dict=None, lazy=False):
     """scripts/ms_marco_eval.py:189-235: {qid: {pid: score}} ordered by rank, min(1001, N) entries per
     query; similarity from os.environ["CCREC_SIM_TYPE"] (KeyError if unset, as in the reference);
-    blocked ids are scored -1e6, not removed; AssertionError("block id not found") on unknown ids."""
+    blocked ids are scored -1e6, not removed; AssertionError("block id not found") on unknown ids.
+    lazy=True (not in the reference): the same Mapping backed by the result tensors (ranking_profile.RankingProfile)."""
     ops.require_gpu()
     queries_ids, corpus_ids = list(queries.keys()), list(corpus.keys())
     sim = "cos" if os.environ["CCREC_SIM_TYPE"] == "cos" else "dot"
@@ -152,4 +159,4 @@ def ranking(corpus, queries, embedding_func, batch_size, block_dict=None):
     bounds = torch.empty(len(corpus_ids), dtype=torch.float32, device="cuda") if corpus_ids else None
     passage_embeddings = generate_embeddings(corpus_ids, corpus, embedding_func, batch_size, pack=sim, norm_bounds=bounds)
     retriever = Retriever(corpus_ids, passage_embeddings, norm_bounds=bounds)
-    return retriever.ranking_profile(queries_ids, queries_embeddings, block_dict)
+    return retriever.ranking_profile(queries_ids, queries_embeddings, block_dict, lazy=lazy)

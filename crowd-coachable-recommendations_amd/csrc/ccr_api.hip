@@ -42,6 +42,7 @@ Knobs read_knobs() {
     kn.stagger = env_int("CCR_GEMM_STAGGER", 1);
     kn.max_lists = env_int("CCR_MAX_LISTS", 0);
     kn.ranges = env_int("CCR_RANGES", 0);
+    kn.item_swap = env_int("CCR_ITEM_SWAP", 0);
     return kn;
 }
 
@@ -976,6 +977,7 @@ static int search_impl(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k, fl
     gm.ranges = p.ranges;
     gm.thr = thr;
     gm.cnt = cnt;
+    gm.item_swap = (ix->knobs.item_swap && !p.item_a) ? 1 : 0;   // the phases' "ranges completed so far" needs the default order
     unsigned long long *stamps = nullptr;   // CCR_GEMM_DBG=16: in-kernel cycle stamps of the main pass (diagnostic build only)
 #ifdef CCR_DIAGNOSTICS
     const bool want_stamps = ix->knobs.gemm_dbg == 16;

@@ -127,6 +127,7 @@ struct GemmArgs {
     int64_t store_pitch;  // floats per stored query row (0: n_rows); a multiple of 4 lets a lane store its 4 consecutive rows as 16 bytes
     int dbg;              // timing-only ablations (CCR_GEMM_DBG; results are WRONG when non-zero)
     int stagger;          // 32x32x16 kernel: 1 = the two wave groups run one barrier interval apart (production), 0 = in phase
+    int item_swap;        // experiment (CCR_ITEM_SWAP, single-launch plans only): co-resident workgroups share the query block, not the range
 };
 
 

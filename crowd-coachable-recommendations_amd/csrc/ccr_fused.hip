@@ -114,8 +114,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
     const int item_end = a.item_end < count_x ? a.item_end : count_x;
 
     for (int item = a.item_begin + jx; item < item_end; item += per_x) {
-        const int rl = item / qb_per;
-        const int qb = qg * qb_per + item % qb_per;
+        // item order: consecutive items (the co-resident workgroups of an XCD) share a RANGE and walk its corpus tiles for
+        // different query blocks; item_swap (experiment, single-launch plans): they share the QUERY BLOCK instead
+        const int n_rl = a.ranges / nrc;
+        const int rl = a.item_swap ? item % n_rl : item / qb_per;
+        const int qb = qg * qb_per + (a.item_swap ? item / n_rl : item % qb_per);
         const int r = rc + nrc * rl;
         const int64_t ntile = (a.n_vt - r + a.ranges - 1) / a.ranges;
         if (ntile <= 0) continue;
@@ -437,8 +440,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
     const int item_end = a.item_end < count_x ? a.item_end : count_x;
 
     for (int item = a.item_begin + jx; item < item_end; item += per_x) {
-        const int rl = item / qb_per;
-        const int qb = qg * qb_per + item % qb_per;
+        // item order: consecutive items (the co-resident workgroups of an XCD) share a RANGE and walk its corpus tiles for
+        // different query blocks; item_swap (experiment, single-launch plans): they share the QUERY BLOCK instead
+        const int n_rl = a.ranges / nrc;
+        const int rl = a.item_swap ? item % n_rl : item / qb_per;
+        const int qb = qg * qb_per + (a.item_swap ? item / n_rl : item % qb_per);
         const int r = rc + nrc * rl;
         const int64_t ntile = (a.n_vt - r + a.ranges - 1) / a.ranges;
         if (ntile <= 0) continue;

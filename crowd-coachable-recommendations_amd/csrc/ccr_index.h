@@ -15,6 +15,7 @@ struct Knobs {
     int gemm_dbg;      // CCR_GEMM_DBG     timing-only ablations of the main pass (WRONG results when non-zero)
     int stagger;       // CCR_GEMM_STAGGER 0 = both wave groups of the 32x32x16 kernel in phase
     int ranges;        // CCR_RANGES       0 = planner's choice, else the pinned range count (rounded to a multiple of 8)
+    int item_swap;     // CCR_ITEM_SWAP    1 = co-resident workgroups share the query block instead of the corpus range (honoured with CCR_PROGRESSIVE=0)
     int max_lists;     // CCR_MAX_LISTS    0 = planner's limit, else a cap on ranges x sublists (A/B of the select stage's walk)
 };
 Knobs read_knobs();
