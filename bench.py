@@ -38,7 +38,7 @@ N_ROWS, DIM, N_Q, TOP_K = 2_681_468, 768, 3_452, 100
 MSMARCO_ROWS, MSMARCO_Q = 8_841_823, 6_980
 MFMA_PEAK_TFLOPS = 2500.0   # dense bf16, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_locality.json")   # tools/exp_locality.py: separate rocprofv3 --pmc passes per workload
 
 
 def parse():
@@ -401,13 +401,16 @@ def main():
     default_shape = (args.rows, args.queries, args.dim, args.k, args.data, args.sim) == (N_ROWS, N_Q, DIM, TOP_K, "gaussian", "dot")
     # HBM traffic of the dominant kernel cannot be read from inside the process (it needs rocprofv3 --pmc passes): the
     # figure below is the offline PMC measurement of THIS command committed under profiles/, labelled as such
-    traffic, traffic_source = None, None
-    if os.path.isfile(PMC_SUMMARY) and default_shape and world == 1:
+    def offline_traffic(tag):
+        """(bytes per step, label) of the main pass from the committed PMC measurement of the same workload, or (None, None)."""
         try:
-            traffic = json.load(open(PMC_SUMMARY)).get("main_pass_hbm_bytes_per_launch")
-            traffic_source = "offline rocprofv3 --pmc run of this command (profiles/r02_pmc_summary.json); not measured in this run"
+            rec = json.load(open(PMC_SUMMARY))[tag]
+            return rec["traffic_bytes"], (f"offline rocprofv3 --pmc passes of this workload (profiles/r03_locality.json[{tag}]: FETCH_SIZE x 2 + "
+                                          f"WRITE_SIZE of the main-pass launches of one step); not measured in this run")
         except Exception:
-            traffic = None
+            return None, None
+
+    traffic, traffic_source = offline_traffic("nq_default") if (default_shape and world == 1) else (None, None)
 
     workload = ("configs[1]: NQ corpus top-100, corpus row-sharded over n_gpus" if default_shape else
                 f"custom shape (not the headline config): {args.rows:,} x {args.dim} corpus ({args.data}, {args.sim}), {args.queries:,} queries, "
@@ -457,7 +460,7 @@ def main():
         w.k = w.k_local = 1001
         r2 = w.run(side_steps, max(1, side_warm), "k1001")
         sec["k1001"] = {"workload": "configs[1] corpus, top-1001 (the k of ranking(), ms_marco_eval.py:230)", "value": round(r2["qps"], 1),
-                        "unit": "queries/s", "ms_per_step": round(r2["ms_per_step"], 3), "roofline": roofline_obj(r2),
+                        "unit": "queries/s", "ms_per_step": round(r2["ms_per_step"], 3), "roofline": roofline_obj(r2, *offline_traffic("nq_k1001")),
                         "phases_ms": phases_obj(r2["stats"]),
                         "candidates_per_query": round(r2["stats"]["n_candidates"] / args.queries, 1),
                         "n_fallback": r2["n_fallback_max"]}
@@ -466,7 +469,7 @@ def main():
         m = Workload(MSMARCO_ROWS, MSMARCO_Q, DIM, TOP_K, "gaussian", dev, 0, 1, args.dist_backend)
         r3 = m.run(side_steps, max(1, side_warm), "msmarco")
         ms = {"workload": "configs[2] shape on one GPU: 8,841,823 x 768 corpus, 6,980 queries, top-100", "value": round(r3["qps"], 1),
-              "unit": "queries/s", "ms_per_step": round(r3["ms_per_step"], 3), "roofline": roofline_obj(r3),
+              "unit": "queries/s", "ms_per_step": round(r3["ms_per_step"], 3), "roofline": roofline_obj(r3, *offline_traffic("msmarco_scale")),
               "phases_ms": phases_obj(r3["stats"]), "n_fallback": r3["n_fallback_max"]}
         if args.cpu_queries > 0:
             cb = cpu_baseline(m.shard, m.qpack, 16, TOP_K, m.ids)

@@ -36,7 +36,7 @@ def get_all_embeddings(item_titles, tokenizer, tokenizer_kw, model, batch_size, 
             tokens = tokenizer(text_batch, **tokenizer_kw)
             emb = torch.as_tensor(model(**tokens, output_step=output_step)).cuda()
             if out is None:
-                out = torch.empty(num, emb.shape[1], dtype=torch.bfloat16, device=emb.device)
+                out = torch.empty(num, ops.padded_dim(emb.shape[1]), dtype=torch.bfloat16, device=emb.device)
             ops.pack_bf16(emb, normalize=(sim_type == "cos"), out=out[step * batch_size:step * batch_size + len(text_batch)])
     return out
 
@@ -92,7 +92,7 @@ class LowRankScore:
     def as_tensor(self, device=None):
         """Dense scores (this materialises n_users x n_items fp32): canonical fp64-ordered values for small problems,
         the MFMA tile kernel (same bf16 rows, fp32 accumulation) above 4e9 multiply-adds."""
-        big = self.shape[0] * self.shape[1] * self.user.shape[1] > 4e9 and self.user.shape[1] % 32 == 0
+        big = self.shape[0] * self.shape[1] * self.user.shape[1] > 4e9
         s = self.index().scores(self.user, "mfma" if big else "canonical")
         return s if device is None else s.to(device)
 

@@ -46,7 +46,7 @@ def generate_embeddings(data_indices, data_dic, embedding_func, batch_size, embe
             emb = torch.as_tensor(embedding_func(text_batch)).to(
                 device, non_blocking=bool(int(os.environ.get("CCREC_NON_BLOCKING", "1"))))
             if out is None:
-                dim = emb.shape[1]
+                dim = emb.shape[1] if pack is None else ops.padded_dim(emb.shape[1])   # packed rows: zero-padded to a multiple of 8
                 out = torch.empty(num, dim, device=device, dtype=torch.float32 if pack is None else torch.bfloat16)
             lo = step * batch_size
             if pack is None:
@@ -57,7 +57,8 @@ def generate_embeddings(data_indices, data_dic, embedding_func, batch_size, embe
     torch.cuda.synchronize()
     print(f"Processed total {num} t={time.time() - tic:.1f}s")
     if out is None:
-        out = torch.empty(0, embedding_size, device=device, dtype=torch.float32 if pack is None else torch.bfloat16)
+        out = torch.empty(0, embedding_size if pack is None else ops.padded_dim(embedding_size), device=device,
+                          dtype=torch.float32 if pack is None else torch.bfloat16)
     if name is not None:
         torch.save(out, name)
     return out
@@ -76,7 +77,7 @@ def cos_sim(a: torch.Tensor, b: torch.Tensor):
     b_n = ops.pack_bf16(b.cuda().float(), normalize=True)
     # small matrices: the canonical fp64-ordered scores (bit-identical to the oracle); large ones: the MFMA tile kernel
     # (fp32 accumulation of the same bf16 rows, within 1e-6 of the canonical value) -- the fp64 path is VALU-bound
-    big = a_n.shape[0] * b_n.shape[0] * a_n.shape[1] > CANONICAL_COS_SIM_MACS and a_n.shape[1] % 32 == 0
+    big = a_n.shape[0] * b_n.shape[0] * a_n.shape[1] > CANONICAL_COS_SIM_MACS
     return ops.CorpusIndex(b_n).scores(a_n, "mfma" if big else "canonical")
 
 

@@ -41,9 +41,16 @@ def _check_bounds(norm_bounds, rows):
     assert norm_bounds.dim() == 1 and norm_bounds.numel() >= rows, "norm_bounds: one fp32 per (destination) row"
 
 
+def padded_dim(dim):
+    """Width of the packed rows: embeddings of any width are stored zero-padded to a multiple of 8 (16-byte chunks)."""
+    return (int(dim) + 7) // 8 * 8
+
+
 def pack_bf16(x, normalize=False, out=None, return_norms=False, norm_bounds=None):
-    """fp32 [rows, dim] (cuda) -> bf16 [rows, dim]; normalize=True applies x / max(||x||, 1e-12) first
+    """fp32 [rows, dim] (cuda) -> bf16 [rows, padded_dim(dim)]; normalize=True applies x / max(||x||, 1e-12) first
     (the cos_sim rule, ms_marco_eval.py:160-161).  `out` may be a slice of a preallocated shard.
+    A width that is not a multiple of 8 (the reference takes any factor width, score_array.py:320-339) is zero-padded to the
+    next one: scores, norms and cosines are unchanged, queries and corpus pad alike.
     norm_bounds: optional [rows] fp32 cuda tensor (the matching slice of a shard-sized one; no initialisation needed) that
     receives an upper bound of every packed row's norm; hand the whole array to CorpusIndex(norm_bounds=...) and the
     index build needs no pass over the shard (the search uses the bounds, per 256-row tile, in its filter margins)."""
@@ -53,15 +60,20 @@ def pack_bf16(x, normalize=False, out=None, return_norms=False, norm_bounds=None
     if x.dtype != torch.float32:
         x = x.float()  # autocast may hand over fp16 encoder outputs (al_0_rank.py:125)
     rows, dim = x.shape
+    pdim = padded_dim(dim)
     if out is None:
-        out = torch.empty(rows, dim, dtype=torch.bfloat16, device=x.device)
-    assert out.is_contiguous() and out.dtype == torch.bfloat16 and tuple(out.shape) == (rows, dim)
+        out = torch.empty(rows, pdim, dtype=torch.bfloat16, device=x.device)
+    assert out.is_contiguous() and out.dtype == torch.bfloat16 and tuple(out.shape) == (rows, pdim)
     norms = torch.empty(rows, dtype=torch.float32, device=x.device) if return_norms else None
     if norm_bounds is not None:
         _check_bounds(norm_bounds, rows)
     with _on(x):
-        _lib.check(lib.ccr_pack_bf16_ex(_ptr(x), _ptr(out), _ptr(norms), _ptr(norm_bounds), rows, dim, int(bool(normalize)),
-                                        _stream(x)), "ccr_pack_bf16")
+        if pdim != dim:
+            _lib.check(lib.ccr_pack_bf16_padded(_ptr(x), rows, dim, _ptr(out), pdim, _ptr(norms), _ptr(norm_bounds),
+                                                int(bool(normalize)), _stream(x)), "ccr_pack_bf16_padded")
+        else:
+            _lib.check(lib.ccr_pack_bf16_ex(_ptr(x), _ptr(out), _ptr(norms), _ptr(norm_bounds), rows, dim, int(bool(normalize)),
+                                            _stream(x)), "ccr_pack_bf16")
     return (out, norms) if return_norms else out
 
 
@@ -326,7 +338,7 @@ class CorpusIndex:
 
     def scores(self, queries_bf16, mode="canonical"):
         """Dense score matrix [n_q, n_rows] fp32 (ccr_scores).  mode "canonical": the fp64-ordered values the ranking
-        reports; "mfma": the same bf16 rows through the MFMA tile kernel (fp32 accumulation; dim % 32 == 0)."""
+        reports; "mfma": the same bf16 rows through the MFMA tile kernel (fp32 accumulation)."""
         q = queries_bf16.contiguous()
         assert q.is_cuda and q.dtype == torch.bfloat16 and q.dim() == 2 and q.shape[1] == self.dim
         out = torch.empty(q.shape[0], self.n_rows, dtype=torch.float32, device=q.device)

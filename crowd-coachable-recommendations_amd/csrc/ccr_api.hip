@@ -190,8 +190,9 @@ static Plan make_plan_for(int64_t n_rows, int dim, int n_q, int k, int flags, in
     }
     auto sample_for = [&](int64_t div) { return std::max<int64_t>({(p.tiles + div - 1) / div, min_sample, 4}); };
     int64_t sample = sample_for(sample_div);
-    bool fused = (dim % TILE_K == 0) && dim >= TILE_K && (sample * 4 <= p.full_tiles) && k <= MAX_K;
-    if ((flags & CCR_SEARCH_FORCE_FUSED) && (dim % TILE_K == 0) && p.full_tiles >= 1) {
+    // any dim the index accepts (a multiple of 8): the fused kernels zero-fill the last 32-element K sub-stage when dim % 32 != 0
+    bool fused = (dim % 8 == 0) && dim >= 8 && (sample * 4 <= p.full_tiles) && k <= MAX_K;
+    if ((flags & CCR_SEARCH_FORCE_FUSED) && (dim % 8 == 0) && p.full_tiles >= 1) {
         // honour the request where at all possible: the sample may be the whole corpus
         if (!fused) sample = std::min<int64_t>(std::max<int64_t>(sample, 1), p.full_tiles);
         fused = sample * GROUPS_PER_TILE >= k;
@@ -543,7 +544,7 @@ static int dense_for_list(const ccr_index *ix, const uint16_t *Q, const uint32_t
 // The same for inner-product scores the fast way: MFMA score rows of the chunk (EPI_STORE of the fused kernel) + margin select
 // (ccr_dense.hip).  Queries are the rows Qc[0 .. n) -- contiguous: the caller gathers a list first -- results go to rows
 // out_rows[i] (or q_begin + i).  Queries the margin select cannot finish are appended to flag_list (flag_count is NOT reset here).
-static bool margin_path_ok(const ccr_index *ix, int k) { return ix->dim % TILE_K == 0 && k <= MAX_K; }
+static bool margin_path_ok(const ccr_index *ix, int k) { return ix->dim % 8 == 0 && k <= MAX_K; }
 
 static int margin_for_rows(const ccr_index *ix, const uint16_t *Qc, const float *hint, const uint32_t *out_rows, int q_begin, int n, int k, float *scratch,
                            size_t scratch_bytes, float *out_scores, int64_t *out_ids, uint32_t *flag_count, uint32_t *flag_list,
@@ -1089,7 +1090,7 @@ extern "C" int ccr_scores(const ccr_index *ix, const uint16_t *Q_bf16, int n_q, 
     if (mode == CCR_SCORES_CANONICAL)
         return launch_dense_scores(ix->D, ix->n_rows, ix->dim, Q_bf16, nullptr, 0, n_q, nullptr, out, (hipStream_t)stream);
     CCR_REQUIRE(mode == CCR_SCORES_MFMA, "ccr_scores: unknown mode %d", mode);
-    CCR_REQUIRE(ix->dim % TILE_K == 0, "ccr_scores: CCR_SCORES_MFMA needs dim %% 32 == 0 (dim=%d)", ix->dim);
+    CCR_REQUIRE(ix->dim % 8 == 0, "ccr_scores: CCR_SCORES_MFMA needs dim %% 8 == 0 (dim=%d)", ix->dim);
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.D = ix->D;

@@ -29,6 +29,10 @@
 
 namespace ccr {
 
+// 16 zero bytes: what the LDS-DMA reads for the K chunks of the LAST sub-stage that lie beyond the row end when dim % 32 != 0
+// (TAIL instantiations; rows are dim * 2 bytes, dim % 8 == 0, so a 16-byte chunk is wholly inside or wholly outside a row)
+__device__ __attribute__((aligned(16))) uint32_t g_zero_chunk[4];
+
 // Wave-uniform 4-byte load through the scalar cache (lgkmcnt, not vmcnt), complete on return.
 __device__ __forceinline__ float load_uniform_f32(const float *p) {
     float v;
@@ -68,7 +72,7 @@ __device__ __forceinline__ unsigned long long stamp() {
 
 // DBG (compile-time, diagnostic instantiations only; results are WRONG when non-zero):
 //   1 corpus rows always tile 0, 2 query slice always 0, 4 no DMA, 8 no MFMA, 16 cycle stamps
-template <int EPI, bool STAGGER, int DBG>
+template <int EPI, bool STAGGER, int DBG, bool TAIL = false>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
     const int l31 = lane & 31;
     const int h = lane >> 5;
     const bool g1 = STAGGER && (wv >= 4);  // the trailing half of the ping-pong (wave-uniform)
-    const int KS2 = a.dim / SUB_K;
+    const int KS2 = TAIL ? (a.dim + SUB_K - 1) / SUB_K : a.dim / SUB_K;   // TAIL: the last sub-stage is partly zero-filled
     unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // DBG 16: cycles per segment of the inner loop
     unsigned long long tprev = 0;
     if constexpr ((DBG & 16) != 0) tprev = stamp();
@@ -175,11 +179,21 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
             char *buf = smem + (int)(iu & (RING - 1)) * SUB_BYTES;
             const int k0 = iks * SUB_K;
             if constexpr (!(DBG & 4)) {
+                if (TAIL && iks == KS2 - 1) {   // wave-uniform: chunks beyond the row end come from the zero chunk
+                    const bool in = k0 + schunk * 8 < a.dim;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) glds16(dsrc[i] + k0, buf + (i * 512 + wv * 64) * 16);
+                    for (int i = 0; i < 2; ++i)
+                        glds16(in ? (const void *)(dsrc[i] + k0) : (const void *)g_zero_chunk, buf + (i * 512 + wv * 64) * 16);
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    glds16(qsrc[i] + ((DBG & 2) ? 0 : k0), buf + SUB_Q_REGION + (i * 512 + wv * 64) * 16);
+                    for (int i = 0; i < 2; ++i)
+                        glds16(in ? (const void *)(qsrc[i] + k0) : (const void *)g_zero_chunk, buf + SUB_Q_REGION + (i * 512 + wv * 64) * 16);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) glds16(dsrc[i] + k0, buf + (i * 512 + wv * 64) * 16);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        glds16(qsrc[i] + ((DBG & 2) ? 0 : k0), buf + SUB_Q_REGION + (i * 512 + wv * 64) * 16);
+                }
             }
             ++iu;
             if (++iks == KS2) {
@@ -410,7 +424,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
 //   the 16x16 fragment read pattern; brute-forced over all xor tables).
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-template <int EPI, int DBG>
+template <int EPI, int DBG, bool TAIL = false>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -421,7 +435,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
     const int l15 = lane & 15;
     const int lq = lane >> 4;  // 0..3: K chunk of the operand fragments, row quad of the accumulator
     const bool g1 = (wv >= 4);
-    const int KS2 = a.dim / SUB_K;
+    const int KS2 = TAIL ? (a.dim + SUB_K - 1) / SUB_K : a.dim / SUB_K;
 
     const int srow = wv * 16 + (lane >> 2);  // + piece*128
     const int schunk = (lane & 3) ^ (((srow >> 2) & 1) << 1);
@@ -494,10 +508,20 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
         auto issue = [&]() {
             char *buf = smem + (int)(iu & (RING - 1)) * SUB_BYTES;
             const int k0 = iks * SUB_K;
+            if (TAIL && iks == KS2 - 1) {   // wave-uniform: chunks beyond the row end come from the zero chunk
+                const bool in = k0 + schunk * 8 < a.dim;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) glds16(dsrc[i] + k0, buf + (i * 512 + wv * 64) * 16);
+                for (int i = 0; i < 2; ++i)
+                    glds16(in ? (const void *)(dsrc[i] + k0) : (const void *)g_zero_chunk, buf + (i * 512 + wv * 64) * 16);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) glds16(qsrc[i] + k0, buf + SUB_Q_REGION + (i * 512 + wv * 64) * 16);
+                for (int i = 0; i < 2; ++i)
+                    glds16(in ? (const void *)(qsrc[i] + k0) : (const void *)g_zero_chunk, buf + SUB_Q_REGION + (i * 512 + wv * 64) * 16);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) glds16(dsrc[i] + k0, buf + (i * 512 + wv * 64) * 16);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) glds16(qsrc[i] + k0, buf + SUB_Q_REGION + (i * 512 + wv * 64) * 16);
+            }
             ++iu;
             if (++iks == KS2) {
                 iks = 0;
@@ -1398,15 +1422,18 @@ static int launch_gemm(const GemmArgs &a, int grid, hipStream_t s) {
         }
     }
 #endif
+    if (a.dim % SUB_K != 0) return launch_kernel(&gemm_topk_kernel<EPI, true, 0, true>, lds, a, grid, s);   // zero-filled last K sub-stage
     if (!a.stagger) return launch_kernel(&gemm_topk_kernel<EPI, false, 0>, lds, a, grid, s);   // CCR_GEMM_STAGGER=0 (A/B of the ping-pong)
     return launch_kernel(&gemm_topk_kernel<EPI, true, 0>, lds, a, grid, s);
 }
 
 int launch_gemm_filter(const GemmArgs &a, int grid, hipStream_t s) { return launch_gemm<EPI_FILTER>(a, grid, s); }
 int launch_gemm16_filter(const GemmArgs &a, int grid, hipStream_t s) {
+    if (a.dim % SUB_K != 0) return launch_kernel(&gemm_topk16_kernel<EPI_FILTER, 0, true>, RING * (size_t)SUB_BYTES, a, grid, s);
     return launch_kernel(&gemm_topk16_kernel<EPI_FILTER, 0>, RING * (size_t)SUB_BYTES, a, grid, s);
 }
 int launch_gemm16_store(const GemmArgs &a, int grid, hipStream_t s) {
+    if (a.dim % SUB_K != 0) return launch_kernel(&gemm_topk16_kernel<EPI_STORE, 0, true>, RING * (size_t)SUB_BYTES, a, grid, s);
     return launch_kernel(&gemm_topk16_kernel<EPI_STORE, 0>, RING * (size_t)SUB_BYTES, a, grid, s);
 }
 int launch_gemm_gmax(const GemmArgs &a, int grid, hipStream_t s) { return launch_gemm<EPI_GMAX>(a, grid, s); }

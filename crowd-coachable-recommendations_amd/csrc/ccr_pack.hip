@@ -153,6 +153,48 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float *__restrict_
     }
 }
 
+// ---------------------------------------------------------------- rows of ANY width -> zero-padded rows of a multiple of 8
+// One wave per row, element-wise loads (source rows of an odd width are not 16-byte aligned).  The sum of squares keeps the
+// canonical order of wave_sumsq: element i belongs to "chunk" i / 4, lane (i / 4) % 64, accumulated in increasing index, then
+// the butterfly -- for dim % 4 == 0 the same bits as pack_rows_kernel, and appending zeros to a row changes nothing (p + 0.0 = p).
+__global__ __launch_bounds__(256) void pack_rows_padded_kernel(const float *__restrict__ src, int src_dim, __bf16 *__restrict__ dst,
+                                                              int dst_dim, float *__restrict__ norms, int64_t rows, int normalize,
+                                                              float *__restrict__ bounds) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int nchunk = (dst_dim + 3) >> 2;
+    for (int64_t r = wave; r < rows; r += nwaves) {
+        const float *x = src + r * src_dim;
+        double p = 0.0;
+        for (int c = lane; c < nchunk; c += 64) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = 4 * c + e;
+                const double v = i < src_dim ? (double)x[i] : 0.0;
+                p = p + v * v;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) p = p + __shfl_xor(p, off, 64);
+        const double nrm = sqrt(p);
+        if (norms && lane == 0) norms[r] = (float)nrm;
+        const double den = nrm > 1e-12 ? nrm : 1e-12;
+        __bf16 *y = dst + r * dst_dim;
+        for (int c = lane; c < nchunk; c += 64) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = 4 * c + e;
+                if (i >= dst_dim) break;
+                float v = i < src_dim ? x[i] : 0.f;
+                if (normalize && i < src_dim) v = (float)((double)v / den);
+                y[i] = (__bf16)v;
+            }
+        }
+        if (bounds && lane == 0) bounds[r] = (float)((normalize ? nrm / den : nrm) * 1.004);
+    }
+}
+
 // ---------------------------------------------------------------- fused masked mean pooling + pack
 // One workgroup of `dim/4` (<=256) threads... generalised: thread t owns float4 chunk columns
 // t, t+blockDim, ...; loop over tokens l ascending (fp32 adds in token order = the oracle's order);
@@ -402,6 +444,21 @@ extern "C" int ccr_pack_bf16_ex(const float *src, uint16_t *dst, float *norms, f
     if (blocks > 65536) blocks = 65536;   // short-lived waves (a few rows each) stream faster than a 2 048-block grid-stride loop
     hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, reinterpret_cast<__bf16 *>(dst),
                        norms, rows, dim, normalize, bounds);
+    CCR_LAUNCH_CHECK();
+    return CCR_OK;
+}
+
+extern "C" int ccr_pack_bf16_padded(const float *src, int64_t rows, int src_dim, uint16_t *dst, int dst_dim, float *norms,
+                                    float *row_norm_bounds, int normalize, void *stream) {
+    CCR_REQUIRE(src && dst, "ccr_pack_bf16_padded: null pointer");
+    CCR_REQUIRE(rows >= 0 && src_dim > 0 && dst_dim >= src_dim && dst_dim % 8 == 0 && dst_dim - src_dim < 8,
+                "ccr_pack_bf16_padded: bad shape rows=%lld src_dim=%d dst_dim=%d (dst_dim = src_dim rounded up to a multiple of 8)",
+                (long long)rows, src_dim, dst_dim);
+    if (rows == 0) return CCR_OK;
+    int64_t blocks = (rows + 3) / 4;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(pack_rows_padded_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, src_dim,
+                       reinterpret_cast<__bf16 *>(dst), dst_dim, norms, rows, normalize, row_norm_bounds);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
 }

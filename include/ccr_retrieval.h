@@ -93,6 +93,14 @@ int ccr_pack_bf16(const float *src, uint16_t *dst, float *norms, int64_t rows, i
 int ccr_pack_bf16_ex(const float *src, uint16_t *dst, float *norms, float *row_norm_bounds, int64_t rows, int dim, int normalize,
                      void *stream);
 
+/* Embeddings of ANY width (the reference takes any factor width: src/rime_lite/util/score_array.py:320-339,
+ * src/ccrec/models/bbpr.py:536-540): rows of src_dim floats are packed into rows of dst_dim = src_dim rounded up to a multiple
+ * of 8, the tail zero-filled -- inner products, norms and cosines are unchanged, and every search path takes the padded width
+ * (the fused kernels zero-fill their last 32-element K step for widths that are not multiples of 32).
+ *   norms / row_norm_bounds: as ccr_pack_bf16_ex.  The canonical sum of squares extends to any width by zero padding. */
+int ccr_pack_bf16_padded(const float *src, int64_t rows, int src_dim, uint16_t *dst, int dst_dim, float *norms,
+                         float *row_norm_bounds, int normalize, void *stream);
+
 /*
  * Fused masked mean pooling (+ optional normalise) + pack of the encoder's last hidden state.
  * Replaces: src/ccrec/models/item_tower.py:137-147 (masked_fill, sum(dim=1), divide) followed by the pack.
@@ -163,7 +171,7 @@ int ccr_search_last_stats(const ccr_index *index, ccr_search_stats *stats /* hos
  * Dense score matrix of n_q queries against the shard: out [n_q][n_rows] fp32.
  * Replaces: cos_sim / the chunked `Q @ chunk^T` of scripts/ms_marco_eval.py:155-162,212-215 and
  * src/ccrec/models/bbpr.py:485-492,536-540 when a caller really wants the matrix (small problems; the ranking path
- * never materialises it).  mode: CCR_SCORES_CANONICAL or CCR_SCORES_MFMA (dim % 32 == 0).
+ * never materialises it).  mode: CCR_SCORES_CANONICAL or CCR_SCORES_MFMA.
  */
 int ccr_scores(const ccr_index *index, const uint16_t *Q_bf16, int n_q, int mode, float *out, void *stream);
 

@@ -14,7 +14,7 @@ def _case(seed):
     rs = np.random.RandomState(seed)
     n = int(rs.choice([rs.randint(260, 3000), rs.randint(3000, 60000), rs.randint(60000, 220000)]))
     nq = int(rs.choice([1, rs.randint(2, 40), rs.randint(40, 700)]))
-    d = int(rs.choice([8, 24, 32, 64, 96, 128, 160, 200, 384, 768, 1024]))
+    d = int(rs.choice([8, 24, 32, 40, 64, 96, 128, 160, 200, 300, 384, 768, 1024]))   # 300: not a multiple of 8 (zero-padded by the pack)
     k = int(min(n, rs.choice([1, rs.randint(2, 30), rs.randint(30, 300), rs.randint(300, 1300)])))
     off = int(rs.choice([0, 7, 1 << 33]))
     quant = bool(rs.rand() < 0.3)
@@ -42,14 +42,15 @@ def test_random_shapes_all_paths_agree(seed):
     st0 = index.last_stats()
     s1, i1 = index.search(Qb, k, 1)
     assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32)), (n, nq, d, k, st0)
-    if d % 32 == 0 and n >= 256:
+    if n >= 256:   # every width runs the fused kernels (the last 32-element K step zero-filled when dim % 32 != 0)
         s2, i2 = index.search(Qb, k, 2)
         st2 = index.last_stats()
         if st2["path"] == 1:
             assert torch.equal(i2, i1) and torch.equal(s2.view(torch.int32), s1.view(torch.int32)), (n, nq, d, k, st2)
+    assert Db.shape[1] == (d + 7) // 8 * 8 and (d % 8 == 0 or not Db[:, d:].any())          # odd widths: zero tail
     if n * nq <= 3_000_000:
         bits = lambda t: t.view(torch.int16).cpu().numpy().view(np.uint16)   # noqa: E731
-        ref_i, ref_s = orc.canonical_search(bits(Qb), bits(Db), k)
+        ref_i, ref_s = orc.canonical_search(bits(Qb)[:, :d], bits(Db)[:, :d], k)                # the oracle sees the unpadded rows
         assert np.array_equal(i1.cpu().numpy() - off, ref_i) and np.array_equal(s1.cpu().numpy(), ref_s)
 
 
@@ -97,3 +98,38 @@ def test_medium_shapes_multi_phase_plans_agree_with_dense(seed):
     pick = torch.cat([torch.arange(b, min(nq, b + 6)) for b in range(0, nq, 256)]).cuda()   # rows of every query block
     s1, i1 = index.search(Q[pick], k, 1)
     assert torch.equal(i[pick], i1) and torch.equal(s[pick].view(torch.int32), s1.view(torch.int32)), (n, nq, d, k, data, st)
+
+
+@pytest.mark.parametrize("d", [8, 24, 40, 200, 300, 301, 50, 7])
+@pytest.mark.parametrize("sim", ["dot", "cos"])
+def test_any_embedding_width_takes_the_fused_path(d, sim):
+    """The reference takes any factor width (rime_lite score_array.py:320-339, bbpr.py:536-540).  Widths that are not multiples
+    of 32 run the fused MFMA kernels with a zero-filled last K step; widths that are not multiples of 8 are zero-padded by the
+    pack kernel (its normalising form keeps the canonical sum order).  Fused == fp64 dense == oracle, bit for bit; the MFMA score
+    matrix agrees with the canonical one to fp32 accumulation noise."""
+    from ccrec_amd import ops
+    n, nq, k = 70_000, 300, 100
+    g = torch.Generator().manual_seed(d)
+    D = torch.randn(n, d, generator=g) / d ** 0.5
+    Q = torch.randn(nq, d, generator=g) / d ** 0.5
+    nb = torch.empty(n, device="cuda")
+    Db, Qb = ops.pack_bf16(D.cuda(), normalize=(sim == "cos"), norm_bounds=nb), ops.pack_bf16(Q.cuda(), normalize=(sim == "cos"))
+    pd = ops.padded_dim(d)
+    assert Db.shape == (n, pd) and Qb.shape == (nq, pd)
+    bits = lambda t: t.view(torch.int16).cpu().numpy().view(np.uint16)   # noqa: E731
+    ref_D = orc.pack(D.numpy(), sim)
+    assert np.array_equal(bits(Db)[:, :d], ref_D) and not bits(Db)[:, d:].any()      # packed rows == oracle's, tail zero
+    for index in (ops.CorpusIndex(Db, norm_bounds=nb), ops.CorpusIndex(Db)):
+        s2, i2 = index.search(Qb, k, 2)
+        st = index.last_stats()
+        assert st["path"] == 1 and st["n_fallback"] == 0, st                           # the fused MFMA path, nothing flagged
+        s1, i1 = index.search(Qb, k, 1)
+        assert torch.equal(i2, i1) and torch.equal(s2.view(torch.int32), s1.view(torch.int32))
+    ref_i, ref_s = orc.canonical_search(orc.pack(Q.numpy(), sim)[:40], ref_D, k)
+    assert np.array_equal(i2.cpu().numpy()[:40], ref_i) and np.array_equal(s2.cpu().numpy()[:40].view(np.uint32), ref_s.view(np.uint32))
+    small = ops.CorpusIndex(Db[:3000].contiguous())                                    # margin path of a small corpus: MFMA score rows
+    s3, i3 = small.search(Qb[:50], 20)
+    s4, i4 = small.search(Qb[:50], 20, 1)
+    assert torch.equal(i3, i4) and torch.equal(s3.view(torch.int32), s4.view(torch.int32))
+    mf, can = small.scores(Qb[:50], "mfma"), small.scores(Qb[:50], "canonical")
+    assert float((mf - can).abs().max()) < 2e-6 * max(1.0, float(can.abs().max()))
