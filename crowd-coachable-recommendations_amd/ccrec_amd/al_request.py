@@ -62,10 +62,12 @@ def build_requests(ranking_profile, ranking_profile_bm25, step_qids, corpus, que
     draw = np.random.RandomState(step)
     columns = BASE_COLUMNS + (IMAGE_COLUMNS if landing_image is not None else [])
     rows, id_track = [], {}
-    for qid in ranking_profile:                   # (only the step's queries are read: a lazy profile builds no other inner dict)
+    top = getattr(ranking_profile, "top", None)   # a lazy RankingProfile names a query's best passages without building its dict
+    for qid in ranking_profile:                   # (only the step's queries are read)
         if qid not in step_qids:
             continue
-        cands = pick_candidates(list(ranking_profile[qid].keys()), list(ranking_profile_bm25[qid].keys()), corpus_keys, draw)
+        dense_order = top(qid, 2) if top is not None else list(ranking_profile[qid].keys())   # the rule reads ranks[0:2] only
+        cands = pick_candidates(dense_order, list(ranking_profile_bm25[qid].keys()), corpus_keys, draw)
         shown = [filter_string(corpus[pid], display_length) for pid in cands]
         row = [queries[qid], *shown, f"q_{qid}", *(f"p_{pid}" for pid in cands)]
         if landing_image is not None:

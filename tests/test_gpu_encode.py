@@ -110,6 +110,28 @@ def test_plan_and_encode_match_fixed_padding():
     assert torch.all(packed_norms <= nb * 1.000001) and torch.all(nb <= packed_norms * 1.001 + 1e-30)
 
 
+def test_chunked_pipeline_equals_one_chunk():
+    """The corpus is tokenised / planned chunk by chunk on a host thread while the GPU encodes the previous chunk: every text
+    lands in its own row exactly once and the rows agree with a single-chunk run up to the encoder's fp32 noise at a different
+    batch composition (bf16 rows: equal bits, rare 1-ulp flips)."""
+    from ccrec_amd.encode import LengthSortedEncoder
+    tower, tok = _tower(), ToyTokenizer()
+    texts = _texts(1000, 5)
+    one = LengthSortedEncoder(tower, tok, max_length=32, max_tokens=1024, max_batch=64, chunk_texts=10_000)
+    many = LengthSortedEncoder(tower, tok, max_length=32, max_tokens=1024, max_batch=64, chunk_texts=130)   # 8 chunks, ragged last
+    nb1, nb2 = torch.full((1003,), -1.0, device="cuda"), torch.full((1003,), -1.0, device="cuda")
+    a = one.encode(texts, sim="cos", norm_bounds=nb1, row_offset=3)
+    b = many.encode(texts, sim="cos", norm_bounds=nb2, row_offset=3)
+    assert one.stats["chunks"] == 1 and many.stats["chunks"] == 8 and many.stats["texts"] == 1000
+    assert many.stats["real_tokens"] == one.stats["real_tokens"] and many.stats["batches"] >= one.stats["batches"]
+    assert many.stats["wall_s"] > 0 and many.stats["gpu_busy_s"] > 0 and many.stats["host_prepare_s"] > 0
+    assert a.shape == b.shape == (1003, 64)
+    diff = (a[3:].view(torch.int16).int() - b[3:].view(torch.int16).int()).abs()
+    assert int(diff.max()) <= 1 and float((diff != 0).float().mean()) < 0.02
+    assert torch.all(nb2[:3] == -1.0) and torch.all(nb2[3:] > 0) and torch.allclose(nb1[3:], nb2[3:], rtol=1e-2)
+    assert many.encode([], sim="dot").shape[0] == 0 and many.stats["chunks"] == 0
+
+
 def test_ranking_sharded_single_rank_equals_ranking_api():
     from ccrec_amd.encode import LengthSortedEncoder, ranking_sharded
     os.environ["CCREC_SIM_TYPE"] = "cos"

@@ -39,8 +39,30 @@ class IdTokenizer:
         return {"input_ids": input_ids, "attention_mask": mask}
 
 
+def fast_tokenizer(vocab_words=30000):
+    """A Rust (HF `tokenizers`) word-level tokenizer over a synthetic vocabulary, built in memory (no hub access): the
+    host cost of a real fast tokenizer -- its batch encoder runs in Rust threads and releases the GIL."""
+    from tokenizers import Tokenizer
+    from tokenizers.models import WordLevel
+    from tokenizers.pre_tokenizers import Whitespace
+    from tokenizers.processors import TemplateProcessing
+    from transformers import PreTrainedTokenizerFast
+    vocab = {"[PAD]": 0, "[UNK]": 1, "[CLS]": 2, "[SEP]": 3}
+    vocab.update({f"w{i}": 4 + i for i in range(vocab_words)})
+    tk = Tokenizer(WordLevel(vocab, unk_token="[UNK]"))
+    tk.pre_tokenizer = Whitespace()
+    tk.post_processor = TemplateProcessing(single="[CLS] $A [SEP]", special_tokens=[("[CLS]", 2), ("[SEP]", 3)])
+    return PreTrainedTokenizerFast(tokenizer_object=tk, pad_token="[PAD]", unk_token="[UNK]", cls_token="[CLS]", sep_token="[SEP]")
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--tokenizer", default="ids", choices=["ids", "fast"],
+                    help="ids: pre-tokenised id strings (isolates the batching policy); fast: a Rust word-level tokenizer (real host cost)")
+    ap.add_argument("--modes", default="fixed,batch_max,sorted",
+                    help="comma list of fixed, batch_max, sorted (chunked pipeline), serial (sorted, but tokenise everything first)")
+    ap.add_argument("--chunk-texts", type=int, default=65536)
+    ap.add_argument("--host-threads", type=int, default=2)
     ap.add_argument("--texts", type=int, default=20000)
     ap.add_argument("--dist", default="titles", choices=["titles", "passages"])
     ap.add_argument("--layers", type=int, default=12)
@@ -56,33 +78,43 @@ def main():
         lens = np.clip(rs.lognormal(np.log(18), 0.5, args.texts).astype(int), 3, args.max_length - 2)
     else:                         # 100-word passages (NQ / MS MARCO-like)
         lens = np.clip(rs.normal(135, 30, args.texts).astype(int), 20, args.max_length - 2)
-    texts = [" ".join(map(str, rs.randint(1000, 30000, n))) for n in lens]
+    if args.tokenizer == "fast":
+        words = np.array([f"w{i}" for i in range(30000)], dtype=object)
+        texts = [" ".join(words[rs.randint(0, 30000, n)]) for n in lens]
+        tok = fast_tokenizer()
+    else:
+        texts = [" ".join(map(str, rs.randint(1000, 30000, n))) for n in lens]
+        tok = IdTokenizer()
     torch.manual_seed(0)
-    cfg = BertConfig(num_hidden_layers=args.layers)   # BERT-base geometry, random weights
+    cfg = BertConfig(num_hidden_layers=args.layers, vocab_size=30522)   # BERT-base geometry, random weights
     tower = NaiveItemTower(BertModel(cfg).eval(), torch.nn.LayerNorm(768, elementwise_affine=False)).cuda()
-    tok = IdTokenizer()
 
     def reference_style(padding):
         nonlocal texts
         out = []
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
             for lo in range(0, len(texts), args.batch):
-                toks = tok(texts[lo:lo + args.batch], padding=padding, max_length=args.max_length)
+                toks = tok(texts[lo:lo + args.batch], truncation=True, padding=padding, max_length=args.max_length, return_tensors="pt")
                 emb = tower(**{k: v.cuda() for k, v in toks.items()}, output_step="mean_pooling")
                 out.append(emb.float().cpu())
         return torch.vstack(out)
 
-    def sorted_style():
+    def sorted_style(chunk=None):
         nonlocal texts
-        enc = LengthSortedEncoder(tower, tok, max_length=args.max_length, max_tokens=args.batch * 128, max_batch=4 * args.batch)
+        enc = LengthSortedEncoder(tower, tok, max_length=args.max_length, max_tokens=args.batch * 128, max_batch=4 * args.batch,
+                                  chunk_texts=chunk or args.chunk_texts, host_threads=args.host_threads)
         with torch.autocast("cuda", dtype=torch.bfloat16):
             shard = enc.encode(texts, sim="dot")
-        return shard, enc.stats
+        st = dict(enc.stats)
+        st["gpu_idle_frac"] = round(1.0 - st["gpu_busy_s"] / max(st["wall_s"], 1e-9), 4)
+        return shard, {k: (round(v, 3) if isinstance(v, float) else v) for k, v in st.items()}
 
     results = {}
     all_texts = texts
-    for name, fn in (("fixed", lambda: reference_style("max_length")), ("batch_max", lambda: reference_style(True)),
-                     ("sorted", sorted_style)):
+    table = {"fixed": lambda: reference_style("max_length"), "batch_max": lambda: reference_style(True), "sorted": sorted_style,
+             "serial": lambda: sorted_style(chunk=10 ** 9)}
+    for name in args.modes.split(","):
+        fn = table[name]
         texts = all_texts[:2048]      # untimed warm-up of this mode's GEMM shapes
         fn()
         texts = all_texts
@@ -94,13 +126,17 @@ def main():
         results[name] = r
         line = {"mode": name, "dist": args.dist, "texts": args.texts, "mean_tokens": float(lens.mean() + 2),
                 "max_length": args.max_length, "seconds": round(dt, 3), "texts_per_s": round(args.texts / dt, 1)}
-        if name == "sorted":
+        if name in ("sorted", "serial"):
             line.update(r[1])
+            line["tokenizer"] = args.tokenizer
         print(json.dumps(line), flush=True)
-    ref = results["fixed"].cuda()
-    got = results["sorted"][0].float()
-    cos = torch.nn.functional.cosine_similarity(ref, got, dim=1)
-    print(json.dumps({"check": "cosine(sorted bf16 rows, fixed-padding fp32 rows)", "min": float(cos.min()), "mean": float(cos.mean())}))
+        if name not in ("fixed", "sorted"):
+            results[name] = None     # keep only what the final check needs
+    if results.get("fixed") is not None and results.get("sorted") is not None:
+        ref = results["fixed"].cuda()
+        got = results["sorted"][0].float()
+        cos = torch.nn.functional.cosine_similarity(ref, got, dim=1)
+        print(json.dumps({"check": "cosine(sorted bf16 rows, fixed-padding fp32 rows)", "min": float(cos.min()), "mean": float(cos.mean())}))
 
 
 if __name__ == "__main__":

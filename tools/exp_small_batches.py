@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(ROOT, "crowd-coachable-recommendations_amd"))
 from bench import gen_rows  # noqa: E402
 from ccrec_amd import ops  # noqa: E402
 
-n, d = 2_681_468, 768
+n, d = (int(sys.argv[1]) if len(sys.argv) > 1 else 2_681_468), 768   # argv[1]: corpus rows (100000 rows = 154 MB sit in the 256-MB Infinity Cache)
 nb = torch.empty(n, device="cuda")
 D = ops.pack_bf16(gen_rows(n, d, 1234, "cuda"), norm_bounds=nb)
 Qall = ops.pack_bf16(gen_rows(1024, d, 4321, "cuda"))
@@ -29,5 +29,6 @@ for nq in (1, 16, 64, 256, 512, 1024):
     ms = (time.time() - t0) / 20 * 1e3
     st = index.last_stats()
     gbs = 2.0 * n * d / (st["ms_main"] * 1e-3) / 1e9
-    print(f"n_q {nq:5d}: {ms:6.3f} ms per search ({nq / ms * 1e3:9.0f} queries/s); main pass {st['ms_main']:.3f} ms = {gbs:6.0f} GB/s of corpus bytes, "
+    tiles = (n + 255) // 256 * ((nq + 255) // 256)
+    print(f"n_q {nq:5d}: [{st['ms_main'] * 1e3 / tiles * 256:.1f} us per 256x256 tile per workgroup; ranges {st['ranges']}] {ms:6.3f} ms per search ({nq / ms * 1e3:9.0f} queries/s); main pass {st['ms_main']:.3f} ms = {gbs:6.0f} GB/s of corpus bytes, "
           f"sample {st['ms_sample']:.3f}, thresholds {st['ms_threshold']:.3f}, select {st['ms_select']:.3f}", flush=True)
