@@ -433,7 +433,7 @@ def main():
         "phases_ms": dict(phases_obj(st), corpus_pack=round(pack_ms, 3)),
         "pack_kernel": {"bound": "hbm", "achieved": round(pack_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(pack_gbs / HBM_PEAK_GBS, 4)},
-        "search_stats": dict({k_: st[k_] for k_ in ("path", "n_fallback", "sample_tiles", "ranges", "sublists", "cap", "n_candidates")},
+        "search_stats": dict({k_: st[k_] for k_ in ("path", "n_fallback", "sample_tiles", "ranges", "sublists", "cap", "n_candidates", "opt_rank", "n_retried", "n_dense")},
                              candidates_per_query=round(st["n_candidates"] / max(1, args.queries), 1), n_fallback_max=r["n_fallback_max"]),
     }
     if world > 1:
@@ -463,7 +463,7 @@ def main():
                         "unit": "queries/s", "ms_per_step": round(r2["ms_per_step"], 3), "roofline": roofline_obj(r2, *offline_traffic("nq_k1001")),
                         "phases_ms": phases_obj(r2["stats"]),
                         "candidates_per_query": round(r2["stats"]["n_candidates"] / args.queries, 1),
-                        "n_fallback": r2["n_fallback_max"]}
+                        "n_fallback": r2["n_fallback_max"], "opt_rank": r2["stats"]["opt_rank"], "launches": r2["stats"]["main_launches"]}
         w.release()
         # (b) the north-star target shape: MS-MARCO scale on ONE GPU, with its own CPU leg on the same host
         m = Workload(MSMARCO_ROWS, MSMARCO_Q, DIM, TOP_K, "gaussian", dev, 0, 1, args.dist_backend)

@@ -102,7 +102,7 @@ class LengthSortedEncoder:
     """
 
     def __init__(self, tower, tokenizer, max_length=None, max_tokens=65536, max_batch=512, pad_multiple=8, chunk_texts=65536,
-                 host_threads=2):
+                 host_threads=4):
         self.tower, self.tokenizer = tower, tokenizer
         self.max_length = int(max_length if max_length is not None else os.environ.get("CCREC_MAX_LENGTH", 200))
         self.max_tokens, self.max_batch, self.pad_multiple = int(max_tokens), int(max_batch), int(pad_multiple)

@@ -43,6 +43,8 @@ Knobs read_knobs() {
     kn.max_lists = env_int("CCR_MAX_LISTS", 0);
     kn.ranges = env_int("CCR_RANGES", 0);
     kn.item_swap = env_int("CCR_ITEM_SWAP", 0);
+    kn.optimistic = env_int("CCR_OPTIMISTIC", -1);
+    kn.opt_rank = env_int("CCR_OPT_RANK", 0);
     return kn;
 }
 
@@ -87,7 +89,23 @@ constexpr size_t DENSE_SCRATCH_TARGET = (size_t)1 << 30;  // ~1 GiB of score row
 struct MainPassChoice {
     int64_t sample, ranges;
     int item_a, item_b;   // phase ends in work items of one XCD set (0 = absent)
+    int opt_rank;         // > 0: ESTIMATED thresholds (the opt_rank-th largest sampled group maximum), single launch, verified by the select
 };
+
+// Estimated ("optimistic") thresholds for large k.  The conservative threshold -- the k-th largest group maximum of a sample of
+// the corpus fraction fs -- lets k / fs rows per query through the first phase, so large k needs a big sample (1/16 at k = 1001:
+// 1/16 of the corpus scored twice) and two re-tightenings.  But the filter does not need a BOUND: any threshold tau works if
+// at least k rows turn out to pass it with their lower bounds (then the k-th largest exact score is >= tau and every row that
+// could reach it was recorded) -- which the select stage checks (L >= tau; a query that fails is retried under the valid bound
+// its candidates give).  So tau is set to the r-th largest sampled group maximum with r = max(48, 3 k fs): about r / fs = 3 k
+// rows pass over the WHOLE corpus in ONE launch; the pass count given r is Gamma(r)-distributed (sd 1 / sqrt(r) = 14 %), so
+// fewer than k pass with probability ~1e-7 per query on exchangeable rows.  A corpus in topical order can fool the estimate
+// (the sample holds a query's whole cluster tile): those queries fail the check and are retried -- exact either way.
+static int optimistic_rank(int k, int64_t sample, int64_t tiles, const Knobs &kn) {
+    if (kn.opt_rank > 0) return kn.opt_rank;   // tests: a small rank makes most queries fail the check
+    const double fs = (double)sample / (double)tiles;
+    return (int)std::max<int64_t>(48, (int64_t)ceil(3.0 * k * fs));
+}
 
 static MainPassChoice choose_main_pass(const Plan &p, int k, int64_t sample_a, int64_t sample_b, int64_t sample_c, const Knobs &kn) {
     const int nrc = NUM_XCD / p.qgroups, qb_per = p.qblocks / p.qgroups, per_x = p.grid / NUM_XCD;
@@ -111,7 +129,7 @@ static MainPassChoice choose_main_pass(const Plan &p, int k, int64_t sample_a, i
         return (double)((smp * p.qblocks + p.grid - 1) / p.grid) + 0.015 * (double)smp * std::max(1.0, qscale);
     };
 
-    MainPassChoice best_choice = {sample_a, target, 0, 0};
+    MainPassChoice best_choice = {sample_a, target, 0, 0, 0};
     double best = 1e300;
     for (int pass = 0; pass < 3; ++pass) {
         const int64_t smp = pass == 0 ? sample_a : (pass == 1 ? sample_b : sample_c);
@@ -136,9 +154,20 @@ static MainPassChoice choose_main_pass(const Plan &p, int k, int64_t sample_a, i
             auto rounds = [&](int64_t n) { return (double)((n + per_x - 1) / per_x); };
             const double common = smp_cost + select_per_range * (double)R + 1e-3 * std::abs((double)(R - target));
             const double single = rounds(items) * item_cost + hit_w * survivors(0.0, 0.0) + common;
-            if (single < best) {
+            if (single < best && kn.optimistic != 1) {
                 best = single;
-                best_choice = {smp, R, 0, 0};
+                best_choice = {smp, R, 0, 0, 0};
+            }
+            if (kn.optimistic != 0 && smp * GROUPS_PER_TILE >= 4 * 48) {   // estimated thresholds: one launch, ~rank / fs rows pass
+                const int rank = optimistic_rank(k, smp, p.tiles, kn);
+                if ((int64_t)rank * 4 <= smp * GROUPS_PER_TILE) {
+                    const double pass = std::max((double)rank / fs, (double)k);
+                    const double opt = rounds(items) * item_cost + hit_w * pass + common - (kn.optimistic == 1 ? 1e9 : 0.0);
+                    if (opt < best) {
+                        best = opt;
+                        best_choice = {smp, R, 0, 0, rank};
+                    }
+                }
             }
             if (!(prog_on && items > per_x && (double)p.tiles / (double)R >= 8.0)) continue;
             // the thresholds after phase A come from the ranges it completed (+ the started one for part of the queries)
@@ -146,7 +175,7 @@ static MainPassChoice choose_main_pass(const Plan &p, int k, int64_t sample_a, i
             const double two = (1.0 + rounds(items - per_x)) * item_cost + phase_w + hit_w * survivors(fa, 0.0) + common;
             if (two < best) {
                 best = two;
-                best_choice = {smp, R, per_x, 0};
+                best_choice = {smp, R, per_x, 0, 0};
             }
             if (max_phases < 3) continue;
             for (int m = 1; m <= 3; ++m) {   // a second re-tightening after m more rounds
@@ -156,7 +185,7 @@ static MainPassChoice choose_main_pass(const Plan &p, int k, int64_t sample_a, i
                 const double three = (1.0 + m + rounds(items - ib)) * item_cost + 2.0 * phase_w + hit_w * survivors(fa, fb) + common;
                 if (three < best) {
                     best = three;
-                    best_choice = {smp, R, per_x, (int)ib};
+                    best_choice = {smp, R, per_x, (int)ib, 0};
                 }
             }
         }
@@ -222,6 +251,7 @@ static Plan make_plan_for(int64_t n_rows, int dim, int n_q, int k, int flags, in
         p.ranges = (int)R;
         p.item_a = choice.item_a;
         p.item_b = choice.item_b;
+        p.opt_rank = choice.opt_rank;
         // ranges that hold items of a phase: the candidate segments (a range started in phase A keeps phase A's capacity)
         const int nrc_p = NUM_XCD / p.qgroups, qb_per_p = p.qblocks / p.qgroups;
         const int64_t items_p = R / nrc_p * qb_per_p;
@@ -241,8 +271,10 @@ static Plan make_plan_for(int64_t n_rows, int dim, int n_q, int k, int flags, in
         // Allowance: one WHOLE tile may pass for a query (a corpus in topical order: all 256 rows of a tile belong to the
         // query's cluster); that is TILE_DOCS / sublists rows for one sub-list on top of its regular share.
         const int64_t tile_rows = TILE_DOCS / p.sublists;
+        // estimated thresholds: about opt_rank / fs rows pass, Gamma(opt_rank)-distributed
+        const double xr = p.opt_rank ? 1.25 * ((double)p.opt_rank + 4.75 * sqrt((double)p.opt_rank) + 8.0) / (double)p.opt_rank : 0.0;
         auto cap_for = [&](double g) -> int {
-            const double mean = xk * (double)k / (g * nlists);
+            const double mean = p.opt_rank ? xr * std::max((double)p.opt_rank / fs, (double)k) / nlists : xk * (double)k / (g * nlists);
             const int64_t c = (int64_t)(mean + 6.0 * sqrt(mean)) + 16 + tile_rows;   // the model's share PLUS one whole tile
             return (int)round_up(std::min<int64_t>(std::max<int64_t>(c, 16), 8192), 4);
         };
@@ -282,8 +314,12 @@ static Plan make_plan_for(int64_t n_rows, int dim, int n_q, int k, int flags, in
         L.seg_end[L.nseg - 1] = INT32_MAX;   // the last segment is open-ended (sub-list lookups never fall off the table)
         p.cap = L.cap[0];
         // survivors per query reaching the select stage: ~12 k after the progressive re-tightening, `expect` without it
+        // (estimated thresholds leave fewer candidates, but the select's staged re-score borrows this area: about 1.15 k rows are
+        // re-scored per query and a 64-byte slice of each needs 80 bytes = 10 entries -- a smaller area sends the re-score down its
+        // unstaged path: measured 2.41 instead of 2.06 ms at k = 1001)
+        const double want_opt = std::max(xr * std::max((double)p.opt_rank / fs, (double)k) + 512.0, k > 256 ? 12.0 * k : 0.0);
         p.select_compact = select_compact_entries(dim, p.ranges * p.sublists, p.rescore_cap,
-                                                  (int64_t)((RA ? 16.0 * k + 512.0 : expect) * 1.25));
+                                                  (int64_t)((p.opt_rank ? want_opt : (RA ? 16.0 * k + 512.0 : expect)) * 1.25));
         p.off_qnorm = take((size_t)p.nq_pad * 4);
         p.off_thr = take((size_t)p.nq_pad * 4 * 2);  // thr then delta
         p.off_gmax = take((size_t)p.sample_tiles * GROUPS_PER_TILE * p.nq_pad * 4);
@@ -665,6 +701,7 @@ static int search_complete(ccr_index *ix) {
     ix->stats.cap = p.cap;
     ix->stats.sublists = p.sublists;
     ix->stats.main_launches = 1 + (p.item_a ? 1 : 0) + (p.item_b ? 1 : 0);
+    ix->stats.opt_rank = p.opt_rank;
     ix->stats.n_candidates = (int64_t)host.ncand;
     const int begin = was_async ? std::min<int>(FALLBACK_ROWS, (int)host.nflag) : 0;   // the on-stream chunk took these
     ix->stats.n_dense = begin;
@@ -778,7 +815,7 @@ static int search_complete(ccr_index *ix) {
                 rc = p.mfma16 ? launch_gemm16_filter(g, p.grid, s) : launch_gemm_filter(g, p.grid, s);
                 if (rc != CCR_OK) return rc;
                 rc = launch_select_rescore(cand, cnt, nsub_all, p.sublists, n_cur, pad2, lay2, k, p.rescore_cap, p.select_compact, ix->n_rows,
-                                           delta2, ix->tile_norm, ix->row_norm, ix->dmax_bits, Q2, ix->D, ix->dim, ix->id_out, pd.out_scores, pd.out_ids, flag2,
+                                           thr2, delta2, ix->tile_norm, ix->row_norm, ix->dmax_bits, Q2, ix->D, ix->dim, ix->id_out, pd.out_scores, pd.out_ids, flag2,
                                            flag2 + 16, nullptr, cur, s);
                 if (rc != CCR_OK) return rc;
                 ix->stats.n_retried += n_cur;
@@ -967,8 +1004,8 @@ static int search_impl(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k, fl
     rc = launch_gemm_gmax(gs, p.grid, s);
     if (rc != CCR_OK) return rc;
     CCR_HIP_CHECK(hipEventRecord(ix->ev[2], s));
-    rc = launch_threshold(gmax, (int64_t)p.sample_tiles * GROUPS_PER_TILE, n_q, p.nq_pad, k, qnorm, ix->dmax_bits, ix->dim,
-                          ix->tile_norm, p.sample_stride, thr, delta, s);
+    rc = launch_threshold(gmax, (int64_t)p.sample_tiles * GROUPS_PER_TILE, n_q, p.nq_pad, p.opt_rank ? p.opt_rank : k, qnorm, ix->dmax_bits,
+                          ix->dim, ix->tile_norm, p.sample_stride, thr, delta, s);
     if (rc != CCR_OK) return rc;
 
     // main pass -> candidates
@@ -1014,7 +1051,7 @@ static int search_impl(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k, fl
         (void)hipFree(stamps);
     }
 
-    rc = launch_select_rescore(cand, cnt, p.ranges * p.sublists, p.sublists, n_q, p.nq_pad, p.cand, k, p.rescore_cap, p.select_compact, ix->n_rows, delta,
+    rc = launch_select_rescore(cand, cnt, p.ranges * p.sublists, p.sublists, n_q, p.nq_pad, p.cand, k, p.rescore_cap, p.select_compact, ix->n_rows, thr, delta,
                                ix->tile_norm, ix->row_norm, ix->dmax_bits, Q_bf16, ix->D, ix->dim,
                                ix->id_out, out_scores, out_ids, flag_count, flag_list, stat_cand, nullptr, s);
     if (rc != CCR_OK) return rc;

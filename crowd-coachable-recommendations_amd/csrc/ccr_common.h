@@ -84,6 +84,7 @@ struct Plan {
     int ranges;           // corpus ranges of the main pass (multiple of NUM_XCD)
     int item_a;           // phase A = work items [0, item_a) of every XCD set (0 = single phase); thresholds are re-tightened after it
     int item_b;           // end of the second phase in items (0: two phases)
+    int opt_rank;         // > 0: estimated thresholds = the opt_rank-th largest sampled group maximum (single launch; the select verifies)
     int qgroups;          // query-block groups over the XCDs
     int cap;              // candidate slots per sub-list (the largest segment's: statistics)
     CandLayout cand;      // per-phase segments of the candidate area

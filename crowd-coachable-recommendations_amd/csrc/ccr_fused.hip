@@ -1010,7 +1010,7 @@ __global__ __launch_bounds__(256) void threshold_update_kernel(const uint2 *__re
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__restrict__ cand, const uint32_t *__restrict__ cnt,
                                                             int ranges, int sp, int nq_pad, const CandLayout lay, int k, int rescore_cap, int compact,
-                                                            int64_t n_rows, const float *__restrict__ cq,
+                                                            int64_t n_rows, float *__restrict__ thr, const float *__restrict__ cq,
                                                             const float *__restrict__ tile_norm, const float *__restrict__ row_norm,
                                                             const uint32_t *__restrict__ dmax_bits,
                                                             const uint16_t *__restrict__ Q, const uint16_t *__restrict__ D,
@@ -1088,6 +1088,8 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
     // budget) -- only the exact dense path helps (FLAG_DENSE, the top bit of the list entry).
     bool bad = (s_flag != 0) || (s_total < (uint32_t)k);
     bool dense_only = (s_flag == 0) && bad;   // nothing was dropped and still fewer than k rows passed: a retry cannot find more
+    // (fewer than k rows passed an ESTIMATED threshold: it was too high, and no list gives a bound -- the exact path, without a hint)
+    if (dense_only && thr && tid == 0) thr[q] = -INFINITY;
 
     // sub-list j = (range j / sp, wave-row / lane part j % sp): cand_sublist() gives its first record and capacity
     auto sub_base = [&](int j) -> int64_t {
@@ -1214,6 +1216,19 @@ __global__ __launch_bounds__(THREADS) void select_rescore_kernel(const uint2 *__
             },
             M, k, s_hist, s_ctl, kth, need_eq);
         const float low = orderable_to_f32(kth);                                  // L: the k-th largest lower bound
+        // Verification of the threshold the main pass filtered with.  Every row whose exact score reaches tau was recorded; if k
+        // candidates have lower bounds >= tau (L >= tau), the k-th largest exact score is >= tau and nothing is missing.  A valid
+        // lower bound (conservative thresholds, re-tightened ones) always passes; an ESTIMATED threshold that came out too high
+        // fails: the query is retried under L, which is a valid bound.
+        if (thr && low < thr[q]) {
+            __syncthreads();
+            if (tid == 0) {
+                thr[q] = low;
+                const uint32_t p = atomicAdd(flag_count, 1u);
+                flag_list[p] = (out_rows ? out_rows[q] : (uint32_t)q);
+            }
+            return;
+        }
         const float loose = fmaf(-2.f * c, __uint_as_float(*dmax_bits), low);    // no row's upper bound is further above its lower one
         for (int i = tid; i < M; i += THREADS) {
             const uint2 e = s_comp[i];
@@ -1531,7 +1546,7 @@ int launch_gather_queries(const uint16_t *Q, int dim, const uint32_t *list, int 
 }
 
 int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, int sp, int n_q, int nq_pad, const CandLayout &lay, int k,
-                          int rescore_cap, int compact, int64_t n_rows, const float *cq, const float *tile_norm, const float *row_norm,
+                          int rescore_cap, int compact, int64_t n_rows, float *thr, const float *cq, const float *tile_norm, const float *row_norm,
                           const uint32_t *dmax_bits, const uint16_t *Q,
                           const uint16_t *D, int dim, int64_t id_offset, float *out_scores, int64_t *out_ids,
                           uint32_t *flag_count, uint32_t *flag_list, unsigned long long *stat_cand, const uint32_t *out_rows,
@@ -1544,7 +1559,7 @@ int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, in
             if (rc != CCR_OK) return rc;
         }
         hipLaunchKernelGGL(kernel, dim3(n_q), dim3(threads), lds, s, cand, cnt, ranges, sp, nq_pad, lay, k, rescore_cap, compact,
-                           n_rows, cq, tile_norm, row_norm, dmax_bits, Q, D, dim, id_offset, out_scores, out_ids, flag_count, flag_list, stat_cand,
+                           n_rows, thr, cq, tile_norm, row_norm, dmax_bits, Q, D, dim, id_offset, out_scores, out_ids, flag_count, flag_list, stat_cand,
                            out_rows);
         CCR_LAUNCH_CHECK();
         return CCR_OK;

@@ -16,6 +16,8 @@ struct Knobs {
     int stagger;       // CCR_GEMM_STAGGER 0 = both wave groups of the 32x32x16 kernel in phase
     int ranges;        // CCR_RANGES       0 = planner's choice, else the pinned range count (rounded to a multiple of 8)
     int item_swap;     // CCR_ITEM_SWAP    1 = co-resident workgroups share the query block instead of the corpus range (honoured with CCR_PROGRESSIVE=0)
+    int optimistic;    // CCR_OPTIMISTIC   -1 = planner's choice, 0 = conservative thresholds only, 1 = estimated thresholds wherever the sample allows
+    int opt_rank;      // CCR_OPT_RANK     0 = max(48, 3 k fs), else the pinned rank (tests: a small rank makes the verification fail)
     int max_lists;     // CCR_MAX_LISTS    0 = planner's limit, else a cap on ranges x sublists (A/B of the select stage's walk)
 };
 Knobs read_knobs();
@@ -41,8 +43,11 @@ int launch_threshold(const float *gmax, int64_t n_groups, int n_q, int nq_pad, i
                      const uint32_t *dmax_bits, int dim, const float *tile_norm, int64_t sample_stride, float *thr, float *cq,
                      hipStream_t s);
 int select_compact_entries(int dim, int ranges, int rescore_cap, int64_t want);
+// thr (device, [n_q], may be null): the thresholds the main pass filtered with.  The select VERIFIES them -- the k-th largest lower
+// bound L of the candidates must reach thr[q], else rows below an over-estimated threshold may be missing: the query is flagged
+// for the retry pass and thr[q] is replaced by L (a valid bound); with fewer than k candidates thr[q] = -inf and the dense path.
 int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, int sp, int n_q, int nq_pad, const CandLayout &lay, int k,
-                          int rescore_cap, int compact, int64_t n_rows, const float *cq, const float *tile_norm, const float *row_norm,
+                          int rescore_cap, int compact, int64_t n_rows, float *thr, const float *cq, const float *tile_norm, const float *row_norm,
                           const uint32_t *dmax_bits, const uint16_t *Q, const uint16_t *D, int dim, int64_t id_offset, float *out_scores, int64_t *out_ids,
                           uint32_t *flag_count, uint32_t *flag_list, unsigned long long *stat_cand, const uint32_t *out_rows,
                           hipStream_t s);

@@ -70,7 +70,8 @@ typedef struct ccr_search_stats {
     int32_t n_dense;           /* flagged queries finished by an exact whole-row path (margin select or fp64: mass ties, flagged again,
                                   on-stream chunk); path 0: queries the margin select left to the fp64 path */
     int32_t main_launches;     /* launches of the main-pass kernel in this search (phases: thresholds are re-tightened between them) */
-    int32_t reserved;
+    int32_t opt_rank;          /* > 0: the thresholds were ESTIMATED (the opt_rank-th largest sampled group maximum; one launch, verified by
+                                  the select stage); 0: conservative lower bounds with re-tightening */
 } ccr_search_stats;
 
 const char *ccr_last_error(void);

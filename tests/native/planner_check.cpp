@@ -19,6 +19,7 @@ int main() {
     kn.max_phases = 3;
     kn.mfma16 = -1;
     kn.stagger = 1;
+    kn.optimistic = -1;   // the planner's choice, as in production
     const long long rows[] = {300, 9862, 70000, 335184, 1105228, 2681468, 8841823, 6250000};
     const int dims[] = {64, 768, 1024};
     const int nqs[] = {1, 40, 300, 3452, 6980, 10000};
@@ -50,6 +51,12 @@ int main() {
                     if (p.item_a && p.item_a % per_x) bad += fail("phase A is not whole rounds", n, d, nq, k);
                     if (p.item_b && p.item_b % per_x) bad += fail("phase B is not whole rounds", n, d, nq, k);
                     if (p.sample_tiles * GROUPS_PER_TILE < k) bad += fail("sample smaller than k groups", n, d, nq, k);
+                    // estimated thresholds: one launch, the rank well inside the sampled groups, never for small k (where the
+                    // conservative bound + re-tightening passes fewer rows)
+                    if (p.opt_rank && (p.item_a || p.item_b)) bad += fail("estimated thresholds with phases", n, d, nq, k);
+                    if (p.opt_rank && (p.opt_rank < 48 || (long long)p.opt_rank * 4 > (long long)p.sample_tiles * GROUPS_PER_TILE))
+                        bad += fail("estimated-threshold rank", n, d, nq, k);
+                    if (p.opt_rank && (long long)p.opt_rank * p.tiles / p.sample_tiles < k) bad += fail("estimated thresholds pass fewer than k rows", n, d, nq, k);
                     if ((long long)p.sample_tiles * p.sample_stride > p.full_tiles + p.sample_stride) bad += fail("sample beyond the shard", n, d, nq, k);
                     // candidate segments: ascending, capacities hold one whole tile per sub-list, area inside the workspace
                     const CandLayout &L = p.cand;
@@ -70,8 +77,8 @@ int main() {
                         bad += fail("workspace layout order", n, d, nq, k);
                     if ((n == 2681468 && d == 768 && nq == 3452 && (k == 100 || k == 1001)) || (n == 8841823 && d == 768 && nq == 6980 && k == 100) ||
                         (n == 6250000 && d == 1024 && nq == 10000 && k == 1001))
-                        printf("n=%lld nq=%d k=%d: ranges %d x %d sub-lists, items/XCD-set %d = %.2f rounds, phases end at %d / %d, sample %d tiles, caps %d/%d/%d, "
-                               "workspace %.2f GB\n", n, nq, k, p.ranges, p.sublists, items, (double)items / per_x, p.item_a, p.item_b, p.sample_tiles,
+                        printf("n=%lld nq=%d k=%d: ranges %d x %d sub-lists, items/XCD-set %d = %.2f rounds, phases end at %d / %d, estimated-threshold rank %d, sample %d tiles, caps %d/%d/%d, "
+                               "workspace %.2f GB\n", n, nq, k, p.ranges, p.sublists, items, (double)items / per_x, p.item_a, p.item_b, p.opt_rank, p.sample_tiles,
                                L.cap[0], L.cap[1], L.cap[2], (double)p.total / 1e9);
                 }
     printf("%d plans (%d fused), %d violations\n", total, fused, bad);

@@ -133,3 +133,51 @@ def test_any_embedding_width_takes_the_fused_path(d, sim):
     assert torch.equal(i3, i4) and torch.equal(s3.view(torch.int32), s4.view(torch.int32))
     mf, can = small.scores(Qb[:50], "mfma"), small.scores(Qb[:50], "canonical")
     assert float((mf - can).abs().max()) < 2e-6 * max(1.0, float(can.abs().max()))
+
+
+@pytest.mark.parametrize("case", ["planner_k1001", "forced_k100", "tiny_rank", "sorted_forced", "clustered_tiny_rank"])
+def test_estimated_thresholds_are_verified_and_exact(case, monkeypatch):
+    """Large k filters under ESTIMATED thresholds (the r-th largest sampled group maximum, r = max(48, 3 k fs): about 3 k rows pass
+    over the whole corpus in one launch, no bound, no re-tightening); the select stage verifies L >= tau per query and a query
+    that fails is retried under the valid bound its candidates give.  Exact in every case: the planner's own choice at k = 1001;
+    the mode forced at k = 100; a rank pinned so low (2) that the estimate is far too high and most queries fail the check; a
+    corpus in topical order, where the sample holds some queries' whole cluster tile; clustered data with the tiny rank."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import gen_rows
+    from ccrec_amd import ops
+    n, nq, d, k, data = 400_000, 600, 128, 1001, "gaussian"
+    if case == "forced_k100":
+        k = 100
+        monkeypatch.setenv("CCR_OPTIMISTIC", "1")
+    elif case == "tiny_rank":
+        k = 300
+        monkeypatch.setenv("CCR_OPTIMISTIC", "1")
+        monkeypatch.setenv("CCR_OPT_RANK", "2")
+    elif case == "sorted_forced":
+        data = "sorted"
+        monkeypatch.setenv("CCR_OPTIMISTIC", "1")
+    elif case == "clustered_tiny_rank":
+        data, k = "clustered", 500
+        monkeypatch.setenv("CCR_OPTIMISTIC", "1")
+        monkeypatch.setenv("CCR_OPT_RANK", "3")
+    nb = torch.empty(n, device="cuda")
+    D = ops.pack_bf16(gen_rows(n, d, 1234, "cuda", data), norm_bounds=nb)
+    Q = ops.pack_bf16(gen_rows(nq, d, 4321, "cuda", data))
+    index = ops.CorpusIndex(D, norm_bounds=nb)            # the knobs are read when the index is created
+    s, i = index.search(Q, k, 2)
+    st = index.last_stats()
+    print(case, st)
+    assert st["path"] == 1 and st["opt_rank"] > 0 and st["main_launches"] == 1, st
+    if "tiny_rank" in case:
+        assert st["opt_rank"] <= 3 and st["n_fallback"] > nq // 2 and st["n_retried"] + st["n_dense"] >= st["n_fallback"], st
+    elif case in ("planner_k1001", "forced_k100"):
+        assert st["n_fallback"] == 0 and st["n_candidates"] / nq < 12 * k, st      # iid: nobody fails, about rank / fs rows pass
+    monkeypatch.setenv("CCR_OPTIMISTIC", "0")
+    ref = ops.CorpusIndex(D, norm_bounds=nb)
+    s0, i0 = ref.search(Q, k, 2)                          # conservative thresholds (round-2 behaviour)
+    assert ref.last_stats()["opt_rank"] == 0
+    s1, i1 = ref.search(Q[:64], k, 1)                     # fp64 dense
+    assert torch.equal(i, i0) and torch.equal(s.view(torch.int32), s0.view(torch.int32))
+    assert torch.equal(i[:64], i1) and torch.equal(s[:64].view(torch.int32), s1.view(torch.int32))

@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--modes", default="fixed,batch_max,sorted",
                     help="comma list of fixed, batch_max, sorted (chunked pipeline), serial (sorted, but tokenise everything first)")
     ap.add_argument("--chunk-texts", type=int, default=65536)
-    ap.add_argument("--host-threads", type=int, default=2)
+    ap.add_argument("--host-threads", type=int, default=4)
     ap.add_argument("--texts", type=int, default=20000)
     ap.add_argument("--dist", default="titles", choices=["titles", "passages"])
     ap.add_argument("--layers", type=int, default=12)
