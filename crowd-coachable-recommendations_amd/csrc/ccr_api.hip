@@ -317,7 +317,7 @@ static Plan make_plan_for(int64_t n_rows, int dim, int n_q, int k, int flags, in
         // (estimated thresholds leave fewer candidates, but the select's staged re-score borrows this area: about 1.15 k rows are
         // re-scored per query and a 64-byte slice of each needs 80 bytes = 10 entries -- a smaller area sends the re-score down its
         // unstaged path: measured 2.41 instead of 2.06 ms at k = 1001)
-        const double want_opt = std::max(xr * std::max((double)p.opt_rank / fs, (double)k) + 512.0, k > 256 ? 12.0 * k : 0.0);
+        const double want_opt = std::max(xr * std::max((double)p.opt_rank / fs, (double)k) + 512.0, k > 256 ? 18.0 * k : 0.0);   // (18 entries per re-scored row: the 128-byte slices, where the LDS budget allows)
         p.select_compact = select_compact_entries(dim, p.ranges * p.sublists, p.rescore_cap,
                                                   (int64_t)((p.opt_rank ? want_opt : (RA ? 16.0 * k + 512.0 : expect)) * 1.25));
         p.off_qnorm = take((size_t)p.nq_pad * 4);

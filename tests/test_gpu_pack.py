@@ -26,18 +26,23 @@ def test_pack_matches_golden_and_torch(golden_dir):
     assert torch.isnan(ops.pack_bf16(nan).float()).cpu().tolist() == [[True, False, True, False] * 2]
 
 
-@pytest.mark.parametrize("rows,dim", [(7, 768), (300, 1024), (65, 64), (5, 772)])
+@pytest.mark.parametrize("rows,dim", [(7, 768), (300, 1024), (65, 64), (5, 772), (9, 301), (3, 5)])
 def test_normalize_pack_bit_exact_vs_oracle(rows, dim):
+    """(772, 301, 5: widths that are no multiple of 8 are stored zero-padded to the next one; the canonical sum of squares treats
+    a partial last chunk as zero-padded, so the bits of the first `dim` columns are the oracle's.)"""
     from ccrec_amd import ops
     g = torch.Generator().manual_seed(rows * dim)
     x = torch.randn(rows, dim, generator=g) * torch.rand(rows, 1, generator=g) * 5
     x[0] = 0  # zero row: x / max(0, 1e-12) = 0
     out, norms = ops.pack_bf16(x.cuda(), normalize=True, return_norms=True)
-    assert np.array_equal(_bits(out), orc.normalize_pack_bf16(x.numpy()))
+    assert out.shape == (rows, ops.padded_dim(dim)) and not _bits(out)[:, dim:].any()
+    assert np.array_equal(_bits(out)[:, :dim], orc.normalize_pack_bf16(x.numpy()))
     assert np.array_equal(norms.cpu().numpy(), orc.row_norms(x.numpy()))
+    plain = ops.pack_bf16(x.cuda())                                  # and the plain pack of an odd width
+    assert np.array_equal(_bits(plain)[:, :dim], orc.pack_bf16(x.numpy())) and not _bits(plain)[:, dim:].any()
     # and it is the reference's F.normalize up to bf16 rounding
     ref = torch.nn.functional.normalize(x, p=2, dim=1)
-    np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), atol=4e-3, rtol=8e-3)
+    np.testing.assert_allclose(out.float().cpu().numpy()[:, :dim], ref.numpy(), atol=4e-3, rtol=8e-3)
 
 
 def test_pack_into_shard_slice():
