@@ -176,8 +176,10 @@ class Workload:
         self.k_local = min(k, n_local)
         if world > 1:
             assert self.k_local == k, "shard smaller than k"
-        self.slots = [{"shard": torch.empty(n_local, dim, dtype=torch.bfloat16, device=dev),
-                       "qpack": torch.empty(queries, dim, dtype=torch.bfloat16, device=dev),
+        from ccrec_amd.ops import padded_dim
+        pdim = padded_dim(dim)    # packed rows are zero-padded to a multiple of 8 (--dim 300 -> 304)
+        self.slots = [{"shard": torch.empty(n_local, pdim, dtype=torch.bfloat16, device=dev),
+                       "qpack": torch.empty(queries, pdim, dtype=torch.bfloat16, device=dev),
                        "bounds": torch.empty(n_local, dtype=torch.float32, device=dev),   # norm bound per packed row (pack kernel)
                        "ws": None,   # search workspace, handed from the slot's previous index to its next one
                        "message": ShardMessage(queries, k, dev, world) if world > 1 else None} for _ in range(2)]
