@@ -44,7 +44,6 @@ Knobs read_knobs() {
     kn.ranges = env_int("CCR_RANGES", 0);
     kn.item_swap = env_int("CCR_ITEM_SWAP", 0);
     kn.optimistic = env_int("CCR_OPTIMISTIC", -1);
-    kn.deep_ring = env_int("CCR_DEEP_RING", -1);
     kn.opt_rank = env_int("CCR_OPT_RANK", 0);
     return kn;
 }
@@ -253,8 +252,6 @@ static Plan make_plan_for(int64_t n_rows, int dim, int n_q, int k, int flags, in
         p.item_a = choice.item_a;
         p.item_b = choice.item_b;
         p.opt_rank = choice.opt_rank;
-        // one or two query blocks: no co-resident workgroup shares a corpus tile, every corpus piece comes from HBM -> deeper corpus ring
-        p.deep_ring = kn.deep_ring >= 0 ? (kn.deep_ring ? 1 : 0) : (p.qblocks <= 2 ? 1 : 0);
         // ranges that hold items of a phase: the candidate segments (a range started in phase A keeps phase A's capacity)
         const int nrc_p = NUM_XCD / p.qgroups, qb_per_p = p.qblocks / p.qgroups;
         const int64_t items_p = R / nrc_p * qb_per_p;
@@ -1018,7 +1015,6 @@ static int search_impl(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k, fl
     gm.ranges = p.ranges;
     gm.thr = thr;
     gm.cnt = cnt;
-    gm.deep_ring = p.deep_ring;
     gm.item_swap = (ix->knobs.item_swap && !p.item_a) ? 1 : 0;   // the phases' "ranges completed so far" needs the default order
     unsigned long long *stamps = nullptr;   // CCR_GEMM_DBG=16: in-kernel cycle stamps of the main pass (diagnostic build only)
 #ifdef CCR_DIAGNOSTICS

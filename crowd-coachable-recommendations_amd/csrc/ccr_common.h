@@ -84,7 +84,6 @@ struct Plan {
     int ranges;           // corpus ranges of the main pass (multiple of NUM_XCD)
     int item_a;           // phase A = work items [0, item_a) of every XCD set (0 = single phase); thresholds are re-tightened after it
     int item_b;           // end of the second phase in items (0: two phases)
-    int deep_ring;        // 1: the main pass runs the DEEP form of the 16x16x32 kernel (corpus pieces five sub-stages ahead)
     int opt_rank;         // > 0: estimated thresholds = the opt_rank-th largest sampled group maximum (single launch; the select verifies)
     int qgroups;          // query-block groups over the XCDs
     int cap;              // candidate slots per sub-list (the largest segment's: statistics)
@@ -129,7 +128,6 @@ struct GemmArgs {
     int64_t store_pitch;  // floats per stored query row (0: n_rows); a multiple of 4 lets a lane store its 4 consecutive rows as 16 bytes
     int dbg;              // timing-only ablations (CCR_GEMM_DBG; results are WRONG when non-zero)
     int stagger;          // 32x32x16 kernel: 1 = the two wave groups run one barrier interval apart (production), 0 = in phase
-    int deep_ring;        // 16x16x32 filter kernel: 1 = six-buffer corpus ring (DEEP instantiation; one or two query blocks)
     int item_swap;        // experiment (CCR_ITEM_SWAP, single-launch plans only): co-resident workgroups share the query block, not the range
 };
 

@@ -424,15 +424,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
 //   the 16x16 fragment read pattern; brute-forced over all xor tables).
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-// DEEP (searches of one or two query blocks, where no co-resident workgroup shares a corpus tile and every corpus piece comes from
-// HBM): the corpus half of a sub-stage gets its own ring of SIX 16-KiB buffers, five sub-stages in flight, beside the FOUR query
-// buffers (three in flight) -- 160 KiB of LDS.  With 48 KB of corpus bytes in flight per CU the stream is latency-bound at ~3.6 TB/s;
-// 80 KB in flight cover the ~3.4 us a loaded HBM access takes.  Issue order per mem(u): [D(u+5), Q(u+3)]; the wait for sub-stage
-// u + 1 still leaves exactly the last group outstanding (Q(u+1) sits in the group issued in mem(u-2), D(u+1) is older), so the counted
-// waits keep their values in the steady state: vmcnt(4); prologue groups [D0 Q0][D1 Q1][D2 Q2][D3][D4] -> vmcnt(12), then 8, 8, 4...;
-// tail: 2 * [u+4 < U] + 2 * [u+2 < U].  WAR as before: D(u+5) overwrites the buffer of D(u-1), read and retired before barrier A_{u-1}.
-constexpr int DRING = 6;
-template <int EPI, int DBG, bool TAIL = false, bool DEEP = false>
+template <int EPI, int DBG, bool TAIL = false>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -449,7 +441,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
     const int schunk = (lane & 3) ^ (((srow >> 2) & 1) << 1);
     const int cofs = ((lq ^ (((lane >> 2) & 1) << 1)) << 4);
     const int a_base = (wd * 128 + l15) * 64 + cofs;                // + dt*1024
-    const int b_base = (DEEP ? 0 : SUB_Q_REGION) + (wq * 64 + l15) * 64 + cofs;  // + qt*1024 (DEEP: relative to its own query buffer)
+    const int b_base = SUB_Q_REGION + (wq * 64 + l15) * 64 + cofs;  // + qt*1024
 
     const int xcd = blockIdx.x & (NUM_XCD - 1);
     const int jx = blockIdx.x >> 3;
@@ -537,35 +529,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
                 tile_ptrs();
             }
         };
-        // DEEP: two issue streams -- the corpus pieces (iu / it / iks above, slot dslot_i of the six-buffer ring) run five sub-stages
-        // ahead of the consumer, the query pieces (qu / qks, the four query buffers behind the corpus ring) three
-        int64_t qu = 0;
-        int qks = 0, dslot_i = 0;
-        auto issue_d = [&]() {
-            char *buf = smem + dslot_i * SUB_Q_REGION;
-            const int k0 = iks * SUB_K;
-            const bool in = !(TAIL && iks == KS2 - 1) || (k0 + schunk * 8 < a.dim);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                glds16(in ? (const void *)(dsrc[i] + k0) : (const void *)g_zero_chunk, buf + (i * 512 + wv * 64) * 16);
-            ++iu;
-            if (++dslot_i == DRING) dslot_i = 0;
-            if (++iks == KS2) {
-                iks = 0;
-                ++it;
-                tile_ptrs();
-            }
-        };
-        auto issue_q = [&]() {
-            char *buf = smem + DRING * SUB_Q_REGION + (int)(qu & (RING - 1)) * SUB_Q_REGION;
-            const int k0 = qks * SUB_K;
-            const bool in = !(TAIL && qks == KS2 - 1) || (k0 + schunk * 8 < a.dim);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                glds16(in ? (const void *)(qsrc[i] + k0) : (const void *)g_zero_chunk, buf + (i * 512 + wv * 64) * 16);
-            ++qu;
-            if (++qks == KS2) qks = 0;
-        };
 
         auto epilogue = [&](int64_t vt, float nt) {   // nt: norm bound of the tile's rows (wave-uniform)
             const int64_t row_base = vt * a.tile_stride * TILE_DOCS + wd * 128 + 4 * lq;  // + dt*16 + e
@@ -618,24 +581,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
             }
         };
 
-        if constexpr (DEEP) {   // (the launcher takes this form only when every item has U >= 8 sub-stages)
-            for (int i = 0; i < 3; ++i) {
-                issue_d();
-                issue_q();
-            }
-            issue_d();
-            issue_d();
-            CCR_WAIT_VM(12);   // groups [D1 Q1][D2 Q2][D3][D4] may still be in flight
-        } else {
-            const int npro = U < 3 ? (int)U : 3;
-            for (int i = 0; i < npro; ++i) issue();
-            if (npro == 3)
-                CCR_WAIT_VM(8);
-            else if (npro == 2)
-                CCR_WAIT_VM(4);
-            else
-                CCR_WAIT_VM(0);
-        }
+        const int npro = U < 3 ? (int)U : 3;
+        for (int i = 0; i < npro; ++i) issue();
+        if (npro == 3)
+            CCR_WAIT_VM(8);
+        else if (npro == 2)
+            CCR_WAIT_VM(4);
+        else
+            CCR_WAIT_VM(0);
         CCR_BARRIER();
         if (g1) CCR_BARRIER();
 
@@ -644,43 +597,24 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
         bool pending = false;
         int64_t pending_vt = 0;
         float pending_nt = 0.f;
-        int dslot_c = 0;   // DEEP: the consumer's slot of the corpus ring
         for (int64_t u = 0; u < U; ++u) {
             if (pending) {
                 epilogue(pending_vt, pending_nt);
                 pending = false;
             }
             if (u + 1 < U) {
-                if constexpr (DEEP) {
-                    if (u < 2)
-                        CCR_WAIT_VM(8);
-                    else if (u + 4 < U)
-                        CCR_WAIT_VM(4);
-                    else if (u + 2 < U)
-                        CCR_WAIT_VM(2);
-                    else
-                        CCR_WAIT_VM(0);
-                } else {
-                    if (u + 2 < U)
-                        CCR_WAIT_VM(4);
-                    else
-                        CCR_WAIT_VM(0);
-                }
+                if (u + 2 < U)
+                    CCR_WAIT_VM(4);
+                else
+                    CCR_WAIT_VM(0);
             }
-            const char *buf = DEEP ? smem + dslot_c * SUB_Q_REGION : smem + (int)(u & (RING - 1)) * SUB_BYTES;
-            const char *qbuf = DEEP ? smem + DRING * SUB_Q_REGION + (int)(u & (RING - 1)) * SUB_Q_REGION : buf;
+            const char *buf = smem + (int)(u & (RING - 1)) * SUB_BYTES;
             bf16x8 af[8], bfr[4];
 #pragma unroll
             for (int dt = 0; dt < 8; ++dt) af[dt] = *reinterpret_cast<const bf16x8 *>(buf + a_base + dt * 1024);
 #pragma unroll
-            for (int qt = 0; qt < 4; ++qt) bfr[qt] = *reinterpret_cast<const bf16x8 *>(qbuf + b_base + qt * 1024);
-            if constexpr (DEEP) {
-                if (u + 5 < U) issue_d();
-                if (u + 3 < U) issue_q();
-                if (++dslot_c == DRING) dslot_c = 0;
-            } else {
-                if (u + 3 < U) issue();
-            }
+            for (int qt = 0; qt < 4; ++qt) bfr[qt] = *reinterpret_cast<const bf16x8 *>(buf + b_base + qt * 1024);
+            if (u + 3 < U) issue();
             CCR_WAIT_LGKM0();
             CCR_BARRIER();
             if (cks == 0) {
@@ -1510,11 +1444,6 @@ static int launch_gemm(const GemmArgs &a, int grid, hipStream_t s) {
 
 int launch_gemm_filter(const GemmArgs &a, int grid, hipStream_t s) { return launch_gemm<EPI_FILTER>(a, grid, s); }
 int launch_gemm16_filter(const GemmArgs &a, int grid, hipStream_t s) {
-    if (a.deep_ring && a.dim >= 8 * SUB_K) {   // every item then has >= 8 sub-stages: six corpus + four query buffers = 160 KiB
-        const size_t lds = (size_t)(DRING + RING) * SUB_Q_REGION;
-        if (a.dim % SUB_K != 0) return launch_kernel(&gemm_topk16_kernel<EPI_FILTER, 0, true, true>, lds, a, grid, s);
-        return launch_kernel(&gemm_topk16_kernel<EPI_FILTER, 0, false, true>, lds, a, grid, s);
-    }
     if (a.dim % SUB_K != 0) return launch_kernel(&gemm_topk16_kernel<EPI_FILTER, 0, true>, RING * (size_t)SUB_BYTES, a, grid, s);
     return launch_kernel(&gemm_topk16_kernel<EPI_FILTER, 0>, RING * (size_t)SUB_BYTES, a, grid, s);
 }

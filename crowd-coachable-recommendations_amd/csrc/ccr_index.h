@@ -16,7 +16,6 @@ struct Knobs {
     int stagger;       // CCR_GEMM_STAGGER 0 = both wave groups of the 32x32x16 kernel in phase
     int ranges;        // CCR_RANGES       0 = planner's choice, else the pinned range count (rounded to a multiple of 8)
     int item_swap;     // CCR_ITEM_SWAP    1 = co-resident workgroups share the query block instead of the corpus range (honoured with CCR_PROGRESSIVE=0)
-    int deep_ring;     // CCR_DEEP_RING    -1 = planner's choice (one or two query blocks), 0 = never, 1 = always (A/B)
     int optimistic;    // CCR_OPTIMISTIC   -1 = planner's choice, 0 = conservative thresholds only, 1 = estimated thresholds wherever the sample allows
     int opt_rank;      // CCR_OPT_RANK     0 = max(48, 3 k fs), else the pinned rank (tests: a small rank makes the verification fail)
     int max_lists;     // CCR_MAX_LISTS    0 = planner's limit, else a cap on ranges x sublists (A/B of the select stage's walk)
