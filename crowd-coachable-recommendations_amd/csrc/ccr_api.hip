@@ -65,6 +65,36 @@ static int pick_qgroups(int qblocks, int dim, const Knobs &kn) {
 
 static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
+// Range count of the SAMPLE pass: its few tiles (1/16 ... 1/64 of the corpus) are cut into (range, query block) items like the main
+// pass's, and with so few tiles per item the rounding decides the time: 82 sample tiles x 14 query blocks in 24 ranges are 42 items per XCD
+// set = two rounds of 4- and 3-tile items, in 16 ranges one round of 6- and 5-tile items (1/8 NQ shard: 0.145 -> 0.115 ms).  The kernel's
+// static assignment is simulated exactly (workgroup j of an XCD set takes items j, j + per_x, ...; item = range-row * blocks + block).
+static int best_sample_ranges(int64_t n_vt, int qblocks, int qgroups, int grid) {
+    const int nrc = NUM_XCD / qgroups, qb_per = qblocks / qgroups, per_x = std::max(1, grid / NUM_XCD);
+    int best_r = NUM_XCD;
+    double best = 1e300;
+    const int64_t r_max = round_up(std::min<int64_t>(n_vt, 1024), NUM_XCD);
+    std::vector<double> load((size_t)per_x);
+    for (int64_t R = NUM_XCD; R <= r_max; R += NUM_XCD) {
+        double worst = 0.0;
+        for (int rc = 0; rc < nrc; ++rc) {   // the XCD sets of one query group differ only in their range class
+            std::fill(load.begin(), load.end(), 0.0);
+            const int64_t items = R / nrc * qb_per;
+            for (int64_t item = 0; item < items; ++item) {
+                const int64_t r = rc + nrc * (item / qb_per);
+                const int64_t ntile = (n_vt - r + R - 1) / R;
+                if (ntile > 0) load[(size_t)(item % per_x)] += (double)ntile + 0.15;   // + pipeline fill per item
+            }
+            worst = std::max(worst, *std::max_element(load.begin(), load.end()));
+        }
+        if (worst < best - 1e-9) {
+            best = worst;
+            best_r = (int)R;
+        }
+    }
+    return best_r;
+}
+
 constexpr size_t DENSE_SCRATCH_TARGET = (size_t)1 << 30;  // ~1 GiB of score rows per dense chunk
 #ifndef CCR_MFMA16_DEFAULT
 #define CCR_MFMA16_DEFAULT 1
@@ -248,6 +278,7 @@ static Plan make_plan_for(int64_t n_rows, int dim, int n_q, int k, int flags, in
         const int64_t R = choice.ranges;
         p.sample_tiles = (int)sample;
         p.sample_stride = std::max<int64_t>(1, p.full_tiles / sample);
+        p.sample_ranges = best_sample_ranges(sample, p.qblocks, p.qgroups, p.grid);
         p.ranges = (int)R;
         p.item_a = choice.item_a;
         p.item_b = choice.item_b;
@@ -996,7 +1027,7 @@ static int search_impl(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k, fl
     GemmArgs gs = g;
     gs.n_vt = p.sample_tiles;
     gs.tile_stride = p.sample_stride;
-    gs.ranges = (int)round_up(std::min<int64_t>(p.ranges, std::max<int64_t>(NUM_XCD, p.sample_tiles / 4)), NUM_XCD);
+    gs.ranges = p.sample_ranges;
     gs.gmax = gmax;
     gs.item_begin = 0;
     gs.item_end = INT32_MAX;

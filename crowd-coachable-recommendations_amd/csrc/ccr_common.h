@@ -81,6 +81,7 @@ struct Plan {
     int64_t full_tiles;   // floor(n_rows / TILE_DOCS)
     int sample_tiles;     // tiles scored by the threshold pass
     int64_t sample_stride;
+    int sample_ranges;    // range count of the sample pass (chosen by simulating its item assignment)
     int ranges;           // corpus ranges of the main pass (multiple of NUM_XCD)
     int item_a;           // phase A = work items [0, item_a) of every XCD set (0 = single phase); thresholds are re-tightened after it
     int item_b;           // end of the second phase in items (0: two phases)
