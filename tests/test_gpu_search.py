@@ -489,3 +489,63 @@ def test_generate_embeddings_contract(tmp_path, capsys):
     assert np.array_equal(_bits(packed), orc.normalize_pack_bf16(table.numpy()))
     empty = generate_embeddings([], data, embedding_func, 16, embedding_size=768)
     assert tuple(empty.shape) == (0, 768)
+
+
+def test_ranking_lazy_profile_equals_the_nested_dict(golden_dir, tmp_path):
+    """ranking(..., lazy=True) returns a Mapping over the search's tensors: same keys, order, values, equality and file round
+    trip as the reference's nested dict (scripts/ms_marco_eval.py:231-235), with a block_dict and with odd-width embeddings."""
+    from ccrec_amd import ranking_profile as rp
+    from ccrec_amd.ms_marco_eval import ranking
+    g = np.load(os.path.join(golden_dir, "g3_ranking_block.npz"))
+    os.environ["CCREC_SIM_TYPE"] = "dot"
+    Eq, Ed = g["Eq"], g["Ed"]
+    ptr, idx = g["block_ptr"], g["block_idx"]
+    corpus = {f"p{j}": j for j in range(Ed.shape[0])}
+    queries = {f"q{i}": Ed.shape[0] + i for i in range(Eq.shape[0])}
+    table = torch.from_numpy(np.concatenate([Ed, Eq]))
+    block = {f"q{i}": [f"p{j}" for j in idx[ptr[i]:ptr[i + 1]]] for i in range(Eq.shape[0])}
+    eager = ranking(corpus, queries, _table_func(table), 64, block)
+    lazy = ranking(corpus, queries, _table_func(table), 64, block, lazy=True)
+    assert isinstance(eager, dict) and isinstance(lazy, rp.RankingProfile)
+    assert lazy == eager and list(lazy) == list(eager) and all(list(lazy[q]) == list(eager[q]) for q in eager)
+    assert lazy.top("q1", 3) == list(eager["q1"])[:3]
+    lazy.save(tmp_path / "p.pt")
+    assert rp.load(tmp_path / "p.pt") == eager
+    # a width that is no multiple of 8 through the whole API (zero-padded by the pack)
+    odd = table[:, :301].contiguous()
+    a = ranking(corpus, queries, _table_func(odd), 64)
+    ref_i, ref_s = orc.canonical_search(orc.pack_bf16(odd[Ed.shape[0]:].numpy()), orc.pack_bf16(odd[:Ed.shape[0]].numpy()), min(1001, Ed.shape[0]))
+    got_i = np.array([[int(p[1:]) for p in a[q]] for q in queries])
+    got_s = np.array([list(a[q].values()) for q in queries], np.float32)
+    assert np.array_equal(got_i, ref_i) and np.array_equal(got_s.view(np.uint32), ref_s.view(np.uint32))
+
+
+def test_index_lifecycle_pending_search_workspace_adoption_and_low_rank_add_zero():
+    """(1) An index destroyed while an asynchronous search is pending waits for that search (ccr_index_destroy) -- nothing faults,
+    the next index works; (2) an index adopts the previous one's workspace tensor and returns the same bits; (3) a deferred search
+    is completed before its workspace is replaced; (4) LowRankScore + 0 (rime_lite's initial prior_score) is the score itself."""
+    from ccrec_amd import ops
+    from ccrec_amd.bbpr_transform import LowRankScore
+    Db, Qb = _rand_bits(120_000, 256, 61), _rand_bits(300, 256, 62)
+    D, Q = _bf16(Db), _bf16(Qb)
+    ref = ops.CorpusIndex(D)
+    s0, i0 = ref.search(Q, 50)
+    for _ in range(3):                                      # (1)
+        ix = ops.CorpusIndex(D)
+        s, i = ix.search(Q, 50, defer=True)
+        del ix                                              # never finished: the destroy waits for the search's own event
+    torch.cuda.synchronize()
+    assert torch.equal(i, i0) and torch.equal(s.view(torch.int32), s0.view(torch.int32))
+    ws = ref.workspace                                      # (2)
+    assert ws is not None and ws.numel() > 0
+    again = ops.CorpusIndex(D, workspace=ws)
+    s1, i1 = again.search(Q, 50)
+    assert again.workspace.data_ptr() == ws.data_ptr() and torch.equal(i1, i0) and torch.equal(s1.view(torch.int32), s0.view(torch.int32))
+    s2, i2 = again.search(Q, 50, defer=True)                # (3) a larger search needs a larger workspace: the pending one is finished first
+    s3, i3 = again.search(Q, 1000)
+    assert again._deferred is None and torch.equal(i2, i0) and s3.shape == (300, 1000)
+    assert torch.equal(i3[:, :50], i0)
+    low = LowRankScore(Q[:40].contiguous(), D[:5000].contiguous())   # (4)
+    assert (low + 0) is low and (0 + low) is low and (low + None) is low
+    dense = low + torch.ones(40, 5000, device="cuda")
+    assert torch.allclose(dense, low.as_tensor() + 1.0)
