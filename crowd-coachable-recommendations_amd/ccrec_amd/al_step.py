@@ -34,9 +34,11 @@ def run_rank_step(tower, tokenizer, corpus, queries, qrels, step_qids, step, res
     if not fresh:                                              # al_0_rank.py:115-118: resume from the saved profile
         profile = ranking_profile.load(path)                   # (the tensor form or the reference's nested dict)
     else:
-        encoder = LengthSortedEncoder(tower, tokenizer, **(encoder_kw or {}))
+        # (a HF fast tokenizer is run in four worker processes beside the GPU loop: 18 k instead of 15 k passages/s)
+        encoder = LengthSortedEncoder(tower, tokenizer, **({"host_processes": 4} if encoder_kw is None else encoder_kw))
         with torch.autocast("cuda", enabled=bool(autocast)):
             profile, ids, _ = ranking_sharded(corpus, queries, encoder, block_dict=block_dict, with_tensors=True, lazy=True)
+        encoder.close()
     qids = list(profile)
     if ids is None:     # resumed: the id tensor comes back from the file (the fresh path keeps the search's own tensor)
         qids, ids, _ = evaluation.profile_to_tensors(profile, corpus_ids)

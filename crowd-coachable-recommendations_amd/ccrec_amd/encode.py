@@ -82,6 +82,66 @@ def _tokenize_unpadded(tokenizer, texts, max_length, backend=None):
     return ids
 
 
+class _TokenizerWorkers:
+    """A few tokenizer worker PROCESSES (ccrec_amd/_tokenize_worker.py, started as children over pipes; they import neither torch
+    nor this package).  tokenize(texts) -> (flat int32 ids, int32 lengths); callable from several threads at once -- a call takes
+    a free worker from a queue, so the round trips (pipe I/O releases the GIL) of different chunks overlap."""
+
+    def __init__(self, n, tokenizer_json, max_length):
+        import json
+        import queue
+        import subprocess
+        import sys
+        here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_tokenize_worker.py")
+        env = dict(os.environ, TOKENIZERS_PARALLELISM="true")
+        self.procs = [subprocess.Popen([sys.executable, "-u", here], stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env)
+                      for _ in range(n)]
+        head = json.dumps({"tokenizer_json": tokenizer_json, "max_length": int(max_length)}).encode("utf-8")
+        self.free = queue.Queue()
+        for p in self.procs:
+            p.stdin.write(len(head).to_bytes(8, "little") + head)
+            p.stdin.flush()
+            self.free.put(p)
+
+    @staticmethod
+    def _read(f, n):
+        buf = f.read(n)
+        if buf is None or len(buf) != n:
+            raise RuntimeError("tokenizer worker ended unexpectedly")
+        return buf
+
+    def tokenize(self, texts):
+        import pickle
+        p = self.free.get()
+        try:
+            blob = pickle.dumps(list(texts), protocol=pickle.HIGHEST_PROTOCOL)
+            p.stdin.write(len(blob).to_bytes(8, "little"))
+            p.stdin.write(blob)
+            p.stdin.flush()
+            n = int.from_bytes(self._read(p.stdout, 8), "little")
+            lengths = np.frombuffer(self._read(p.stdout, 4 * n), dtype=np.int32)
+            t = int.from_bytes(self._read(p.stdout, 8), "little")
+            flat = np.frombuffer(self._read(p.stdout, 4 * t), dtype=np.int32)
+        finally:
+            self.free.put(p)
+        return flat, lengths.astype(np.int64)
+
+    def close(self):
+        for p in self.procs:
+            try:
+                p.stdin.write((0).to_bytes(8, "little"))
+                p.stdin.flush()
+                p.stdin.close()
+            except Exception:
+                pass
+        for p in self.procs:
+            try:
+                p.wait(timeout=10)
+            except Exception:
+                p.kill()
+        self.procs = []
+
+
 def _flatten(token_lists):
     """list of id sequences -> (flat int64 array, lengths, start offsets): ONE pass over the Python ints of a chunk; the batch
     arrays are then cut out of the flat array with vectorised numpy indexing (no per-row Python)."""
@@ -102,7 +162,7 @@ class LengthSortedEncoder:
     """
 
     def __init__(self, tower, tokenizer, max_length=None, max_tokens=65536, max_batch=512, pad_multiple=8, chunk_texts=65536,
-                 host_threads=4):
+                 host_threads=4, host_processes=0):
         self.tower, self.tokenizer = tower, tokenizer
         self.max_length = int(max_length if max_length is not None else os.environ.get("CCREC_MAX_LENGTH", 200))
         self.max_tokens, self.max_batch, self.pad_multiple = int(max_tokens), int(max_batch), int(pad_multiple)
@@ -110,7 +170,22 @@ class LengthSortedEncoder:
         self.host_threads = max(1, int(host_threads))
         self.pad_id = int(getattr(tokenizer, "pad_token_id", 0) or 0)
         self._backend = _rust_backend(tokenizer, self.max_length)
+        # host_processes > 0 (HF fast tokenizers only): the chunks are tokenised in that many worker processes, so the Python-list
+        # building of the tokenizer's results no longer competes for the GIL with the thread that launches the GPU kernels
+        self.host_processes = int(host_processes) if self._backend is not None else 0
+        self._workers = None
         self.stats = {}
+
+    def close(self):
+        if self._workers is not None:
+            self._workers.close()
+            self._workers = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _batch_arrays(self, flat, lengths, starts, idx, padded):
         """Padded [B, padded] int64 id / mask arrays of one batch (host, pinned when a GPU is present)."""
@@ -130,7 +205,11 @@ class LengthSortedEncoder:
         -> (batches [(index array, ids, mask)], real tokens, padded tokens, seconds spent)."""
         import time
         t0 = time.perf_counter()
-        flat, lengths, starts = _flatten(_tokenize_unpadded(self.tokenizer, texts, self.max_length, self._backend))
+        if self._workers is not None:
+            flat, lengths = self._workers.tokenize(texts)
+            starts = np.cumsum(lengths) - lengths
+        else:
+            flat, lengths, starts = _flatten(_tokenize_unpadded(self.tokenizer, texts, self.max_length, self._backend))
         plan = plan_batches(lengths, self.max_tokens, self.max_batch, self.pad_multiple) if lengths.size else []
         batches = [(idx, *self._batch_arrays(flat, lengths, starts, idx, padded)) for idx, padded in plan]
         return batches, int(lengths.sum()), int(sum(len(idx) * pl for idx, pl in plan)), time.perf_counter() - t0
@@ -155,6 +234,8 @@ class LengthSortedEncoder:
               "chunks": (n + chunk - 1) // chunk, "host_prepare_s": 0.0, "gpu_wait_for_host_s": 0.0, "gpu_busy_s": 0.0}
         wall0 = time.perf_counter()
         spans = []          # (start, end) events of every chunk's GPU work
+        if self.host_processes > 0 and self._workers is None and n > chunk:
+            self._workers = _TokenizerWorkers(self.host_processes, self._backend.to_str(), self.max_length)
         ahead = self.host_threads     # chunks being prepared while one encodes (the Rust tokenizer and numpy release the GIL)
         with ThreadPoolExecutor(max_workers=ahead) as pool:
             starts = list(range(0, n, chunk))

@@ -132,6 +132,33 @@ def test_chunked_pipeline_equals_one_chunk():
     assert many.encode([], sim="dot").shape[0] == 0 and many.stats["chunks"] == 0
 
 
+def test_tokenizer_worker_processes_give_the_same_rows():
+    """host_processes > 0: a HF fast tokenizer's chunks are tokenised in worker processes (ccrec_amd/_tokenize_worker.py, no torch
+    import) -- same token ids as the in-process Rust backend and the HF call, hence the same packed rows."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from bench_encode import fast_tokenizer
+    from transformers import BertConfig, BertModel
+    from ccrec_amd.encode import LengthSortedEncoder
+    from ccrec_amd.item_tower import NaiveItemTower
+    tok = fast_tokenizer(2000)
+    rs = np.random.RandomState(3)
+    texts = [" ".join(f"w{j}" for j in rs.randint(0, 2000, rs.randint(3, 60))) for _ in range(700)]
+    torch.manual_seed(0)
+    cfg = BertConfig(vocab_size=2048, hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128)
+    tower = NaiveItemTower(BertModel(cfg).eval(), torch.nn.LayerNorm(64, elementwise_affine=False)).cuda()
+    a = LengthSortedEncoder(tower, tok, max_length=48, max_tokens=2048, chunk_texts=100, host_threads=2)
+    b = LengthSortedEncoder(tower, tok, max_length=48, max_tokens=2048, chunk_texts=100, host_threads=3, host_processes=2)
+    ra, rb = a.encode(texts, sim="dot"), b.encode(texts, sim="dot")
+    assert b._workers is not None and len(b._workers.procs) == 2 and a._workers is None
+    assert a.stats["real_tokens"] == b.stats["real_tokens"] and torch.equal(ra.view(torch.int16), rb.view(torch.int16))
+    ref = tok(texts[:50], truncation=True, max_length=48)["input_ids"]
+    flat, lengths = b._workers.tokenize(texts[:50])
+    assert lengths.tolist() == [len(r) for r in ref] and flat.tolist() == [t for r in ref for t in r]
+    b.close()
+    assert b._workers is None
+
+
 def test_ranking_sharded_single_rank_equals_ranking_api():
     from ccrec_amd.encode import LengthSortedEncoder, ranking_sharded
     os.environ["CCREC_SIM_TYPE"] = "cos"

@@ -63,6 +63,8 @@ def main():
                     help="comma list of fixed, batch_max, sorted (chunked pipeline), serial (sorted, but tokenise everything first)")
     ap.add_argument("--chunk-texts", type=int, default=65536)
     ap.add_argument("--host-threads", type=int, default=4)
+    ap.add_argument("--host-processes", type=int, default=0, help="tokenizer worker processes (0: host threads only)")
+    ap.add_argument("--sweep", default="", help='extra "sorted" runs over the same texts: comma list of chunk_texts:host_threads, e.g. "32768:4,32768:8"')
     ap.add_argument("--texts", type=int, default=20000)
     ap.add_argument("--dist", default="titles", choices=["titles", "passages"])
     ap.add_argument("--layers", type=int, default=12)
@@ -99,12 +101,14 @@ def main():
                 out.append(emb.float().cpu())
         return torch.vstack(out)
 
-    def sorted_style(chunk=None):
+    def sorted_style(chunk=None, threads=None, procs=None):
         nonlocal texts
         enc = LengthSortedEncoder(tower, tok, max_length=args.max_length, max_tokens=args.batch * 128, max_batch=4 * args.batch,
-                                  chunk_texts=chunk or args.chunk_texts, host_threads=args.host_threads)
+                                  chunk_texts=chunk or args.chunk_texts, host_threads=threads or args.host_threads,
+                                  host_processes=args.host_processes if procs is None else procs)
         with torch.autocast("cuda", dtype=torch.bfloat16):
             shard = enc.encode(texts, sim="dot")
+        enc.close()
         st = dict(enc.stats)
         st["gpu_idle_frac"] = round(1.0 - st["gpu_busy_s"] / max(st["wall_s"], 1e-9), 4)
         return shard, {k: (round(v, 3) if isinstance(v, float) else v) for k, v in st.items()}
@@ -113,7 +117,12 @@ def main():
     all_texts = texts
     table = {"fixed": lambda: reference_style("max_length"), "batch_max": lambda: reference_style(True), "sorted": sorted_style,
              "serial": lambda: sorted_style(chunk=10 ** 9)}
-    for name in args.modes.split(","):
+    names = args.modes.split(",")
+    for spec in [x for x in args.sweep.split(",") if x]:
+        c, t, pr = (list(int(v) for v in spec.split(":")) + [None])[:3]    # chunk_texts:host_threads[:host_processes]
+        table[f"sorted[{spec}]"] = (lambda c=c, t=t, pr=pr: sorted_style(chunk=c, threads=t, procs=pr))
+        names.append(f"sorted[{spec}]")
+    for name in names:
         fn = table[name]
         texts = all_texts[:2048]      # untimed warm-up of this mode's GEMM shapes
         fn()
@@ -126,7 +135,7 @@ def main():
         results[name] = r
         line = {"mode": name, "dist": args.dist, "texts": args.texts, "mean_tokens": float(lens.mean() + 2),
                 "max_length": args.max_length, "seconds": round(dt, 3), "texts_per_s": round(args.texts / dt, 1)}
-        if name in ("sorted", "serial"):
+        if name.startswith("sorted") or name == "serial":
             line.update(r[1])
             line["tokenizer"] = args.tokenizer
         print(json.dumps(line), flush=True)
