@@ -198,7 +198,8 @@ def sharded_search(index, queries_bf16, k, group=None, merge_fn=None, search_fn=
             return index.search_blocked(queries_bf16, k_local, block[0], block[1])
         return (search_fn or index.search)(queries_bf16, k_local)
     world = dist.get_world_size(group)
-    if block is None and search_fn is None and k_local == k:   # the kernel writes the exchange message itself, no host round trip
+    direct = block is None and search_fn is None and k_local == k and 0 < queries_bf16.shape[0] <= ops.MAX_QUERIES_PER_SEARCH
+    if direct:   # the kernel writes the exchange message itself, no host round trip (larger batches are searched in pieces below)
         return submit_sharded_search(index, queries_bf16, k, group, message, merge_fn).result()
     # blocked lists, tiny shards (k_local < k: the message pads with (-inf, distinct ids), so every output slot is written even
     # when the whole corpus holds fewer than k rows -- pass n_total to clamp k instead) and test hooks: ordinary results -> message
