@@ -359,6 +359,8 @@ static Plan make_plan_for(int64_t n_rows, int dim, int n_q, int k, int flags, in
         p.off_flag = take(64 + (size_t)n_q * 4);
         // the k best lower bounds per query between two re-tightenings (three-phase plans only)
         p.off_top = take(p.item_b ? ((size_t)p.nq_pad + (size_t)n_q * k) * 4 : 0);
+        // estimated thresholds: room for the conservative bounds (+ margin coefficients) a failing search computes after the fact
+        p.off_safe = take(p.opt_rank ? (size_t)p.nq_pad * 8 : 0);
         p.dense_rows_per_chunk = FALLBACK_ROWS;
         p.off_dense = take((size_t)FALLBACK_ROWS * n_rows * 4);
         // retry pass of flagged queries: compact query rows, thresholds + margins, the two lists, counts, second flag area
@@ -762,7 +764,20 @@ static int search_complete(ccr_index *ix) {
 
     uint32_t *list_b = (uint32_t *)carve((size_t)n_q * 4);   // the rounds of a group ping-pong between these two lists
     uint32_t *list_c = (uint32_t *)carve((size_t)n_q * 4);
-    int rc = launch_partition_flags(flag_list, begin, (int)host.nflag, retry_list, dense_list, counts, s);
+    int rc = CCR_OK;
+    if (p.opt_rank) {
+        // Estimated thresholds: a query for which fewer than k rows passed has no list to take a bound from (the select left
+        // thr = -inf and FLAG_DENSE).  The sample's group maxima are still in the workspace: the CONSERVATIVE threshold (the k-th
+        // largest, a valid bound) is computed now -- only on this path -- and those queries join the retry under it.
+        float *thr_safe = (float *)(ws + p.off_safe);
+        rc = launch_threshold((const float *)(ws + p.off_gmax), (int64_t)p.sample_tiles * GROUPS_PER_TILE, n_q, p.nq_pad, k,
+                              (const float *)(ws + p.off_qnorm), ix->dmax_bits, ix->dim, ix->tile_norm, p.sample_stride, thr_safe,
+                              thr_safe + p.nq_pad, s);
+        if (rc != CCR_OK) return rc;
+        rc = launch_underfilled_to_retry(flag_list, begin, (int)host.nflag, thr_safe, thr, s);
+        if (rc != CCR_OK) return rc;
+    }
+    rc = launch_partition_flags(flag_list, begin, (int)host.nflag, retry_list, dense_list, counts, s);
     if (rc != CCR_OK) return rc;
     uint32_t hc[2] = {0, 0};
     CCR_HIP_CHECK(hipMemcpyAsync(hc, counts, 8, hipMemcpyDeviceToHost, s));

@@ -95,7 +95,7 @@ struct Plan {
     int mfma16;           // 1: main pass on the 16x16x32 MFMA kernel
     int sublists;         // candidate sub-lists per (range, query): 4 (32x32x16 kernel) or 8 (16x16x32 kernel)
     // workspace layout (byte offsets)
-    size_t off_qnorm, off_thr, off_gmax, off_cnt, off_cand, off_flag, off_dense, off_retry, off_top, total;
+    size_t off_qnorm, off_thr, off_gmax, off_cnt, off_cand, off_flag, off_dense, off_retry, off_top, off_safe, total;
     int64_t dense_rows_per_chunk;  // queries per dense chunk
 };
 

@@ -1372,6 +1372,20 @@ __global__ __launch_bounds__(256) void partition_flags_kernel(const uint32_t *__
     if (threadIdx.x < 2) counts[threadIdx.x] = s_n[threadIdx.x];
 }
 
+// Estimated thresholds: a query for which FEWER than k rows passed (the select left thr[q] = -inf and FLAG_DENSE) gets the conservative
+// bound of the sample instead -- a valid lower bound of its k-th largest score -- and becomes an ordinary retry.
+__global__ __launch_bounds__(256) void underfilled_to_retry_kernel(uint32_t *__restrict__ flags, int begin, int n,
+                                                                  const float *__restrict__ thr_safe, float *__restrict__ thr) {
+    const int i = begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t f = flags[i];
+    const uint32_t q = f & ~FLAG_DENSE;
+    if ((f & FLAG_DENSE) && thr[q] == -INFINITY && thr_safe[q] > -INFINITY) {   // (a NaN bound -- non-finite embeddings -- stays on the exact path)
+        thr[q] = thr_safe[q];
+        flags[i] = q;
+    }
+}
+
 // thr[list[i]] = thr2[i]: the re-tightened thresholds of a retry round go back to the original query order
 __global__ __launch_bounds__(256) void scatter_thresholds_kernel(const uint32_t *__restrict__ list, int n, const float *__restrict__ thr2,
                                                                 float *__restrict__ thr) {
@@ -1526,6 +1540,13 @@ int select_compact_entries(int dim, int ranges, int rescore_cap, int64_t want) {
 int launch_partition_flags(const uint32_t *flags, int begin, int n, uint32_t *retry_list, uint32_t *dense_list, uint32_t *counts,
                            hipStream_t s) {
     hipLaunchKernelGGL(partition_flags_kernel, dim3(1), dim3(256), 0, s, flags, begin, n, retry_list, dense_list, counts);
+    CCR_LAUNCH_CHECK();
+    return CCR_OK;
+}
+
+int launch_underfilled_to_retry(uint32_t *flags, int begin, int n, const float *thr_safe, float *thr, hipStream_t s) {
+    if (n <= begin) return CCR_OK;
+    hipLaunchKernelGGL(underfilled_to_retry_kernel, dim3((n - begin + 255) / 256), dim3(256), 0, s, flags, begin, n, thr_safe, thr);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
 }

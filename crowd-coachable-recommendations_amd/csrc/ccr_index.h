@@ -53,6 +53,7 @@ int launch_select_rescore(const uint2 *cand, const uint32_t *cnt, int ranges, in
                           hipStream_t s);
 int launch_partition_flags(const uint32_t *flags, int begin, int n, uint32_t *retry_list, uint32_t *dense_list, uint32_t *counts,
                            hipStream_t s);
+int launch_underfilled_to_retry(uint32_t *flags, int begin, int n, const float *thr_safe, float *thr, hipStream_t s);
 int launch_scatter_thresholds(const uint32_t *list, int n, const float *thr2, float *thr, hipStream_t s);
 int launch_gather_queries(const uint16_t *Q, int dim, const uint32_t *list, int n, const float *thr, const float *cq, uint16_t *Q2,
                           float *thr2, float *cq2, hipStream_t s);
