@@ -8,9 +8,9 @@ single-GPU search.
 
 No host round trip before the collective: the per-shard search is asynchronous (CCR_SEARCH_ASYNC) and leaves the number of
 queries it flagged in the message HEADER, on the stream.  After the all-gather every rank holds every rank's header, so all
-ranks take the same branch: lists final (the usual case: nothing flagged, or at most the 16 queries the search re-does on
-the stream by itself) -> merge; otherwise every rank completes its search (ccr_search_finish: a no-op where nothing was
-flagged) and ALL ranks repeat the all-gather -- the second collective is matched by construction."""
+ranks take the same branch: lists final (the usual case: no rank flagged a query) -> merge; otherwise every rank completes its
+search (ccr_search_finish: a no-op where nothing was flagged) and ALL ranks repeat the all-gather -- the second collective is
+matched by construction."""
 import ctypes
 
 import torch
@@ -152,7 +152,7 @@ class ShardExchange:
             words = m.all_headers.cpu()
         self.headers = m.parse_headers(words)
         if self.index is not None and getattr(self.index, "_deferred", None) is not None:
-            self.index.finish()    # its own event is long complete: fills last_stats(); re-does flagged queries beyond the on-stream chunk
+            self.index.finish()    # its own event is long complete: fills last_stats(); re-does the queries the search flagged (rare)
         if any(h["n_flagged"] > h["n_covered"] for h in self.headers):
             # some rank's lists were not final when they were exchanged.  Every rank sees the same headers, so every rank is
             # here: the flagged ranks have completed their lists in finish() above, all ranks repeat the collective.

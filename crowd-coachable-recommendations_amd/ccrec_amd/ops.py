@@ -206,7 +206,7 @@ class CorpusIndex:
         """-> (scores [n_q, k] fp32, ids [n_q, k] int64 global), canonical order.
         out=(scores, ids): contiguous [n_q, k] destinations (e.g. views of a packed all-gather message).
         defer=True: CCR_SEARCH_ASYNC -- the call returns without synchronising the stream; call finish() before trusting
-        the result of an input that may flag more than 16 queries (finish() also fills last_stats())."""
+        the result (it completes the -- rare -- flagged queries and fills last_stats())."""
         q = queries_bf16
         assert q.is_cuda and q.dtype == torch.bfloat16 and q.dim() == 2 and q.shape[1] == self.dim
         q = q.contiguous()
@@ -237,7 +237,7 @@ class CorpusIndex:
 
     def finish(self):
         """Complete a deferred search: waits for THAT search's stream work (its own event -- not for work enqueued after it),
-        fills last_stats(), and re-does flagged queries beyond the on-stream chunk (only then does it synchronise the stream)."""
+        fills last_stats(), and re-does the queries the search flagged (only then does it synchronise the stream)."""
         with _on(self.corpus):
             _lib.check(self._lib.ccr_search_finish(self._h), "ccr_search_finish")
         self._deferred = None

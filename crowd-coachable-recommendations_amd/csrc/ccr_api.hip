@@ -122,19 +122,28 @@ struct MainPassChoice {
     int opt_rank;         // > 0: ESTIMATED thresholds (the opt_rank-th largest sampled group maximum), single launch, verified by the select
 };
 
-// Estimated ("optimistic") thresholds for large k.  The conservative threshold -- the k-th largest group maximum of a sample of
-// the corpus fraction fs -- lets k / fs rows per query through the first phase, so large k needs a big sample (1/16 at k = 1001:
-// 1/16 of the corpus scored twice) and two re-tightenings.  But the filter does not need a BOUND: any threshold tau works if
-// at least k rows turn out to pass it with their lower bounds (then the k-th largest exact score is >= tau and every row that
-// could reach it was recorded) -- which the select stage checks (L >= tau; a query that fails is retried under the valid bound
-// its candidates give).  So tau is set to the r-th largest sampled group maximum with r = max(48, 3 k fs): about r / fs = 3 k
-// rows pass over the WHOLE corpus in ONE launch; the pass count given r is Gamma(r)-distributed (sd 1 / sqrt(r) = 14 %), so
-// fewer than k pass with probability ~1e-7 per query on exchangeable rows.  A corpus in topical order can fool the estimate
-// (the sample holds a query's whole cluster tile): those queries fail the check and are retried -- exact either way.
+// Estimated ("optimistic") thresholds.  The conservative threshold -- the k-th largest group maximum of a sample of the corpus
+// fraction fs -- lets k / fs rows per query through the first phase, so large k needs a big sample (1/16 at k = 1001: 1/16 of the
+// corpus scored twice) and two re-tightenings.  But the filter does not need a BOUND: any threshold tau works if at least k rows
+// turn out to pass it with their lower bounds (then the k-th largest exact score is >= tau and every row that could reach it was
+// recorded) -- which the select stage checks (L >= tau; a query that fails is retried under a valid bound).  So tau is set to
+// the r-th largest sampled group maximum: about r / fs rows pass over the WHOLE corpus in ONE launch.  Given r, the pass count is
+// (r / fs) x Gamma(r) / r: fewer than k rows pass iff Gamma(r) < k fs.  r is the smallest rank whose 1e-7 lower quantile
+// (Wilson-Hilferty: r (1 - 1/(9r) - 5.2 sqrt(1/(9r)))^3) reaches k fs, and at least 40 -- k = 1001 on a 1/64 sample: r = 41,
+// 2 700 rows pass.  Why the floor: a corpus in topical order can fool the estimate when the sample holds a query's whole
+// cluster tile; with r <= 16 that ONE tile's 16 group maxima set tau (measured with r = 13 at k = 100 on the topically sorted
+// bench corpus: one query in 3 452 fails the check, and its retry costs 5 ms of an 18-ms step), with r >= 40 at least three
+// tiles contribute (k = 1001, same corpus: nobody fails).  With the floor the planner keeps the conservative plan at small k
+// (2 560 rows would pass at k = 100 against 1 296), where the phased plan is cheap anyway.  Exact either way.
 static int optimistic_rank(int k, int64_t sample, int64_t tiles, const Knobs &kn) {
     if (kn.opt_rank > 0) return kn.opt_rank;   // tests: a small rank makes most queries fail the check
-    const double fs = (double)sample / (double)tiles;
-    return (int)std::max<int64_t>(48, (int64_t)ceil(3.0 * k * fs));
+    const double need = (double)k * (double)sample / (double)tiles;
+    int r = 40;
+    for (; r < 1 << 20; ++r) {
+        const double a = 1.0 / (9.0 * r), t = 1.0 - a - 5.2 * sqrt(a);
+        if (t > 0.0 && (double)r * t * t * t >= need) break;
+    }
+    return r;
 }
 
 static MainPassChoice choose_main_pass(const Plan &p, int k, int64_t sample_a, int64_t sample_b, int64_t sample_c, const Knobs &kn) {
@@ -188,7 +197,7 @@ static MainPassChoice choose_main_pass(const Plan &p, int k, int64_t sample_a, i
                 best = single;
                 best_choice = {smp, R, 0, 0, 0};
             }
-            if (kn.optimistic != 0 && smp * GROUPS_PER_TILE >= 4 * 48) {   // estimated thresholds: one launch, ~rank / fs rows pass
+            if (kn.optimistic != 0 && smp * GROUPS_PER_TILE >= 4 * 40) {   // estimated thresholds: one launch, ~rank / fs rows pass
                 const int rank = optimistic_rank(k, smp, p.tiles, kn);
                 if ((int64_t)rank * 4 <= smp * GROUPS_PER_TILE) {
                     const double pass = std::max((double)rank / fs, (double)k);
@@ -736,9 +745,9 @@ static int search_complete(ccr_index *ix) {
     ix->stats.main_launches = 1 + (p.item_a ? 1 : 0) + (p.item_b ? 1 : 0);
     ix->stats.opt_rank = p.opt_rank;
     ix->stats.n_candidates = (int64_t)host.ncand;
-    const int begin = was_async ? std::min<int>(FALLBACK_ROWS, (int)host.nflag) : 0;   // the on-stream chunk took these
-    ix->stats.n_dense = begin;
-    if ((int)host.nflag <= begin) return CCR_OK;
+    const int begin = 0;
+    ix->stats.n_dense = 0;
+    if (host.nflag == 0) return CCR_OK;
 
     const int n_q = pd.n_q, k = pd.k;
     uint32_t *flag_list = (uint32_t *)(ws + p.off_flag + 64);
@@ -1111,14 +1120,10 @@ static int search_impl(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k, fl
     ix->pending.ws = ws;
     ix->pending.stream = s;
     if (async) {
-        // The host does not learn the flag count here.  One chunk of the exact dense path runs on the stream for the first
-        // FALLBACK_ROWS flagged queries (its kernels read the count on the device and exit at once when it is zero);
-        // ccr_search_finish() covers the rest -- more than that many flagged queries means mass ties or adversarial data.
-        rc = launch_dense_scores(ix->D, ix->n_rows, ix->dim, Q_bf16, flag_list, 0, FALLBACK_ROWS, flag_count, dense_scratch, s);
-        if (rc != CCR_OK) return rc;
-        rc = launch_dense_select(dense_scratch, ix->n_rows, k, flag_list, 0, FALLBACK_ROWS, flag_count, ix->id_out, out_scores,
-                                 out_ids, s);
-        if (rc != CCR_OK) return rc;
+        // The host does not learn the flag count here, and nothing is re-done on the stream: flagged queries (rare: a sub-list
+        // overflow, mass ties, an estimated threshold that failed its check) are completed by ccr_search_finish(), which has the
+        // retry pass and the margin path at its disposal (2-3 ms for a handful of NQ queries; an unconditional on-stream chunk of
+        // the fp64 path cost 35 ms as soon as ONE query was flagged, and two no-op launches per search when none was).
         // the shard message's header learns the count on the stream: the exchange can be enqueued without the host knowing it
         if (flagged_out) CCR_HIP_CHECK(hipMemcpyAsync(flagged_out, flag_count, 4, hipMemcpyDeviceToDevice, s));
         CCR_HIP_CHECK(hipMemcpyAsync((void *)ix->host_flags, flag_count, 16, hipMemcpyDeviceToHost, s));   // pinned: stays asynchronous
@@ -1154,7 +1159,7 @@ extern "C" int ccr_search_shard(ccr_index *ix, const uint16_t *Q_bf16, int n_q, 
     memset(&h, 0, sizeof(h));
     h.magic = CCR_SHARD_MAGIC;
     h.k_valid = (uint32_t)k;
-    h.n_covered = (flags & CCR_SEARCH_ASYNC) ? (uint32_t)FALLBACK_ROWS : 0u;
+    h.n_covered = 0u;   // (an asynchronous search completes no flagged query by itself: ccr_search_finish does)
     h.row_offset = ix->offset;
     h.n_rows = ix->n_rows;
     int rc = launch_shard_header(h, message, s);   // by value through a kernel: no host buffer, no synchronisation

@@ -42,7 +42,7 @@ extern "C" {
 #define CCR_SEARCH_FORCE_DENSE 1   /* fp64 brute-force path for every query (tests; the default path of a tiny corpus scores on the matrix
                                       cores and re-scores only the rows inside the error margin in fp64 -- same result) */
 #define CCR_SEARCH_FORCE_FUSED 2   /* MFMA fused path even where the planner would pick dense */
-#define CCR_SEARCH_ASYNC 4         /* do not synchronise: results complete on `stream` once ccr_search_finish() has run */
+#define CCR_SEARCH_ASYNC 4         /* do not synchronise: flagged queries (rare) are completed by ccr_search_finish() */
 
 /* ccr_scores modes */
 #define CCR_SCORES_CANONICAL 0     /* fp64-ordered canonical scores (bit-identical to the ranking's scores) */
@@ -154,10 +154,11 @@ int ccr_index_dim(const ccr_index *index);
  *   1 <= k <= min(n_rows, 4096).
  * The call returns after the results are complete on `stream` (it synchronises the stream once
  * to read the fallback count).  With CCR_SEARCH_ASYNC in `flags` it returns without synchronising: the kernels are
- * enqueued, including one on-stream chunk of the exact path that covers up to 16 flagged queries; the caller may enqueue
- * more work (e.g. the shard exchange) and must call ccr_search_finish(index) -- which synchronises, re-does any further
- * flagged queries and fills the statistics -- before it trusts the results of an input that can flag more than that
- * (ccr_search_last_stats().n_fallback tells).  Buffers and workspace must stay valid until then.
+ * enqueued and the caller may enqueue more work (e.g. the shard exchange); ccr_search_finish(index) -- which waits for THIS
+ * search's own event (not for work enqueued after it), fills the statistics and re-does the queries the search flagged
+ * (sub-list overflow, mass ties, an estimated threshold that failed its check: rare) -- must run before the results of
+ * flagged queries are trusted (ccr_search_last_stats().n_fallback tells how many there were; the lists of all other queries
+ * are final on the stream).  Buffers and workspace must stay valid until then.
  * Embeddings are expected to be finite.  NaN / Inf values do not fault: the filter margins become infinite, every
  * query takes the exact dense path, +-Inf scores rank as numbers and NaN scores rank by bit pattern (not torch.sort's
  * NaN-first rule) -- identically on every path.
@@ -235,7 +236,7 @@ int ccr_merge_topk_strided(const float *scores, const int64_t *ids, int64_t scor
  *   8 bytes per entry on the wire (12 with int64 global ids); the merge adds header.row_offset.
  * ccr_search_shard == ccr_search writing that message.  With CCR_SEARCH_ASYNC the call does not synchronise and the header's
  * n_flagged is written ON THE STREAM (the select stage's flag count): after the all-gather every rank reads every rank's
- * {n_flagged, n_covered} and all ranks take the same branch -- lists are final iff n_flagged <= n_covered on every rank, otherwise
+ * {n_flagged, n_covered} and all ranks take the same branch -- lists are final iff n_flagged <= n_covered (= 0) on every rank, otherwise
  * the flagged ranks call ccr_search_finish and the exchange is repeated by ALL ranks (a matched second collective).
  * 1 <= k <= min(n_rows, 4096); a shard smaller than k searches k_valid = n_rows entries and fills the message with
  * ccr_shard_message_fill instead.
@@ -245,7 +246,7 @@ typedef struct ccr_shard_header {
     uint32_t magic;
     uint32_t n_flagged;   /* queries flagged by the shard's asynchronous search (0 after a synchronous one) */
     uint32_t k_valid;     /* entries of every list that are real rows; slots [k_valid, k) are padding */
-    uint32_t n_covered;   /* flagged queries the search completed on the stream by itself (CCR_SEARCH_ASYNC: 16) */
+    uint32_t n_covered;   /* flagged queries the search completed on the stream by itself (0: ccr_search_finish completes them) */
     int64_t row_offset;   /* global id of the shard's row 0 */
     int64_t n_rows;       /* rows of the shard */
 } ccr_shard_header;

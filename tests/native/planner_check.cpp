@@ -54,7 +54,7 @@ int main() {
                     // estimated thresholds: one launch, the rank well inside the sampled groups, never for small k (where the
                     // conservative bound + re-tightening passes fewer rows)
                     if (p.opt_rank && (p.item_a || p.item_b)) bad += fail("estimated thresholds with phases", n, d, nq, k);
-                    if (p.opt_rank && (p.opt_rank < 48 || (long long)p.opt_rank * 4 > (long long)p.sample_tiles * GROUPS_PER_TILE))
+                    if (p.opt_rank && (p.opt_rank < 40 || (long long)p.opt_rank * 4 > (long long)p.sample_tiles * GROUPS_PER_TILE))
                         bad += fail("estimated-threshold rank", n, d, nq, k);
                     if (p.opt_rank && (long long)p.opt_rank * p.tiles / p.sample_tiles < k) bad += fail("estimated thresholds pass fewer than k rows", n, d, nq, k);
                     if ((long long)p.sample_tiles * p.sample_stride > p.full_tiles + p.sample_stride) bad += fail("sample beyond the shard", n, d, nq, k);
