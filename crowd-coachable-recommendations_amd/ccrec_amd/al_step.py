@@ -20,7 +20,11 @@ from .encode import LengthSortedEncoder, ranking_sharded
 def run_rank_step(tower, tokenizer, corpus, queries, qrels, step_qids, step, results_dir, ranking_profile_bm25=None,
                   block_dict=None, landing_image=None, n_repeats=3, repeat_seed=42, encoder_kw=None, autocast=True,
                   compat_profile=False):
-    """-> {"ranking_profile", "mrr", "requests"}; files are written to results_dir/data_iteration_{step}/."""
+    """-> {"ranking_profile", "mrr", "requests", "timings"}; files are written to results_dir/data_iteration_{step}/.
+    timings: wall seconds of the stages (rank = encode + search; mrr; bm25; requests; save) and the corpus encoder's own statistics."""
+    import time
+    t_start = time.perf_counter()
+    timings = {}
     work = os.path.join(results_dir, f"data_iteration_{step}")
     os.makedirs(work, exist_ok=True)
     path = os.path.join(work, "ranking_profile.pt")
@@ -36,21 +40,34 @@ def run_rank_step(tower, tokenizer, corpus, queries, qrels, step_qids, step, res
     else:
         # (a HF fast tokenizer is run in four worker processes beside the GPU loop: 18 k instead of 15 k passages/s)
         encoder = LengthSortedEncoder(tower, tokenizer, **({"host_processes": 4} if encoder_kw is None else encoder_kw))
+        t0 = time.perf_counter()
         with torch.autocast("cuda", enabled=bool(autocast)):
             profile, ids, _ = ranking_sharded(corpus, queries, encoder, block_dict=block_dict, with_tensors=True, lazy=True)
+        torch.cuda.synchronize()
+        timings["rank_s"] = time.perf_counter() - t0
+        timings["corpus_encoder"] = dict(encoder.stats)      # (the corpus is encoded last: its statistics are the ones left)
         encoder.close()
     qids = list(profile)
     if ids is None:     # resumed: the id tensor comes back from the file (the fresh path keeps the search's own tensor)
         qids, ids, _ = evaluation.profile_to_tensors(profile, corpus_ids)
     rel = [[pos[p] for p in qrels.get(q, {}) if p in pos] for q in qids]
     kmax = ids.shape[1]
+    t0 = time.perf_counter()
     mrr = evaluation.rank_metrics(ids.cuda(), rel, tuple(k for k in (1, 5, 10, 100) if k <= kmax))
+    timings["mrr_s"] = time.perf_counter() - t0
     for name, value in mrr.items():
         print(name, ":", value)
     if ranking_profile_bm25 is None:
+        t0 = time.perf_counter()
         ranking_profile_bm25 = ranking_bm25(corpus, queries)
+        timings["bm25_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
     requests = build_requests(profile, ranking_profile_bm25, step_qids, corpus, queries, step, n_repeats=n_repeats,
                               repeat_seed=repeat_seed, landing_image=landing_image, out_dir=work)
+    timings["requests_s"] = time.perf_counter() - t0
     if fresh:   # the tensor form (loads under torch.load's weights_only default); save(path, compat=True) writes the nested dict
+        t0 = time.perf_counter()
         profile.save(path, compat=compat_profile)
-    return {"ranking_profile": profile, "mrr": mrr, "requests": requests}
+        timings["save_s"] = time.perf_counter() - t0
+    timings["total_s"] = time.perf_counter() - t_start
+    return {"ranking_profile": profile, "mrr": mrr, "requests": requests, "timings": timings}
