@@ -187,7 +187,7 @@ class Workload:
         self.prev = None        # the step whose search / exchange is still in flight
         self.nstep = 0
         self.done_stats = []    # last_stats() of every completed step
-        self.repeats = 0        # exchanges that had to be repeated (some rank flagged more queries than its search re-did on the stream)
+        self.repeats = 0        # exchanges that had to be repeated (some rank's search had flagged queries: completed by finish(), gathered again)
         self.index = self.scores = self.ids = None
 
     def step(self):
