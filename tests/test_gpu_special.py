@@ -660,3 +660,46 @@ def test_margin_path_small_corpus_and_flagged_queries():
     assert st["path"] == 1 and st["n_fallback"] == 6 and st["n_dense"] == 6, st
     s1, i1 = index.search(Q[10:30], 100, 1)
     assert torch.equal(i0[10:30], i1) and torch.equal(s0[10:30].view(torch.int32), s1.view(torch.int32))
+
+
+def test_two_host_threads_search_their_own_indices_concurrently():
+    """one index must not be searched from two host threads at once, DISTINCT indices are independent.  Two
+    threads, each with its own index, stream and workspace, run searches at the same time (ctypes releases the GIL inside the
+    library: the per-device slab / block caches, the LDS opt-in table and the error text are what they share); every result
+    must equal the serial one bit for bit, index creation and destruction included."""
+    import threading
+    from ccrec_amd import ops
+    shapes = [(150_000, 700, 256, 100), (90_000, 300, 768, 1001)]
+    data, serial = [], []
+    for t, (n, nq, d, k) in enumerate(shapes):
+        D, Q = _bf16(_rand_bits(n, d, 300 + t)), _bf16(_rand_bits(nq, d, 400 + t))
+        data.append((D, Q, k))
+        s, i = ops.CorpusIndex(D).search(Q, k)
+        serial.append((s.clone(), i.clone()))
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(t):
+        try:
+            D, Q, k = data[t]
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                for rep in range(12):
+                    index = ops.CorpusIndex(D, global_row_offset=0)       # a fresh index per repetition: slab / block cache traffic
+                    s, i = index.search(Q, k, defer=(rep % 2 == 1))
+                    if rep % 2 == 1:
+                        index.finish()
+                    stream.synchronize()
+                    if not (torch.equal(i, serial[t][1]) and torch.equal(s.view(torch.int32), serial[t][0].view(torch.int32))):
+                        errors.append((t, rep, "mismatch"))
+                    del index
+        except Exception as e:   # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+    assert not any(th.is_alive() for th in threads), "a search thread did not finish"
+    assert not errors, errors
