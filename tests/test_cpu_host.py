@@ -401,3 +401,26 @@ def test_unwrap_item_tower_shapes():
     with_attr.item_tower = tower
     wrapper.model = with_attr
     assert unwrap_item_tower(with_attr) is tower and unwrap_item_tower(wrapper) is tower and unwrap_item_tower(tower) is tower
+
+
+def test_a_hung_child_fails_with_stacks_and_kernel_state(tmp_path):
+    """The harness the GPU rehearsal tests run bench.py children under (helpers.run_child_with_evidence): a child that is still
+    running at the limit is a FAILURE that carries every thread's Python stack (SIGUSR1 -> the faulthandler bench.install_watchdog
+    registers, written to a file that survives the kill), the kernel-side state / wait channel of its threads and its stderr --
+    and the whole process group is gone afterwards.  (Round 2 turned such a timeout into a skip and kept no record.)"""
+    from helpers import run_child_with_evidence
+    code = ("import sys, time; sys.path.insert(0, %r); import bench; bench.install_watchdog(); "
+            "print('child: waiting forever', file=sys.stderr, flush=True)\n"
+            "def stuck_here():\n    time.sleep(1000)\n"
+            "stuck_here()") % ROOT
+    env = dict(os.environ, CCR_BENCH_WATCHDOG="900")
+    with pytest.raises(pytest.fail.Exception) as info:
+        run_child_with_evidence([sys.executable, "-c", code], env, tmp_path, "hung", limit=20)
+    msg = str(info.value)
+    assert "child still running after" in msg and "stuck_here" in msg
+    assert "State:" in msg and "wchan=" in msg and "child: waiting forever" in msg and "stacks.rank0.txt" in msg
+    pids = [int(m) for m in re.findall(r"^pid (\d+):", msg, flags=re.M)]
+    assert pids and not any(os.path.exists(f"/proc/{p}") for p in pids), pids       # the whole group was killed and reaped
+    # a child that exits non-zero (the in-child watchdog's exit path) is a failure with its stderr as well
+    with pytest.raises(pytest.fail.Exception, match="exit code 3"):
+        run_child_with_evidence([sys.executable, "-c", "import sys; print('boom', file=sys.stderr); sys.exit(3)"], env, tmp_path, "bad", limit=20)

@@ -89,77 +89,7 @@ def test_shard_message_through_rccl_world1():
         dist.destroy_process_group()
 
 
-def _proc_state(pid):
-    """What the kernel says a process and its threads are doing: state + wait channel of every thread (readable without root)."""
-    lines = []
-    try:
-        for tid in sorted(os.listdir(f"/proc/{pid}/task"), key=int):
-            base = f"/proc/{pid}/task/{tid}"
-            try:
-                comm = open(base + "/comm").read().strip()
-                state = [ln for ln in open(base + "/status").read().splitlines() if ln.startswith("State:")][0]
-                wchan = open(base + "/wchan").read().strip()
-                lines.append(f"  tid {tid} {comm}: {state} wchan={wchan}")
-            except OSError:
-                pass
-    except OSError:
-        lines.append(f"  pid {pid}: gone")
-    return lines
-
-
-def _children_of(pid):
-    try:
-        out = subprocess.run(["ps", "-o", "pid=", "--ppid", str(pid)], capture_output=True, text=True).stdout.split()
-        kids = [int(x) for x in out]
-    except Exception:
-        kids = []
-    return kids + [g for c in kids for g in _children_of(c)]
-
-
-def _run_child(cmd, env, tmp_path, tag, limit=240):
-    """Run a bench.py child in its own process group.  A child that overruns `limit` is a FAILURE with evidence: the Python
-    stacks of every rank (SIGUSR1 -> faulthandler, written to files that survive the kill), the kernel-side state and wait
-    channel of every thread of every process of the group, and the child's stderr so far.  The whole group is killed then
-    (a killed launcher alone would leave its ranks holding the GPU)."""
-    dump_dir = tmp_path / f"{tag}_stacks"
-    dump_dir.mkdir(exist_ok=True)
-    env = dict(env, CCR_BENCH_WATCHDOG_DIR=str(dump_dir))
-    err_path, out_path = tmp_path / f"{tag}.stderr", tmp_path / f"{tag}.stdout"
-    with open(err_path, "w") as ferr, open(out_path, "w") as fout:
-        proc = subprocess.Popen(cmd, stdout=fout, stderr=ferr, env=env, start_new_session=True)
-        t0 = time.time()
-        try:
-            proc.wait(timeout=limit)
-        except subprocess.TimeoutExpired:
-            pids = [proc.pid] + _children_of(proc.pid)
-            evidence = [f"{tag}: child still running after {time.time() - t0:.0f} s: {' '.join(cmd)}"]
-            for pid in pids:
-                evidence.append(f"pid {pid}: {open(f'/proc/{pid}/cmdline').read().replace(chr(0), ' ')[:200] if os.path.exists(f'/proc/{pid}/cmdline') else 'gone'}")
-                evidence += _proc_state(pid)
-            for pid in pids:
-                if not _children_of(pid):                  # the ranks (leaves): launchers have no handler and would just die
-                    try:
-                        os.kill(pid, signal.SIGUSR1)       # faulthandler: every thread's Python stack into the dump file
-                    except OSError:
-                        pass
-            time.sleep(3)
-            try:
-                os.killpg(proc.pid, signal.SIGKILL)
-            except OSError:
-                pass
-            try:
-                proc.wait(timeout=30)
-            except subprocess.TimeoutExpired:
-                evidence.append("child did not die within 30 s of SIGKILL (uninterruptible)")
-            for f in sorted(dump_dir.iterdir()):
-                evidence.append(f"--- {f.name}\n{f.read_text()[-6000:]}")
-            evidence.append(f"--- stderr\n{err_path.read_text()[-6000:]}")
-            pytest.fail("\n".join(evidence))
-    stderr, stdout = err_path.read_text(), out_path.read_text()
-    if proc.returncode != 0:   # includes the in-child watchdog (exit code 1 after its stack dump)
-        dumps = "".join(f"--- {f.name}\n{f.read_text()[-6000:]}\n" for f in sorted(dump_dir.iterdir()))
-        pytest.fail(f"{tag}: exit code {proc.returncode}\n{dumps}--- stderr\n{stderr[-6000:]}")
-    return stdout, stderr
+from helpers import run_child_with_evidence as _run_child   # noqa: E402  (a child that overruns FAILS the test, with evidence)
 
 
 @pytest.mark.parametrize("world,rows,launcher", [(2, 200000, "plain"), (2, 200000, "torchrun"), (3, 200003, "plain")])
