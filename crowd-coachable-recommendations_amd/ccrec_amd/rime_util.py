@@ -52,19 +52,9 @@ def _low_rank_plus_sparse(S):
             fac = _factors(c)
             if fac is not None:
                 ops.require_gpu()
-                U, V = (_pad8(t, fac[1].shape[0] >= FUSED_MIN_ITEMS) for t in fac)
+                U, V = fac      # any factor width: the pack zero-pads to a multiple of 8, the fused kernels zero-fill their K tail
                 low = LowRankScore(ops.pack_bf16(U.cuda()), ops.pack_bf16(V.cuda()))
     return LowRankPlusSparse(low, prior) if low is not None and prior is not None else None
-
-
-def _pad8(t, fused=False):
-    """Zero columns do not change any dot product: pad the factor width to a multiple of 8 (what every kernel wants), or of
-    64 (what the fused MFMA search wants -- a 100- or 300-wide factor would otherwise take the exact dense path for every row)."""
-    pad = (-t.shape[1]) % (64 if fused else 8)
-    return torch.nn.functional.pad(t, (0, pad)) if pad else t
-
-
-FUSED_MIN_ITEMS = 4096   # below this many item rows the planner picks the exact dense path anyway
 
 
 def _assign_topk(S, k, tie_breaker=1e-10, device="cpu", batch_size=None):
@@ -81,8 +71,7 @@ def _assign_topk(S, k, tie_breaker=1e-10, device="cpu", batch_size=None):
                                   "prior; other LazyScore expressions stay on rime_lite's own path")
     U, V = fac
     ops.require_gpu()
-    U, V = (_pad8(t, V.shape[0] >= FUSED_MIN_ITEMS) for t in (U, V))
-    index = ops.CorpusIndex(ops.pack_bf16(V.cuda()))
+    index = ops.CorpusIndex(ops.pack_bf16(V.cuda()))     # any factor width (zero-padded to a multiple of 8 by the pack)
     _, ids = index.search(ops.pack_bf16(U.cuda()), k)
     indices = ids.cpu().numpy()
     shape = (U.shape[0], V.shape[0])

@@ -309,6 +309,22 @@ def test_assign_topk_golden(golden_dir):
     assert np.array_equal(_assign_topk(FakeMatMul(), k).indices, csr.indices)
 
 
+@pytest.mark.parametrize("d", [300, 50])
+def test_assign_topk_odd_width_golden(golden_dir, d):
+    """g15: the reference's own _assign_topk on 300- and 50-wide factors; here the factors are zero-padded by the pack (304 / 56) and
+    searched by the fused / margin paths with a zero-filled K tail.  ids == oracle bit for bit, == the reference's wherever its fp32
+    scores are separated."""
+    from ccrec_amd.rime_util import _assign_topk
+    g = np.load(os.path.join(golden_dir, "g15_assign_topk_odd_width.npz"))
+    U, V, ref, k = g[f"U{d}"], g[f"V{d}"], g[f"indices{d}"], int(g[f"k{d}"])
+    csr = _assign_topk((U, V), k)
+    ids = csr.indices.reshape(U.shape[0], k)
+    ref_i, ref_s = orc.canonical_search(orc.pack_bf16(U), orc.pack_bf16(V), k)
+    assert np.array_equal(ids, ref_i)
+    ref_sc = np.take_along_axis(U.astype(np.float64) @ V.astype(np.float64).T, ref, 1).astype(np.float32)
+    assert_rank_close(ids, ref_s, ref, ref_sc, tol=2e-6, truncated=True)
+
+
 def test_many_query_blocks_multi_item_workgroups():
     """3,452 queries = 14 query blocks: every workgroup walks several (range, query-block) items.
     All queries are compared against the exact dense GPU path, a subset against the CPU oracle."""

@@ -109,6 +109,16 @@ def test_assign_topk(golden_dir):
     assert np.array_equal(g["indptr"], np.arange(0, ref.size + 1, k))
 
 
+@pytest.mark.parametrize("d", [300, 50])
+def test_assign_topk_odd_width(golden_dir, d):
+    """g15 = the reference's _assign_topk on factors whose width is no multiple of 8 (score_array.py:320-339 takes any)."""
+    g = _load(golden_dir, "g15_assign_topk_odd_width.npz")
+    U, V, ref, k = g[f"U{d}"], g[f"V{d}"], g[f"indices{d}"], int(g[f"k{d}"])
+    ids, sc = orc.canonical_search(orc.pack_bf16(U), orc.pack_bf16(V), k)
+    ref_sc = np.take_along_axis(U.astype(np.float64) @ V.astype(np.float64).T, ref, 1).astype(np.float32)
+    assert_rank_close(ids, sc, ref, ref_sc, tol=2e-6, truncated=True)
+
+
 def test_sparse_prior_topk_and_score_op(golden_dir):
     """g14 = the reference's rime_lite on (U @ V.T + sparse prior): _assign_topk, score_op (bbpr.py:592-595)."""
     g = _load(golden_dir, "g14_sparse_prior.npz")

@@ -26,6 +26,7 @@ Fixtures:
   G13 rime_lite.metrics.evaluate_item_rec on a MatMulExpression score (the §8b signature that consumes _assign_topk)
   G14 low-rank + sparse prior: _assign_topk / evaluate_item_rec / score_op on
       ElementWiseExpression(add, [U @ V.T, sparse]) -- the post-fit expression of bbpr.py:592-595 (reranking_prior 1e5)
+  G15 _assign_topk on MatMulExpressions of width 300 and 50 (any factor width: score_array.py:320-339)
 """
 import contextlib
 import importlib.abc
@@ -253,6 +254,25 @@ def g_assign_topk():
                         indptr=csr.indptr.astype(np.int64), k=10)
 
 
+def g_assign_topk_odd_width():
+    """G15: the reference's rime_lite takes factors of ANY width (score_array.py:320-339): _assign_topk on 300- and 50-wide
+    MatMulExpressions (the widths the fused kernels' zero-filled K tail and the zero-padding pack exist for)."""
+    _import_reference("dot")
+    from rime_lite.util import _assign_topk
+    from rime_lite.util.score_array import auto_cast_lazy_score
+
+    out = {}
+    for d, nu, nv, k in ((300, 40, 3000, 10), (50, 30, 2500, 7)):
+        g = torch.Generator().manual_seed(1000 + d)
+        U = bf16_exact(torch.randn(nu, d, generator=g) / d ** 0.5).numpy()
+        V = bf16_exact(torch.randn(nv, d, generator=g) / d ** 0.5).numpy()
+        S = auto_cast_lazy_score(U) @ auto_cast_lazy_score(V).T
+        with contextlib.redirect_stdout(io.StringIO()):
+            csr = _assign_topk(S, k)
+        out.update({f"U{d}": U, f"V{d}": V, f"indices{d}": csr.indices.reshape(nu, k).astype(np.int64), f"k{d}": k})
+    np.savez_compressed(f"{OUT}/g15_assign_topk_odd_width.npz", **out)
+
+
 def g_pack():
     g = torch.Generator().manual_seed(3)
     x = torch.randn(64, 768, generator=g)
@@ -457,7 +477,8 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     want = set(sys.argv[1:])
     groups = [("g1", lambda: g_ranking(_import_reference("dot"))), ("g6", g_item_tower), ("g7", g_contrastive),
-              ("g8", g_assign_topk), ("g9", g_pack), ("g10", g_requests), ("g11", g_train_data), ("g12", g_bm25), ("g13", g_item_rec), ("g14", g_sparse_prior)]
+              ("g8", g_assign_topk), ("g9", g_pack), ("g10", g_requests), ("g11", g_train_data), ("g12", g_bm25), ("g13", g_item_rec), ("g14", g_sparse_prior),
+              ("g15", g_assign_topk_odd_width)]
     for name, fn in groups:
         if not want or name in want:
             fn()
