@@ -529,8 +529,7 @@ static int index_create_impl(const uint16_t *D_bf16, int64_t n_rows, int dim, in
         if (rc != CCR_OK) return rc;
         ix->tile_norm = (float *)tn;
         uint32_t *tile_bits = reinterpret_cast<uint32_t *>(ix->tile_norm);   // non-negative floats: bit patterns order as unsigned
-        CCR_HIP_CHECK(hipMemsetAsync(ix->dmax_bits, 0, 4, s));
-        if (row_bounds) {   // no pass over the shard, no synchronisation
+        if (row_bounds) {   // no pass over the shard, no synchronisation (max_tile_norm_kernel WRITES the maximum: no memset)
             ix->row_norm = row_bounds;
             rc = launch_tile_norms(row_bounds, n_rows, tile_bits, ix->dmax_bits, s);
             if (rc != CCR_OK) return rc;
@@ -539,6 +538,7 @@ static int index_create_impl(const uint16_t *D_bf16, int64_t n_rows, int dim, in
             rc = block_take(ix->device, (size_t)n_rows * 4, &rn, &ix->row_bytes);
             if (rc != CCR_OK) return rc;
             ix->row_norm = ix->row_norm_own = (float *)rn;
+            CCR_HIP_CHECK(hipMemsetAsync(ix->dmax_bits, 0, 4, s));   // (this path max-accumulates with atomics)
             CCR_HIP_CHECK(hipMemsetAsync(tile_bits, 0, (size_t)tiles * 4, s));
             rc = launch_row_norms_bf16(D_bf16, n_rows, dim, ix->row_norm_own, ix->dmax_bits, tile_bits, s);
             if (rc != CCR_OK) return rc;
@@ -1028,7 +1028,9 @@ static int search_impl(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k, fl
     uint32_t *flag_list = (uint32_t *)(ws + p.off_flag + 64);
 
     CCR_HIP_CHECK(hipMemsetAsync(flag_count, 0, 64, s));
-    CCR_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)p.ranges * p.nq_pad * p.sublists * 4, s));  // ranges with no tiles write nothing
+    // every (range, query block) item with at least one tile writes its counters at its end (padded query columns included);
+    // only a plan with more ranges than tiles (forced fused searches of tiny corpora) leaves counters unwritten
+    if ((int64_t)p.ranges > p.tiles) CCR_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)p.ranges * p.nq_pad * p.sublists * 4, s));
     int rc = launch_row_norms_bf16(Q_bf16, n_q, ix->dim, qnorm, nullptr, nullptr, s);
     if (rc != CCR_OK) return rc;
 
