@@ -9,6 +9,105 @@ __device__ __forceinline__ bool precedes(float sa, int64_t ia, float sb, int64_t
     return (sa > sb) || (sa == sb && ia < ib);
 }
 
+// ---- merge of R sorted lists staged in LDS (s_sc / s_id: [R][k]), keeping the k best.
+// Only k of the R k staged elements end up in the result -- on average k / R per list -- so the ranks of the others are never
+// computed.  Phase 1: per list r the CUT c_r = number of its elements whose global rank is < k, by bisection on the position
+// (the rank p + sum over the other lists of the elements that precede (r, p) is monotone in p); the R (R - 1) binary searches of a
+// bisection step are spread over the workgroup's threads.  Phase 2: element (r, p < c_r) goes to rank p + sum_o #{elements of list o BEFORE ITS CUT
+// that precede it} -- an element behind its list's cut has rank >= k and precedes nothing that is kept.  Keys (score desc, id asc)
+// are distinct (ids are unique across shards, padding slots carry distinct ids), so the ranks are a permutation and sum c_r = k.
+// R = 8, 3 452 queries (tools/bench_merge.py): k = 100 66 -> 39 us, k = 1001 1 006 -> 442 us (the full rank-by-counting did
+// R k (R - 1) log k LDS probes per query; it stays for R k < 600, where the bisection's block barriers cost more than they save).
+__device__ __forceinline__ int lds_lower_bound(const float *os, const int64_t *oi, int n, float s, int64_t id) {
+    int lo = 0, hi = n;   // first position whose element does NOT precede (s, id)
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const float so = os[mid];
+        if (so > s || (so == s && oi[mid] < id))   // the id is only read on an exact score tie
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ void merge_lists_lds(const float *s_sc, const int64_t *s_id, int R, int k, int *s_cut, int *s_lohi, int *s_cnt,
+                                                int64_t out_base, float *__restrict__ out_scores, int64_t *__restrict__ out_ids) {
+    const int tid = threadIdx.x;
+    // ---- phase 1: cuts (s_lohi[2r] / [2r+1] = the bisection interval of list r, s_cnt[r] = rank accumulator of its probe).
+    // The whole workgroup takes part (uniform trip count, block barriers): the R (R - 1) searches of a step are spread over its threads.
+    for (int r = tid; r < R; r += blockDim.x) {
+        s_lohi[2 * r] = 0;
+        s_lohi[2 * r + 1] = k;
+        s_cnt[r] = 0;
+    }
+    __syncthreads();
+    int steps = 1;
+    while ((1 << steps) < k + 1) ++steps;
+    for (int it = 0; it < steps; ++it) {
+        for (int pr = tid; pr < R * R; pr += blockDim.x) {   // pair (r, o): how many elements of list o precede (r, mid_r)
+            const int r = pr / R, o = pr - r * R;
+            const int lo = s_lohi[2 * r], hi = s_lohi[2 * r + 1];
+            if (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const int c = (o == r) ? mid : lds_lower_bound(s_sc + o * k, s_id + o * k, k, s_sc[r * k + mid], s_id[r * k + mid]);
+                atomicAdd(&s_cnt[r], c);
+            }
+        }
+        __syncthreads();
+        for (int r = tid; r < R; r += blockDim.x) {
+            const int lo = s_lohi[2 * r], hi = s_lohi[2 * r + 1];
+            if (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (s_cnt[r] < k)
+                    s_lohi[2 * r] = mid + 1;
+                else
+                    s_lohi[2 * r + 1] = mid;
+            }
+            s_cnt[r] = 0;
+        }
+        __syncthreads();
+    }
+    for (int r = tid; r < R; r += blockDim.x) s_cut[r] = s_lohi[2 * r];
+    __syncthreads();
+    // ---- phase 2: the kept elements (sum of the cuts = k) find their ranks among the kept prefixes
+    for (int t = tid; t < k; t += blockDim.x) {
+        int r = 0, p = t;
+        while (r < R - 1 && p >= s_cut[r]) {
+            p -= s_cut[r];
+            ++r;
+        }
+        if (p >= s_cut[r]) continue;   // (cannot happen: the cuts add up to k)
+        const float s = s_sc[r * k + p];
+        const int64_t id = s_id[r * k + p];
+        int rank = p;
+        for (int o = 0; o < R; ++o)
+            if (o != r) rank += lds_lower_bound(s_sc + o * k, s_id + o * k, s_cut[o], s, id);
+        if (rank < k) {
+            out_scores[out_base + rank] = s;
+            out_ids[out_base + rank] = id;
+        }
+    }
+}
+
+// Few short lists (R k < 600: R = 2 or 4 at k = 100): the bisection's block barriers cost more than ranking all R k elements.
+__device__ __forceinline__ void merge_lists_lds_all(const float *s_sc, const int64_t *s_id, int R, int k, int64_t out_base,
+                                                    float *__restrict__ out_scores, int64_t *__restrict__ out_ids) {
+    const int n = R * k;
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        const int r = e / k, p = e - r * k;
+        const float s = s_sc[e];
+        const int64_t id = s_id[e];
+        int rank = p;
+        for (int o = 0; o < R && rank < k; ++o)
+            if (o != r) rank += lds_lower_bound(s_sc + o * k, s_id + o * k, k, s, id);
+        if (rank < k) {
+            out_scores[out_base + rank] = s;
+            out_ids[out_base + rank] = id;
+        }
+    }
+}
+
 // Rank-by-counting merge: element p of list r has global rank p + sum over the other lists of the
 // number of their elements that precede it (binary search; every list is already in canonical
 // order and ids are unique across shards, so the order is strict and ranks are a permutation).
@@ -61,32 +160,15 @@ __global__ __launch_bounds__(1024) void merge_topk_lds_kernel(const float *__res
         s_id[e] = ids[r * rs_ids + (int64_t)q * k + p];
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < n; e += blockDim.x) {
-        const int r = e / k, p = e - r * k;
-        const float s = s_sc[e];
-        const int64_t id = s_id[e];
-        int rank = p;
-        for (int o = 0; o < R && rank < k; ++o) {
-            if (o == r) continue;
-            const float *os = s_sc + o * k;
-            const int64_t *oi = s_id + o * k;
-            int lo = 0, hi = k;  // first position whose element does NOT precede (s, id)
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                const float so = os[mid];
-                if (so > s || (so == s && oi[mid] < id))   // the id is only read on an exact score tie
-                    lo = mid + 1;
-                else
-                    hi = mid;
-            }
-            rank += lo;
-        }
-        if (rank < k) {
-            out_scores[(int64_t)q * k + rank] = s;
-            out_ids[(int64_t)q * k + rank] = id;
-        }
-    }
+    __shared__ int s_cut[64], s_lohi[128], s_cnt[64];
+    if (R * k < 600)
+        merge_lists_lds_all(s_sc, s_id, R, k, (int64_t)q * k, out_scores, out_ids);
+    else
+        merge_lists_lds(s_sc, s_id, R, k, s_cut, s_lohi, s_cnt, (int64_t)q * k, out_scores, out_ids);
 }
+
+}  // namespace ccr
+namespace ccr {
 
 // ---- packed shard messages (include/ccr_retrieval.h: header | scores [n_q][k] fp32 | rows [n_q][k] u32 local)
 __host__ __device__ __forceinline__ size_t shard_rows_at(int n_q, int k) { return (sizeof(ccr_shard_header) + (size_t)n_q * k * 4 + 15) / 16 * 16; }
@@ -126,36 +208,31 @@ __global__ __launch_bounds__(1024) void merge_messages_lds_kernel(ShardSrc m, in
     int64_t *s_id = reinterpret_cast<int64_t *>(sm);
     float *s_sc = reinterpret_cast<float *>(sm + (size_t)n * 8);
     const int q = blockIdx.x;
-    for (int e = threadIdx.x; e < n; e += blockDim.x) {
-        const int r = e / k, p = e - r * k;
-        shard_entry(m, r, q, p, s_sc[e], s_id[e]);
+    __shared__ int s_valid[64];
+    __shared__ int64_t s_off[64];
+    for (int r = threadIdx.x; r < R; r += blockDim.x) {   // the R headers once per workgroup, not once per staged element
+        const ccr_shard_header *h = reinterpret_cast<const ccr_shard_header *>(m.base + (int64_t)r * m.stride);
+        s_valid[r] = (int)h->k_valid;
+        s_off[r] = h->row_offset;
     }
     __syncthreads();
     for (int e = threadIdx.x; e < n; e += blockDim.x) {
         const int r = e / k, p = e - r * k;
-        const float s = s_sc[e];
-        const int64_t id = s_id[e];
-        int rank = p;
-        for (int o = 0; o < R && rank < k; ++o) {
-            if (o == r) continue;
-            const float *os = s_sc + o * k;
-            const int64_t *oi = s_id + o * k;
-            int lo = 0, hi = k;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                const float so = os[mid];
-                if (so > s || (so == s && oi[mid] < id))
-                    lo = mid + 1;
-                else
-                    hi = mid;
-            }
-            rank += lo;
-        }
-        if (rank < k) {
-            out_scores[(int64_t)q * k + rank] = s;
-            out_ids[(int64_t)q * k + rank] = id;
+        const char *msg = m.base + (int64_t)r * m.stride;
+        if (p < s_valid[r]) {
+            s_sc[e] = reinterpret_cast<const float *>(msg + sizeof(ccr_shard_header))[(int64_t)q * k + p];
+            s_id[e] = s_off[r] + (int64_t) reinterpret_cast<const uint32_t *>(msg + m.rows_at)[(int64_t)q * k + p];
+        } else {   // padding slot: ranks last, distinct id
+            s_sc[e] = -INFINITY;
+            s_id[e] = INT64_MAX - ((int64_t)r * k + p);
         }
     }
+    __syncthreads();
+    __shared__ int s_cut[64], s_lohi[128], s_cnt[64];
+    if (R * k < 600)
+        merge_lists_lds_all(s_sc, s_id, R, k, (int64_t)q * k, out_scores, out_ids);
+    else
+        merge_lists_lds(s_sc, s_id, R, k, s_cut, s_lohi, s_cnt, (int64_t)q * k, out_scores, out_ids);
 }
 
 // lists too long for the LDS: every probe decodes its entry from the messages.  grid = (ceil(R*k/256), n_q)
@@ -267,7 +344,7 @@ extern "C" int ccr_merge_topk_strided(const float *scores, const int64_t *ids, i
                 (long long)id_rank_stride);
     if (n_q == 0) return CCR_OK;
     const size_t lds = (size_t)R * k * 12;
-    if (lds <= 96 * 1024) {
+    if (lds <= 96 * 1024 && R <= 64) {   // (the LDS merge keeps one cut per list in a 64-entry table)
         if (lds > 48 * 1024)
             CCR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&merge_topk_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int threads = R * k >= 2048 ? 1024 : 256;

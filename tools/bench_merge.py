@@ -24,3 +24,26 @@ for R,k in ((2,100),(4,100),(8,100),(8,1001),(16,1001)):
     torch.cuda.synchronize(); t=time.perf_counter()
     for _ in range(30): ops.merge_topk(s,i)
     torch.cuda.synchronize(); print("R",R,"k",k,"merge", round((time.perf_counter()-t)/30*1e6,1),"us")
+
+# ---- the packed shard messages of the multi-GPU exchange (ccr_merge_shard_messages)
+from ccrec_amd.dist import ShardMessage
+for R, k, nq in ((8, 100, 3452), (8, 100, 6980), (8, 1001, 3452), (4, 100, 3452), (2, 100, 3452)):
+    ranks = torch.rand(nq, R * k, device="cuda").argsort(dim=1).float()
+    s = ranks.view(nq, R, k).permute(1, 0, 2).contiguous().sort(dim=2, descending=True).values
+    rows = torch.randint(0, 335184, (R, nq, k), device="cuda")
+    g = ShardMessage(nq, k, "cuda", R)
+    for r in range(R):
+        m = ShardMessage(nq, k, "cuda", 1)
+        m.fill(s[r], rows[r] + r * 335184, r * 335184, 335184)
+        g.recv.view(R, -1)[r].copy_(m.send)
+    a, b = g.merge()
+    os_, oi = orc.merge_topk(s[:, :40].cpu().numpy(), (rows + torch.arange(R, device="cuda").view(R, 1, 1) * 335184)[:, :40].cpu().numpy())
+    assert np.array_equal(a[:40].cpu().numpy(), os_) and np.array_equal(b[:40].cpu().numpy(), oi)
+    for _ in range(3):
+        g.merge()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(50):
+        g.merge()
+    torch.cuda.synchronize()
+    print("messages R", R, "k", k, "n_q", nq, "merge", round((time.perf_counter() - t) / 50 * 1e6, 1), "us")
