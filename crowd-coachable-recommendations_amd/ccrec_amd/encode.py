@@ -162,13 +162,19 @@ class LengthSortedEncoder:
     """
 
     def __init__(self, tower, tokenizer, max_length=None, max_tokens=65536, max_batch=512, pad_multiple=8, chunk_texts=65536,
-                 host_threads=4, host_processes=0):
+                 host_threads=4, host_processes=0, output_step="mean_pooling"):
         self.tower, self.tokenizer = tower, tokenizer
         self.max_length = int(max_length if max_length is not None else os.environ.get("CCREC_MAX_LENGTH", 200))
         self.max_tokens, self.max_batch, self.pad_multiple = int(max_tokens), int(max_batch), int(pad_multiple)
         self.chunk_texts = max(1, int(chunk_texts))
         self.host_threads = max(1, int(host_threads))
         self.pad_id = int(getattr(tokenizer, "pad_token_id", 0) or 0)
+        # the tower's output steps (src/ccrec/models/item_tower.py:133-147): masked mean pooling (fused pool + pack), the CLS row
+        # (cls | mu | mean) or LayerNorm(CLS) (mean_layer_norm, the reference's CCREC_EMBEDDING_TYPE default); "embedding" reads the env
+        if output_step == "embedding":
+            output_step = os.environ["CCREC_EMBEDDING_TYPE"]
+        assert output_step in ("mean_pooling", "cls", "mu", "mean", "mean_layer_norm"), output_step
+        self.output_step = output_step
         self._backend = _rust_backend(tokenizer, self.max_length)
         # host_processes > 0 (HF fast tokenizers only): the chunks are tokenised in that many worker processes, so the Python-list
         # building of the tokenizer's results no longer competes for the GIL with the thread that launches the GPU kernels
@@ -260,7 +266,15 @@ class LengthSortedEncoder:
                     if out is None:
                         out = torch.empty(n + row_offset, hidden.shape[-1], dtype=torch.bfloat16, device=hidden.device)
                     rows = torch.as_tensor(np.asarray(idx, dtype=np.int64) + int(row_offset) + c0)
-                    ops.meanpool_pack(hidden, inputs["attention_mask"], normalize=(sim == "cos"), want_f32=False, out_bf16=out,
+                    mask = inputs["attention_mask"]
+                    if self.output_step != "mean_pooling":
+                        # CLS-type outputs through the same scatter + pack kernel: a one-token "sequence" [B, 1, dim] with a mask
+                        # of ones pools to the row itself (sum of one element / 1)
+                        first = hidden[:, 0]
+                        if self.output_step == "mean_layer_norm":
+                            first = tower.standard_layer_norm(first)
+                        hidden, mask = first.unsqueeze(1).contiguous(), mask[:, :1]
+                    ops.meanpool_pack(hidden, mask, normalize=(sim == "cos"), want_f32=False, out_bf16=out,
                                       out_f32=out_f32, dst_rows=rows, norm_bounds=norm_bounds)
                 e1.record()
                 spans.append((e0, e1))

@@ -132,6 +132,29 @@ def test_chunked_pipeline_equals_one_chunk():
     assert many.encode([], sim="dot").shape[0] == 0 and many.stats["chunks"] == 0
 
 
+@pytest.mark.parametrize("step", ["cls", "mean_layer_norm"])
+def test_cls_output_steps_through_the_length_sorted_encoder(step):
+    """The tower's other output steps (item_tower.py:133-136: h[:, 0] and LayerNorm(h[:, 0]), the reference's default
+    CCREC_EMBEDDING_TYPE) through the length-sorted encoder: packed rows == pack(the tower's own output at fixed padding) up to
+    the encoder's fp32 noise at a different padded length."""
+    from ccrec_amd import ops
+    from ccrec_amd.encode import LengthSortedEncoder
+    tower, tok = _tower(), ToyTokenizer()
+    texts = _texts(257, 7)
+    enc = LengthSortedEncoder(tower, tok, max_length=32, max_tokens=1024, max_batch=64, output_step=step)
+    out32 = torch.zeros(len(texts), 64, dtype=torch.float32, device="cuda")
+    got = enc.encode(texts, sim="dot", out_f32=out32)
+    ref = []
+    with torch.no_grad():
+        for lo in range(0, len(texts), 50):
+            toks = tok(texts[lo:lo + 50], padding="max_length", max_length=32)
+            ref.append(tower(**{k: v.cuda() for k, v in toks.items()}, output_step=step))
+    ref = torch.cat(ref)
+    torch.testing.assert_close(out32, ref.float(), rtol=1e-4, atol=1e-5)
+    diff = (got.view(torch.int16).int() - ops.pack_bf16(ref.float()).view(torch.int16).int()).abs()
+    assert int(diff.max()) <= 1 and float((diff != 0).float().mean()) < 0.02
+
+
 def test_tokenizer_worker_processes_give_the_same_rows():
     """host_processes > 0: a HF fast tokenizer's chunks are tokenised in worker processes (ccrec_amd/_tokenize_worker.py, no torch
     import) -- same token ids as the in-process Rust backend and the HF call, hence the same packed rows."""
