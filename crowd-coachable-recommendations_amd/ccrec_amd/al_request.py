@@ -63,11 +63,14 @@ def build_requests(ranking_profile, ranking_profile_bm25, step_qids, corpus, que
     columns = BASE_COLUMNS + (IMAGE_COLUMNS if landing_image is not None else [])
     rows, id_track = [], {}
     top = getattr(ranking_profile, "top", None)   # a lazy RankingProfile names a query's best passages without building its dict
+    bm25_top = getattr(ranking_profile_bm25, "top", None)
     for qid in ranking_profile:                   # (only the step's queries are read)
         if qid not in step_qids:
             continue
         dense_order = top(qid, 2) if top is not None else list(ranking_profile[qid].keys())   # the rule reads ranks[0:2] only
-        cands = pick_candidates(dense_order, list(ranking_profile_bm25[qid].keys()), corpus_keys, draw)
+        # (and the first BM25 passage that is not one of those two: it is among the first three)
+        bm25_order = bm25_top(qid, 3) if bm25_top is not None else list(ranking_profile_bm25[qid].keys())
+        cands = pick_candidates(dense_order, bm25_order, corpus_keys, draw)
         shown = [filter_string(corpus[pid], display_length) for pid in cands]
         row = [queries[qid], *shown, f"q_{qid}", *(f"p_{pid}" for pid in cands)]
         if landing_image is not None:

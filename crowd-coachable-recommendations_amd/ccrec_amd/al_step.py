@@ -59,7 +59,7 @@ def run_rank_step(tower, tokenizer, corpus, queries, qrels, step_qids, step, res
         print(name, ":", value)
     if ranking_profile_bm25 is None:
         t0 = time.perf_counter()
-        ranking_profile_bm25 = ranking_bm25(corpus, queries)
+        ranking_profile_bm25 = ranking_bm25(corpus, queries, lazy=True)
         timings["bm25_s"] = time.perf_counter() - t0
     t0 = time.perf_counter()
     requests = build_requests(profile, ranking_profile_bm25, step_qids, corpus, queries, step, n_repeats=n_repeats,

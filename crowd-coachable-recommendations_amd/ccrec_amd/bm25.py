@@ -106,18 +106,24 @@ class BM25:
         return out
 
 
-def ranking_bm25(corpus, queries, b=0.75, k1=1.2, keep=KEEP, batch=4096):
-    """scripts/ms_marco_eval.py:165-186: {qid: {pid: score}} in rank order, min(1001, N) entries per query."""
+def ranking_bm25(corpus, queries, b=0.75, k1=1.2, keep=KEEP, batch=4096, lazy=False):
+    """scripts/ms_marco_eval.py:165-186: {qid: {pid: score}} in rank order, min(1001, N) entries per query.
+    lazy=True: the same mapping backed by the result tensors (ranking_profile.RankingProfile) -- the request builder reads the first
+    three passages of a few hundred queries, not 1001 x Q Python pairs."""
+    from .ranking_profile import RankingProfile
     print("Fitting BM-25 model")
     model = BM25(b=b, k1=k1).fit(list(corpus.values()))
     print("Retrieval with BM-25 model")
     queries_ids, corpus_ids = list(queries.keys()), list(corpus.keys())
-    profile = {}
+    rows, scores = [], []
     for lo in range(0, len(queries_ids), batch):
         qids = queries_ids[lo:lo + batch]
         print("processing query: {} | {}".format(lo, len(queries_ids)))
         s, i = model.transform_topk([queries[q] for q in qids], keep)
-        s, i = s.cpu().tolist(), i.cpu().tolist()
-        for qid, row_i, row_s in zip(qids, i, s):
-            profile[qid] = dict(zip([corpus_ids[j] for j in row_i], row_s))
-    return profile
+        rows.append(i.cpu())
+        scores.append(s.cpu())
+    k = min(int(keep), model.n_docs)
+    rows = torch.cat(rows) if rows else torch.zeros(0, k, dtype=torch.int64)
+    scores = torch.cat(scores) if scores else torch.zeros(0, k, dtype=torch.float32)
+    profile = RankingProfile(queries_ids, corpus_ids, rows, scores)
+    return profile if lazy else profile.to_dict()

@@ -65,6 +65,8 @@ def test_hip_bm25_bit_exact_vs_oracle_and_profile(golden_dir):
     for qid in g["queries"]:
         np.testing.assert_allclose(list(prof[qid].values()), list(g["profile"][qid].values()), rtol=2e-7)
         assert len(prof[qid]) == len(g["profile"][qid])
+    lazy = ranking_bm25(g["corpus"], g["queries"], lazy=True)       # the tensor-backed form: the same mapping
+    assert lazy == prof and list(lazy) == list(prof) and lazy.top(qid, 3) == list(prof[qid])[:3]
 
 
 @pytest.mark.gpu
