@@ -32,28 +32,42 @@ class BM25:
         self.b, self.k1 = float(b), float(k1)
         self._h = None
 
-    def fit(self, X):
-        """X: iterable of document strings."""
+    def fit(self, X, processes=None, chunk_docs=50_000):
+        """X: iterable of document strings.  processes: text-analysis worker processes (ccrec_amd/_bm25_worker.py; None: 8 from
+        200 000 documents up, else in this interpreter; 0: never).  The analysis is pure-Python work -- 37 s per million 135-word
+        passages in one interpreter -- and embarrassingly parallel over documents; the workers return per-chunk vocabularies and
+        (document, term, count) runs, merged here into the same vocabulary / postings / idf / length factors."""
         self._lib = require_gpu()
-        docs = [analyse(t) for t in X]
-        self.vocabulary_ = {w: i for i, w in enumerate(sorted({w for d in docs for w in d}))}
-        n, V = len(docs), len(self.vocabulary_)
+        X = X if isinstance(X, list) else list(X)
+        n = len(X)
+        if processes is None:
+            processes = 8 if n >= 200_000 else 0
+        parts = self._analyse_parallel(X, int(processes), int(chunk_docs)) if processes > 0 and n > chunk_docs else [self._analyse(X)]
+        vocab = sorted(set().union(*(p[0] for p in parts)))
+        self.vocabulary_ = {w: i for i, w in enumerate(vocab)}
+        V = len(vocab)
         assert n >= 1 and V >= 1, "empty corpus or empty vocabulary"
         voc = self.vocabulary_
-        flat = np.fromiter((voc[w] for d in docs for w in d), dtype=np.int64)
-        owner = np.repeat(np.arange(n, dtype=np.int64), [len(d) for d in docs])
-        # (term, doc) pairs with counts: sort by term then doc, run-length encode
-        key = flat * n + owner
-        key.sort()
-        uniq, counts = np.unique(key, return_counts=True)
-        terms, rows = uniq // n, uniq % n
-        indptr = np.zeros(V + 1, np.int64)
-        np.add.at(indptr, terms + 1, 1)
-        self.indptr = np.cumsum(indptr)
-        length = np.bincount(owner, minlength=n).astype(np.float64)
-        self.avdl = float(length.mean())
+        # chunk CSRs (documents x chunk vocabulary) -> one CSR over the global vocabulary -> CSC = term-major postings, documents
+        # ascending inside a term (scipy's conversion is O(nnz) C code: no 270-M-element sort of (term, document) keys at the NQ size)
+        import scipy.sparse as sps
+        lengths = np.concatenate([p[1] for p in parts]).astype(np.float64)
+        indptr_parts, terms_parts, counts_parts, base = [np.zeros(1, np.int64)], [], [], 0
+        for pv, _, pin, pterms, pcounts in parts:
+            remap = np.fromiter((voc[w] for w in pv), dtype=np.int64, count=len(pv))
+            terms_parts.append(remap[pterms] if len(pv) else pterms.astype(np.int64))
+            counts_parts.append(pcounts)
+            indptr_parts.append(pin[1:] + base)
+            base += int(pin[-1])
+        csr = sps.csr_matrix((np.concatenate(counts_parts).astype(np.float32), np.concatenate(terms_parts), np.concatenate(indptr_parts)),
+                             shape=(n, V))
+        csc = csr.tocsc()
+        csc.sort_indices()
+        self.indptr = csc.indptr.astype(np.int64)
+        rows, counts = csc.indices, csc.data
+        self.avdl = float(lengths.mean())
         self.idf = np.log(n / np.diff(self.indptr).astype(np.float64))          # idf_ - 1 with smooth_idf=False
-        doc_k = self.k1 * (1 - self.b + self.b * length / self.avdl)
+        doc_k = self.k1 * (1 - self.b + self.b * lengths / self.avdl)
         self.n_docs = n
         self._doc_ids = torch.from_numpy(rows.astype(np.int32)).cuda()
         self._tf = torch.from_numpy(counts.astype(np.float32)).cuda()
@@ -63,6 +77,61 @@ class BM25:
                                                    self._tf.data_ptr(), self._doc_k.data_ptr(), V, n, self.k1,
                                                    ctypes.byref(self._h)), "ccr_bm25_index_create")
         return self
+
+    @staticmethod
+    def _analyse(texts):
+        from ._bm25_worker import analyse_chunk
+        return analyse_chunk(texts)
+
+    @staticmethod
+    def _analyse_parallel(X, processes, chunk_docs):
+        """Chunks of documents through worker processes (children over pipes: pickled texts out, pickled arrays back); a thread per
+        worker keeps its pipe busy, the pipe I/O releases the GIL."""
+        import os
+        import pickle
+        import subprocess
+        import sys
+        from concurrent.futures import ThreadPoolExecutor
+        here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_bm25_worker.py")
+        chunks = [(lo, min(len(X), lo + chunk_docs)) for lo in range(0, len(X), chunk_docs)]
+        processes = max(1, min(processes, len(chunks)))
+        procs = [subprocess.Popen([sys.executable, "-u", here], stdin=subprocess.PIPE, stdout=subprocess.PIPE) for _ in range(processes)]
+        out = [None] * len(chunks)
+
+        def drive(w):
+            p = procs[w]
+            for ci in range(w, len(chunks), processes):
+                lo, hi = chunks[ci]
+                blob = pickle.dumps(X[lo:hi], protocol=pickle.HIGHEST_PROTOCOL)
+                p.stdin.write(len(blob).to_bytes(8, "little"))
+                p.stdin.write(blob)
+                p.stdin.flush()
+                head = p.stdout.read(8)
+                if len(head) != 8:
+                    raise RuntimeError("BM25 analysis worker ended unexpectedly")
+                size = int.from_bytes(head, "little")
+                data = p.stdout.read(size)
+                if len(data) != size:
+                    raise RuntimeError("BM25 analysis worker ended unexpectedly")
+                out[ci] = pickle.loads(data)
+
+        try:
+            with ThreadPoolExecutor(max_workers=processes) as pool:
+                list(pool.map(drive, range(processes)))
+        finally:
+            for p in procs:
+                try:
+                    p.stdin.write((0).to_bytes(8, "little"))
+                    p.stdin.flush()
+                    p.stdin.close()
+                except Exception:
+                    pass
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except Exception:
+                    p.kill()
+        return out
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None

@@ -86,3 +86,24 @@ def test_hip_bm25_larger_corpus_many_batches():
     ref_i, ref_s = orc.bm25_ranking(model, [qtexts[j] for j in sub], 100)
     assert np.array_equal(i.cpu().numpy()[sub], ref_i)
     assert np.array_equal(s.cpu().numpy()[sub].view(np.uint32), ref_s.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_parallel_analysis_builds_the_same_index():
+    """BM25.fit(processes=n): the text analysis in worker processes (chunk vocabularies + per-document runs merged through one
+    CSR -> CSC conversion) gives the same vocabulary, postings, idf, length factors and scores as the single-interpreter fit."""
+    from ccrec_amd.bm25 import BM25
+    rs = np.random.RandomState(9)
+    words = np.array([f"t{i}" for i in range(2000)] + ["a", "über", "x2"])
+    texts = [" ".join(rs.choice(words, rs.randint(0, 50))) + (" Don't STOP-me, now!" if j % 5 == 0 else "") for j in range(9000)]
+    qtexts = [" ".join(rs.choice(words, rs.randint(1, 10))) for _ in range(200)]
+    a = BM25(0.75, 1.2).fit(texts, processes=0)
+    b = BM25(0.75, 1.2).fit(texts, processes=3, chunk_docs=1000)
+    assert a.vocabulary_ == b.vocabulary_ and np.array_equal(a.indptr, b.indptr) and a.avdl == b.avdl
+    assert torch.equal(a._doc_ids, b._doc_ids) and torch.equal(a._tf, b._tf) and torch.equal(a._doc_k, b._doc_k)
+    sa, ia = a.transform_topk(qtexts, 100)
+    sb, ib = b.transform_topk(qtexts, 100)
+    assert torch.equal(ia, ib) and torch.equal(sa.view(torch.int32), sb.view(torch.int32))
+    model = orc.bm25_fit(texts, 0.75, 1.2)
+    ref_i, ref_s = orc.bm25_ranking(model, qtexts[:40], 100)
+    assert np.array_equal(ib.cpu().numpy()[:40], ref_i) and np.array_equal(sb.cpu().numpy()[:40].view(np.uint32), ref_s.view(np.uint32))

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--queries", type=int, default=3_452)
     ap.add_argument("--step-queries", type=int, default=300)
     ap.add_argument("--layers", type=int, default=12)
+    ap.add_argument("--bm25", action="store_true", help="compute the BM25 leg inside the step (ranking_bm25 beside the encode) instead of passing it in")
     args = ap.parse_args()
     from transformers import BertConfig, BertModel
     from bench_encode import fast_tokenizer
@@ -57,14 +58,15 @@ def main():
     out_dir = tempfile.mkdtemp()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    res = run_rank_step(tower, tok, corpus, queries, qrels, step_qids, 0, out_dir, ranking_profile_bm25=bm25, encoder_kw=kw)
+    res = run_rank_step(tower, tok, corpus, queries, qrels, step_qids, 0, out_dir, ranking_profile_bm25=None if args.bm25 else bm25,
+                        encoder_kw=kw)
     wall = time.perf_counter() - t0
     tm = res["timings"]
     enc = tm.pop("corpus_encoder")
     line = {"passages": args.passages, "queries": args.queries, "keep": 1001, "step_queries": len(step_qids), "wall_s": round(wall, 2),
             "timings_s": {k: round(v, 3) for k, v in tm.items()},
             "corpus_encode": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in enc.items()},
-            "passages_per_s_end_to_end": round(args.passages / wall, 1), "text_generation_s": round(gen_s, 1),
+            "bm25_inside_the_step": bool(args.bm25), "passages_per_s_end_to_end": round(args.passages / wall, 1), "text_generation_s": round(gen_s, 1),
             "files": sorted(os.listdir(os.path.join(out_dir, "data_iteration_0")))}
     print(json.dumps(line))
 
