@@ -19,9 +19,11 @@ from .encode import LengthSortedEncoder, ranking_sharded
 
 def run_rank_step(tower, tokenizer, corpus, queries, qrels, step_qids, step, results_dir, ranking_profile_bm25=None,
                   block_dict=None, landing_image=None, n_repeats=3, repeat_seed=42, encoder_kw=None, autocast=True,
-                  compat_profile=False):
+                  compat_profile=False, rank=0, world=1, group=None):
     """-> {"ranking_profile", "mrr", "requests", "timings"}; files are written to results_dir/data_iteration_{step}/.
-    timings: wall seconds of the stages (rank = encode + search; mrr; bm25; requests; save) and the corpus encoder's own statistics."""
+    timings: wall seconds of the stages (rank = encode + search; mrr; bm25; requests; save) and the corpus encoder's own statistics.
+    rank / world / group: one process per GPU (torch.distributed initialised by the caller): every rank encodes and indexes its own
+    block of the corpus, all ranks hold the same merged profile afterwards; only rank 0 writes the files (the others return them)."""
     import time
     t_start = time.perf_counter()
     timings = {}
@@ -50,7 +52,8 @@ def run_rank_step(tower, tokenizer, corpus, queries, qrels, step_qids, step, res
         encoder = LengthSortedEncoder(tower, tokenizer, **({"host_processes": 4} if encoder_kw is None else encoder_kw))
         t0 = time.perf_counter()
         with torch.autocast("cuda", enabled=bool(autocast)):
-            profile, ids, _ = ranking_sharded(corpus, queries, encoder, block_dict=block_dict, with_tensors=True, lazy=True)
+            profile, ids, _ = ranking_sharded(corpus, queries, encoder, block_dict=block_dict, with_tensors=True, lazy=True,
+                                              rank=rank, world=world, group=group)
         torch.cuda.synchronize()
         timings["rank_s"] = time.perf_counter() - t0
         timings["corpus_encoder"] = dict(encoder.stats)      # (the corpus is encoded last: its statistics are the ones left)
@@ -73,9 +76,9 @@ def run_rank_step(tower, tokenizer, corpus, queries, qrels, step_qids, step, res
         timings["bm25_since_start_s"] = time.perf_counter() - t_bm25
     t0 = time.perf_counter()
     requests = build_requests(profile, ranking_profile_bm25, step_qids, corpus, queries, step, n_repeats=n_repeats,
-                              repeat_seed=repeat_seed, landing_image=landing_image, out_dir=work)
+                              repeat_seed=repeat_seed, landing_image=landing_image, out_dir=work if rank == 0 else None)
     timings["requests_s"] = time.perf_counter() - t0
-    if fresh:   # the tensor form (loads under torch.load's weights_only default); save(path, compat=True) writes the nested dict
+    if fresh and rank == 0:   # the tensor form (loads under torch.load's weights_only default); save(path, compat=True) writes the nested dict
         t0 = time.perf_counter()
         profile.save(path, compat=compat_profile)
         timings["save_s"] = time.perf_counter() - t0

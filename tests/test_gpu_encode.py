@@ -225,6 +225,16 @@ def _rank_worker(rank, world, port, out_dir):
     enc = LengthSortedEncoder(tower, tok, max_length=32, max_tokens=4096)
     prof = ranking_sharded(corpus, queries, enc, rank=rank, world=world, keep=40)
     torch.save(prof, os.path.join(out_dir, f"prof{rank}.pt"))
+    # the whole rank step in the same two-process layout: every rank returns the same requests, rank 0 alone writes the files
+    from ccrec_amd.al_step import run_rank_step
+    os.environ["CCREC_DISPLAY_LENGTH"] = "40"
+    big = {f"p{j}": t for j, t in enumerate(_texts(1300, 6))}
+    qrels = {q: {"p3": 1} for q in queries}
+    bm25 = {q: {"p5": 2.0, "p6": 1.0, "p7": 0.5} for q in queries}
+    res = run_rank_step(tower, tok, big, queries, qrels, list(queries)[:3], 0, os.path.join(out_dir, "step"), ranking_profile_bm25=bm25,
+                        encoder_kw={"max_length": 32, "max_tokens": 4096}, autocast=False, rank=rank, world=world)
+    res["requests"]["request_orig"].to_csv(os.path.join(out_dir, f"orig{rank}.csv"), index=False)
+    torch.save(dict(res["mrr"]), os.path.join(out_dir, f"mrr{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -238,6 +248,9 @@ def test_ranking_sharded_two_ranks_equal_one(tmp_path):
     mp.spawn(_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     p0, p1 = torch.load(tmp_path / "prof0.pt"), torch.load(tmp_path / "prof1.pt")
     assert p0 == p1                                            # every rank holds the same merged result
+    assert open(tmp_path / "orig0.csv").read() == open(tmp_path / "orig1.csv").read() == open(tmp_path / "step" / "data_iteration_0" / "request_orig.csv").read()
+    assert torch.load(tmp_path / "mrr0.pt") == torch.load(tmp_path / "mrr1.pt")
+    assert sorted(os.listdir(tmp_path / "step" / "data_iteration_0")) == ["id_track.pt", "ranking_profile.pt", "request_orig.csv", "request_perm.csv"]
     os.environ["CCREC_SIM_TYPE"] = "dot"
     tower, tok = _tower(), ToyTokenizer()
     corpus = {f"p{j}": t for j, t in enumerate(_texts(901, 4))}
