@@ -132,3 +132,40 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus(tmp_path):
     run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1"], capture_output=True, text=True,
                          timeout=120, env=env)
     assert run.returncode == 2 and "WORLD_SIZE=2" in run.stderr and "{" not in run.stdout
+
+
+def _flagged_rank_worker(rank, world, port, out_dir):
+    """Real kernels, two processes on this GPU over gloo: rank 1's shard holds 9 000 identical rows and the queries equal that row,
+    so ITS asynchronous search flags every query (mass ties beyond the re-score cap) while rank 0 flags none; the headers tell both
+    ranks, both repeat the all-gather after finish(), and the merged lists equal the single-index search."""
+    import torch.distributed as dist
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "crowd-coachable-recommendations_amd")]
+    from ccrec_amd import ops
+    from ccrec_amd.dist import shard_bounds, submit_sharded_search
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    n, d, k, nq = 140_000, 128, 64, 40
+    Db = _rand_bits(n, d, 71)
+    Db[n - 9000:] = Db[n - 1]                       # the tail (rank 1's shard) is one row 9 000 times
+    Qb = np.tile(Db[n - 1], (nq, 1))
+    lo, hi = shard_bounds(n, world, rank)
+    index = ops.CorpusIndex(_bf16(Db[lo:hi]), global_row_offset=lo)
+    ex = submit_sharded_search(index, _bf16(Qb), k)
+    s, i = ex.result()
+    flagged = [h["n_flagged"] for h in ex.headers]
+    whole = ops.CorpusIndex(_bf16(Db))
+    s1, i1 = whole.search(_bf16(Qb), k)
+    ok = torch.equal(i, i1) and torch.equal(s.view(torch.int32), s1.view(torch.int32))
+    ok = ok and ex.repeated and flagged[0] == 0 and flagged[1] == nq and index.last_stats()["n_fallback"] == (nq if rank == 1 else 0)
+    open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if ok else f"MISMATCH {flagged} {ex.repeated}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_rank_flags_every_query_and_all_ranks_repeat_the_exchange(tmp_path):
+    import torch.multiprocessing as mp
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    mp.spawn(_flagged_rank_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert open(tmp_path / f"rank{r}.txt").read() == "ok"
