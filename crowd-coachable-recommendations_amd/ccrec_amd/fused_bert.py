@@ -1,0 +1,111 @@
+"""The item tower's encoder forward, layer by layer on this library's kernels (encoder-side fusion).
+
+The reference encodes with transformers' BertModel under autocast (src/ccrec/models/item_tower.py:122
+`cls_model(**inputs).last_hidden_state`; scripts/al_0_rank.py:92-101,125).  Run as torch modules on one MI355X that forward
+spends 38 % of its GPU time in the projections (hipBLASLt, already at library speed), 22 % in the attention call (57 TFLOP/s at
+these sequence lengths) and 30 % in separate residual-add / LayerNorm / dtype-cast passes (profiles/r03_encode_kernel_stats.csv).
+FusedBertEncoder keeps the projections as library GEMMs (torch.nn.functional.linear on bf16 weights: one stacked Q|K|V
+projection instead of three) and replaces the rest with ccr_attention_bf16 and ccr_add_layernorm (csrc/ccr_encoder.hip).
+
+Arithmetic: what autocast(bf16) does in the reference's layer -- bf16 projection operands and outputs, fp32 attention scores and
+softmax, fp32 residual stream and LayerNorm -- so the hidden states agree with the module forward to bf16 rounding (the
+tests compare both with the fp32 forward).  Inference only (eval mode, no dropout, no autograd).
+
+Only what the kernels cover is accepted (unsupported_reason): a BertModel encoder (post-LayerNorm layers, absolute positions,
+exact GELU), head width 64, hidden size a multiple of 256, at most 512 tokens, right-padded batches.  Every other encoder keeps
+running as its own torch module -- LengthSortedEncoder picks per model."""
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+
+def unsupported_reason(model):
+    """None when FusedBertEncoder can run `model` (a transformers BertModel); otherwise why not."""
+    if type(model).__name__ != "BertModel":
+        return f"{type(model).__name__} is not a BertModel"
+    cfg = model.config
+    heads, hidden = int(cfg.num_attention_heads), int(cfg.hidden_size)
+    if hidden % heads or hidden // heads != 64:
+        return f"head width {hidden / heads:g} (the attention kernel is built for 64)"
+    if hidden % 256 or hidden > 2048:
+        return f"hidden size {hidden} (the LayerNorm kernel takes multiples of 256 up to 2048)"
+    if getattr(cfg, "hidden_act", "gelu") != "gelu":
+        return f"activation {cfg.hidden_act!r} (exact GELU only)"
+    if getattr(cfg, "position_embedding_type", None) not in (None, "absolute"):
+        return f"position_embedding_type {cfg.position_embedding_type!r}"
+    if getattr(cfg, "is_decoder", False) or getattr(cfg, "add_cross_attention", False):
+        return "decoder / cross-attention layers"
+    if not hasattr(model, "embeddings") or not hasattr(model, "encoder"):
+        return "no embeddings / encoder modules"
+    return None
+
+
+class _Layer:
+    __slots__ = ("wqkv", "bqkv", "wo", "bo", "g1", "b1", "eps1", "wi", "bi", "wo2", "bo2", "g2", "b2", "eps2")
+
+
+class FusedBertEncoder:
+    """bf16 forward of a transformers BertModel: forward(input_ids [B, L] right-padded, lengths [B]) -> last hidden state
+    fp32 [B, L, hidden].  Holds bf16 copies of the projection weights (rebuilt when the model's parameters change: fine-tuning
+    between two ranking steps, load_state_dict, .to(device))."""
+
+    def __init__(self, model):
+        reason = unsupported_reason(model)
+        if reason is not None:
+            raise ValueError(f"FusedBertEncoder: {reason}")
+        self.model = model
+        self.heads = int(model.config.num_attention_heads)
+        self.hidden = int(model.config.hidden_size)
+        self._layers, self._signature = None, None
+
+    def _params_signature(self):
+        return tuple((p.data_ptr(), p._version, p.device) for p in self.model.encoder.parameters())
+
+    def refresh(self):
+        """(Re)build the bf16 weight copies if the module's parameters changed since the last call."""
+        sig = self._params_signature()
+        if sig == self._signature:
+            return False
+        bf = torch.bfloat16
+        layers = []
+        with torch.no_grad():
+            for mod in self.model.encoder.layer:
+                att, so, ff, out = mod.attention.self, mod.attention.output, mod.intermediate, mod.output
+                l = _Layer()
+                l.wqkv = torch.cat([att.query.weight, att.key.weight, att.value.weight]).to(bf).contiguous()
+                l.bqkv = torch.cat([att.query.bias, att.key.bias, att.value.bias]).to(bf).contiguous()
+                l.wo, l.bo = so.dense.weight.to(bf).contiguous(), so.dense.bias.to(bf).contiguous()
+                l.g1, l.b1, l.eps1 = so.LayerNorm.weight.float().contiguous(), so.LayerNorm.bias.float().contiguous(), so.LayerNorm.eps
+                l.wi, l.bi = ff.dense.weight.to(bf).contiguous(), ff.dense.bias.to(bf).contiguous()
+                l.wo2, l.bo2 = out.dense.weight.to(bf).contiguous(), out.dense.bias.to(bf).contiguous()
+                l.g2, l.b2, l.eps2 = out.LayerNorm.weight.float().contiguous(), out.LayerNorm.bias.float().contiguous(), out.LayerNorm.eps
+                layers.append(l)
+        self._layers, self._signature = layers, sig
+        return True
+
+    @torch.no_grad()
+    def forward(self, input_ids, lengths, token_type_ids=None):
+        """input_ids [B, L] int64 (cuda, right-padded), lengths [B] int32 (cuda): real tokens per row, 1 .. L.
+        -> fp32 [B, L, hidden]; rows of padding tokens hold finite values nobody reads (the pooling masks them)."""
+        ops.require_gpu()
+        model = self.model
+        assert not model.training, "FusedBertEncoder is an inference forward: call model.eval() first"
+        assert input_ids.is_cuda and input_ids.dim() == 2
+        B, L = input_ids.shape
+        assert L <= 512 and lengths.dtype == torch.int32 and lengths.is_cuda and lengths.numel() == B
+        if self._layers is None:
+            self.refresh()
+        with torch.autocast("cuda", enabled=False):
+            emb = model.embeddings(input_ids=input_ids, token_type_ids=token_type_ids)     # word + position + type, LayerNorm: fp32
+            h = emb.reshape(B * L, self.hidden).float().contiguous()
+            hb = h.to(torch.bfloat16)
+            seq_start = torch.arange(B, dtype=torch.int32, device=input_ids.device) * L
+            last = len(self._layers) - 1
+            for i, l in enumerate(self._layers):
+                qkv = F.linear(hb, l.wqkv, l.bqkv)
+                ctx = ops.attention(qkv, seq_start, lengths, self.heads, max_len=L, pad_len=L, scale=0.125)
+                h, hb = ops.add_layernorm(F.linear(ctx, l.wo, l.bo), h, l.g1, l.b1, l.eps1)
+                mid = F.gelu(F.linear(hb, l.wi, l.bi))
+                h, hb = ops.add_layernorm(F.linear(mid, l.wo2, l.bo2), h, l.g2, l.b2, l.eps2, want_bf16=i != last)
+        return h.view(B, L, self.hidden)

@@ -141,6 +141,45 @@ def meanpool(hidden, mask):
 MAX_QUERIES_PER_SEARCH = 16384   # larger batches are searched in pieces (last_stats() then describes the last piece)
 
 
+def attention(qkv, seq_start, seq_len, n_heads, max_len, pad_len=0, scale=0.125, out=None):
+    """Multi-head self-attention of a token array (ccr_attention_bf16; head width 64): qkv [T, 3 * n_heads * 64] bf16 = the stacked
+    query | key | value projection of every token, seq_start / seq_len [n_seq] int32 = each sequence's first row and real tokens,
+    max_len = the longest seq_len (host int, <= 512), pad_len = L for a right-padded [n_seq, L] batch (its padding rows get
+    zeros) or 0 for a packed array.  -> context rows [T, n_heads * 64] bf16."""
+    lib = require_gpu()
+    assert qkv.is_cuda and qkv.dtype == torch.bfloat16 and qkv.dim() == 2 and qkv.is_contiguous()
+    T, width = qkv.shape
+    assert width == 3 * n_heads * 64, f"qkv rows are {width} wide, expected 3 x {n_heads} heads x 64"
+    assert seq_start.dtype == torch.int32 and seq_len.dtype == torch.int32 and seq_start.is_cuda and seq_len.is_cuda
+    assert seq_start.is_contiguous() and seq_len.is_contiguous() and seq_start.numel() == seq_len.numel()
+    if out is None:
+        out = torch.empty(T, n_heads * 64, dtype=torch.bfloat16, device=qkv.device)
+    assert out.is_cuda and out.dtype == torch.bfloat16 and tuple(out.shape) == (T, n_heads * 64) and out.is_contiguous()
+    with _on(qkv):
+        _lib.check(lib.ccr_attention_bf16(_ptr(qkv), _ptr(seq_start), _ptr(seq_len), _ptr(out), seq_len.numel(), int(n_heads),
+                                          int(max_len), int(pad_len), float(scale), _stream(qkv)), "ccr_attention_bf16")
+    return out
+
+
+def add_layernorm(x, residual, gamma, beta, eps, want_f32=True, want_bf16=True):
+    """LayerNorm(x + residual) * gamma + beta per row (ccr_add_layernorm): x [rows, dim] bf16, residual [rows, dim] fp32 or None,
+    gamma / beta [dim] fp32, dim a multiple of 256 (<= 2048).  -> (fp32 rows or None, their bf16 copy or None)."""
+    lib = require_gpu()
+    assert x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2 and x.is_contiguous()
+    rows, dim = x.shape
+    if residual is not None:
+        assert residual.is_cuda and residual.dtype == torch.float32 and tuple(residual.shape) == (rows, dim) and residual.is_contiguous()
+    for t in (gamma, beta):
+        assert t.is_cuda and t.dtype == torch.float32 and tuple(t.shape) == (dim,) and t.is_contiguous()
+    assert want_f32 or want_bf16
+    f32 = torch.empty(rows, dim, dtype=torch.float32, device=x.device) if want_f32 else None
+    b16 = torch.empty(rows, dim, dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    with _on(x):
+        _lib.check(lib.ccr_add_layernorm(_ptr(x), _ptr(residual), _ptr(gamma), _ptr(beta), float(eps), _ptr(f32), _ptr(b16),
+                                         rows, dim, _stream(x)), "ccr_add_layernorm")
+    return f32, b16
+
+
 class CorpusIndex:
     """A resident bf16 corpus shard + its search state (ccr_index).  Build once per AL step, query many.
 

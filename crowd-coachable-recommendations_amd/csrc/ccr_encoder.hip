@@ -1,0 +1,347 @@
+// ccr_encoder.hip -- the non-GEMM pieces of a BERT encoder layer as gfx950 kernels (encoder-side fusion).
+// The reference encodes with transformers' BertModel under autocast (src/ccrec/models/item_tower.py:122, scripts/al_0_rank.py:92-101);
+// measured on one MI355X (profiles/r03_encode_kernel_stats.csv) its projections run at hipBLASLt speed (38 % of the GPU time) and
+// the rest is attention at 57 TFLOP/s (22 %) plus separate residual-add / LayerNorm / cast passes (30 %).  Two kernels replace those:
+//
+//   attention_kernel      softmax(Q K^T * scale + key mask) V for every (sequence, head) of a batch of right-padded or packed
+//                         sequences, head width 64, straight from the fused QKV projection's output.  VALU (exp) bound.
+//   add_layernorm_kernel  LayerNorm(x_bf16 + residual_f32) -> the fp32 residual stream AND its bf16 copy (the next
+//                         projection's operand) in one pass: 12 bytes per element instead of 28 over three kernels.  HBM bound.
+//
+// Arithmetic = what autocast(bf16) does in the reference's layer: bf16 operands, fp32 scores / softmax / accumulation,
+// probabilities rounded to bf16 for the P V product, fp32 residual sum and LayerNorm.
+#include "ccr_common.h"
+#include "ccr_index.h"
+
+namespace ccr {
+
+typedef __bf16 ebf16x8 __attribute__((ext_vector_type(8)));
+typedef float ef32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int ATT_MAX_THREADS = 512;   // up to 8 waves: one workgroup per (sequence, head) stages K / V once, wave w takes query blocks w, w + waves, ..
+constexpr int ATT_QW = 32;             // query rows per wave step (the N side of one 32x32 MFMA tile)
+constexpr int ATT_KMAX = 8, ATT_VMAX = 4;   // 16-byte key pieces / value-row pairs a thread stages (all in flight at once)
+constexpr int ATT_KB = 64;         // keys per loop step (two 32-key score tiles: halves the online-softmax rescaling)
+constexpr int ATT_HEAD = 64;       // head width
+constexpr int ATT_KROW = 144;      // bytes per key row in LDS: 128 + 16, so the 16 lanes of a ds_read_b128 group hit distinct banks
+
+// LDS: K [lk_pad rows][144 B] row-major | V TRANSPOSED [64 d][2 * lk_pad + 8 B] (row stride = 8 * odd: the 32 lanes of a ds_read_b64
+// group, one d each, hit distinct banks).  lk_pad = longest sequence rounded up to 64.
+__host__ __device__ inline size_t attention_lds_bytes(int lk_pad) {
+    return (size_t)lk_pad * ATT_KROW + (size_t)ATT_HEAD * (2 * (size_t)lk_pad + 8);
+}
+
+// S^T = K Q^T on v_mfma_f32_32x32x16_bf16: A = 32 keys (lane & 31) x 8 head columns (8 * (lane >> 5) + j), B = 32 queries
+// likewise -- both operands are 16 contiguous bytes of a row, no transposition.  C layout: lane -> query (lane & 31),
+// register e -> key (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5): a lane owns ONE query and 16 of the tile's 32 keys, so the
+// softmax row reductions are in-lane plus one exchange with lane ^ 32, and the probabilities, rounded to bf16, ARE the B
+// operand of O^T = V^T P^T (contraction index = key; the A operand V^T is read from the transposed LDS image with the
+// same key permutation: element j of lane half g <-> key 16 s + 4 g + (j & 3) + 8 (j >> 2)).
+__global__ __launch_bounds__(ATT_MAX_THREADS) void attention_kernel(const uint16_t *__restrict__ qkv,
+                                                                  const int32_t *__restrict__ seq_start,
+                                                                  const int32_t *__restrict__ seq_len,
+                                                                  uint16_t *__restrict__ out, int H, int pad_len, int lk_pad,
+                                                                  float scale_log2e) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int nthreads = blockDim.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwaves = nthreads >> 6;
+    const int b = blockIdx.y, h = blockIdx.x;
+    const int len = seq_len[b];
+    const int rows = len > pad_len ? len : pad_len;   // rows the sequence occupies in the token arrays (padding rows get zeros)
+    const int HD = H * ATT_HEAD;
+    const int64_t stride = 3 * (int64_t)HD;
+    const int64_t row0 = seq_start[b];
+    const uint16_t *Qg = qkv + row0 * stride + h * ATT_HEAD;
+    const uint16_t *Kg = Qg + HD;
+    const uint16_t *Vg = Qg + 2 * HD;
+    uint16_t *Og = out + row0 * HD + h * ATT_HEAD;
+    const int ql = lane & 31, g = lane >> 5;
+
+    char *Ks = smem;
+    char *Vt = smem + (size_t)lk_pad * ATT_KROW;
+    const int VS = 2 * lk_pad + 8;
+    const int nkb = (len + ATT_KB - 1) / ATT_KB;
+    const int nk = nkb * ATT_KB;
+
+    // ---- stage K (row-major) and V (transposed, two keys per dword) of this (sequence, head); rows beyond len are zeros.
+    // Every load of the staging -- and the wave's first query fragment -- is issued before the first LDS store: one memory
+    // latency per workgroup instead of one per piece.  The launcher sizes the workgroup so that a thread has at most
+    // ATT_KMAX key pieces and ATT_VMAX value pairs.
+    uint4 kreg[ATT_KMAX], va[ATT_VMAX], vb[ATT_VMAX];
+#pragma unroll
+    for (int u = 0; u < ATT_KMAX; ++u) {
+        const int i = tid + u * nthreads;
+        const int r = i >> 3, c = i & 7;
+        kreg[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (r < len) kreg[u] = *reinterpret_cast<const uint4 *>(Kg + (int64_t)r * stride + c * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < ATT_VMAX; ++u) {
+        const int i = tid + u * nthreads;
+        const int p = i >> 3, c = i & 7;
+        va[u] = vb[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (2 * p < len) va[u] = *reinterpret_cast<const uint4 *>(Vg + (int64_t)(2 * p) * stride + c * 8);
+        if (2 * p + 1 < len) vb[u] = *reinterpret_cast<const uint4 *>(Vg + (int64_t)(2 * p + 1) * stride + c * 8);
+    }
+    ebf16x8 qf[4];
+    {
+        const int q = wv * ATT_QW + ql;
+        const int qr = q < len ? q : len - 1;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const ebf16x8 *>(Qg + (int64_t)qr * stride + 16 * s + 8 * g);
+    }
+#pragma unroll
+    for (int u = 0; u < ATT_KMAX; ++u) {
+        const int i = tid + u * nthreads;
+        if (i < nk * 8) *reinterpret_cast<uint4 *>(Ks + (i >> 3) * ATT_KROW + (i & 7) * 16) = kreg[u];
+    }
+#pragma unroll
+    for (int u = 0; u < ATT_VMAX; ++u) {
+        const int i = tid + u * nthreads;
+        if (i < nk * 4) {
+            const int p = i >> 3, c = i & 7;
+            const uint32_t a[4] = {va[u].x, va[u].y, va[u].z, va[u].w}, bb[4] = {vb[u].x, vb[u].y, vb[u].z, vb[u].w};
+            char *dst = Vt + (size_t)(8 * c) * VS + 4 * p;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                *reinterpret_cast<uint32_t *>(dst + (size_t)(2 * j) * VS) = (a[j] & 0xffffu) | (bb[j] << 16);
+                *reinterpret_cast<uint32_t *>(dst + (size_t)(2 * j + 1) * VS) = (a[j] >> 16) | (bb[j] & 0xffff0000u);
+            }
+        }
+    }
+    __syncthreads();
+
+    for (int q0w = wv * ATT_QW; q0w < rows; q0w += nwaves * ATT_QW) {   // wave-uniform; no barrier below
+        const int q = q0w + ql;
+        if (q0w >= len) {   // a block of padding rows only: defined output (zeros), no NaNs into the next projection
+            if (q < rows) {
+                uint2 *dst = reinterpret_cast<uint2 *>(Og + (int64_t)q * HD);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) dst[i * 2 + g] = make_uint2(0u, 0u);
+            }
+            continue;
+        }
+        if (q0w != wv * ATT_QW) {   // sequences longer than 256 tokens: the wave's next query block
+            const int qr = q < len ? q : len - 1;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const ebf16x8 *>(Qg + (int64_t)qr * stride + 16 * s + 8 * g);
+        }
+
+        ef32x16 o0, o1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o0[e] = o1[e] = 0.f;
+        float m = -INFINITY, lsum = 0.f;
+
+        for (int kb = 0; kb < nkb; ++kb) {
+            ef32x16 s0, s1;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s0[e] = s1[e] = 0.f;
+            const char *kp = Ks + (kb * ATT_KB + ql) * ATT_KROW + g * 16;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const ebf16x8 k0 = *reinterpret_cast<const ebf16x8 *>(kp + 32 * s);
+                const ebf16x8 k1 = *reinterpret_cast<const ebf16x8 *>(kp + 32 * ATT_KROW + 32 * s);
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[s], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[s], s1, 0, 0, 0);
+            }
+            float x[32];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                x[e] = s0[e];
+                x[16 + e] = s1[e];
+            }
+            if (kb * ATT_KB + ATT_KB > len) {   // the last step: keys beyond the sequence
+#pragma unroll
+                for (int e = 0; e < 32; ++e) {
+                    const int key = kb * ATT_KB + (e >> 4) * 32 + (e & 3) + 8 * ((e & 15) >> 2) + 4 * g;
+                    if (key >= len) x[e] = -INFINITY;
+                }
+            }
+            float mx = x[0];
+#pragma unroll
+            for (int e = 1; e < 32; ++e) mx = fmaxf(mx, x[e]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mn = fmaxf(m, mx);            // finite: every step holds at least one key < len
+            const float alpha = __builtin_amdgcn_exp2f((m - mn) * scale_log2e);   // m = -inf on the first step: 0
+            const float bias = -mn * scale_log2e;
+            m = mn;
+            float ps = 0.f;
+#pragma unroll
+            for (int e = 0; e < 32; ++e) {
+                x[e] = __builtin_amdgcn_exp2f(fmaf(x[e], scale_log2e, bias));
+                ps += x[e];
+            }
+            lsum = fmaf(lsum, alpha, ps);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                o0[e] *= alpha;
+                o1[e] *= alpha;
+            }
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    ebf16x8 pf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[j] = (__bf16)x[hb * 16 + s2 * 8 + j];
+                    const int kbase = kb * ATT_KB + hb * 32 + s2 * 16 + 4 * g;
+                    const char *vp = Vt + (size_t)ql * VS + 2 * kbase;
+                    union {
+                        uint2 u[2];
+                        ebf16x8 v;
+                    } a0, a1;
+                    a0.u[0] = *reinterpret_cast<const uint2 *>(vp);
+                    a0.u[1] = *reinterpret_cast<const uint2 *>(vp + 16);
+                    a1.u[0] = *reinterpret_cast<const uint2 *>(vp + (size_t)32 * VS);
+                    a1.u[1] = *reinterpret_cast<const uint2 *>(vp + (size_t)32 * VS + 16);
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.v, pf, o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, pf, o1, 0, 0, 0);
+                }
+            }
+        }
+
+        const float inv = 1.f / (lsum + __shfl_xor(lsum, 32));
+        if (q < len) {
+            // O^T tile: lane -> query, register e -> head column 32 db + (e & 3) + 8 (e >> 2) + 4 g: four consecutive columns per 8-byte store
+            uint16_t *dst = Og + (int64_t)q * HD + 4 * g;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                union {
+                    __bf16 hv[4];
+                    uint2 u;
+                } w0, w1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    w0.hv[j] = (__bf16)(o0[4 * c4 + j] * inv);
+                    w1.hv[j] = (__bf16)(o1[4 * c4 + j] * inv);
+                }
+                *reinterpret_cast<uint2 *>(dst + 8 * c4) = w0.u;
+                *reinterpret_cast<uint2 *>(dst + 32 + 8 * c4) = w1.u;
+            }
+        } else if (q < rows) {
+            uint2 *dst = reinterpret_cast<uint2 *>(Og + (int64_t)q * HD);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dst[i * 2 + g] = make_uint2(0u, 0u);
+        }
+    }   // query blocks of this wave
+}
+
+// One wave per row of dim = 256 * C elements; lane owns elements 4 * (64 c + lane) .. + 3 of every 256-element slice.
+template <int C>
+__global__ __launch_bounds__(256) void add_layernorm_kernel(const uint16_t *__restrict__ x, const float *__restrict__ res,
+                                                           const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                           float eps, float *__restrict__ out_f32,
+                                                           uint16_t *__restrict__ out_bf16, int64_t rows) {
+    constexpr int DIM = 256 * C;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[C][4];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int col = 4 * (64 * c + lane);
+        const uint2 xb = *reinterpret_cast<const uint2 *>(x + row * DIM + col);
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (res) r = *reinterpret_cast<const float4 *>(res + row * DIM + col);
+        v[c][0] = __uint_as_float(xb.x << 16) + r.x;
+        v[c][1] = __uint_as_float(xb.x & 0xffff0000u) + r.y;
+        v[c][2] = __uint_as_float(xb.y << 16) + r.z;
+        v[c][3] = __uint_as_float(xb.y & 0xffff0000u) + r.w;
+        sum += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum * (1.f / DIM);
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = v[c][j] - mean;
+            sq = fmaf(d, d, sq);
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    const float rstd = rsqrtf(sq * (1.f / DIM) + eps);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int col = 4 * (64 * c + lane);
+        const float4 gm = *reinterpret_cast<const float4 *>(gamma + col);
+        const float4 bt = *reinterpret_cast<const float4 *>(beta + col);
+        float4 y;
+        y.x = fmaf((v[c][0] - mean) * rstd, gm.x, bt.x);
+        y.y = fmaf((v[c][1] - mean) * rstd, gm.y, bt.y);
+        y.z = fmaf((v[c][2] - mean) * rstd, gm.z, bt.z);
+        y.w = fmaf((v[c][3] - mean) * rstd, gm.w, bt.w);
+        if (out_f32) *reinterpret_cast<float4 *>(out_f32 + row * DIM + col) = y;
+        if (out_bf16) {
+            union {
+                __bf16 hv[4];
+                uint2 u;
+            } w;
+            w.hv[0] = (__bf16)y.x;
+            w.hv[1] = (__bf16)y.y;
+            w.hv[2] = (__bf16)y.z;
+            w.hv[3] = (__bf16)y.w;
+            *reinterpret_cast<uint2 *>(out_bf16 + row * DIM + col) = w.u;
+        }
+    }
+}
+
+template <int C>
+static int launch_add_layernorm(const uint16_t *x, const float *res, const float *gamma, const float *beta, float eps,
+                                float *out_f32, uint16_t *out_bf16, int64_t rows, hipStream_t s) {
+    hipLaunchKernelGGL(add_layernorm_kernel<C>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, res, gamma, beta, eps,
+                       out_f32, out_bf16, rows);
+    CCR_LAUNCH_CHECK();
+    return CCR_OK;
+}
+
+}  // namespace ccr
+
+using namespace ccr;
+
+extern "C" int ccr_attention_bf16(const uint16_t *qkv, const int32_t *seq_start, const int32_t *seq_len, uint16_t *out,
+                                  int n_seq, int n_heads, int max_len, int pad_len, float scale, void *stream) {
+    CCR_REQUIRE(qkv && seq_start && seq_len && out, "ccr_attention_bf16: null pointer");
+    CCR_REQUIRE(n_seq >= 0 && n_seq <= 65535 && n_heads > 0 && n_heads <= 1024, "ccr_attention_bf16: bad shape n_seq=%d n_heads=%d",
+                n_seq, n_heads);
+    CCR_REQUIRE(max_len > 0 && max_len <= 512 && pad_len >= 0 && pad_len <= 512,
+                "ccr_attention_bf16: max_len=%d pad_len=%d (1..512 tokens per sequence)", max_len, pad_len);
+    CCR_REQUIRE(scale > 0.f, "ccr_attention_bf16: scale must be positive");
+    if (n_seq == 0) return CCR_OK;
+    const int lk_pad = (max_len + ATT_KB - 1) / ATT_KB * ATT_KB;
+    const size_t lds = attention_lds_bytes(lk_pad);
+    const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&attention_kernel), lds);
+    if (rc != CCR_OK) return rc;
+    int waves = (max_len + ATT_QW - 1) / ATT_QW;   // one wave per 32 query rows, at most 8 (longer sequences: the waves loop)
+    if (waves > ATT_MAX_THREADS / 64) waves = ATT_MAX_THREADS / 64;
+    CCR_REQUIRE(lk_pad * 8 <= ATT_KMAX * 64 * waves && lk_pad * 4 <= ATT_VMAX * 64 * waves, "ccr_attention_bf16: staging bound (internal)");
+    hipLaunchKernelGGL(attention_kernel, dim3(n_heads, n_seq), dim3(64 * waves), lds, (hipStream_t)stream, qkv, seq_start, seq_len,
+                       out, n_heads, pad_len, lk_pad, scale * 1.4426950408889634f);
+    CCR_LAUNCH_CHECK();
+    return CCR_OK;
+}
+
+extern "C" int ccr_add_layernorm(const uint16_t *x_bf16, const float *residual, const float *gamma, const float *beta, float eps,
+                                 float *out_f32, uint16_t *out_bf16, int64_t rows, int dim, void *stream) {
+    CCR_REQUIRE(x_bf16 && gamma && beta && (out_f32 || out_bf16), "ccr_add_layernorm: null pointer");
+    CCR_REQUIRE(rows >= 0 && dim > 0 && dim % 256 == 0 && dim <= 2048, "ccr_add_layernorm: rows=%lld dim=%d (dim %% 256 == 0, dim <= 2048)",
+                (long long)rows, dim);
+    if (rows == 0) return CCR_OK;
+    hipStream_t s = (hipStream_t)stream;
+    switch (dim / 256) {
+        case 1: return launch_add_layernorm<1>(x_bf16, residual, gamma, beta, eps, out_f32, out_bf16, rows, s);
+        case 2: return launch_add_layernorm<2>(x_bf16, residual, gamma, beta, eps, out_f32, out_bf16, rows, s);
+        case 3: return launch_add_layernorm<3>(x_bf16, residual, gamma, beta, eps, out_f32, out_bf16, rows, s);
+        case 4: return launch_add_layernorm<4>(x_bf16, residual, gamma, beta, eps, out_f32, out_bf16, rows, s);
+        case 5: return launch_add_layernorm<5>(x_bf16, residual, gamma, beta, eps, out_f32, out_bf16, rows, s);
+        case 6: return launch_add_layernorm<6>(x_bf16, residual, gamma, beta, eps, out_f32, out_bf16, rows, s);
+        case 7: return launch_add_layernorm<7>(x_bf16, residual, gamma, beta, eps, out_f32, out_bf16, rows, s);
+        default: return launch_add_layernorm<8>(x_bf16, residual, gamma, beta, eps, out_f32, out_bf16, rows, s);
+    }
+}

@@ -128,6 +128,32 @@ int ccr_meanpool_bwd(const float *grad, const int64_t *mask, void *dhidden, int 
                      void *stream);
 
 /*
+ * The non-GEMM pieces of the encoder layer that produces `hidden` (the reference runs transformers' BertModel under autocast:
+ * src/ccrec/models/item_tower.py:122 `cls_model(**inputs).last_hidden_state`, scripts/al_0_rank.py:92-101,125).  The
+ * projections stay library GEMMs on the host side (hipBLASLt through torch); these two kernels replace the attention call
+ * and the residual-add / LayerNorm / cast passes between them.  Arithmetic = the layer's under autocast(bf16): bf16 operands,
+ * fp32 scores, softmax and accumulation, probabilities rounded to bf16 for the P.V product, fp32 residual sum and LayerNorm.
+ *
+ * ccr_attention_bf16: multi-head self-attention over n_seq sequences of a token array, head width 64.
+ *   qkv [T][3 * n_heads * 64] bf16: row t = (Q | K | V) of token t, each n_heads * 64 wide -- the output of ONE projection with
+ *     the query / key / value weights stacked (transformers' BertSelfAttention.query / .key / .value);
+ *   seq_start [n_seq] int32: first row of sequence s in the token array; seq_len [n_seq] int32 (1 .. max_len): its real tokens
+ *     (keys beyond are masked, as attention_mask = 0 is in the reference's inputs, scripts/al_0_rank.py:76-81 padding=True);
+ *   out [T][n_heads * 64] bf16: context rows, heads side by side (the operand of BertSelfOutput.dense);
+ *   max_len: longest seq_len (<= 512; sizes the LDS image of one head's keys and values);
+ *   pad_len: 0 for a packed token array, or the padded length L of a right-padded [n_seq][L] batch (seq_start[s] = s * L):
+ *     rows seq_len[s] .. pad_len - 1 of a sequence receive zeros;
+ *   scale: 1 / sqrt(64) for BERT.
+ * ccr_add_layernorm: y = LayerNorm(x + residual) * gamma + beta per row (BertSelfOutput / BertOutput: LayerNorm(dense(h) + input)).
+ *   x_bf16 [rows][dim] bf16, residual [rows][dim] fp32 or NULL, gamma / beta [dim] fp32, dim % 256 == 0, dim <= 2048;
+ *   out_f32 [rows][dim] or NULL (the residual stream), out_bf16 [rows][dim] or NULL (the next projection's operand).
+ */
+int ccr_attention_bf16(const uint16_t *qkv, const int32_t *seq_start, const int32_t *seq_len, uint16_t *out, int n_seq,
+                       int n_heads, int max_len, int pad_len, float scale, void *stream);
+int ccr_add_layernorm(const uint16_t *x_bf16, const float *residual, const float *gamma, const float *beta, float eps,
+                      float *out_f32, uint16_t *out_bf16, int64_t rows, int dim, void *stream);
+
+/*
  * Build a search index over a resident bf16 corpus shard (borrowed pointer, no copy).
  * Replaces: the host-resident fp32 passage matrix of scripts/ms_marco_eval.py:199-201,208-210.
  *   global_row_offset: id of row 0 of this shard in the whole corpus (multi-GPU row sharding).

@@ -1,0 +1,173 @@
+"""SURVEY 8 f2, encoder-side fusion: the attention and add + LayerNorm kernels of the item tower's encoder layer
+(csrc/ccr_encoder.hip) and the layer-by-layer forward built on them (ccrec_amd/fused_bert.py).
+
+These are floating-point kernels, so the reference is plain PyTorch in fp32 on the same (bf16-rounded) operands, with the
+tolerance written in each test: two bf16 ulps for the attention output (probabilities are rounded to bf16 for the P.V
+product, the output is rounded once more), fp32 rounding for LayerNorm, and for the whole encoder "no further from the fp32
+module forward than the module's own autocast(bf16) forward is" (src/ccrec/models/item_tower.py:122, scripts/al_0_rank.py:125)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, PKG  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def _attention_reference(qkv, starts, lens, H):
+    """fp32 softmax(Q K^T / 8) V per (sequence, head) on the bf16 operands."""
+    T = qkv.shape[0]
+    out = torch.zeros(T, H * 64, dtype=torch.float32, device=qkv.device)
+    x = qkv.float().view(T, 3, H, 64)
+    for s0, n in zip(starts, lens):
+        q, k, v = (x[s0:s0 + n, i].transpose(0, 1) for i in range(3))          # [H, n, 64]
+        p = torch.softmax(q @ k.transpose(1, 2) * 0.125, dim=-1)
+        out[s0:s0 + n] = (p @ v).transpose(0, 1).reshape(n, H * 64)
+    return out
+
+
+@pytest.mark.parametrize("lens,H,padded", [
+    ([1, 2, 31, 32, 33], 2, True),
+    ([63, 64, 65, 127, 128, 129], 3, True),
+    ([200, 17, 136, 136, 5], 12, True),
+    ([512, 300, 257, 1], 2, True),
+    ([1, 2, 31, 32, 33, 64, 65, 100], 4, False),
+    ([129, 255, 256, 384], 2, False),
+])
+def test_attention_matches_fp32_reference(lens, H, padded):
+    from ccrec_amd import ops
+    torch.manual_seed(sum(lens) + H)
+    L = max(lens)
+    if padded:
+        pad = (L + 7) // 8 * 8
+        starts = [i * pad for i in range(len(lens))]
+        T = pad * len(lens)
+    else:
+        pad = 0
+        starts = list(np.cumsum([0] + lens[:-1]))
+        T = sum(lens)
+    # scores with a real spread (softmax far from uniform), values O(1); padding rows hold NaN to prove nothing reads them as keys
+    qkv = (torch.randn(T, 3 * H * 64, device="cuda") * 1.5).to(torch.bfloat16)
+    if padded:
+        live = torch.zeros(T, dtype=torch.bool, device="cuda")
+        for s0, n in zip(starts, lens):
+            live[s0:s0 + n] = True
+        qkv[~live] = float("nan")
+    seq_start = torch.tensor(starts, dtype=torch.int32, device="cuda")
+    seq_len = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    out = torch.full((T, H * 64), 7.0, dtype=torch.bfloat16, device="cuda")
+    ops.attention(qkv, seq_start, seq_len, H, max_len=L, pad_len=pad, out=out)
+    ref = _attention_reference(torch.nan_to_num(qkv.float()).to(torch.bfloat16), starts, lens, H)
+    got = out.float()
+    assert torch.isfinite(got).all()
+    for s0, n in zip(starts, lens):
+        # two bf16 ulps of the value + the bf16 rounding of the probabilities (relative 2^-9 each, summed with weights <= 1)
+        torch.testing.assert_close(got[s0:s0 + n], ref[s0:s0 + n], atol=1.5e-2, rtol=1.6e-2)
+        if padded:
+            assert (got[s0 + n:s0 + pad] == 0).all(), "padding rows must be zeros"
+    err = (got - ref).abs().max().item()
+    assert err < 5e-2
+
+
+def test_attention_rejects_bad_shapes():
+    from ccrec_amd import ops, _lib
+    qkv = torch.zeros(16, 3 * 64, dtype=torch.bfloat16, device="cuda")
+    s = torch.zeros(1, dtype=torch.int32, device="cuda")
+    n = torch.full((1,), 16, dtype=torch.int32, device="cuda")
+    with pytest.raises(_lib.CcrError):
+        ops.attention(qkv, s, n, 1, max_len=513)
+    with pytest.raises(_lib.CcrError):
+        ops.attention(qkv, s, n, 1, max_len=0)
+    with pytest.raises(AssertionError):
+        ops.attention(qkv, s, n, 2, max_len=16)     # rows are 192 wide, not 3 x 2 x 64
+
+
+@pytest.mark.parametrize("rows,dim", [(1, 256), (7, 768), (1000, 768), (333, 1024), (5, 2048)])
+def test_add_layernorm_matches_torch(rows, dim):
+    from ccrec_amd import ops
+    torch.manual_seed(rows + dim)
+    x = torch.randn(rows, dim, device="cuda").to(torch.bfloat16)
+    res = torch.randn(rows, dim, device="cuda") * 3 + 0.5
+    gamma = torch.rand(dim, device="cuda") + 0.5
+    beta = torch.randn(dim, device="cuda")
+    f32, b16 = ops.add_layernorm(x, res, gamma, beta, 1e-12)
+    ref = torch.nn.functional.layer_norm(x.float() + res, (dim,), gamma, beta, 1e-12)
+    torch.testing.assert_close(f32, ref, atol=2e-5, rtol=2e-5)       # fp32 reduction order only
+    assert torch.equal(b16, f32.to(torch.bfloat16))                   # the bf16 copy is the rounded fp32 row, bit for bit
+    only_b16 = ops.add_layernorm(x, None, gamma, beta, 1e-5, want_f32=False)
+    assert only_b16[0] is None
+    ref2 = torch.nn.functional.layer_norm(x.float(), (dim,), gamma, beta, 1e-5)
+    torch.testing.assert_close(only_b16[1].float(), ref2, atol=2e-2, rtol=8e-3)
+
+
+def _bert(hidden=256, heads=4, layers=2, inter=512, seed=0, scale=1.0):
+    from transformers import BertConfig, BertModel
+    torch.manual_seed(seed)
+    m = BertModel(BertConfig(vocab_size=600, hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads,
+                             intermediate_size=inter, max_position_embeddings=512)).cuda().eval()
+    if scale != 1.0:   # the default init (std 0.02) leaves every softmax near uniform: widen the attention projections
+        with torch.no_grad():
+            for layer in m.encoder.layer:
+                layer.attention.self.query.weight.mul_(scale)
+                layer.attention.self.key.weight.mul_(scale)
+    return m
+
+
+def _batch(lens, L, vocab=600, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.zeros(len(lens), L, dtype=torch.int64)
+    mask = torch.zeros(len(lens), L, dtype=torch.int64)
+    for r, n in enumerate(lens):
+        ids[r, :n] = torch.randint(1, vocab, (n,), generator=g)
+        mask[r, :n] = 1
+    return ids.cuda(), mask.cuda(), torch.tensor(lens, dtype=torch.int32, device="cuda")
+
+
+@pytest.mark.parametrize("hidden,heads,layers,scale", [(256, 4, 2, 1.0), (256, 4, 3, 25.0), (768, 12, 2, 12.0)])
+def test_fused_forward_is_as_close_to_fp32_as_the_autocast_module(hidden, heads, layers, scale):
+    from ccrec_amd.fused_bert import FusedBertEncoder, unsupported_reason
+    model = _bert(hidden, heads, layers, hidden * 2, seed=hidden + layers, scale=scale)
+    assert unsupported_reason(model) is None
+    lens = [40, 1, 17, 33, 64, 65, 128, 130, 97, 200]
+    ids, mask, lengths = _batch(lens, 200)
+    with torch.no_grad():
+        ref = model(input_ids=ids, attention_mask=mask).last_hidden_state                       # fp32 module forward
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            amp = model(input_ids=ids, attention_mask=mask).last_hidden_state.float()           # what the reference's layer computes
+    got = FusedBertEncoder(model).forward(ids, lengths)
+    assert got.dtype == torch.float32 and got.shape == ref.shape
+    live = mask.bool()
+    e_amp = (amp - ref)[live].abs()
+    e_got = (got - ref)[live].abs()
+    # tolerance: at most 1.5 x the autocast module's own distance from fp32 (max and mean), plus an absolute floor of 1e-3
+    assert e_got.max().item() <= 1.5 * e_amp.max().item() + 1e-3, (e_got.max().item(), e_amp.max().item())
+    assert e_got.mean().item() <= 1.5 * e_amp.mean().item() + 1e-4, (e_got.mean().item(), e_amp.mean().item())
+    cos = torch.nn.functional.cosine_similarity(got[live], ref[live], dim=-1)
+    cos_amp = torch.nn.functional.cosine_similarity(amp[live], ref[live], dim=-1)
+    assert cos.min().item() > cos_amp.min().item() - 1e-3 and cos.min().item() > 0.995, (cos.min().item(), cos_amp.min().item())
+    assert torch.isfinite(got).all()
+
+
+def test_fused_forward_follows_weight_updates_and_rejects_other_encoders():
+    from ccrec_amd.fused_bert import FusedBertEncoder, unsupported_reason
+    model = _bert(256, 4, 1, 512)
+    ids, mask, lengths = _batch([9, 30], 32)
+    enc = FusedBertEncoder(model)
+    a = enc.forward(ids, lengths).clone()
+    assert enc.refresh() is False
+    with torch.no_grad():
+        model.encoder.layer[0].output.dense.weight.add_(0.05)      # an optimiser step between two ranking steps
+    assert enc.refresh() is True
+    b = enc.forward(ids, lengths)
+    assert (a - b).abs().max().item() > 1e-3
+    with torch.no_grad():
+        ref = model(input_ids=ids, attention_mask=mask).last_hidden_state
+    assert (b - ref)[mask.bool()].abs().max().item() < 5e-2
+    # head width 32: not covered -> a reason, and the constructor refuses
+    other = _bert(256, 8, 1, 512)
+    assert "head width" in unsupported_reason(other)
+    with pytest.raises(ValueError):
+        FusedBertEncoder(other)
+    model.train()
+    with pytest.raises(AssertionError):
+        enc.forward(ids, lengths)
