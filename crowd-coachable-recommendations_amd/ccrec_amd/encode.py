@@ -162,7 +162,7 @@ class LengthSortedEncoder:
     """
 
     def __init__(self, tower, tokenizer, max_length=None, max_tokens=65536, max_batch=512, pad_multiple=8, chunk_texts=65536,
-                 host_threads=4, host_processes=0, output_step="mean_pooling"):
+                 host_threads=4, host_processes=0, output_step="mean_pooling", fused="auto"):
         self.tower, self.tokenizer = tower, tokenizer
         self.max_length = int(max_length if max_length is not None else os.environ.get("CCREC_MAX_LENGTH", 200))
         self.max_tokens, self.max_batch, self.pad_multiple = int(max_tokens), int(max_batch), int(pad_multiple)
@@ -181,6 +181,17 @@ class LengthSortedEncoder:
         self.host_processes = int(host_processes) if self._backend is not None else 0
         self._workers = None
         self.stats = {}
+        # fused: run the encoder layer by layer on this library's attention / add + LayerNorm kernels (fused_bert.FusedBertEncoder)
+        # instead of the torch module.  "auto": whenever the model is one the kernels cover (a BertModel with 64-wide heads ...);
+        # True: required (ValueError otherwise); False: always the module's own forward.
+        self._fused = None
+        if fused:
+            from .fused_bert import FusedBertEncoder, unsupported_reason
+            reason = unsupported_reason(tower.cls_model)
+            if reason is None:
+                self._fused = FusedBertEncoder(tower.cls_model)
+            elif fused is True:
+                raise ValueError(f"LengthSortedEncoder(fused=True): {reason}")
 
     def close(self):
         if self._workers is not None:
@@ -194,7 +205,7 @@ class LengthSortedEncoder:
             pass
 
     def _batch_arrays(self, flat, lengths, starts, idx, padded):
-        """Padded [B, padded] int64 id / mask arrays of one batch (host, pinned when a GPU is present)."""
+        """Padded [B, padded] int64 id / mask arrays of one batch + its int32 token counts (host, pinned when a GPU is present)."""
         lens = lengths[idx]
         pin = torch.cuda.is_available()
         ids_t = torch.full((len(idx), padded), self.pad_id, dtype=torch.int64, pin_memory=pin)
@@ -204,11 +215,13 @@ class LengthSortedEncoder:
         c_of = np.arange(total) - np.repeat(np.cumsum(lens) - lens, lens)
         ids_t.numpy()[r_of, c_of] = flat[np.repeat(starts[idx], lens) + c_of]
         mask_t.numpy()[r_of, c_of] = 1
-        return ids_t, mask_t
+        lens_t = torch.empty(len(idx), dtype=torch.int32, pin_memory=pin)
+        lens_t.numpy()[:] = lens
+        return ids_t, mask_t, lens_t
 
     def _prepare(self, texts):
         """Host side of one chunk: tokenise without padding, plan length-sorted batches, build their padded arrays.
-        -> (batches [(index array, ids, mask)], real tokens, padded tokens, seconds spent)."""
+        -> (batches [(index array, ids, mask, token counts)], real tokens, padded tokens, seconds spent)."""
         import time
         t0 = time.perf_counter()
         if self._workers is not None:
@@ -234,10 +247,13 @@ class LengthSortedEncoder:
         tower = self.tower
         tower.eval()
         device = tower.cls_model.device
+        if self._fused is not None:
+            self._fused.refresh()     # bf16 weight copies follow the module (fine-tuning between two ranking steps)
         texts = texts if isinstance(texts, (list, tuple)) else list(texts)
         n, chunk = len(texts), self.chunk_texts
         st = {"texts": n, "batches": 0, "real_tokens": 0, "padded_tokens": 0, "fixed_length_tokens": n * self.max_length,
-              "chunks": (n + chunk - 1) // chunk, "host_prepare_s": 0.0, "gpu_wait_for_host_s": 0.0, "gpu_busy_s": 0.0}
+              "chunks": (n + chunk - 1) // chunk, "host_prepare_s": 0.0, "gpu_wait_for_host_s": 0.0, "gpu_busy_s": 0.0,
+              "fused_layers": self._fused is not None}
         wall0 = time.perf_counter()
         spans = []          # (start, end) events of every chunk's GPU work
         if self.host_processes > 0 and self._workers is None and n > chunk:
@@ -260,9 +276,12 @@ class LengthSortedEncoder:
                 st["host_prepare_s"] += secs
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                for idx, ids_t, mask_t in batches:
+                for idx, ids_t, mask_t, lens_t in batches:
                     inputs = {"input_ids": ids_t.to(device, non_blocking=True), "attention_mask": mask_t.to(device, non_blocking=True)}
-                    hidden = tower.cls_model(**inputs).last_hidden_state
+                    if self._fused is not None:
+                        hidden = self._fused.forward(inputs["input_ids"], lens_t.to(device, non_blocking=True))
+                    else:
+                        hidden = tower.cls_model(**inputs).last_hidden_state
                     if out is None:
                         out = torch.empty(n + row_offset, hidden.shape[-1], dtype=torch.bfloat16, device=hidden.device)
                     rows = torch.as_tensor(np.asarray(idx, dtype=np.int64) + int(row_offset) + c0)

@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--max-length", type=int, default=200)
     ap.add_argument("--batch", type=int, default=512)
+    ap.add_argument("--fused", default="auto", choices=["auto", "off"],
+                    help="sorted modes: encoder layers on the library's attention / add + LayerNorm kernels (auto) or as torch modules (off); "
+                         "the extra mode name sorted_modules always runs the torch modules")
     args = ap.parse_args()
     from transformers import BertConfig, BertModel
     from ccrec_amd.item_tower import NaiveItemTower
@@ -101,11 +104,12 @@ def main():
                 out.append(emb.float().cpu())
         return torch.vstack(out)
 
-    def sorted_style(chunk=None, threads=None, procs=None):
+    def sorted_style(chunk=None, threads=None, procs=None, fused=None):
         nonlocal texts
         enc = LengthSortedEncoder(tower, tok, max_length=args.max_length, max_tokens=args.batch * 128, max_batch=4 * args.batch,
                                   chunk_texts=chunk or args.chunk_texts, host_threads=threads or args.host_threads,
-                                  host_processes=args.host_processes if procs is None else procs)
+                                  host_processes=args.host_processes if procs is None else procs,
+                                  fused=(args.fused == "auto") if fused is None else fused)
         with torch.autocast("cuda", dtype=torch.bfloat16):
             shard = enc.encode(texts, sim="dot")
         enc.close()
@@ -116,7 +120,7 @@ def main():
     results = {}
     all_texts = texts
     table = {"fixed": lambda: reference_style("max_length"), "batch_max": lambda: reference_style(True), "sorted": sorted_style,
-             "serial": lambda: sorted_style(chunk=10 ** 9)}
+             "serial": lambda: sorted_style(chunk=10 ** 9), "sorted_modules": lambda: sorted_style(fused=False)}
     names = args.modes.split(",")
     for spec in [x for x in args.sweep.split(",") if x]:
         c, t, pr = (list(int(v) for v in spec.split(":")) + [None])[:3]    # chunk_texts:host_threads[:host_processes]
@@ -135,17 +139,21 @@ def main():
         results[name] = r
         line = {"mode": name, "dist": args.dist, "texts": args.texts, "mean_tokens": float(lens.mean() + 2),
                 "max_length": args.max_length, "seconds": round(dt, 3), "texts_per_s": round(args.texts / dt, 1)}
-        if name.startswith("sorted") or name == "serial":
+        if name.startswith("sorted") or name == "serial":   # (sorted, sorted_modules, sorted[...])
             line.update(r[1])
             line["tokenizer"] = args.tokenizer
         print(json.dumps(line), flush=True)
-        if name not in ("fixed", "sorted"):
-            results[name] = None     # keep only what the final check needs
+        if name not in ("fixed", "sorted", "sorted_modules"):
+            results[name] = None     # keep only what the final checks need
     if results.get("fixed") is not None and results.get("sorted") is not None:
         ref = results["fixed"].cuda()
         got = results["sorted"][0].float()
         cos = torch.nn.functional.cosine_similarity(ref, got, dim=1)
         print(json.dumps({"check": "cosine(sorted bf16 rows, fixed-padding fp32 rows)", "min": float(cos.min()), "mean": float(cos.mean())}))
+    if results.get("sorted") is not None and results.get("sorted_modules") is not None:
+        cos = torch.nn.functional.cosine_similarity(results["sorted_modules"][0].float(), results["sorted"][0].float(), dim=1)
+        print(json.dumps({"check": "cosine(rows through the library's layer kernels, rows through the torch modules)",
+                          "min": float(cos.min()), "mean": float(cos.mean())}))
 
 
 if __name__ == "__main__":
