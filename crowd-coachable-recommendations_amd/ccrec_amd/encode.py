@@ -260,16 +260,27 @@ class LengthSortedEncoder:
             self._workers = _TokenizerWorkers(self.host_processes, self._backend.to_str(), self.max_length)
         ahead = self.host_threads     # chunks being prepared while one encodes (the Rust tokenizer and numpy release the GIL)
         with ThreadPoolExecutor(max_workers=ahead) as pool:
-            starts = list(range(0, n, chunk))
-            futs = [pool.submit(self._prepare, texts[c:c + chunk]) for c in starts[:ahead]]
+            # chunk boundaries: full chunks, except a ramp at the start of a long corpus (1/8, 1/4, 1/2 of a chunk) so that the
+            # first GPU batch waits for the tokenisation of 8 K texts, not of 64 K
+            bounds, c = [], 0
+            ramp = [chunk // 8, chunk // 4, chunk // 2] if n > 2 * chunk and chunk >= 1024 else []
+            while c < n:
+                size = ramp.pop(0) if ramp else chunk
+                bounds.append((c, min(n, c + size)))
+                c += size
+            st["chunks"] = len(bounds)
+            starts = [lo for lo, _ in bounds]
+            futs = [pool.submit(self._prepare, texts[lo:hi]) for lo, hi in bounds[:ahead]]
             for ci, c0 in enumerate(starts):
                 t0 = time.perf_counter()
                 batches, real, padded_tokens, secs = futs[ci].result()
                 futs[ci] = None
                 st["gpu_wait_for_host_s"] += time.perf_counter() - t0
+                if ci == 0:
+                    st["first_chunk_wait_s"] = time.perf_counter() - t0
                 if ci + ahead < len(starts):   # keep `ahead` chunks in preparation while this one encodes
-                    c = starts[ci + ahead]
-                    futs.append(pool.submit(self._prepare, texts[c:c + chunk]))
+                    lo, hi = bounds[ci + ahead]
+                    futs.append(pool.submit(self._prepare, texts[lo:hi]))
                 st["batches"] += len(batches)
                 st["real_tokens"] += real
                 st["padded_tokens"] += padded_tokens

@@ -48,6 +48,7 @@ __global__ __launch_bounds__(ATT_MAX_THREADS) void attention_kernel(const uint16
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nwaves = nthreads >> 6;
+    const int wq = (wv + blockIdx.x) % nwaves;   // the wave's first query block rotates with the head: second rounds spread over the SIMDs
     const int b = blockIdx.y, h = blockIdx.x;
     const int len = seq_len[b];
     const int rows = len > pad_len ? len : pad_len;   // rows the sequence occupies in the token arrays (padding rows get zeros)
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(ATT_MAX_THREADS) void attention_kernel(const uint16
     }
     ebf16x8 qf[4];
     {
-        const int q = wv * ATT_QW + ql;
+        const int q = wq * ATT_QW + ql;
         const int qr = q < len ? q : len - 1;
 #pragma unroll
         for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const ebf16x8 *>(Qg + (int64_t)qr * stride + 16 * s + 8 * g);
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(ATT_MAX_THREADS) void attention_kernel(const uint16
     }
     __syncthreads();
 
-    for (int q0w = wv * ATT_QW; q0w < rows; q0w += nwaves * ATT_QW) {   // wave-uniform; no barrier below
+    for (int q0w = wq * ATT_QW; q0w < rows; q0w += nwaves * ATT_QW) {   // wave-uniform; no barrier below
         const int q = q0w + ql;
         if (q0w >= len) {   // a block of padding rows only: defined output (zeros), no NaNs into the next projection
             if (q < rows) {
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(ATT_MAX_THREADS) void attention_kernel(const uint16
             }
             continue;
         }
-        if (q0w != wv * ATT_QW) {   // sequences longer than 256 tokens: the wave's next query block
+        if (q0w != wq * ATT_QW) {   // the wave's next query block (sequences beyond 32 x waves tokens)
             const int qr = q < len ? q : len - 1;
 #pragma unroll
             for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const ebf16x8 *>(Qg + (int64_t)qr * stride + 16 * s + 8 * g);
@@ -320,6 +321,11 @@ extern "C" int ccr_attention_bf16(const uint16_t *qkv, const int32_t *seq_start,
     if (rc != CCR_OK) return rc;
     int waves = (max_len + ATT_QW - 1) / ATT_QW;   // one wave per 32 query rows, at most 8 (longer sequences: the waves loop)
     if (waves > ATT_MAX_THREADS / 64) waves = ATT_MAX_THREADS / 64;
+    // 129..192 tokens: the LDS image lets three workgroups share a CU, but workgroups of 5 or 6 waves do not pack three times into
+    // its four SIMDs' wave slots (measured residency ~1.5 workgroups); 4 waves, the fifth / sixth query block on a second round
+    // of a wave that rotates with the head: 134 -> 120 us at 136 tokens, 125 -> 111 at 160 (longer sequences: two workgroups
+    // fit either way and 7-8 waves are faster)
+    if (lk_pad == 192 && waves > 4) waves = 4;
     CCR_REQUIRE(lk_pad * 8 <= ATT_KMAX * 64 * waves && lk_pad * 4 <= ATT_VMAX * 64 * waves, "ccr_attention_bf16: staging bound (internal)");
     hipLaunchKernelGGL(attention_kernel, dim3(n_heads, n_seq), dim3(64 * waves), lds, (hipStream_t)stream, qkv, seq_start, seq_len,
                        out, n_heads, pad_len, lk_pad, scale * 1.4426950408889634f);
