@@ -69,6 +69,39 @@ def test_attention_matches_fp32_reference(lens, H, padded):
     assert err < 5e-2
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_attention_fuzz_against_fp32_reference(seed):
+    """Random batches: 1-40 sequences of 1-512 tokens, 1 / 2 / 12 / 16 heads, right-padded (pad_len >= the longest, also beyond the
+    512-token kernel limit's neighbourhood) or packed; same tolerance as above."""
+    from ccrec_amd import ops
+    rs = np.random.RandomState(1000 + seed)
+    H = int(rs.choice([1, 2, 12, 16]))
+    n = int(rs.randint(1, 41))
+    top = int(rs.choice([8, 33, 70, 130, 200, 260, 512]))
+    lens = [int(v) for v in rs.randint(1, top + 1, n)]
+    L = max(lens)
+    padded = bool(rs.randint(0, 2))
+    if padded:
+        pad = min(512, L + int(rs.randint(0, 20)))
+        starts = [i * pad for i in range(n)]
+        T = pad * n
+    else:
+        pad = 0
+        starts = [int(v) for v in np.cumsum([0] + lens[:-1])]
+        T = sum(lens)
+    torch.manual_seed(seed)
+    qkv = (torch.randn(T, 3 * H * 64, device="cuda") * float(rs.choice([0.5, 1.5, 3.0]))).to(torch.bfloat16)
+    out = torch.full((T, H * 64), -3.0, dtype=torch.bfloat16, device="cuda")
+    ops.attention(qkv, torch.tensor(starts, dtype=torch.int32, device="cuda"), torch.tensor(lens, dtype=torch.int32, device="cuda"),
+                  H, max_len=L, pad_len=pad, out=out)
+    ref = _attention_reference(qkv, starts, lens, H)
+    got = out.float()
+    for s0, m in zip(starts, lens):
+        torch.testing.assert_close(got[s0:s0 + m], ref[s0:s0 + m], atol=1.5e-2, rtol=1.6e-2)
+        if padded:
+            assert (got[s0 + m:s0 + pad] == 0).all()
+
+
 def test_attention_rejects_bad_shapes():
     from ccrec_amd import ops, _lib
     qkv = torch.zeros(16, 3 * 64, dtype=torch.bfloat16, device="cuda")
