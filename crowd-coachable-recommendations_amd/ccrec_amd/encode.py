@@ -182,16 +182,14 @@ class LengthSortedEncoder:
         self._workers = None
         self.stats = {}
         # fused: run the encoder layer by layer on this library's attention / add + LayerNorm kernels (fused_bert.FusedBertEncoder)
-        # instead of the torch module.  "auto": whenever the model is one the kernels cover (a BertModel with 64-wide heads ...);
-        # True: required (ValueError otherwise); False: always the module's own forward.
-        self._fused = None
-        if fused:
-            from .fused_bert import FusedBertEncoder, unsupported_reason
-            reason = unsupported_reason(tower.cls_model)
-            if reason is None:
-                self._fused = FusedBertEncoder(tower.cls_model)
-            elif fused is True:
-                raise ValueError(f"LengthSortedEncoder(fused=True): {reason}")
+        # instead of the torch module.  "auto": whenever the model is one the kernels cover (a BertModel with 64-wide heads ...) AND the
+        # caller asks for reduced precision (an autocast context around encode(), or CCREC_FUSED_ENCODER=1: fused_bert.wanted);
+        # True: required (ValueError if the model is not covered); False: always the module's own forward.
+        from . import fused_bert
+        self.fused = fused if fused in (True, False) else "auto"
+        self._fused = fused_bert.for_model(tower.cls_model) if self.fused is not False else None
+        if self.fused is True and self._fused is None:
+            raise ValueError(f"LengthSortedEncoder(fused=True): {fused_bert.unsupported_reason(tower.cls_model)}")
 
     def close(self):
         if self._workers is not None:
@@ -247,13 +245,15 @@ class LengthSortedEncoder:
         tower = self.tower
         tower.eval()
         device = tower.cls_model.device
-        if self._fused is not None:
-            self._fused.refresh()     # bf16 weight copies follow the module (fine-tuning between two ranking steps)
+        from . import fused_bert
+        fused = self._fused if (self._fused is not None and fused_bert.wanted(self.fused)) else None
+        if fused is not None:
+            fused.refresh()     # bf16 weight copies follow the module (fine-tuning between two ranking steps)
         texts = texts if isinstance(texts, (list, tuple)) else list(texts)
         n, chunk = len(texts), self.chunk_texts
         st = {"texts": n, "batches": 0, "real_tokens": 0, "padded_tokens": 0, "fixed_length_tokens": n * self.max_length,
               "chunks": (n + chunk - 1) // chunk, "host_prepare_s": 0.0, "gpu_wait_for_host_s": 0.0, "gpu_busy_s": 0.0,
-              "fused_layers": self._fused is not None}
+              "fused_layers": fused is not None}
         wall0 = time.perf_counter()
         spans = []          # (start, end) events of every chunk's GPU work
         if self.host_processes > 0 and self._workers is None and n > chunk:
@@ -289,8 +289,8 @@ class LengthSortedEncoder:
                 e0.record()
                 for idx, ids_t, mask_t, lens_t in batches:
                     inputs = {"input_ids": ids_t.to(device, non_blocking=True), "attention_mask": mask_t.to(device, non_blocking=True)}
-                    if self._fused is not None:
-                        hidden = self._fused.forward(inputs["input_ids"], lens_t.to(device, non_blocking=True))
+                    if fused is not None:
+                        hidden = fused.forward(inputs["input_ids"], lens_t.to(device, non_blocking=True))
                     else:
                         hidden = tower.cls_model(**inputs).last_hidden_state
                     if out is None:

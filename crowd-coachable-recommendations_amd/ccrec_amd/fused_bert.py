@@ -14,6 +14,9 @@ tests compare both with the fp32 forward).  Inference only (eval mode, no dropou
 Only what the kernels cover is accepted (unsupported_reason): a BertModel encoder (post-LayerNorm layers, absolute positions,
 exact GELU), head width 64, hidden size a multiple of 256, at most 512 tokens, right-padded batches.  Every other encoder keeps
 running as its own torch module -- LengthSortedEncoder picks per model."""
+import os
+import weakref
+
 import torch
 import torch.nn.functional as F
 
@@ -39,6 +42,44 @@ def unsupported_reason(model):
     if not hasattr(model, "embeddings") or not hasattr(model, "encoder"):
         return "no embeddings / encoder modules"
     return None
+
+
+def wanted(explicit="auto"):
+    """Should an inference forward take the kernel path?  explicit True / False wins.  "auto": the environment variable
+    CCREC_FUSED_ENCODER (0 / 1) if set; otherwise only inside a CUDA autocast context -- the reference always encodes under
+    torch.cuda.amp.autocast() (scripts/al_0_rank.py:125), and a caller who runs the tower in fp32 gets the fp32 module forward.
+    The kernel path's reduced-precision type is bf16 whatever the autocast dtype says (this build packs bf16 rows anyway)."""
+    if explicit is True or explicit is False:
+        return explicit
+    env = os.environ.get("CCREC_FUSED_ENCODER", "").strip()
+    if env in ("0", "1"):
+        return env == "1"
+    return torch.cuda.is_available() and torch.is_autocast_enabled("cuda")
+
+
+_BY_MODEL = weakref.WeakKeyDictionary()    # BertModel module -> FusedBertEncoder | None (DataParallel replicas are modules of their own)
+
+
+def for_model(model):
+    """The FusedBertEncoder of `model` (one per module object, built on first use), or None if the kernels do not cover it."""
+    try:
+        return _BY_MODEL[model]
+    except KeyError:
+        enc = FusedBertEncoder(model) if unsupported_reason(model) is None else None
+        _BY_MODEL[model] = enc
+        return enc
+
+
+def prefix_lengths(attention_mask):
+    """int32 [B] token counts if every row of the 0/1 mask is ones followed by zeros with at least one token (right padding: what
+    the tokenizers of the reference's models produce); None otherwise.  One small reduction + a host read per batch."""
+    m = attention_mask
+    if m.dim() != 2 or m.shape[1] == 0 or m.shape[1] > 512:
+        return None
+    lengths = m.sum(dim=1)
+    L = m.shape[1]
+    ok = ((m != 0) == (torch.arange(L, device=m.device)[None, :] < lengths[:, None])).all() & (lengths > 0).all()
+    return lengths.to(torch.int32) if bool(ok) else None
 
 
 class _Layer:

@@ -94,7 +94,28 @@ class NaiveItemTower(ItemTowerBase):
 
     def _encode(self, inputs):
         on_model = {name: value.to(self.cls_model.device) for name, value in inputs.items()}
-        return self.cls_model(**on_model).last_hidden_state
+        hidden = self._encode_on_kernels(on_model)
+        return hidden if hidden is not None else self.cls_model(**on_model).last_hidden_state
+
+    def _encode_on_kernels(self, inputs):
+        """Inference forward on the library's layer kernels (fused_bert) when all of this holds: no gradients, eval mode, the
+        caller asks for reduced precision (autocast -- al_0_rank.py:125 -- or CCREC_FUSED_ENCODER=1), the encoder is a BertModel the
+        kernels cover, and the batch is plain right-padded token ids.  None = run the module."""
+        from . import fused_bert
+        if torch.is_grad_enabled() or self.cls_model.training or not fused_bert.wanted("auto"):
+            return None
+        if not set(inputs) <= {"input_ids", "attention_mask", "token_type_ids"} or "input_ids" not in inputs or "attention_mask" not in inputs:
+            return None
+        if not inputs["input_ids"].is_cuda:
+            return None
+        enc = fused_bert.for_model(self.cls_model)
+        if enc is None:
+            return None
+        lengths = fused_bert.prefix_lengths(inputs["attention_mask"])
+        if lengths is None:
+            return None
+        enc.refresh()
+        return enc.forward(inputs["input_ids"], lengths, inputs.get("token_type_ids"))
 
     def forward(self, cls=None, text=None, input_step="inputs", output_step="embedding", **inputs):
         if input_step == "text":

@@ -251,3 +251,59 @@ def test_length_sorted_encoder_runs_the_layer_kernels_and_agrees_with_the_module
     assert LengthSortedEncoder(other, tok, max_length=64)._fused is None
     with pytest.raises(ValueError):
         LengthSortedEncoder(other, tok, max_length=64, fused=True)
+
+
+def test_item_tower_forward_takes_the_kernels_only_under_autocast_with_right_padded_batches(monkeypatch):
+    """The drop-in path (al_0_rank.py:98-101: tower(**tokenizer(texts), output_step=...)) runs the layer kernels when -- and only
+    when -- gradients are off, the model is in eval mode, the caller asked for reduced precision (autocast) and the batch is
+    right-padded; everything else is the module forward, bit for bit."""
+    from ccrec_amd import fused_bert
+    from ccrec_amd.item_tower import NaiveItemTower
+    monkeypatch.delenv("CCREC_FUSED_ENCODER", raising=False)
+    model = _bert(256, 4, 2, 512, seed=5, scale=8.0)
+    tower = NaiveItemTower(model, torch.nn.LayerNorm(256, elementwise_affine=False)).cuda().eval()
+    ids, mask, lengths = _batch([12, 40, 1, 33, 64], 64)
+    calls = []
+    real = fused_bert.FusedBertEncoder.forward
+    monkeypatch.setattr(fused_bert.FusedBertEncoder, "forward", lambda self, *a, **k: (calls.append(1), real(self, *a, **k))[1])
+
+    with torch.no_grad():
+        plain = tower(input_ids=ids, attention_mask=mask, output_step="mean_pooling")          # fp32, no autocast: the module
+        assert not calls
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            fast = tower(input_ids=ids, attention_mask=mask, output_step="mean_pooling")
+            assert len(calls) == 1
+            monkeypatch.setenv("CCREC_FUSED_ENCODER", "0")
+            amp = tower(input_ids=ids, attention_mask=mask, output_step="mean_pooling")        # the module under autocast
+            assert len(calls) == 1
+            monkeypatch.delenv("CCREC_FUSED_ENCODER")
+            # left padding: not a prefix mask -> module forward, same bits as the module run above on the same inputs
+            lmask = torch.flip(mask, dims=[1])
+            lids = torch.flip(ids, dims=[1])
+            tower(input_ids=lids, attention_mask=lmask, output_step="mean_pooling")
+            assert len(calls) == 1
+            # extra model inputs (position_ids) -> module forward
+            tower(input_ids=ids, attention_mask=mask, position_ids=torch.arange(64, device="cuda")[None].expand(5, -1), output_step="mean_pooling")
+            assert len(calls) == 1
+        monkeypatch.setenv("CCREC_FUSED_ENCODER", "1")                                         # forced, also outside autocast
+        forced = tower(input_ids=ids, attention_mask=mask, output_step="mean_pooling")
+        assert len(calls) == 2
+    cos = torch.nn.functional.cosine_similarity
+    assert cos(fast.float(), plain.float(), dim=1).min().item() > 0.9995
+    assert cos(fast.float(), amp.float(), dim=1).min().item() > 0.9995
+    assert torch.equal(forced, fast)
+    # gradients on (the training forward, bbpr.py:130-141): always the module
+    monkeypatch.delenv("CCREC_FUSED_ENCODER")
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = tower(input_ids=ids, attention_mask=mask, output_step="mean_pooling")
+    assert out.requires_grad and len(calls) == 2
+
+
+def test_prefix_lengths():
+    from ccrec_amd.fused_bert import prefix_lengths
+    m = torch.tensor([[1, 1, 0, 0], [1, 1, 1, 1], [1, 0, 0, 0]], device="cuda")
+    assert prefix_lengths(m).tolist() == [2, 4, 1]
+    assert prefix_lengths(torch.tensor([[1, 0, 1, 0]], device="cuda")) is None       # a hole
+    assert prefix_lengths(torch.tensor([[0, 1, 1, 1]], device="cuda")) is None       # left padding
+    assert prefix_lengths(torch.tensor([[0, 0, 0, 0], [1, 1, 0, 0]], device="cuda")) is None   # an empty row
+    assert prefix_lengths(torch.ones(2, 513, dtype=torch.long, device="cuda")) is None
