@@ -301,6 +301,51 @@ def inbatch_side_run(dev, B=1024, d=768, iters=30):
     return out
 
 
+def encode_side_run(dev, texts=16384):
+    """SURVEY 8 f2 beside the search: `texts` synthetic passages (mean 136 tokens, pre-tokenised ids) through a random-init BERT-base
+    under bf16 autocast with the length-sorted encoder -- the encoder layers as torch modules, then on the library's attention /
+    add + LayerNorm kernels (ccrec_amd/fused_bert.py).  GPU seconds from events around the batches; host tokenisation excluded
+    (one chunk, prepared before the GPU starts).  Bounded: ~10 s with the model construction."""
+    import numpy as np
+    try:
+        from transformers import BertConfig, BertModel
+    except Exception as e:      # the encoder itself is the reference's dependency, not this library's
+        return {"skipped": f"transformers not importable: {e}"}
+    from ccrec_amd.encode import LengthSortedEncoder
+    from ccrec_amd.item_tower import NaiveItemTower
+
+    class IdTokenizer:          # texts are id strings: batching + GPU time only
+        pad_token_id = 0
+
+        def __call__(self, texts, truncation=True, padding=False, max_length=200, return_tensors="pt"):
+            ids = [[101] + [int(w) for w in t.split()][: max_length - 2] + [102] for t in texts]
+            return {"input_ids": ids, "attention_mask": [[1] * len(r) for r in ids]}
+
+    rs = np.random.RandomState(0)
+    lens = np.clip(rs.normal(135, 30, texts).astype(int), 20, 198)
+    corpus = [" ".join(map(str, rs.randint(1000, 30000, n))) for n in lens]
+    torch.manual_seed(0)
+    tower = NaiveItemTower(BertModel(BertConfig(vocab_size=30522)).eval(), torch.nn.LayerNorm(768, elementwise_affine=False)).to(dev)
+    out = {"workload": f"{texts} synthetic passages (mean {float(lens.mean()) + 2:.0f} tokens), random-init BERT-base, bf16 autocast, "
+                       "length-sorted batches of <= 65,536 tokens, masked mean pooling + bf16 pack into the shard", "unit": "passages/s (GPU time of the batches)"}
+    rows = {}
+    for name, fused in (("torch_modules", False), ("layer_kernels", True)):
+        enc = LengthSortedEncoder(tower, IdTokenizer(), max_length=200, max_tokens=65536, max_batch=2048, chunk_texts=10 ** 9, fused=fused)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            enc.encode(corpus[:2048])                 # GEMM shapes, library load: untimed
+            f32 = torch.empty(texts, 768, dtype=torch.float32, device=dev)
+            enc.encode(corpus, out_f32=f32)
+        rows[name] = f32
+        out[name] = {"value": round(texts / enc.stats["gpu_busy_s"], 1), "gpu_busy_s": round(enc.stats["gpu_busy_s"], 3),
+                     "batches": enc.stats["batches"], "padded_tokens": enc.stats["padded_tokens"]}
+    cos = torch.nn.functional.cosine_similarity(rows["torch_modules"], rows["layer_kernels"], dim=1)
+    out["speedup"] = round(out["layer_kernels"]["value"] / out["torch_modules"]["value"], 3)
+    out["cosine_of_pooled_rows_min"] = round(float(cos.min()), 6)
+    del rows, tower
+    torch.cuda.empty_cache()
+    return out
+
+
 def roofline_obj(r, traffic=None, traffic_source=None):
     """`achieved` = algorithmic flops of one step's main pass (2 n_q n_rows dim: every launch of the pass covers its share of the
     corpus, together exactly once) / the main pass's duration per step from the library's HIP events on the search stream."""
@@ -481,6 +526,7 @@ def main():
         sec["msmarco_scale"] = ms
         m.release()
         sec["inbatch_b1024"] = inbatch_side_run(dev)
+        sec["encode_passages"] = encode_side_run(dev)
         out["secondary"] = sec
     if rank == 0:
         print(json.dumps(out), flush=True)
