@@ -15,6 +15,7 @@ Only what the kernels cover is accepted (unsupported_reason): a BertModel encode
 exact GELU), head width 64, hidden size a multiple of 256, at most 512 tokens, right-padded batches.  Every other encoder keeps
 running as its own torch module -- LengthSortedEncoder picks per model."""
 import os
+import threading
 import weakref
 
 import torch
@@ -60,14 +61,18 @@ def wanted(explicit="auto"):
 _BY_MODEL = weakref.WeakKeyDictionary()    # BertModel module -> FusedBertEncoder | None (DataParallel replicas are modules of their own)
 
 
+_BY_MODEL_LOCK = threading.Lock()          # DataParallel runs its replicas' forwards on threads
+
+
 def for_model(model):
     """The FusedBertEncoder of `model` (one per module object, built on first use), or None if the kernels do not cover it."""
-    try:
-        return _BY_MODEL[model]
-    except KeyError:
-        enc = FusedBertEncoder(model) if unsupported_reason(model) is None else None
-        _BY_MODEL[model] = enc
-        return enc
+    with _BY_MODEL_LOCK:
+        try:
+            return _BY_MODEL[model]
+        except KeyError:
+            enc = FusedBertEncoder(model) if unsupported_reason(model) is None else None
+            _BY_MODEL[model] = enc
+            return enc
 
 
 def prefix_lengths(attention_mask):

@@ -40,8 +40,8 @@ __host__ __device__ inline size_t attention_lds_bytes(int lk_pad) {
 __global__ __launch_bounds__(ATT_MAX_THREADS) void attention_kernel(const uint16_t *__restrict__ qkv,
                                                                   const int32_t *__restrict__ seq_start,
                                                                   const int32_t *__restrict__ seq_len,
-                                                                  uint16_t *__restrict__ out, int H, int pad_len, int lk_pad,
-                                                                  float scale_log2e) {
+                                                                  uint16_t *__restrict__ out, int H, int pad_len, int max_len,
+                                                                  int lk_pad, float scale_log2e) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int nthreads = blockDim.x;
@@ -50,7 +50,9 @@ __global__ __launch_bounds__(ATT_MAX_THREADS) void attention_kernel(const uint16
     const int nwaves = nthreads >> 6;
     const int wq = (wv + blockIdx.x) % nwaves;   // the wave's first query block rotates with the head: second rounds spread over the SIMDs
     const int b = blockIdx.y, h = blockIdx.x;
-    const int len = seq_len[b];
+    int len = seq_len[b];
+    if (len > max_len) len = max_len;   // the LDS image holds max_len keys: a longer entry is cut (the caller's contract: seq_len <= max_len)
+    if (len < 0) len = 0;
     const int rows = len > pad_len ? len : pad_len;   // rows the sequence occupies in the token arrays (padding rows get zeros)
     const int HD = H * ATT_HEAD;
     const int64_t stride = 3 * (int64_t)HD;
@@ -60,6 +62,14 @@ __global__ __launch_bounds__(ATT_MAX_THREADS) void attention_kernel(const uint16
     const uint16_t *Vg = Qg + 2 * HD;
     uint16_t *Og = out + row0 * HD + h * ATT_HEAD;
     const int ql = lane & 31, g = lane >> 5;
+    if (len == 0) {   // an empty sequence (workgroup-uniform): its padding rows get zeros, nothing is read
+        for (int q = tid; q < rows; q += nthreads) {
+            uint4 *dst = reinterpret_cast<uint4 *>(Og + (int64_t)q * HD);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dst[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        return;
+    }
 
     char *Ks = smem;
     char *Vt = smem + (size_t)lk_pad * ATT_KROW;
@@ -328,7 +338,7 @@ extern "C" int ccr_attention_bf16(const uint16_t *qkv, const int32_t *seq_start,
     if (lk_pad == 192 && waves > 4) waves = 4;
     CCR_REQUIRE(lk_pad * 8 <= ATT_KMAX * 64 * waves && lk_pad * 4 <= ATT_VMAX * 64 * waves, "ccr_attention_bf16: staging bound (internal)");
     hipLaunchKernelGGL(attention_kernel, dim3(n_heads, n_seq), dim3(64 * waves), lds, (hipStream_t)stream, qkv, seq_start, seq_len,
-                       out, n_heads, pad_len, lk_pad, scale * 1.4426950408889634f);
+                       out, n_heads, pad_len, max_len, lk_pad, scale * 1.4426950408889634f);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
 }

@@ -137,7 +137,8 @@ int ccr_meanpool_bwd(const float *grad, const int64_t *mask, void *dhidden, int 
  * ccr_attention_bf16: multi-head self-attention over n_seq sequences of a token array, head width 64.
  *   qkv [T][3 * n_heads * 64] bf16: row t = (Q | K | V) of token t, each n_heads * 64 wide -- the output of ONE projection with
  *     the query / key / value weights stacked (transformers' BertSelfAttention.query / .key / .value);
- *   seq_start [n_seq] int32: first row of sequence s in the token array; seq_len [n_seq] int32 (1 .. max_len): its real tokens
+ *   seq_start [n_seq] int32: first row of sequence s in the token array; seq_len [n_seq] int32 (0 .. max_len; device memory, so the
+ *     kernel itself cuts a larger entry to max_len and treats a negative one as 0): its real tokens
  *     (keys beyond are masked, as attention_mask = 0 is in the reference's inputs, scripts/al_0_rank.py:76-81 padding=True);
  *   out [T][n_heads * 64] bf16: context rows, heads side by side (the operand of BertSelfOutput.dense);
  *   max_len: longest seq_len (<= 512; sizes the LDS image of one head's keys and values);

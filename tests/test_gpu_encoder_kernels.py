@@ -102,6 +102,32 @@ def test_attention_fuzz_against_fp32_reference(seed):
             assert (got[s0 + m:s0 + pad] == 0).all()
 
 
+def test_attention_empty_and_overlong_entries_are_memory_safe():
+    """seq_len lives in device memory, so the kernel guards it itself: 0 (or negative) = an empty sequence whose padding rows get
+    zeros and whose row range is never read; an entry above max_len is cut to max_len (the LDS image holds max_len keys)."""
+    from ccrec_amd import ops
+    H, pad = 2, 40
+    torch.manual_seed(0)
+    qkv = torch.randn(4 * pad, 3 * H * 64, device="cuda").to(torch.bfloat16)
+    start = torch.arange(4, dtype=torch.int32, device="cuda") * pad
+    lens = torch.tensor([0, 17, -3, 40], dtype=torch.int32, device="cuda")
+    out = torch.full((4 * pad, H * 64), 5.0, dtype=torch.bfloat16, device="cuda")
+    ops.attention(qkv, start, lens, H, max_len=40, pad_len=pad, out=out)
+    ref = _attention_reference(qkv, [pad, 3 * pad], [17, 40], H)
+    got = out.float()
+    assert (got[:pad] == 0).all() and (got[2 * pad:3 * pad] == 0).all()
+    torch.testing.assert_close(got[pad:pad + 17], ref[pad:pad + 17], atol=1.5e-2, rtol=1.6e-2)
+    torch.testing.assert_close(got[3 * pad:], ref[3 * pad:], atol=1.5e-2, rtol=1.6e-2)
+    # an entry longer than max_len: attended as its first max_len tokens, no access beyond them
+    lens2 = torch.tensor([40, 17, 40, 40], dtype=torch.int32, device="cuda")
+    out2 = torch.full((4 * pad, H * 64), 5.0, dtype=torch.bfloat16, device="cuda")
+    ops.attention(qkv, start, lens2, H, max_len=24, pad_len=pad, out=out2)
+    ref2 = _attention_reference(qkv, [0, pad, 2 * pad, 3 * pad], [24, 17, 24, 24], H)
+    torch.testing.assert_close(out2.float()[:24], ref2[:24], atol=1.5e-2, rtol=1.6e-2)
+    torch.testing.assert_close(out2.float()[pad:pad + 17], ref2[pad:pad + 17], atol=1.5e-2, rtol=1.6e-2)
+    assert (out2.float()[24:pad] == 0).all()
+
+
 def test_attention_rejects_bad_shapes():
     from ccrec_amd import ops, _lib
     qkv = torch.zeros(16, 3 * 64, dtype=torch.bfloat16, device="cuda")
