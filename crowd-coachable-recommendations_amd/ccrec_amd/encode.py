@@ -290,7 +290,7 @@ class LengthSortedEncoder:
                 for idx, ids_t, mask_t, lens_t in batches:
                     inputs = {"input_ids": ids_t.to(device, non_blocking=True), "attention_mask": mask_t.to(device, non_blocking=True)}
                     if fused is not None:
-                        hidden = fused.forward(inputs["input_ids"], lens_t.to(device, non_blocking=True))
+                        hidden = fused.forward(inputs["input_ids"], lens_t.to(device, non_blocking=True), packed=False)   # length-sorted: < 3 % padding
                     else:
                         hidden = tower.cls_model(**inputs).last_hidden_state
                     if out is None:

@@ -131,9 +131,15 @@ class FusedBertEncoder:
         return True
 
     @torch.no_grad()
-    def forward(self, input_ids, lengths, token_type_ids=None):
+    def forward(self, input_ids, lengths, token_type_ids=None, packed=None, lengths_host=None):
         """input_ids [B, L] int64 (cuda, right-padded), lengths [B] int32 (cuda): real tokens per row, 1 .. L.
-        -> fp32 [B, L, hidden]; rows of padding tokens hold finite values nobody reads (the pooling masks them)."""
+        -> fp32 [B, L, hidden]; rows of padding tokens hold finite values nobody reads (the pooling masks them).
+
+        packed: run the layers on the REAL tokens only (a packed token array: the projections, LayerNorms and GELU skip the
+        padding, the attention kernel takes row offsets + lengths) and scatter the result back into a zero-filled [B, L, hidden].
+        That is what makes the reference-style batches cheap -- corpus-order batches padded to their longest text
+        (scripts/al_0_rank.py:76-81) or to max_length (src/ccrec/models/item_tower.py:27-33) are 30-90 % padding.  None: packed
+        when more than a tenth of the batch is padding (needs the lengths on the host: `lengths_host`, or one device read)."""
         ops.require_gpu()
         model = self.model
         assert not model.training, "FusedBertEncoder is an inference forward: call model.eval() first"
@@ -142,16 +148,36 @@ class FusedBertEncoder:
         assert L <= 512 and lengths.dtype == torch.int32 and lengths.is_cuda and lengths.numel() == B
         if self._layers is None:
             self.refresh()
+        dev = input_ids.device
+        if packed is None or packed:
+            lens_h = lengths.cpu() if lengths_host is None else torch.as_tensor(lengths_host)
+            total, longest = int(lens_h.sum()), int(lens_h.max()) if B else 0
+            if packed is None:
+                packed = total < 0.9 * B * L
         with torch.autocast("cuda", enabled=False):
-            emb = model.embeddings(input_ids=input_ids, token_type_ids=token_type_ids)     # word + position + type, LayerNorm: fp32
-            h = emb.reshape(B * L, self.hidden).float().contiguous()
+            if packed:
+                keep = (torch.arange(L, device=dev)[None, :] < lengths[:, None]).flatten().nonzero().squeeze(1)   # rows of the real tokens
+                assert keep.numel() == total, "lengths_host does not match lengths"
+                ids = input_ids.flatten()[keep][None]
+                types = (torch.zeros_like(ids) if token_type_ids is None else token_type_ids.flatten()[keep][None])
+                emb = model.embeddings(input_ids=ids, token_type_ids=types, position_ids=(keep % L)[None])
+                rows, max_len, pad_len = total, max(longest, 1), 0
+                seq_start = (torch.cumsum(lengths, 0, dtype=torch.int32) - lengths).contiguous()
+            else:
+                emb = model.embeddings(input_ids=input_ids, token_type_ids=token_type_ids)     # word + position + type, LayerNorm: fp32
+                rows, max_len, pad_len = B * L, L, L
+                seq_start = torch.arange(B, dtype=torch.int32, device=dev) * L
+            h = emb.reshape(rows, self.hidden).float().contiguous()
             hb = h.to(torch.bfloat16)
-            seq_start = torch.arange(B, dtype=torch.int32, device=input_ids.device) * L
             last = len(self._layers) - 1
             for i, l in enumerate(self._layers):
                 qkv = F.linear(hb, l.wqkv, l.bqkv)
-                ctx = ops.attention(qkv, seq_start, lengths, self.heads, max_len=L, pad_len=L, scale=0.125)
+                ctx = ops.attention(qkv, seq_start, lengths, self.heads, max_len=max_len, pad_len=pad_len, scale=0.125)
                 h, hb = ops.add_layernorm(F.linear(ctx, l.wo, l.bo), h, l.g1, l.b1, l.eps1)
                 mid = F.gelu(F.linear(hb, l.wi, l.bi))
                 h, hb = ops.add_layernorm(F.linear(mid, l.wo2, l.bo2), h, l.g2, l.b2, l.eps2, want_bf16=i != last)
+            if packed:
+                full = torch.zeros(B * L, self.hidden, dtype=torch.float32, device=dev)
+                full[keep] = h
+                h = full
         return h.view(B, L, self.hidden)

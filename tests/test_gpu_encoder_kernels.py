@@ -333,3 +333,27 @@ def test_prefix_lengths():
     assert prefix_lengths(torch.tensor([[0, 1, 1, 1]], device="cuda")) is None       # left padding
     assert prefix_lengths(torch.tensor([[0, 0, 0, 0], [1, 1, 0, 0]], device="cuda")) is None   # an empty row
     assert prefix_lengths(torch.ones(2, 513, dtype=torch.long, device="cuda")) is None
+
+
+def test_packed_forward_equals_the_padded_forward_on_the_real_tokens():
+    """packed=True runs the layers on the real tokens only and scatters back: same hidden states as the padded forward (GEMM row
+    blocks differ, so to fp32 summation order of a bf16 pipeline: 2 bf16 ulps of the LayerNorm-scale values), zeros on padding;
+    packed=None picks it for a batch that is mostly padding."""
+    from ccrec_amd.fused_bert import FusedBertEncoder
+    model = _bert(256, 4, 2, 512, seed=11, scale=10.0)
+    enc = FusedBertEncoder(model)
+    lens = [3, 60, 1, 17, 33, 9]
+    ids, mask, lengths = _batch(lens, 64)
+    types = torch.zeros_like(ids)
+    types[:, 5:] = 1
+    for tt in (None, types):
+        a = enc.forward(ids, lengths, token_type_ids=tt, packed=False)
+        b = enc.forward(ids, lengths, token_type_ids=tt, packed=True)
+        c = enc.forward(ids, lengths, token_type_ids=tt, lengths_host=lens)           # 123 of 384 tokens are real: packed
+        live = mask.bool()
+        torch.testing.assert_close(b[live], a[live], atol=3e-2, rtol=2e-2)
+        assert torch.nn.functional.cosine_similarity(b[live], a[live], dim=-1).min().item() > 0.9995
+        assert (b[~live] == 0).all() and torch.equal(b, c)
+    with torch.no_grad():
+        ref = model(input_ids=ids, attention_mask=mask, token_type_ids=types).last_hidden_state
+    assert (b - ref)[live].abs().max().item() < 6e-2
