@@ -180,6 +180,7 @@ class LengthSortedEncoder:
         # building of the tokenizer's results no longer competes for the GIL with the thread that launches the GPU kernels
         self.host_processes = int(host_processes) if self._backend is not None else 0
         self._workers = None
+        self._packed_batches = False
         self.stats = {}
         # fused: run the encoder layer by layer on this library's attention / add + LayerNorm kernels (fused_bert.FusedBertEncoder)
         # instead of the torch module.  "auto": whenever the model is one the kernels cover (a BertModel with 64-wide heads ...) AND the
@@ -217,9 +218,28 @@ class LengthSortedEncoder:
         lens_t.numpy()[:] = lens
         return ids_t, mask_t, lens_t
 
+    def _batch_arrays_packed(self, flat, lengths, starts, idx, padded):
+        """One batch as a PACKED token array for the kernel forward (fused_bert.forward_packed): token ids and in-sequence positions
+        [T] int64, sequence starts / token counts [B] int32 (host, pinned when a GPU is present), and the longest sequence."""
+        lens = lengths[idx].astype(np.int64)
+        pin = torch.cuda.is_available()
+        total = int(lens.sum())
+        first = np.cumsum(lens) - lens
+        c_of = np.arange(total, dtype=np.int64) - np.repeat(first, lens)
+        ids_t = torch.empty(total, dtype=torch.int64, pin_memory=pin)
+        pos_t = torch.empty(total, dtype=torch.int64, pin_memory=pin)
+        ids_t.numpy()[:] = flat[np.repeat(starts[idx], lens) + c_of]
+        pos_t.numpy()[:] = c_of
+        start_t = torch.empty(len(idx), dtype=torch.int32, pin_memory=pin)
+        lens_t = torch.empty(len(idx), dtype=torch.int32, pin_memory=pin)
+        start_t.numpy()[:] = first
+        lens_t.numpy()[:] = lens
+        return ids_t, pos_t, start_t, lens_t, int(lens.max())
+
     def _prepare(self, texts):
         """Host side of one chunk: tokenise without padding, plan length-sorted batches, build their padded arrays.
-        -> (batches [(index array, ids, mask, token counts)], real tokens, padded tokens, seconds spent)."""
+        -> (batches [(index array, ids, mask, token counts)] -- or [(index array, *_batch_arrays_packed)] for the kernel forward --,
+        real tokens, padded tokens, seconds spent)."""
         import time
         t0 = time.perf_counter()
         if self._workers is not None:
@@ -228,7 +248,8 @@ class LengthSortedEncoder:
         else:
             flat, lengths, starts = _flatten(_tokenize_unpadded(self.tokenizer, texts, self.max_length, self._backend))
         plan = plan_batches(lengths, self.max_tokens, self.max_batch, self.pad_multiple) if lengths.size else []
-        batches = [(idx, *self._batch_arrays(flat, lengths, starts, idx, padded)) for idx, padded in plan]
+        build = self._batch_arrays_packed if self._packed_batches else self._batch_arrays
+        batches = [(idx, *build(flat, lengths, starts, idx, padded)) for idx, padded in plan]
         return batches, int(lengths.sum()), int(sum(len(idx) * pl for idx, pl in plan)), time.perf_counter() - t0
 
     @torch.no_grad()
@@ -249,6 +270,7 @@ class LengthSortedEncoder:
         fused = self._fused if (self._fused is not None and fused_bert.wanted(self.fused)) else None
         if fused is not None:
             fused.refresh()     # bf16 weight copies follow the module (fine-tuning between two ranking steps)
+        self._packed_batches = fused is not None     # the kernel forward takes packed token arrays: no padding row is ever computed
         texts = texts if isinstance(texts, (list, tuple)) else list(texts)
         n, chunk = len(texts), self.chunk_texts
         st = {"texts": n, "batches": 0, "real_tokens": 0, "padded_tokens": 0, "fixed_length_tokens": n * self.max_length,
@@ -287,20 +309,32 @@ class LengthSortedEncoder:
                 st["host_prepare_s"] += secs
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                for idx, ids_t, mask_t, lens_t in batches:
-                    inputs = {"input_ids": ids_t.to(device, non_blocking=True), "attention_mask": mask_t.to(device, non_blocking=True)}
-                    if fused is not None:
-                        hidden = fused.forward(inputs["input_ids"], lens_t.to(device, non_blocking=True), packed=False)   # length-sorted: < 3 % padding
-                    else:
-                        hidden = tower.cls_model(**inputs).last_hidden_state
-                    if out is None:
-                        out = torch.empty(n + row_offset, hidden.shape[-1], dtype=torch.bfloat16, device=hidden.device)
+                for idx, *arrays in batches:
                     rows = torch.as_tensor(np.asarray(idx, dtype=np.int64) + int(row_offset) + c0)
-                    mask = inputs["attention_mask"]
+                    if fused is not None:
+                        ids_t, pos_t, start_t, lens_t, longest = arrays
+                        seq_start, seq_len = start_t.to(device, non_blocking=True), lens_t.to(device, non_blocking=True)
+                        hidden = fused.forward_packed(ids_t.to(device, non_blocking=True), pos_t.to(device, non_blocking=True),
+                                                      seq_start, seq_len, longest)                       # [T, dim] fp32
+                        if out is None:
+                            out = torch.empty(n + row_offset, hidden.shape[-1], dtype=torch.bfloat16, device=hidden.device)
+                        if self.output_step == "mean_pooling":
+                            ops.meanpool_pack_packed(hidden, seq_start, seq_len, normalize=(sim == "cos"), out_bf16=out, out_f32=out_f32,
+                                                     dst_rows=rows, norm_bounds=norm_bounds)
+                            continue
+                        first = hidden[seq_start.long()]                                                   # the CLS rows
+                        mask = torch.ones(len(idx), 1, dtype=torch.int64, device=device)
+                    else:
+                        ids_t, mask_t, lens_t = arrays
+                        inputs = {"input_ids": ids_t.to(device, non_blocking=True), "attention_mask": mask_t.to(device, non_blocking=True)}
+                        hidden = tower.cls_model(**inputs).last_hidden_state
+                        if out is None:
+                            out = torch.empty(n + row_offset, hidden.shape[-1], dtype=torch.bfloat16, device=hidden.device)
+                        mask = inputs["attention_mask"]
+                        first = hidden[:, 0]
                     if self.output_step != "mean_pooling":
                         # CLS-type outputs through the same scatter + pack kernel: a one-token "sequence" [B, 1, dim] with a mask
                         # of ones pools to the row itself (sum of one element / 1)
-                        first = hidden[:, 0]
                         if self.output_step == "mean_layer_norm":
                             first = tower.standard_layer_norm(first)
                         hidden, mask = first.unsqueeze(1).contiguous(), mask[:, :1]

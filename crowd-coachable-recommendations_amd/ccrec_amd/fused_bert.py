@@ -130,6 +130,34 @@ class FusedBertEncoder:
         self._layers, self._signature = layers, sig
         return True
 
+    def _layers_forward(self, emb, seq_start, lengths, max_len, pad_len):
+        """The encoder layers over token rows emb [T, hidden] fp32 (sequence s = rows seq_start[s] ..) -> last hidden state [T, hidden] fp32."""
+        h = emb.float().contiguous()
+        hb = h.to(torch.bfloat16)
+        last = len(self._layers) - 1
+        for i, l in enumerate(self._layers):
+            qkv = F.linear(hb, l.wqkv, l.bqkv)
+            ctx = ops.attention(qkv, seq_start, lengths, self.heads, max_len=max_len, pad_len=pad_len, scale=0.125)
+            h, hb = ops.add_layernorm(F.linear(ctx, l.wo, l.bo), h, l.g1, l.b1, l.eps1)
+            mid = F.gelu(F.linear(hb, l.wi, l.bi))
+            h, hb = ops.add_layernorm(F.linear(mid, l.wo2, l.bo2), h, l.g2, l.b2, l.eps2, want_bf16=i != last)
+        return h
+
+    @torch.no_grad()
+    def forward_packed(self, token_ids, positions, seq_start, lengths, max_len, token_type_ids=None):
+        """The forward over a packed token array that the caller built itself (no padded batch ever exists): token_ids / positions
+        [T] int64 (position of each token inside its sequence), seq_start / lengths [n_seq] int32 (cuda), max_len = the longest
+        sequence (host int).  -> fp32 [T, hidden]; pool it with ops.meanpool_pack_packed."""
+        ops.require_gpu()
+        assert not self.model.training, "FusedBertEncoder is an inference forward: call model.eval() first"
+        assert token_ids.is_cuda and token_ids.dim() == 1 and positions.shape == token_ids.shape and 1 <= int(max_len) <= 512
+        if self._layers is None:
+            self.refresh()
+        with torch.autocast("cuda", enabled=False):
+            types = torch.zeros_like(token_ids) if token_type_ids is None else token_type_ids
+            emb = self.model.embeddings(input_ids=token_ids[None], token_type_ids=types[None], position_ids=positions[None])
+            return self._layers_forward(emb.reshape(token_ids.numel(), self.hidden), seq_start, lengths, int(max_len), 0)
+
     @torch.no_grad()
     def forward(self, input_ids, lengths, token_type_ids=None, packed=None, lengths_host=None):
         """input_ids [B, L] int64 (cuda, right-padded), lengths [B] int32 (cuda): real tokens per row, 1 .. L.
@@ -167,15 +195,7 @@ class FusedBertEncoder:
                 emb = model.embeddings(input_ids=input_ids, token_type_ids=token_type_ids)     # word + position + type, LayerNorm: fp32
                 rows, max_len, pad_len = B * L, L, L
                 seq_start = torch.arange(B, dtype=torch.int32, device=dev) * L
-            h = emb.reshape(rows, self.hidden).float().contiguous()
-            hb = h.to(torch.bfloat16)
-            last = len(self._layers) - 1
-            for i, l in enumerate(self._layers):
-                qkv = F.linear(hb, l.wqkv, l.bqkv)
-                ctx = ops.attention(qkv, seq_start, lengths, self.heads, max_len=max_len, pad_len=pad_len, scale=0.125)
-                h, hb = ops.add_layernorm(F.linear(ctx, l.wo, l.bo), h, l.g1, l.b1, l.eps1)
-                mid = F.gelu(F.linear(hb, l.wi, l.bi))
-                h, hb = ops.add_layernorm(F.linear(mid, l.wo2, l.bo2), h, l.g2, l.b2, l.eps2, want_bf16=i != last)
+            h = self._layers_forward(emb.reshape(rows, self.hidden), seq_start, lengths, max_len, pad_len)
             if packed:
                 full = torch.zeros(B * L, self.hidden, dtype=torch.float32, device=dev)
                 full[keep] = h

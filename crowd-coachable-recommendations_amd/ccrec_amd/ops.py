@@ -109,6 +109,32 @@ def meanpool_pack(hidden, mask, normalize=False, want_f32=True, want_bf16=True, 
     return f32, b16
 
 
+def meanpool_pack_packed(hidden, seq_start, seq_len, normalize=False, out_bf16=None, out_f32=None, dst_rows=None, norm_bounds=None):
+    """meanpool_pack for a packed token array: hidden [T, dim], sequence s = rows seq_start[s] .. + seq_len[s] - 1 (int32 cuda
+    tensors).  Writes into out_bf16 / out_f32 ([rows, dim], at dst_rows or rows 0 .. n_seq - 1); returns (out_f32, out_bf16)."""
+    lib = require_gpu()
+    assert hidden.is_cuda and hidden.dim() == 2 and hidden.dtype in _DTYPES and hidden.is_contiguous()
+    n_seq, dim = seq_len.numel(), hidden.shape[1]
+    for t in (seq_start, seq_len):
+        assert t.is_cuda and t.dtype == torch.int32 and t.is_contiguous() and t.numel() == n_seq
+    if out_bf16 is None and out_f32 is None:
+        out_bf16 = torch.empty(n_seq, dim, dtype=torch.bfloat16, device=hidden.device)
+    for t, dt in ((out_f32, torch.float32), (out_bf16, torch.bfloat16)):
+        if t is not None:
+            assert t.is_cuda and t.dtype == dt and t.dim() == 2 and t.shape[1] == dim and t.is_contiguous()
+            assert dst_rows is not None or t.shape[0] >= n_seq
+    if dst_rows is not None:
+        dst_rows = dst_rows.to(device=hidden.device, dtype=torch.int64).contiguous()
+        assert dst_rows.numel() == n_seq
+    if norm_bounds is not None:
+        _check_bounds(norm_bounds, out_bf16.shape[0] if (out_bf16 is not None and dst_rows is not None) else n_seq)
+    with _on(hidden):
+        _lib.check(lib.ccr_meanpool_pack_bf16_packed(_ptr(hidden), _DTYPES[hidden.dtype], _ptr(seq_start), _ptr(seq_len), _ptr(out_bf16),
+                                                     _ptr(out_f32), _ptr(dst_rows), _ptr(norm_bounds), n_seq, dim, int(bool(normalize)),
+                                                     _stream(hidden)), "ccr_meanpool_pack_bf16_packed")
+    return out_f32, out_bf16
+
+
 class _MeanPool(torch.autograd.Function):
     """Differentiable masked mean pooling (item_tower.py:141-146): forward = the fused pooling kernel (fp32 rows),
     backward = ccr_meanpool_bwd (grad / count broadcast over the unmasked tokens)."""

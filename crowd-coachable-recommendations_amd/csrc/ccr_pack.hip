@@ -224,14 +224,21 @@ __global__ __launch_bounds__(256) void meanpool_pack_kernel(const T *__restrict_
                                                            __bf16 *__restrict__ dst_bf16,
                                                            float *__restrict__ dst_f32, int L, int dim,
                                                            int normalize, const int64_t *__restrict__ dst_rows,
-                                                           float *__restrict__ bounds) {
+                                                           float *__restrict__ bounds,
+                                                           const int32_t *__restrict__ seq_start,
+                                                           const int32_t *__restrict__ seq_len) {
     __shared__ double red[4];
     __shared__ float redf[4];
     const int b = blockIdx.x;
+    // packed token array (seq_start != NULL): sequence b is rows seq_start[b] .. + seq_len[b] - 1 of hidden [T][dim], every one a
+    // real token; the sum runs over them in the same order as over the unmasked positions of the padded form: same bits
+    const bool packed = seq_start != nullptr;
+    if (packed) L = seq_len[b] > 0 ? seq_len[b] : 0;
+    const int64_t first_row = packed ? (int64_t)seq_start[b] : (int64_t)b * L;
     const int64_t ob = dst_rows ? dst_rows[b] : (int64_t)b;   // destination row (length-sorted batches scatter back)
     const int tid = threadIdx.x;
     const int nchunk = dim >> 2;
-    const int64_t *m = mask + (int64_t)b * L;
+    const int64_t *m = packed ? nullptr : mask + (int64_t)b * L;
     // pass 1: pooled fp32 value per owned chunk, kept in registers (<= 4 chunks per thread for dim <= 4096).
     // Every thread walks the whole mask row anyway, so it counts the tokens itself (no serial pre-pass, no barrier);
     // 8 token positions are loaded unconditionally and masked with an AND (a masked value becomes +0.0, and x + (+0.0) == x
@@ -242,7 +249,7 @@ __global__ __launch_bounds__(256) void meanpool_pack_kernel(const T *__restrict_
     float inv_is_div = 1.f;
     for (int c = tid; c < nchunk && nown < 4; c += blockDim.x, ++nown) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        const T *h = hidden + (int64_t)b * L * dim + 4 * c;
+        const T *h = hidden + first_row * dim + 4 * c;
         long long cnt = 0;
         for (int l0 = 0; l0 < L; l0 += 8) {
             uint32_t keep[8];
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(256) void meanpool_pack_kernel(const T *__restrict_
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int l = l0 + u < L ? l0 + u : L - 1;
-                const long long mv = m[l];
+                const long long mv = packed ? 1 : m[l];
                 cnt += (l0 + u < L) ? mv : 0;            // the reference divides by mask.sum(1) (item_tower.py:145)
                 keep[u] = (l0 + u < L && mv != 0) ? 0xffffffffu : 0u;
                 v[u] = load4<T>(h + (int64_t)l * dim);
@@ -483,18 +490,50 @@ extern "C" int ccr_meanpool_pack_bf16_ex(const void *hidden, int hidden_dtype, c
     switch (hidden_dtype) {
         case CCR_DTYPE_F32:
             hipLaunchKernelGGL(meanpool_pack_kernel<float>, dim3(B), dim3(threads), 0, s, (const float *)hidden, mask, db,
-                               dst_f32, L, dim, normalize, dst_rows, mb);
+                               dst_f32, L, dim, normalize, dst_rows, mb, (const int32_t *)nullptr, (const int32_t *)nullptr);
             break;
         case CCR_DTYPE_F16:
             hipLaunchKernelGGL(meanpool_pack_kernel<_Float16>, dim3(B), dim3(threads), 0, s, (const _Float16 *)hidden,
-                               mask, db, dst_f32, L, dim, normalize, dst_rows, mb);
+                               mask, db, dst_f32, L, dim, normalize, dst_rows, mb, (const int32_t *)nullptr, (const int32_t *)nullptr);
             break;
         case CCR_DTYPE_BF16:
             hipLaunchKernelGGL(meanpool_pack_kernel<__bf16>, dim3(B), dim3(threads), 0, s, (const __bf16 *)hidden, mask,
-                               db, dst_f32, L, dim, normalize, dst_rows, mb);
+                               db, dst_f32, L, dim, normalize, dst_rows, mb, (const int32_t *)nullptr, (const int32_t *)nullptr);
             break;
         default:
             set_error("ccr_meanpool_pack_bf16: unknown hidden_dtype %d", hidden_dtype);
+            return CCR_ERR_INVALID;
+    }
+    CCR_LAUNCH_CHECK();
+    return CCR_OK;
+}
+
+extern "C" int ccr_meanpool_pack_bf16_packed(const void *hidden, int hidden_dtype, const int32_t *seq_start, const int32_t *seq_len,
+                                             uint16_t *dst_bf16, float *dst_f32, const int64_t *dst_rows, float *row_norm_bounds,
+                                             int n_seq, int dim, int normalize, void *stream) {
+    CCR_REQUIRE(hidden && seq_start && seq_len && (dst_bf16 || dst_f32), "ccr_meanpool_pack_bf16_packed: null pointer");
+    CCR_REQUIRE(n_seq >= 0 && dim > 0 && dim % 4 == 0 && dim <= 4096,
+                "ccr_meanpool_pack_bf16_packed: bad shape n_seq=%d dim=%d (dim %% 4 == 0, dim <= 4096)", n_seq, dim);
+    if (n_seq == 0) return CCR_OK;
+    hipStream_t s = (hipStream_t)stream;
+    int threads = ((dim / 4 + 63) / 64) * 64;
+    if (threads > 256) threads = 256;
+    __bf16 *db = reinterpret_cast<__bf16 *>(dst_bf16);
+    switch (hidden_dtype) {
+        case CCR_DTYPE_F32:
+            hipLaunchKernelGGL(meanpool_pack_kernel<float>, dim3(n_seq), dim3(threads), 0, s, (const float *)hidden, nullptr, db,
+                               dst_f32, 0, dim, normalize, dst_rows, row_norm_bounds, seq_start, seq_len);
+            break;
+        case CCR_DTYPE_F16:
+            hipLaunchKernelGGL(meanpool_pack_kernel<_Float16>, dim3(n_seq), dim3(threads), 0, s, (const _Float16 *)hidden, nullptr,
+                               db, dst_f32, 0, dim, normalize, dst_rows, row_norm_bounds, seq_start, seq_len);
+            break;
+        case CCR_DTYPE_BF16:
+            hipLaunchKernelGGL(meanpool_pack_kernel<__bf16>, dim3(n_seq), dim3(threads), 0, s, (const __bf16 *)hidden, nullptr, db,
+                               dst_f32, 0, dim, normalize, dst_rows, row_norm_bounds, seq_start, seq_len);
+            break;
+        default:
+            set_error("ccr_meanpool_pack_bf16_packed: unknown hidden_dtype %d", hidden_dtype);
             return CCR_ERR_INVALID;
     }
     CCR_LAUNCH_CHECK();

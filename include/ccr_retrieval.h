@@ -121,6 +121,13 @@ int ccr_meanpool_pack_bf16_ex(const void *hidden, int hidden_dtype, const int64_
                               float *dst_f32, const int64_t *dst_rows, float *row_norm_bounds, int B, int L, int dim,
                               int normalize, void *stream);
 
+/* Same for a PACKED token array (the kernel forward of the encoder layers runs on the real tokens only: no padding rows exist):
+ *   hidden [T][dim]; sequence s is rows seq_start[s] .. seq_start[s] + seq_len[s] - 1 (int32 device arrays, as ccr_attention_bf16).
+ * The sum runs over a sequence's tokens in order -- the same bits as the padded form gives for the same hidden states. */
+int ccr_meanpool_pack_bf16_packed(const void *hidden, int hidden_dtype, const int32_t *seq_start, const int32_t *seq_len,
+                                  uint16_t *dst_bf16, float *dst_f32, const int64_t *dst_rows, float *row_norm_bounds, int n_seq,
+                                  int dim, int normalize, void *stream);
+
 /* Backward of the pooling for the training forward (the reference's tower is called with gradients on in
  * src/ccrec/models/bbpr.py:130-141,195-197): dhidden[b][l][:] = mask[b][l] ? grad[b][:] / sum(mask[b]) : 0.
  *   grad [B][dim] fp32 (gradient w.r.t. the un-normalised pooled rows), dhidden [B][L][dim] of hidden_dtype. */

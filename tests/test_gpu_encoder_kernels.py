@@ -357,3 +357,39 @@ def test_packed_forward_equals_the_padded_forward_on_the_real_tokens():
     with torch.no_grad():
         ref = model(input_ids=ids, attention_mask=mask, token_type_ids=types).last_hidden_state
     assert (b - ref)[live].abs().max().item() < 6e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("normalize", [False, True])
+def test_packed_pooling_gives_the_padded_pooling_bits(dtype, normalize):
+    """ccr_meanpool_pack_bf16_packed over a packed token array == ccr_meanpool_pack_bf16_ex over the same tokens in a right-padded
+    [B, L, dim] batch, bit for bit (fp32 rows, bf16 rows, norm bounds, scattered destination rows)."""
+    from ccrec_amd import ops
+    torch.manual_seed(3)
+    lens = [5, 1, 24, 17, 9, 24]
+    B, L, d = len(lens), 24, 768
+    padded = torch.zeros(B, L, d, device="cuda", dtype=dtype)
+    mask = torch.zeros(B, L, dtype=torch.int64, device="cuda")
+    pieces = []
+    for b, n in enumerate(lens):
+        x = (torch.randn(n, d, device="cuda") * 0.4).to(dtype)
+        padded[b, :n] = x
+        mask[b, :n] = 1
+        pieces.append(x)
+    packed = torch.cat(pieces).contiguous()
+    seq_len = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    seq_start = (torch.cumsum(seq_len, 0, dtype=torch.int32) - seq_len).contiguous()
+    rows = torch.tensor([7, 0, 3, 9, 1, 4], device="cuda")
+    outs = []
+    for form in ("padded", "packed"):
+        b16 = torch.zeros(10, d, dtype=torch.bfloat16, device="cuda")
+        f32 = torch.zeros(10, d, dtype=torch.float32, device="cuda")
+        nb = torch.zeros(10, dtype=torch.float32, device="cuda")
+        if form == "padded":
+            ops.meanpool_pack(padded, mask, normalize=normalize, out_bf16=b16, out_f32=f32, dst_rows=rows, norm_bounds=nb)
+        else:
+            ops.meanpool_pack_packed(packed, seq_start, seq_len, normalize=normalize, out_bf16=b16, out_f32=f32, dst_rows=rows, norm_bounds=nb)
+        outs.append((b16, f32, nb))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert outs[0][1][7].abs().sum().item() > 0
