@@ -526,7 +526,10 @@ def main():
         sec["msmarco_scale"] = ms
         m.release()
         sec["inbatch_b1024"] = inbatch_side_run(dev)
-        sec["encode_passages"] = encode_side_run(dev)
+        try:
+            sec["encode_passages"] = encode_side_run(dev)
+        except Exception as e:      # a side run must never cost the line its headline
+            sec["encode_passages"] = {"skipped": f"{type(e).__name__}: {e}"}
         out["secondary"] = sec
     if rank == 0:
         print(json.dumps(out), flush=True)
