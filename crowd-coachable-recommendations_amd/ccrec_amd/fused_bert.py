@@ -130,10 +130,22 @@ class FusedBertEncoder:
         self._layers, self._signature = layers, sig
         return True
 
-    def _layers_forward(self, emb, seq_start, lengths, max_len, pad_len):
-        """The encoder layers over token rows emb [T, hidden] fp32 (sequence s = rows seq_start[s] ..) -> last hidden state [T, hidden] fp32."""
-        h = emb.float().contiguous()
-        hb = h.to(torch.bfloat16)
+    def _embed(self, token_ids, positions, token_types):
+        """The embedding block (BertEmbeddings.forward: word + type + position, LayerNorm) over flat int64 index vectors [T] ->
+        (fp32 [T, hidden], its bf16 copy): one kernel on the module's own fp32 tables (ccr_embed_layernorm), or the module itself
+        when its tables are not plain fp32 (a quantised / half-precision checkpoint)."""
+        e = self.model.embeddings
+        tables = (e.word_embeddings.weight, e.position_embeddings.weight, e.token_type_embeddings.weight, e.LayerNorm.weight, e.LayerNorm.bias)
+        if all(t.dtype == torch.float32 and t.is_contiguous() for t in tables):
+            return ops.embed_layernorm(tables[0], tables[1], tables[2], token_ids.contiguous(), positions.contiguous(),
+                                       None if token_types is None else token_types.contiguous(), tables[3], tables[4], e.LayerNorm.eps)
+        types = torch.zeros_like(token_ids) if token_types is None else token_types
+        h = e(input_ids=token_ids[None], token_type_ids=types[None], position_ids=positions[None]).reshape(-1, self.hidden).float().contiguous()
+        return h, h.to(torch.bfloat16)
+
+    def _layers_forward(self, h, hb, seq_start, lengths, max_len, pad_len):
+        """The encoder layers over token rows h [T, hidden] fp32 / hb (its bf16 copy); sequence s = rows seq_start[s] .. -> last
+        hidden state [T, hidden] fp32."""
         last = len(self._layers) - 1
         for i, l in enumerate(self._layers):
             qkv = F.linear(hb, l.wqkv, l.bqkv)
@@ -154,9 +166,8 @@ class FusedBertEncoder:
         if self._layers is None:
             self.refresh()
         with torch.autocast("cuda", enabled=False):
-            types = torch.zeros_like(token_ids) if token_type_ids is None else token_type_ids
-            emb = self.model.embeddings(input_ids=token_ids[None], token_type_ids=types[None], position_ids=positions[None])
-            return self._layers_forward(emb.reshape(token_ids.numel(), self.hidden), seq_start, lengths, int(max_len), 0)
+            h, hb = self._embed(token_ids, positions, token_type_ids)
+            return self._layers_forward(h, hb, seq_start, lengths, int(max_len), 0)
 
     @torch.no_grad()
     def forward(self, input_ids, lengths, token_type_ids=None, packed=None, lengths_host=None):
@@ -186,16 +197,15 @@ class FusedBertEncoder:
             if packed:
                 keep = (torch.arange(L, device=dev)[None, :] < lengths[:, None]).flatten().nonzero().squeeze(1)   # rows of the real tokens
                 assert keep.numel() == total, "lengths_host does not match lengths"
-                ids = input_ids.flatten()[keep][None]
-                types = (torch.zeros_like(ids) if token_type_ids is None else token_type_ids.flatten()[keep][None])
-                emb = model.embeddings(input_ids=ids, token_type_ids=types, position_ids=(keep % L)[None])
-                rows, max_len, pad_len = total, max(longest, 1), 0
+                h, hb = self._embed(input_ids.flatten()[keep], keep % L, None if token_type_ids is None else token_type_ids.flatten()[keep])
+                max_len, pad_len = max(longest, 1), 0
                 seq_start = (torch.cumsum(lengths, 0, dtype=torch.int32) - lengths).contiguous()
             else:
-                emb = model.embeddings(input_ids=input_ids, token_type_ids=token_type_ids)     # word + position + type, LayerNorm: fp32
-                rows, max_len, pad_len = B * L, L, L
+                h, hb = self._embed(input_ids.flatten(), torch.arange(L, device=dev).repeat(B),
+                                    None if token_type_ids is None else token_type_ids.flatten())
+                max_len, pad_len = L, L
                 seq_start = torch.arange(B, dtype=torch.int32, device=dev) * L
-            h = self._layers_forward(emb.reshape(rows, self.hidden), seq_start, lengths, max_len, pad_len)
+            h = self._layers_forward(h, hb, seq_start, lengths, max_len, pad_len)
             if packed:
                 full = torch.zeros(B * L, self.hidden, dtype=torch.float32, device=dev)
                 full[keep] = h

@@ -187,6 +187,28 @@ def attention(qkv, seq_start, seq_len, n_heads, max_len, pad_len=0, scale=0.125,
     return out
 
 
+def embed_layernorm(word_table, position_table, type_table, token_ids, positions, token_types, gamma, beta, eps):
+    """LayerNorm((word_table[ids] + type_table[types]) + position_table[positions]) per token (ccr_embed_layernorm): fp32 tables
+    [n, dim], int64 index vectors [T] (token_types may be None = type 0).  -> (fp32 [T, dim], bf16 [T, dim])."""
+    lib = require_gpu()
+    dim = word_table.shape[1]
+    for t in (word_table, position_table, type_table):
+        assert t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.shape[1] == dim and t.is_contiguous()
+    for t in (gamma, beta):
+        assert t.is_cuda and t.dtype == torch.float32 and tuple(t.shape) == (dim,) and t.is_contiguous()
+    T = token_ids.numel()
+    for t in (token_ids, positions) + ((token_types,) if token_types is not None else ()):
+        assert t.is_cuda and t.dtype == torch.int64 and t.dim() == 1 and t.numel() == T and t.is_contiguous()
+    f32 = torch.empty(T, dim, dtype=torch.float32, device=word_table.device)
+    b16 = torch.empty(T, dim, dtype=torch.bfloat16, device=word_table.device)
+    with _on(word_table):
+        _lib.check(lib.ccr_embed_layernorm(_ptr(word_table), word_table.shape[0], _ptr(position_table), position_table.shape[0],
+                                           _ptr(type_table), type_table.shape[0], _ptr(token_ids), _ptr(positions), _ptr(token_types),
+                                           _ptr(gamma), _ptr(beta), float(eps), _ptr(f32), _ptr(b16), T, dim, _stream(word_table)),
+                   "ccr_embed_layernorm")
+    return f32, b16
+
+
 def add_layernorm(x, residual, gamma, beta, eps, want_f32=True, want_bf16=True):
     """LayerNorm(x + residual) * gamma + beta per row (ccr_add_layernorm): x [rows, dim] bf16, residual [rows, dim] fp32 or None,
     gamma / beta [dim] fp32, dim a multiple of 256 (<= 2048).  -> (fp32 rows or None, their bf16 copy or None)."""

@@ -303,6 +303,77 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const uint16_t *__re
     }
 }
 
+// The embedding block of the encoder (transformers BertEmbeddings.forward): (word[id] + type[t]) + position[p] in that order, fp32,
+// then LayerNorm -> the fp32 residual stream and its bf16 copy.  One wave per token; ids outside a table are clamped (memory safety).
+template <int C>
+__global__ __launch_bounds__(256) void embed_layernorm_kernel(const float *__restrict__ word, int64_t vocab,
+                                                             const float *__restrict__ pos_tab, int64_t n_pos,
+                                                             const float *__restrict__ type_tab, int64_t n_types,
+                                                             const int64_t *__restrict__ ids, const int64_t *__restrict__ pos,
+                                                             const int64_t *__restrict__ types, const float *__restrict__ gamma,
+                                                             const float *__restrict__ beta, float eps, float *__restrict__ out_f32,
+                                                             uint16_t *__restrict__ out_bf16, int64_t rows) {
+    constexpr int DIM = 256 * C;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    auto clamp = [](int64_t v, int64_t n) { return v < 0 ? (int64_t)0 : (v >= n ? n - 1 : v); };
+    const float *w = word + clamp(ids[row], vocab) * DIM;
+    const float *p = pos_tab + clamp(pos[row], n_pos) * DIM;
+    const float *t = type_tab + clamp(types ? types[row] : 0, n_types) * DIM;
+    float v[C][4];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int col = 4 * (64 * c + lane);
+        const float4 a = *reinterpret_cast<const float4 *>(w + col);
+        const float4 b = *reinterpret_cast<const float4 *>(t + col);
+        const float4 d = *reinterpret_cast<const float4 *>(p + col);
+        v[c][0] = (a.x + b.x) + d.x;
+        v[c][1] = (a.y + b.y) + d.y;
+        v[c][2] = (a.z + b.z) + d.z;
+        v[c][3] = (a.w + b.w) + d.w;
+        sum += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum * (1.f / DIM);
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = v[c][j] - mean;
+            sq = fmaf(d, d, sq);
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    const float rstd = rsqrtf(sq * (1.f / DIM) + eps);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int col = 4 * (64 * c + lane);
+        const float4 gm = *reinterpret_cast<const float4 *>(gamma + col);
+        const float4 bt = *reinterpret_cast<const float4 *>(beta + col);
+        float4 y;
+        y.x = fmaf((v[c][0] - mean) * rstd, gm.x, bt.x);
+        y.y = fmaf((v[c][1] - mean) * rstd, gm.y, bt.y);
+        y.z = fmaf((v[c][2] - mean) * rstd, gm.z, bt.z);
+        y.w = fmaf((v[c][3] - mean) * rstd, gm.w, bt.w);
+        if (out_f32) *reinterpret_cast<float4 *>(out_f32 + row * DIM + col) = y;
+        if (out_bf16) {
+            union {
+                __bf16 hv[4];
+                uint2 u;
+            } wv;
+            wv.hv[0] = (__bf16)y.x;
+            wv.hv[1] = (__bf16)y.y;
+            wv.hv[2] = (__bf16)y.z;
+            wv.hv[3] = (__bf16)y.w;
+            *reinterpret_cast<uint2 *>(out_bf16 + row * DIM + col) = wv.u;
+        }
+    }
+}
+
 template <int C>
 static int launch_add_layernorm(const uint16_t *x, const float *res, const float *gamma, const float *beta, float eps,
                                 float *out_f32, uint16_t *out_bf16, int64_t rows, hipStream_t s) {
@@ -360,4 +431,38 @@ extern "C" int ccr_add_layernorm(const uint16_t *x_bf16, const float *residual, 
         case 7: return launch_add_layernorm<7>(x_bf16, residual, gamma, beta, eps, out_f32, out_bf16, rows, s);
         default: return launch_add_layernorm<8>(x_bf16, residual, gamma, beta, eps, out_f32, out_bf16, rows, s);
     }
+}
+
+extern "C" int ccr_embed_layernorm(const float *word_table, int64_t vocab, const float *position_table, int64_t n_positions,
+                                   const float *type_table, int64_t n_types, const int64_t *token_ids, const int64_t *positions,
+                                   const int64_t *token_types, const float *gamma, const float *beta, float eps, float *out_f32,
+                                   uint16_t *out_bf16, int64_t rows, int dim, void *stream) {
+    CCR_REQUIRE(word_table && position_table && type_table && token_ids && positions && gamma && beta && (out_f32 || out_bf16),
+                "ccr_embed_layernorm: null pointer");
+    CCR_REQUIRE(vocab > 0 && n_positions > 0 && n_types > 0, "ccr_embed_layernorm: empty table");
+    CCR_REQUIRE(rows >= 0 && dim > 0 && dim % 256 == 0 && dim <= 2048, "ccr_embed_layernorm: rows=%lld dim=%d (dim %% 256 == 0, dim <= 2048)",
+                (long long)rows, dim);
+    if (rows == 0) return CCR_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+#define CCR_EMBED_CASE(C)                                                                                                             \
+    case C:                                                                                                                           \
+        hipLaunchKernelGGL(embed_layernorm_kernel<C>, grid, block, 0, s, word_table, vocab, position_table, n_positions, type_table,   \
+                           n_types, token_ids, positions, token_types, gamma, beta, eps, out_f32, out_bf16, rows);                     \
+        break;
+    switch (dim / 256) {
+        CCR_EMBED_CASE(1)
+        CCR_EMBED_CASE(2)
+        CCR_EMBED_CASE(3)
+        CCR_EMBED_CASE(4)
+        CCR_EMBED_CASE(5)
+        CCR_EMBED_CASE(6)
+        CCR_EMBED_CASE(7)
+        default:
+            hipLaunchKernelGGL(embed_layernorm_kernel<8>, grid, block, 0, s, word_table, vocab, position_table, n_positions, type_table,
+                               n_types, token_ids, positions, token_types, gamma, beta, eps, out_f32, out_bf16, rows);
+    }
+#undef CCR_EMBED_CASE
+    CCR_LAUNCH_CHECK();
+    return CCR_OK;
 }

@@ -156,6 +156,13 @@ int ccr_meanpool_bwd(const float *grad, const int64_t *mask, void *dhidden, int 
  *   x_bf16 [rows][dim] bf16, residual [rows][dim] fp32 or NULL, gamma / beta [dim] fp32, dim % 256 == 0, dim <= 2048;
  *   out_f32 [rows][dim] or NULL (the residual stream), out_bf16 [rows][dim] or NULL (the next projection's operand).
  */
+/* ccr_embed_layernorm: the embedding block in front of the layers (transformers BertEmbeddings.forward): row r =
+ * LayerNorm((word_table[token_ids[r]] + type_table[token_types[r]]) + position_table[positions[r]]) * gamma + beta, fp32 tables
+ * [n][dim], int64 indices (token_types NULL = type 0; an index outside its table is clamped), outputs as ccr_add_layernorm. */
+int ccr_embed_layernorm(const float *word_table, int64_t vocab, const float *position_table, int64_t n_positions,
+                        const float *type_table, int64_t n_types, const int64_t *token_ids, const int64_t *positions,
+                        const int64_t *token_types, const float *gamma, const float *beta, float eps, float *out_f32,
+                        uint16_t *out_bf16, int64_t rows, int dim, void *stream);
 int ccr_attention_bf16(const uint16_t *qkv, const int32_t *seq_start, const int32_t *seq_len, uint16_t *out, int n_seq,
                        int n_heads, int max_len, int pad_len, float scale, void *stream);
 int ccr_add_layernorm(const uint16_t *x_bf16, const float *residual, const float *gamma, const float *beta, float eps,

@@ -393,3 +393,30 @@ def test_packed_pooling_gives_the_padded_pooling_bits(dtype, normalize):
     for a, b in zip(*outs):
         assert torch.equal(a, b)
     assert outs[0][1][7].abs().sum().item() > 0
+
+
+def test_embed_layernorm_gives_the_module_bits():
+    """ccr_embed_layernorm == transformers' BertEmbeddings.forward in eval mode: the same fp32 sum order, LayerNorm to fp32
+    reduction order (2e-5); the bf16 copy is the rounded fp32 row; an index outside its table is clamped, not read."""
+    from ccrec_amd import ops
+    model = _bert(768, 12, 1, 1536, seed=2)
+    e = model.embeddings
+    g = torch.Generator().manual_seed(1)
+    T = 3000
+    ids = torch.randint(0, 600, (T,), generator=g).cuda()
+    pos = torch.randint(0, 512, (T,), generator=g).cuda()
+    types = torch.randint(0, 2, (T,), generator=g).cuda()
+    with torch.no_grad():
+        e.LayerNorm.weight.uniform_(0.5, 1.5)
+        e.LayerNorm.bias.normal_()
+        for tt in (types, None):
+            ref = e(input_ids=ids[None], token_type_ids=(types if tt is not None else torch.zeros_like(ids))[None], position_ids=pos[None])[0]
+            f32, b16 = ops.embed_layernorm(e.word_embeddings.weight, e.position_embeddings.weight, e.token_type_embeddings.weight,
+                                           ids, pos, tt, e.LayerNorm.weight, e.LayerNorm.bias, e.LayerNorm.eps)
+            torch.testing.assert_close(f32, ref, atol=2e-5, rtol=2e-5)
+            assert torch.equal(b16, f32.to(torch.bfloat16))
+        bad = ids.clone()
+        bad[0], bad[1] = 10 ** 9, -5
+        f32, _ = ops.embed_layernorm(e.word_embeddings.weight, e.position_embeddings.weight, e.token_type_embeddings.weight,
+                                     bad, pos, None, e.LayerNorm.weight, e.LayerNorm.bias, e.LayerNorm.eps)
+        assert torch.isfinite(f32).all()
