@@ -16,7 +16,6 @@ exact GELU), head width 64, hidden size a multiple of 256, at most 512 tokens, r
 running as its own torch module -- LengthSortedEncoder picks per model."""
 import os
 import threading
-import weakref
 
 import torch
 import torch.nn.functional as F
@@ -58,21 +57,20 @@ def wanted(explicit="auto"):
     return torch.cuda.is_available() and torch.is_autocast_enabled("cuda")
 
 
-_BY_MODEL = weakref.WeakKeyDictionary()    # BertModel module -> FusedBertEncoder | None (DataParallel replicas are modules of their own)
-
-
-_BY_MODEL_LOCK = threading.Lock()          # DataParallel runs its replicas' forwards on threads
+_SLOT = "_ccr_fused_encoder"        # the encoder lives in its model's __dict__: model <-> encoder is an ordinary cycle the GC collects
+_SLOT_LOCK = threading.Lock()      # DataParallel runs its replicas' forwards on threads
 
 
 def for_model(model):
-    """The FusedBertEncoder of `model` (one per module object, built on first use), or None if the kernels do not cover it."""
-    with _BY_MODEL_LOCK:
-        try:
-            return _BY_MODEL[model]
-        except KeyError:
+    """The FusedBertEncoder of `model` (one per module object, built on first use), or None if the kernels do not cover it.
+    torch's replicate() copies a module's __dict__ shallowly, so a DataParallel replica arrives holding its ORIGINAL's encoder:
+    an encoder that belongs to another module object is replaced by one of the replica's own (its weights sit on the replica's device)."""
+    with _SLOT_LOCK:
+        enc = model.__dict__.get(_SLOT, False)
+        if enc is False or (enc is not None and enc.model is not model):
             enc = FusedBertEncoder(model) if unsupported_reason(model) is None else None
-            _BY_MODEL[model] = enc
-            return enc
+            model.__dict__[_SLOT] = enc
+        return enc
 
 
 def prefix_lengths(attention_mask):
@@ -103,6 +101,13 @@ class FusedBertEncoder:
         self.model = model
         self.heads = int(model.config.num_attention_heads)
         self.hidden = int(model.config.hidden_size)
+        self._layers, self._signature = None, None
+
+    def __getstate__(self):      # pickled with its model (torch.save(model)): without the bf16 weight copies
+        return {"model": self.model, "heads": self.heads, "hidden": self.hidden}
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
         self._layers, self._signature = None, None
 
     def _params_signature(self):

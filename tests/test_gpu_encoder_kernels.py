@@ -420,3 +420,31 @@ def test_embed_layernorm_gives_the_module_bits():
         f32, _ = ops.embed_layernorm(e.word_embeddings.weight, e.position_embeddings.weight, e.token_type_embeddings.weight,
                                      bad, pos, None, e.LayerNorm.weight, e.LayerNorm.bias, e.LayerNorm.eps)
         assert torch.isfinite(f32).all()
+
+
+def test_encoder_slot_follows_replicas_and_does_not_pin_the_model():
+    """fused_bert.for_model keeps the encoder in the model's own __dict__: a shallow copy of the module (what torch's replicate()
+    makes) gets an encoder of its own, a dead model is collectable (no registry holds it), and pickling the model drops the weight copies."""
+    import copy
+    import gc
+    import io
+    import weakref
+    from ccrec_amd import fused_bert
+    model = _bert(256, 4, 1, 512)
+    enc = fused_bert.for_model(model)
+    assert enc is not None and fused_bert.for_model(model) is enc
+    replica = copy.copy(model)                       # __dict__ copied shallowly, as _replicate_for_data_parallel does
+    replica.__dict__ = dict(model.__dict__)
+    assert replica.__dict__["_ccr_fused_encoder"] is enc
+    enc2 = fused_bert.for_model(replica)
+    assert enc2 is not enc and enc2.model is replica and fused_bert.for_model(model) is enc
+    ids, mask, lengths = _batch([5, 9], 16)
+    enc.forward(ids, lengths)
+    buf = io.BytesIO()
+    torch.save(model, buf)
+    assert buf.tell() < 2.5 * sum(p.numel() * 4 for p in model.parameters())      # no bf16 weight copies inside
+    ref = weakref.ref(model)
+    del model, enc, enc2, replica
+    gc.collect()
+    assert ref() is None
+    assert fused_bert.for_model(_bert(256, 8, 1, 512)) is None
