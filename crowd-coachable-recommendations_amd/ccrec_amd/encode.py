@@ -122,8 +122,11 @@ class _TokenizerWorkers:
             lengths = np.frombuffer(self._read(p.stdout, 4 * n), dtype=np.int32)
             t = int.from_bytes(self._read(p.stdout, 8), "little")
             flat = np.frombuffer(self._read(p.stdout, 4 * t), dtype=np.int32)
-        finally:
-            self.free.put(p)
+        except BaseException:
+            p.kill()                 # a worker that failed mid-message is out of step with the protocol: never reuse it
+            self.free.put(p)         # (callers waiting on the queue get it, fail on its closed pipes and raise too -- loudly, not a hang)
+            raise
+        self.free.put(p)
         return flat, lengths.astype(np.int64)
 
     def close(self):
