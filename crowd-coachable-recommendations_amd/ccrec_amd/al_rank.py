@@ -40,14 +40,32 @@ class TextEmbedder:
         return self.runner(**self.tokenizer(texts, **self.tokenizer_kw), output_step=self.output_step)
 
 
-def generate_ranking_profile(model, model_name, corpus, queries, block_dict=None, tokenizer=None):
-    """al_0_rank.py:69-105.  Returns {qid: {pid: score}} in rank order."""
+def generate_ranking_profile(model, model_name, corpus, queries, block_dict=None, tokenizer=None, length_sorted=None):
+    """al_0_rank.py:69-105.  Returns {qid: {pid: score}} in rank order.
+
+    length_sorted (default: the environment variable CCREC_LENGTH_SORTED == "1"): encode through encode.LengthSortedEncoder --
+    texts tokenised once without padding, sorted by length, batched under a token budget, pooled and packed straight into the
+    resident shard (no host copy per batch), the next chunk tokenised while the GPU encodes -- instead of the script's corpus-order
+    batches of 512 padded to their longest text.  Same contract and ranking rule; the embeddings differ from the padded batches'
+    by the encoder's own summation-order noise.  One process per GPU (this process's current device), not DataParallel."""
     if tokenizer is None:   # needs the hub or a local cache; offline callers pass their tokenizer in
         from transformers import AutoTokenizer
         tokenizer = AutoTokenizer.from_pretrained(model_name)
     gpus = list(range(torch.cuda.device_count()))
     tower = unwrap_item_tower(model)
     tower.eval()
+    if length_sorted is None:
+        length_sorted = os.environ.get("CCREC_LENGTH_SORTED", "0") == "1"
+    if length_sorted:
+        from .encode import LengthSortedEncoder, ranking_sharded
+        output_step = os.environ["CCREC_EMBEDDING_TYPE"]
+        if output_step != "mean_pooling":
+            warnings.warn(f"{output_step} != mean_pooling for contriever models")
+        encoder = LengthSortedEncoder(tower.cuda(), tokenizer, max_length=int(os.environ.get("CCREC_MAX_LENGTH", 512)), output_step=output_step)
+        try:
+            return ranking_sharded(corpus, queries, encoder, block_dict=block_dict)
+        finally:
+            encoder.close()
     runner = DataParallel(tower.cuda(), device_ids=gpus).cache_replicas()
     output_step = os.environ["CCREC_EMBEDDING_TYPE"]
     if output_step != "mean_pooling":

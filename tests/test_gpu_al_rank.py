@@ -88,3 +88,44 @@ def test_generate_ranking_profile_end_to_end(tmp_path):
         assert len(p1[q]) == 700
         s32, s16 = np.array(list(prof[q].values())[:5]), np.array(list(p1[q].values())[:5])
         np.testing.assert_allclose(s16, s32, rtol=0.05, atol=0.05)
+
+
+def test_generate_ranking_profile_length_sorted_route_gives_the_same_ranking():
+    """length_sorted=True (CCREC_LENGTH_SORTED=1) encodes through the length-sorted pipeline instead of the script's padded
+    corpus-order batches: same contract (rank-ordered dicts of all 700 passages), same neighbours -- the two routes' scores differ only
+    by the encoder's summation-order noise over different batch shapes, so the top passage agrees for every query and the score
+    vectors agree to 1e-4."""
+    from ccrec_amd.al_rank import generate_ranking_profile
+    os.environ["CCREC_SIM_TYPE"] = "dot"
+    os.environ["CCREC_EMBEDDING_TYPE"] = "mean_pooling"
+    os.environ["CCREC_MAX_LENGTH"] = "32"
+    rs = np.random.RandomState(1)
+    words = [f"w{i}" for i in range(200)]
+    corpus = {f"p{j}": " ".join(rs.choice(words, rs.randint(3, 20))) for j in range(700)}
+    queries = {f"q{i}": " ".join(rs.choice(words, rs.randint(2, 8))) for i in range(9)}
+    block = {q: [f"p{int(j)}" for j in rs.choice(700, 3, replace=False)] for q in queries}
+
+    class UnpaddedToy(ToyTokenizer):      # the length-sorted encoder asks for padding=False
+        def __call__(self, texts, truncation=True, padding=True, max_length=32, return_tensors="pt", **kw):
+            if padding is False:
+                ids = [[1] + [2 + (hash(w) % 500) for w in t.split()][: max_length - 2] + [3] for t in texts]
+                return {"input_ids": ids, "attention_mask": [[1] * len(r) for r in ids]}
+            return super().__call__(texts, truncation, padding, max_length, return_tensors)
+
+    tower, tok = _tower(), UnpaddedToy()
+    a = generate_ranking_profile(tower, "unused", corpus, queries, block_dict=block, tokenizer=tok)
+    b = generate_ranking_profile(tower, "unused", corpus, queries, block_dict=block, tokenizer=tok, length_sorted=True)
+    assert list(a) == list(b) == list(queries)
+    for q in queries:
+        assert len(b[q]) == 700 and set(a[q]) == set(b[q])
+        assert next(iter(a[q])) == next(iter(b[q]))
+        sa = np.array([a[q][p] for p in a[q]], np.float32)
+        sb = np.array([b[q][p] for p in a[q]], np.float32)
+        assert np.abs(sa - sb).max() < 1e-4 * max(1.0, np.abs(sa[sa > -1e5]).max())
+        assert all(b[q][p] == -1e6 for p in block[q])
+    os.environ["CCREC_LENGTH_SORTED"] = "1"
+    try:
+        c = generate_ranking_profile(tower, "unused", corpus, queries, block_dict=block, tokenizer=tok)
+    finally:
+        del os.environ["CCREC_LENGTH_SORTED"]
+    assert all(list(c[q]) == list(b[q]) for q in queries)
