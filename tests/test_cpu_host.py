@@ -424,3 +424,35 @@ def test_a_hung_child_fails_with_stacks_and_kernel_state(tmp_path):
     # a child that exits non-zero (the in-child watchdog's exit path) is a failure with its stderr as well
     with pytest.raises(pytest.fail.Exception, match="exit code 3"):
         run_child_with_evidence([sys.executable, "-c", "import sys; print('boom', file=sys.stderr); sys.exit(3)"], env, tmp_path, "bad", limit=20)
+
+
+def test_kernel_forward_policy_and_coverage_checks_run_without_a_gpu(monkeypatch):
+    """Host logic of ccrec_amd/fused_bert.py: which encoders the layer kernels cover, and when an inference forward may take them
+    (explicit flag > CCREC_FUSED_ENCODER > "inside a CUDA autocast context" -- never on a machine without a GPU by default)."""
+    import torch
+    from transformers import BertConfig, BertModel
+    from ccrec_amd import fused_bert
+
+    def bert(hidden, heads, act="gelu"):
+        return BertModel(BertConfig(vocab_size=50, hidden_size=hidden, num_hidden_layers=1, num_attention_heads=heads,
+                                    intermediate_size=2 * hidden, max_position_embeddings=32, hidden_act=act))
+
+    assert fused_bert.unsupported_reason(bert(256, 4)) is None
+    assert "head width" in fused_bert.unsupported_reason(bert(256, 8))
+    assert "hidden size" in fused_bert.unsupported_reason(bert(192, 3))
+    assert "activation" in fused_bert.unsupported_reason(bert(256, 4, "relu"))
+    assert "not a BertModel" in fused_bert.unsupported_reason(torch.nn.Linear(4, 4))
+    monkeypatch.delenv("CCREC_FUSED_ENCODER", raising=False)
+    assert fused_bert.wanted(True) is True and fused_bert.wanted(False) is False
+    assert fused_bert.wanted("auto") is False                       # no GPU here: never by default
+    monkeypatch.setenv("CCREC_FUSED_ENCODER", "1")
+    assert fused_bert.wanted("auto") is True and fused_bert.wanted(False) is False
+    monkeypatch.setenv("CCREC_FUSED_ENCODER", "0")
+    assert fused_bert.wanted("auto") is False
+    # the encoder object itself refuses to run without the HIP library (no CPU fallback)
+    model = bert(256, 4).eval()
+    enc = fused_bert.for_model(model)
+    assert enc is not None and fused_bert.for_model(model) is enc and fused_bert.for_model(bert(256, 8)) is None
+    from ccrec_amd import _lib
+    with pytest.raises((_lib.CcrError, AssertionError)):
+        enc.forward(torch.zeros(1, 4, dtype=torch.long), torch.ones(1, dtype=torch.int32))
