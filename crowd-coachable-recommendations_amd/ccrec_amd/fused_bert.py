@@ -156,7 +156,7 @@ class FusedBertEncoder:
             qkv = F.linear(hb, l.wqkv, l.bqkv)
             ctx = ops.attention(qkv, seq_start, lengths, self.heads, max_len=max_len, pad_len=pad_len, scale=0.125)
             h, hb = ops.add_layernorm(F.linear(ctx, l.wo, l.bo), h, l.g1, l.b1, l.eps1)
-            mid = F.gelu(F.linear(hb, l.wi, l.bi))
+            mid = ops.gelu_(F.linear(hb, l.wi, l.bi))      # exact GELU, in place (torch's bits)
             h, hb = ops.add_layernorm(F.linear(mid, l.wo2, l.bo2), h, l.g2, l.b2, l.eps2, want_bf16=i != last)
         return h
 

@@ -209,6 +209,15 @@ def embed_layernorm(word_table, position_table, type_table, token_ids, positions
     return f32, b16
 
 
+def gelu_(x):
+    """Exact (erf) GELU of a contiguous bf16 cuda tensor, IN PLACE (ccr_gelu_bf16); returns x."""
+    lib = require_gpu()
+    assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and x.numel() % 8 == 0
+    with _on(x):
+        _lib.check(lib.ccr_gelu_bf16(_ptr(x), _ptr(x), x.numel(), _stream(x)), "ccr_gelu_bf16")
+    return x
+
+
 def add_layernorm(x, residual, gamma, beta, eps, want_f32=True, want_bf16=True):
     """LayerNorm(x + residual) * gamma + beta per row (ccr_add_layernorm): x [rows, dim] bf16, residual [rows, dim] fp32 or None,
     gamma / beta [dim] fp32, dim a multiple of 256 (<= 2048).  -> (fp32 rows or None, their bf16 copy or None)."""

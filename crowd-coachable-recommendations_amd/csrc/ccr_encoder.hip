@@ -374,6 +374,31 @@ __global__ __launch_bounds__(256) void embed_layernorm_kernel(const float *__res
     }
 }
 
+// Exact (erf) GELU of a bf16 array, in place or out of place: 16 bytes per lane per access, grid-stride.  The same formula and fp32
+// arithmetic as torch's GELU kernel (0.5 x (1 + erf(x / sqrt 2)), rounded to bf16 once): a pass of its own between the two FFN
+// projections because the library's GEMM epilogue only offers the tanh form.
+__global__ __launch_bounds__(256) void gelu_bf16_kernel(const uint4 *__restrict__ x, uint4 *__restrict__ y, int64_t n16) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint4 v = x[i];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a = __uint_as_float(w[j] << 16), b = __uint_as_float(w[j] & 0xffff0000u);
+            const float ga = 0.5f * a * (1.f + erff(a * 0.70710678118654752440f));
+            const float gb = 0.5f * b * (1.f + erff(b * 0.70710678118654752440f));
+            union {
+                __bf16 h[2];
+                uint32_t u;
+            } o;
+            o.h[0] = (__bf16)ga;
+            o.h[1] = (__bf16)gb;
+            r[j] = o.u;
+        }
+        y[i] = make_uint4(r[0], r[1], r[2], r[3]);
+    }
+}
+
 template <int C>
 static int launch_add_layernorm(const uint16_t *x, const float *res, const float *gamma, const float *beta, float eps,
                                 float *out_f32, uint16_t *out_bf16, int64_t rows, hipStream_t s) {
@@ -463,6 +488,20 @@ extern "C" int ccr_embed_layernorm(const float *word_table, int64_t vocab, const
                                n_types, token_ids, positions, token_types, gamma, beta, eps, out_f32, out_bf16, rows);
     }
 #undef CCR_EMBED_CASE
+    CCR_LAUNCH_CHECK();
+    return CCR_OK;
+}
+
+extern "C" int ccr_gelu_bf16(const uint16_t *x, uint16_t *y, int64_t n, void *stream) {
+    CCR_REQUIRE(x && y, "ccr_gelu_bf16: null pointer");
+    CCR_REQUIRE(n >= 0 && n % 8 == 0, "ccr_gelu_bf16: n=%lld (a multiple of 8 elements)", (long long)n);
+    CCR_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0, "ccr_gelu_bf16: 16-byte aligned arrays");
+    if (n == 0) return CCR_OK;
+    const int64_t n16 = n / 8;
+    int64_t blocks = (n16 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(gelu_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint4 *>(x),
+                       reinterpret_cast<uint4 *>(y), n16);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
 }

@@ -163,6 +163,9 @@ int ccr_embed_layernorm(const float *word_table, int64_t vocab, const float *pos
                         const float *type_table, int64_t n_types, const int64_t *token_ids, const int64_t *positions,
                         const int64_t *token_types, const float *gamma, const float *beta, float eps, float *out_f32,
                         uint16_t *out_bf16, int64_t rows, int dim, void *stream);
+/* ccr_gelu_bf16: y = GELU(x) elementwise on n bf16 values (n % 8 == 0, 16-byte aligned; y may be x), the exact erf form of
+ * transformers' BertIntermediate (hidden_act "gelu") in fp32, rounded to bf16 once. */
+int ccr_gelu_bf16(const uint16_t *x, uint16_t *y, int64_t n, void *stream);
 int ccr_attention_bf16(const uint16_t *qkv, const int32_t *seq_start, const int32_t *seq_len, uint16_t *out, int n_seq,
                        int n_heads, int max_len, int pad_len, float scale, void *stream);
 int ccr_add_layernorm(const uint16_t *x_bf16, const float *residual, const float *gamma, const float *beta, float eps,

@@ -448,3 +448,16 @@ def test_encoder_slot_follows_replicas_and_does_not_pin_the_model():
     gc.collect()
     assert ref() is None
     assert fused_bert.for_model(_bert(256, 8, 1, 512)) is None
+
+
+def test_gelu_matches_torch_bit_for_bit():
+    """ccr_gelu_bf16 (in place) == torch.nn.functional.gelu on bf16 (the exact erf form BERT uses), same bits: both evaluate
+    0.5 x (1 + erf(x / sqrt 2)) in fp32 and round once."""
+    from ccrec_amd import ops
+    torch.manual_seed(0)
+    x = (torch.randn(4096, 3072, device="cuda") * 3).to(torch.bfloat16)
+    x[0, :8] = torch.tensor([0.0, -0.0, 1e-30, -1e-30, 50.0, -50.0, float("inf"), float("-inf")], device="cuda").to(torch.bfloat16)
+    ref = torch.nn.functional.gelu(x)
+    got = ops.gelu_(x.clone())
+    same = (got.view(torch.int16) == ref.view(torch.int16)) | (torch.isnan(got) & torch.isnan(ref))
+    assert same.all(), int((~same).sum())
