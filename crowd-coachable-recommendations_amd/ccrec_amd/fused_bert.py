@@ -11,8 +11,8 @@ Arithmetic: what autocast(bf16) does in the reference's layer -- bf16 projection
 softmax, fp32 residual stream and LayerNorm -- so the hidden states agree with the module forward to bf16 rounding (the
 tests compare both with the fp32 forward).  Inference only (eval mode, no dropout, no autograd).
 
-Only what the kernels cover is accepted (unsupported_reason): a BertModel encoder (post-LayerNorm layers, absolute positions,
-exact GELU), head width 64, hidden size a multiple of 256, at most 512 tokens, right-padded batches.  Every other encoder keeps
+Only what the kernels cover is accepted (unsupported_reason): a BertModel or DistilBertModel encoder (post-LayerNorm layers, absolute
+positions, exact GELU), head width 64, hidden size a multiple of 256, at most 512 tokens, right-padded batches.  Every other encoder keeps
 running as its own torch module -- LengthSortedEncoder picks per model."""
 import os
 import threading
@@ -23,24 +23,50 @@ import torch.nn.functional as F
 from . import ops
 
 
+class _Arch:
+    """Where a supported architecture keeps the pieces of its (post-LayerNorm, GELU) encoder layer."""
+
+    def __init__(self, heads, hidden, activation, stack, embeddings, type_table, layer_parts):
+        self.heads, self.hidden, self.activation = heads, hidden, activation
+        self.stack = stack                    # the module whose parameters are the layers' weights
+        self.embeddings, self.type_table = embeddings, type_table
+        self.layer_parts = layer_parts        # layer module -> (q, k, v, attention out, LayerNorm 1, ffn in, ffn out, LayerNorm 2)
+
+
+def _describe(model):
+    """-> _Arch for a transformers BertModel or DistilBertModel (the reference's encoders: facebook/contriever and bert-base-uncased are
+    BertModels, src/ccrec/models/bbpr.py:334, scripts/al_0_rank.py:120; distilbert-base-uncased is its default model_name,
+    bbpr.py:50, bert_mt.py:35), or a string saying why the class is not covered."""
+    name, cfg = type(model).__name__, getattr(model, "config", None)
+    if name == "BertModel" and hasattr(model, "embeddings") and hasattr(model, "encoder"):
+        if getattr(cfg, "position_embedding_type", None) not in (None, "absolute"):
+            return f"position_embedding_type {cfg.position_embedding_type!r}"
+        if getattr(cfg, "is_decoder", False) or getattr(cfg, "add_cross_attention", False):
+            return "decoder / cross-attention layers"
+        e = model.embeddings
+        return _Arch(int(cfg.num_attention_heads), int(cfg.hidden_size), getattr(cfg, "hidden_act", "gelu"), model.encoder, e,
+                     e.token_type_embeddings.weight,
+                     lambda m: (m.attention.self.query, m.attention.self.key, m.attention.self.value, m.attention.output.dense,
+                                m.attention.output.LayerNorm, m.intermediate.dense, m.output.dense, m.output.LayerNorm))
+    if name == "DistilBertModel" and hasattr(model, "embeddings") and hasattr(model, "transformer"):
+        return _Arch(int(cfg.n_heads), int(cfg.dim), getattr(cfg, "activation", "gelu"), model.transformer, model.embeddings, None,
+                     lambda m: (m.attention.q_lin, m.attention.k_lin, m.attention.v_lin, m.attention.out_lin, m.sa_layer_norm,
+                                m.ffn.lin1, m.ffn.lin2, m.output_layer_norm))
+    return f"{name} is not a BertModel or DistilBertModel"
+
+
 def unsupported_reason(model):
-    """None when FusedBertEncoder can run `model` (a transformers BertModel); otherwise why not."""
-    if type(model).__name__ != "BertModel":
-        return f"{type(model).__name__} is not a BertModel"
-    cfg = model.config
-    heads, hidden = int(cfg.num_attention_heads), int(cfg.hidden_size)
+    """None when FusedBertEncoder can run `model` (a transformers BertModel or DistilBertModel); otherwise why not."""
+    arch = _describe(model)
+    if isinstance(arch, str):
+        return arch
+    heads, hidden = arch.heads, arch.hidden
     if hidden % heads or hidden // heads != 64:
         return f"head width {hidden / heads:g} (the attention kernel is built for 64)"
     if hidden % 256 or hidden > 2048:
         return f"hidden size {hidden} (the LayerNorm kernel takes multiples of 256 up to 2048)"
-    if getattr(cfg, "hidden_act", "gelu") != "gelu":
-        return f"activation {cfg.hidden_act!r} (exact GELU only)"
-    if getattr(cfg, "position_embedding_type", None) not in (None, "absolute"):
-        return f"position_embedding_type {cfg.position_embedding_type!r}"
-    if getattr(cfg, "is_decoder", False) or getattr(cfg, "add_cross_attention", False):
-        return "decoder / cross-attention layers"
-    if not hasattr(model, "embeddings") or not hasattr(model, "encoder"):
-        return "no embeddings / encoder modules"
+    if arch.activation != "gelu":
+        return f"activation {arch.activation!r} (exact GELU only)"
     return None
 
 
@@ -99,19 +125,20 @@ class FusedBertEncoder:
         if reason is not None:
             raise ValueError(f"FusedBertEncoder: {reason}")
         self.model = model
-        self.heads = int(model.config.num_attention_heads)
-        self.hidden = int(model.config.hidden_size)
-        self._layers, self._signature = None, None
+        arch = _describe(model)
+        self.heads, self.hidden = arch.heads, arch.hidden
+        self.has_token_types = arch.type_table is not None
+        self._layers, self._signature, self._no_types = None, None, None
 
     def __getstate__(self):      # pickled with its model (torch.save(model)): without the bf16 weight copies
-        return {"model": self.model, "heads": self.heads, "hidden": self.hidden}
+        return {"model": self.model, "heads": self.heads, "hidden": self.hidden, "has_token_types": self.has_token_types}
 
     def __setstate__(self, state):
         self.__dict__.update(state)
-        self._layers, self._signature = None, None
+        self._layers, self._signature, self._no_types = None, None, None
 
     def _params_signature(self):
-        return tuple((p.data_ptr(), p._version, p.device) for p in self.model.encoder.parameters())
+        return tuple((p.data_ptr(), p._version, p.device) for p in _describe(self.model).stack.parameters())
 
     def refresh(self):
         """(Re)build the bf16 weight copies if the module's parameters changed since the last call."""
@@ -121,31 +148,41 @@ class FusedBertEncoder:
         bf = torch.bfloat16
         layers = []
         with torch.no_grad():
-            for mod in self.model.encoder.layer:
-                att, so, ff, out = mod.attention.self, mod.attention.output, mod.intermediate, mod.output
+            arch = _describe(self.model)
+            for mod in arch.stack.layer:
+                q, k, v, so, ln1, ff, out, ln2 = arch.layer_parts(mod)
                 l = _Layer()
-                l.wqkv = torch.cat([att.query.weight, att.key.weight, att.value.weight]).to(bf).contiguous()
-                l.bqkv = torch.cat([att.query.bias, att.key.bias, att.value.bias]).to(bf).contiguous()
-                l.wo, l.bo = so.dense.weight.to(bf).contiguous(), so.dense.bias.to(bf).contiguous()
-                l.g1, l.b1, l.eps1 = so.LayerNorm.weight.float().contiguous(), so.LayerNorm.bias.float().contiguous(), so.LayerNorm.eps
-                l.wi, l.bi = ff.dense.weight.to(bf).contiguous(), ff.dense.bias.to(bf).contiguous()
-                l.wo2, l.bo2 = out.dense.weight.to(bf).contiguous(), out.dense.bias.to(bf).contiguous()
-                l.g2, l.b2, l.eps2 = out.LayerNorm.weight.float().contiguous(), out.LayerNorm.bias.float().contiguous(), out.LayerNorm.eps
+                l.wqkv = torch.cat([q.weight, k.weight, v.weight]).to(bf).contiguous()
+                l.bqkv = torch.cat([q.bias, k.bias, v.bias]).to(bf).contiguous()
+                l.wo, l.bo = so.weight.to(bf).contiguous(), so.bias.to(bf).contiguous()
+                l.g1, l.b1, l.eps1 = ln1.weight.float().contiguous(), ln1.bias.float().contiguous(), ln1.eps
+                l.wi, l.bi = ff.weight.to(bf).contiguous(), ff.bias.to(bf).contiguous()
+                l.wo2, l.bo2 = out.weight.to(bf).contiguous(), out.bias.to(bf).contiguous()
+                l.g2, l.b2, l.eps2 = ln2.weight.float().contiguous(), ln2.bias.float().contiguous(), ln2.eps
                 layers.append(l)
         self._layers, self._signature = layers, sig
         return True
 
     def _embed(self, token_ids, positions, token_types):
-        """The embedding block (BertEmbeddings.forward: word + type + position, LayerNorm) over flat int64 index vectors [T] ->
-        (fp32 [T, hidden], its bf16 copy): one kernel on the module's own fp32 tables (ccr_embed_layernorm), or the module itself
-        when its tables are not plain fp32 (a quantised / half-precision checkpoint)."""
-        e = self.model.embeddings
-        tables = (e.word_embeddings.weight, e.position_embeddings.weight, e.token_type_embeddings.weight, e.LayerNorm.weight, e.LayerNorm.bias)
+        """The embedding block (BertEmbeddings.forward: (word + type) + position, LayerNorm; DistilBERT's Embeddings: word + position,
+        LayerNorm) over flat int64 index vectors [T] -> (fp32 [T, hidden], its bf16 copy): one kernel on the module's own fp32
+        tables (ccr_embed_layernorm; an all-zero type row stands in where the architecture has no token types), or the same sum
+        in torch when the tables are not plain fp32 (a half-precision checkpoint)."""
+        arch = _describe(self.model)
+        e = arch.embeddings
+        word, pos, ln = e.word_embeddings.weight, e.position_embeddings.weight, e.LayerNorm
+        types = arch.type_table
+        if types is None:
+            assert token_types is None, "this architecture has no token types"
+            if self._no_types is None or self._no_types.device != word.device:
+                self._no_types = torch.zeros(1, self.hidden, dtype=torch.float32, device=word.device)
+            types = self._no_types
+        tables = (word, pos, types, ln.weight, ln.bias)
         if all(t.dtype == torch.float32 and t.is_contiguous() for t in tables):
-            return ops.embed_layernorm(tables[0], tables[1], tables[2], token_ids.contiguous(), positions.contiguous(),
-                                       None if token_types is None else token_types.contiguous(), tables[3], tables[4], e.LayerNorm.eps)
-        types = torch.zeros_like(token_ids) if token_types is None else token_types
-        h = e(input_ids=token_ids[None], token_type_ids=types[None], position_ids=positions[None]).reshape(-1, self.hidden).float().contiguous()
+            return ops.embed_layernorm(word, pos, types, token_ids.contiguous(), positions.contiguous(),
+                                       None if token_types is None else token_types.contiguous(), ln.weight, ln.bias, ln.eps)
+        x = word[token_ids].float() + types[token_types if token_types is not None else torch.zeros_like(token_ids)].float()
+        h = F.layer_norm(x + pos[positions].float(), (self.hidden,), ln.weight.float(), ln.bias.float(), ln.eps).contiguous()
         return h, h.to(torch.bfloat16)
 
     def _layers_forward(self, h, hb, seq_start, lengths, max_len, pad_len):

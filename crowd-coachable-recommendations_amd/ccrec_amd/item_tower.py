@@ -109,7 +109,7 @@ class NaiveItemTower(ItemTowerBase):
         if not inputs["input_ids"].is_cuda:
             return None
         enc = fused_bert.for_model(self.cls_model)
-        if enc is None:
+        if enc is None or ("token_type_ids" in inputs and not enc.has_token_types):
             return None
         lengths = fused_bert.prefix_lengths(inputs["attention_mask"])
         if lengths is None:

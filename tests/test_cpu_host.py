@@ -442,6 +442,9 @@ def test_kernel_forward_policy_and_coverage_checks_run_without_a_gpu(monkeypatch
     assert "hidden size" in fused_bert.unsupported_reason(bert(192, 3))
     assert "activation" in fused_bert.unsupported_reason(bert(256, 4, "relu"))
     assert "not a BertModel" in fused_bert.unsupported_reason(torch.nn.Linear(4, 4))
+    from transformers import DistilBertConfig, DistilBertModel
+    assert fused_bert.unsupported_reason(DistilBertModel(DistilBertConfig(vocab_size=50, dim=256, n_layers=1, n_heads=4, hidden_dim=512))) is None
+    assert "head width" in fused_bert.unsupported_reason(DistilBertModel(DistilBertConfig(vocab_size=50, dim=256, n_layers=1, n_heads=2, hidden_dim=512)))
     monkeypatch.delenv("CCREC_FUSED_ENCODER", raising=False)
     assert fused_bert.wanted(True) is True and fused_bert.wanted(False) is False
     assert fused_bert.wanted("auto") is False                       # no GPU here: never by default

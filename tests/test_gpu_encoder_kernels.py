@@ -477,3 +477,44 @@ def test_kernel_forward_is_deterministic_run_to_run():
         a = enc.encode(texts).clone()
         b = enc.encode(texts)
     assert torch.equal(a, b)
+
+
+def test_distilbert_takes_the_same_kernels():
+    """DistilBertModel (the reference's default model_name, src/ccrec/models/bbpr.py:50, bert_mt.py:35) is the same post-LayerNorm GELU
+    layer under other attribute names and without token types: same parity bar as BertModel (no further from the fp32 module forward
+    than its autocast forward), padded and packed, and through the tower's drop-in forward."""
+    from transformers import DistilBertConfig, DistilBertModel
+    from ccrec_amd import fused_bert
+    from ccrec_amd.item_tower import NaiveItemTower
+    torch.manual_seed(21)
+    model = DistilBertModel(DistilBertConfig(vocab_size=600, dim=256, n_layers=3, n_heads=4, hidden_dim=512, max_position_embeddings=512)).cuda().eval()
+    with torch.no_grad():
+        for layer in model.transformer.layer:
+            layer.attention.q_lin.weight.mul_(8.0)
+            layer.attention.k_lin.weight.mul_(8.0)
+    assert fused_bert.unsupported_reason(model) is None
+    lens = [40, 1, 17, 33, 64, 65, 128, 130, 97, 200]
+    ids, mask, lengths = _batch(lens, 200)
+    with torch.no_grad():
+        ref = model(input_ids=ids, attention_mask=mask).last_hidden_state
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            amp = model(input_ids=ids, attention_mask=mask).last_hidden_state.float()
+    enc = fused_bert.for_model(model)
+    assert enc is not None and enc.has_token_types is False
+    live = mask.bool()
+    e_amp = (amp - ref)[live].abs()
+    for packed in (False, True):
+        got = enc.forward(ids, lengths, packed=packed)
+        e_got = (got - ref)[live].abs()
+        assert e_got.max().item() <= 1.5 * e_amp.max().item() + 1e-3, (packed, e_got.max().item(), e_amp.max().item())
+        assert e_got.mean().item() <= 1.5 * e_amp.mean().item() + 1e-4
+    tower = NaiveItemTower(model, torch.nn.LayerNorm(256, elementwise_affine=False)).cuda().eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        fast = tower(input_ids=ids, attention_mask=mask, output_step="mean_pooling")
+        os_env = __import__("os").environ
+        os_env["CCREC_FUSED_ENCODER"] = "0"
+        try:
+            slow = tower(input_ids=ids, attention_mask=mask, output_step="mean_pooling")
+        finally:
+            del os_env["CCREC_FUSED_ENCODER"]
+    assert torch.nn.functional.cosine_similarity(fast.float(), slow.float(), dim=1).min().item() > 0.9995
