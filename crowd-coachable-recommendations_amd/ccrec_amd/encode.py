@@ -192,6 +192,10 @@ class LengthSortedEncoder:
         from . import fused_bert
         self.fused = fused if fused in (True, False) else "auto"
         self._fused = fused_bert.for_model(tower.cls_model) if self.fused is not False else None
+        if self._fused is not None and self.max_length > 512:
+            self._fused = None          # the attention kernel holds one head's keys and values in LDS: 512 tokens at most
+            if self.fused is True:
+                raise ValueError(f"LengthSortedEncoder(fused=True): max_length {self.max_length} > 512 tokens")
         if self.fused is True and self._fused is None:
             raise ValueError(f"LengthSortedEncoder(fused=True): {fused_bert.unsupported_reason(tower.cls_model)}")
 
