@@ -116,8 +116,8 @@ class _Layer:
 
 
 class FusedBertEncoder:
-    """bf16 forward of a transformers BertModel: forward(input_ids [B, L] right-padded, lengths [B]) -> last hidden state
-    fp32 [B, L, hidden].  Holds bf16 copies of the projection weights (rebuilt when the model's parameters change: fine-tuning
+    """bf16 forward of a transformers BertModel / DistilBertModel: forward(input_ids [B, L] right-padded, lengths [B]) -> last hidden
+    state fp32 [B, L, hidden]; forward_packed(...) over a packed token array.  Holds bf16 copies of the projection weights (rebuilt when the model's parameters change: fine-tuning
     between two ranking steps, load_state_dict, .to(device))."""
 
     def __init__(self, model):
@@ -170,6 +170,8 @@ class FusedBertEncoder:
         in torch when the tables are not plain fp32 (a half-precision checkpoint)."""
         arch = _describe(self.model)
         e = arch.embeddings
+        token_ids, positions = token_ids.long(), positions.long()          # (tokenizers may hand over int32 ids)
+        token_types = None if token_types is None else token_types.long()
         word, pos, ln = e.word_embeddings.weight, e.position_embeddings.weight, e.LayerNorm
         types = arch.type_table
         if types is None:
