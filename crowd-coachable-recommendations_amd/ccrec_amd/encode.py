@@ -322,14 +322,15 @@ class LengthSortedEncoder:
                         ids_t, pos_t, start_t, lens_t, longest = arrays
                         seq_start, seq_len = start_t.to(device, non_blocking=True), lens_t.to(device, non_blocking=True)
                         hidden = fused.forward_packed(ids_t.to(device, non_blocking=True), pos_t.to(device, non_blocking=True),
-                                                      seq_start, seq_len, longest)                       # [T, dim] fp32
+                                                      seq_start, seq_len, longest,                       # [T, dim] fp32, or the CLS rows [B, dim]
+                                                      cls_only=self.output_step != "mean_pooling")
                         if out is None:
                             out = torch.empty(n + row_offset, hidden.shape[-1], dtype=torch.bfloat16, device=hidden.device)
                         if self.output_step == "mean_pooling":
                             ops.meanpool_pack_packed(hidden, seq_start, seq_len, normalize=(sim == "cos"), out_bf16=out, out_f32=out_f32,
                                                      dst_rows=rows, norm_bounds=norm_bounds)
                             continue
-                        first = hidden[seq_start.long()]                                                   # the CLS rows
+                        first = hidden                                                                     # the CLS rows
                         mask = torch.ones(len(idx), 1, dtype=torch.int64, device=device)
                     else:
                         ids_t, mask_t, lens_t = arrays

@@ -187,23 +187,34 @@ class FusedBertEncoder:
         h = F.layer_norm(x + pos[positions].float(), (self.hidden,), ln.weight.float(), ln.bias.float(), ln.eps).contiguous()
         return h, h.to(torch.bfloat16)
 
-    def _layers_forward(self, h, hb, seq_start, lengths, max_len, pad_len):
+    def _layers_forward(self, h, hb, seq_start, lengths, max_len, pad_len, cls_rows=None):
         """The encoder layers over token rows h [T, hidden] fp32 / hb (its bf16 copy); sequence s = rows seq_start[s] .. -> last
-        hidden state [T, hidden] fp32."""
+        hidden state [T, hidden] fp32.
+
+        cls_rows ([n_seq] int64 rows of the sequences' first tokens): the caller reads only those rows of the last hidden state (the
+        tower's cls | mu | mean | mean_layer_norm output steps, src/ccrec/models/item_tower.py:133-136 -- mean_layer_norm is the
+        reference's CCREC_EMBEDDING_TYPE default).  The LAST layer then needs every token's keys and values but only the first
+        tokens' attention output, so its output projection, both LayerNorms, the FFN and the GELU run on n_seq rows instead of T
+        (same values: every one of those operations is row-wise) -> [n_seq, hidden]."""
         last = len(self._layers) - 1
         for i, l in enumerate(self._layers):
             qkv = F.linear(hb, l.wqkv, l.bqkv)
             ctx = ops.attention(qkv, seq_start, lengths, self.heads, max_len=max_len, pad_len=pad_len, scale=0.125)
+            if i == last and cls_rows is not None:
+                ctx, h = ctx[cls_rows].contiguous(), h[cls_rows].contiguous()
             h, hb = ops.add_layernorm(F.linear(ctx, l.wo, l.bo), h, l.g1, l.b1, l.eps1)
             mid = ops.gelu_(F.linear(hb, l.wi, l.bi))      # exact GELU, in place (torch's bits)
             h, hb = ops.add_layernorm(F.linear(mid, l.wo2, l.bo2), h, l.g2, l.b2, l.eps2, want_bf16=i != last)
+        if last < 0 and cls_rows is not None:
+            h = h[cls_rows].contiguous()
         return h
 
     @torch.no_grad()
-    def forward_packed(self, token_ids, positions, seq_start, lengths, max_len, token_type_ids=None):
+    def forward_packed(self, token_ids, positions, seq_start, lengths, max_len, token_type_ids=None, cls_only=False):
         """The forward over a packed token array that the caller built itself (no padded batch ever exists): token_ids / positions
         [T] int64 (position of each token inside its sequence), seq_start / lengths [n_seq] int32 (cuda), max_len = the longest
-        sequence (host int).  -> fp32 [T, hidden]; pool it with ops.meanpool_pack_packed."""
+        sequence (host int).  -> fp32 [T, hidden]; pool it with ops.meanpool_pack_packed.  cls_only: -> [n_seq, hidden], the last
+        hidden state of every sequence's first token only (_layers_forward)."""
         ops.require_gpu()
         assert not self.model.training, "FusedBertEncoder is an inference forward: call model.eval() first"
         assert token_ids.is_cuda and token_ids.dim() == 1 and positions.shape == token_ids.shape and 1 <= int(max_len) <= 512
@@ -211,10 +222,10 @@ class FusedBertEncoder:
             self.refresh()
         with torch.autocast("cuda", enabled=False):
             h, hb = self._embed(token_ids, positions, token_type_ids)
-            return self._layers_forward(h, hb, seq_start, lengths, int(max_len), 0)
+            return self._layers_forward(h, hb, seq_start, lengths, int(max_len), 0, seq_start.long() if cls_only else None)
 
     @torch.no_grad()
-    def forward(self, input_ids, lengths, token_type_ids=None, packed=None, lengths_host=None):
+    def forward(self, input_ids, lengths, token_type_ids=None, packed=None, lengths_host=None, cls_only=False):
         """input_ids [B, L] int64 (cuda, right-padded), lengths [B] int32 (cuda): real tokens per row, 1 .. L.
         -> fp32 [B, L, hidden]; rows of padding tokens hold finite values nobody reads (the pooling masks them).
 
@@ -222,7 +233,8 @@ class FusedBertEncoder:
         padding, the attention kernel takes row offsets + lengths) and scatter the result back into a zero-filled [B, L, hidden].
         That is what makes the reference-style batches cheap -- corpus-order batches padded to their longest text
         (scripts/al_0_rank.py:76-81) or to max_length (src/ccrec/models/item_tower.py:27-33) are 30-90 % padding.  None: packed
-        when more than a tenth of the batch is padding (needs the lengths on the host: `lengths_host`, or one device read)."""
+        when more than a tenth of the batch is padding (needs the lengths on the host: `lengths_host`, or one device read).
+        cls_only: the caller reads only hidden[:, 0] -> fp32 [B, 1, hidden] (the last layer runs on the first tokens' rows only)."""
         ops.require_gpu()
         model = self.model
         assert not model.training, "FusedBertEncoder is an inference forward: call model.eval() first"
@@ -249,7 +261,9 @@ class FusedBertEncoder:
                                     None if token_type_ids is None else token_type_ids.flatten())
                 max_len, pad_len = L, L
                 seq_start = torch.arange(B, dtype=torch.int32, device=dev) * L
-            h = self._layers_forward(h, hb, seq_start, lengths, max_len, pad_len)
+            h = self._layers_forward(h, hb, seq_start, lengths, max_len, pad_len, seq_start.long() if cls_only else None)
+            if cls_only:
+                return h.view(B, 1, self.hidden)
             if packed:
                 full = torch.zeros(B * L, self.hidden, dtype=torch.float32, device=dev)
                 full[keep] = h

@@ -92,12 +92,13 @@ class NaiveItemTower(ItemTowerBase):
         self.cls_model = cls_model
         self.standard_layer_norm = standard_layer_norm
 
-    def _encode(self, inputs):
+    def _encode(self, inputs, cls_only=False):
+        """-> last hidden state [B, L, hidden]; with cls_only (the caller reads only [:, 0]) the kernel forward may return [B, 1, hidden]."""
         on_model = {name: value.to(self.cls_model.device) for name, value in inputs.items()}
-        hidden = self._encode_on_kernels(on_model)
+        hidden = self._encode_on_kernels(on_model, cls_only)
         return hidden if hidden is not None else self.cls_model(**on_model).last_hidden_state
 
-    def _encode_on_kernels(self, inputs):
+    def _encode_on_kernels(self, inputs, cls_only=False):
         """Inference forward on the library's layer kernels (fused_bert) when all of this holds: no gradients, eval mode, the
         caller asks for reduced precision (autocast -- al_0_rank.py:125 -- or CCREC_FUSED_ENCODER=1), the encoder is a BertModel the
         kernels cover, and the batch is plain right-padded token ids.  None = run the module."""
@@ -115,14 +116,15 @@ class NaiveItemTower(ItemTowerBase):
         if lengths is None:
             return None
         enc.refresh()
-        return enc.forward(inputs["input_ids"], lengths, inputs.get("token_type_ids"))
+        return enc.forward(inputs["input_ids"], lengths, inputs.get("token_type_ids"), cls_only=cls_only)
 
     def forward(self, cls=None, text=None, input_step="inputs", output_step="embedding", **inputs):
         if input_step == "text":
             inputs, input_step = self.text_to_inputs(text=text), "inputs"
         hidden = None
         if input_step == "inputs":
-            hidden = self._encode(inputs)
+            step = os.environ.get("CCREC_EMBEDDING_TYPE", "") if output_step == "embedding" else output_step
+            hidden = self._encode(inputs, cls_only=step in _CLS_STEPS or step == "mean_layer_norm")
             cls = hidden[:, 0]
         else:
             cls = cls.to(self.device)

@@ -93,8 +93,8 @@ def test_generate_ranking_profile_end_to_end(tmp_path):
 def test_generate_ranking_profile_length_sorted_route_gives_the_same_ranking():
     """length_sorted=True (CCREC_LENGTH_SORTED=1) encodes through the length-sorted pipeline instead of the script's padded
     corpus-order batches: same contract (rank-ordered dicts of all 700 passages), same neighbours -- the two routes' scores differ only
-    by the encoder's summation-order noise over different batch shapes, so the top passage agrees for every query and the score
-    vectors agree to 1e-4."""
+    by the encoder's summation-order noise over different batch shapes, so the score vectors agree to 1e-4 and either route's top
+    passage is within that noise of the other's top score (a near-tie may swap two passages)."""
     from ccrec_amd.al_rank import generate_ranking_profile
     os.environ["CCREC_SIM_TYPE"] = "dot"
     os.environ["CCREC_EMBEDDING_TYPE"] = "mean_pooling"
@@ -118,10 +118,12 @@ def test_generate_ranking_profile_length_sorted_route_gives_the_same_ranking():
     assert list(a) == list(b) == list(queries)
     for q in queries:
         assert len(b[q]) == 700 and set(a[q]) == set(b[q])
-        assert next(iter(a[q])) == next(iter(b[q]))
         sa = np.array([a[q][p] for p in a[q]], np.float32)
         sb = np.array([b[q][p] for p in a[q]], np.float32)
-        assert np.abs(sa - sb).max() < 1e-4 * max(1.0, np.abs(sa[sa > -1e5]).max())
+        tol = 1e-4 * max(1.0, np.abs(sa[sa > -1e5]).max())
+        assert np.abs(sa - sb).max() < tol
+        # the other route's best passage is (within that noise) this route's best: a near-tie may swap the two, nothing more
+        assert max(b[q].values()) - b[q][next(iter(a[q]))] < 2 * tol
         assert all(b[q][p] == -1e6 for p in block[q])
     os.environ["CCREC_LENGTH_SORTED"] = "1"
     try:

@@ -518,3 +518,33 @@ def test_distilbert_takes_the_same_kernels():
         finally:
             del os_env["CCREC_FUSED_ENCODER"]
     assert torch.nn.functional.cosine_similarity(fast.float(), slow.float(), dim=1).min().item() > 0.9995
+
+
+def test_cls_only_last_layer_equals_the_full_forward_first_rows():
+    """cls_only=True runs the last layer's output projection / LayerNorms / FFN on the sequences' first tokens only: the same rows as
+    the full forward's hidden[:, 0] (row-wise operations; GEMM row blocks differ -> bf16-pipeline noise), padded, packed and through the
+    tower's cls / mean_layer_norm output steps (src/ccrec/models/item_tower.py:133-136)."""
+    from ccrec_amd import fused_bert
+    from ccrec_amd.item_tower import NaiveItemTower
+    model = _bert(256, 4, 3, 512, seed=13, scale=9.0)
+    enc = fused_bert.for_model(model)
+    lens = [3, 60, 1, 17, 33, 9, 64]
+    ids, mask, lengths = _batch(lens, 64)
+    full = enc.forward(ids, lengths, packed=False)
+    for packed in (False, True):
+        got = enc.forward(ids, lengths, packed=packed, cls_only=True)
+        assert got.shape == (len(lens), 1, 256)
+        torch.testing.assert_close(got[:, 0], full[:, 0], atol=3e-2, rtol=2e-2)
+        assert torch.nn.functional.cosine_similarity(got[:, 0], full[:, 0], dim=-1).min().item() > 0.9995
+    tower = NaiveItemTower(model, torch.nn.LayerNorm(256, elementwise_affine=False)).cuda().eval()
+    import os
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        for step in ("cls", "mean_layer_norm"):
+            fast = tower(input_ids=ids, attention_mask=mask, output_step=step)
+            os.environ["CCREC_FUSED_ENCODER"] = "0"
+            try:
+                slow = tower(input_ids=ids, attention_mask=mask, output_step=step)
+            finally:
+                del os.environ["CCREC_FUSED_ENCODER"]
+            assert fast.shape == slow.shape == (len(lens), 256)
+            assert torch.nn.functional.cosine_similarity(fast.float(), slow.float(), dim=1).min().item() > 0.9995
