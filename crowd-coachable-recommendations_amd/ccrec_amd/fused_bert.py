@@ -91,6 +91,8 @@ def for_model(model):
     """The FusedBertEncoder of `model` (one per module object, built on first use), or None if the kernels do not cover it.
     torch's replicate() copies a module's __dict__ shallowly, so a DataParallel replica arrives holding its ORIGINAL's encoder:
     an encoder that belongs to another module object is replaced by one of the replica's own (its weights sit on the replica's device)."""
+    if not isinstance(model, torch.nn.Module):      # a stand-in encoder (tests, wrappers): never covered
+        return None
     with _SLOT_LOCK:
         enc = model.__dict__.get(_SLOT, False)
         if enc is False or (enc is not None and enc.model is not model):

@@ -103,7 +103,7 @@ class NaiveItemTower(ItemTowerBase):
         caller asks for reduced precision (autocast -- al_0_rank.py:125 -- or CCREC_FUSED_ENCODER=1), the encoder is a BertModel the
         kernels cover, and the batch is plain right-padded token ids.  None = run the module."""
         from . import fused_bert
-        if torch.is_grad_enabled() or self.cls_model.training or not fused_bert.wanted("auto"):
+        if not fused_bert.wanted("auto") or torch.is_grad_enabled() or getattr(self.cls_model, "training", True):
             return None
         if not set(inputs) <= {"input_ids", "attention_mask", "token_type_ids"} or "input_ids" not in inputs or "attention_mask" not in inputs:
             return None
