@@ -548,3 +548,29 @@ def test_cls_only_last_layer_equals_the_full_forward_first_rows():
                 del os.environ["CCREC_FUSED_ENCODER"]
             assert fast.shape == slow.shape == (len(lens), 256)
             assert torch.nn.functional.cosine_similarity(fast.float(), slow.float(), dim=1).min().item() > 0.9995
+
+
+def test_golden_tower_on_a_real_encoder(golden_dir):
+    """Golden g16 (the reference's own NaiveItemTower + a real BertModel, fp32 CPU): this package's tower reproduces it with the module
+    forward in fp32 (1e-4: fp32 GEMM order on another device) and with the kernel forward under autocast to bf16 activation rounding
+    (weights are bf16-exact in the fixture): cosine >= 0.9995 per row, |error| <= 2 bf16 ulps of the largest value."""
+    import json
+    from transformers import BertConfig, BertModel
+    from ccrec_amd import fused_bert
+    from ccrec_amd.item_tower import NaiveItemTower
+    g = np.load(f"{golden_dir}/g16_item_tower_bert.npz")
+    model = BertModel(BertConfig(**json.loads(str(g["config"])))).eval()
+    state = {k[2:]: torch.from_numpy(g[k].astype(np.int16)).view(torch.bfloat16).float() for k in g.files if k.startswith("w_")}
+    model.load_state_dict(state, strict=False)
+    tower = NaiveItemTower(model, torch.nn.LayerNorm(256, elementwise_affine=False)).cuda().eval()
+    ids, mask = torch.from_numpy(g["ids"]).cuda(), torch.from_numpy(g["mask"]).cuda()
+    assert fused_bert.unsupported_reason(model) is None
+    for step in ("mean_pooling", "cls", "mean_layer_norm"):
+        ref = torch.from_numpy(g["out_" + step]).cuda()
+        with torch.no_grad():
+            plain = tower(input_ids=ids, attention_mask=mask, output_step=step).float()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                fast = tower(input_ids=ids, attention_mask=mask, output_step=step).float()
+        torch.testing.assert_close(plain, ref, atol=1e-4, rtol=1e-4)
+        assert torch.nn.functional.cosine_similarity(fast, ref, dim=1).min().item() >= 0.9995, step
+        assert (fast - ref).abs().max().item() <= 2 * 2.0 ** -8 * ref.abs().max().item() + 1e-2, step

@@ -155,3 +155,23 @@ def test_merge_topk_is_topk_of_union():
         alls, alli = sc[:, q].ravel(), ids[:, q].ravel()
         o = np.lexsort((alli, -alls))[:k]
         assert np.array_equal(mi[q], alli[o]) and np.array_equal(ms[q], alls[o])
+
+
+def test_item_tower_on_a_real_encoder(golden_dir):
+    """g16 = the reference's NaiveItemTower around a real (local, seeded) transformers BertModel, fp32: transformers' own forward on
+    the fixture's weights here + the oracle's pooling / LayerNorm restatement reproduce the reference's three output steps -- the
+    fixture pins tower + encoder together for the GPU tests of the module and kernel forwards."""
+    import json
+    import torch
+    from transformers import BertConfig, BertModel
+    g = _load(golden_dir, "g16_item_tower_bert.npz")
+    cfg = json.loads(str(g["config"]))
+    model = BertModel(BertConfig(**cfg)).eval()
+    state = {k[2:]: torch.from_numpy(g[k].astype(np.int16)).view(torch.bfloat16).float() for k in g.files if k.startswith("w_")}
+    missing, unexpected = model.load_state_dict(state, strict=False)
+    assert not unexpected and all("position_ids" in m or "token_type_ids" in m for m in missing)
+    with torch.no_grad():
+        hidden = model(input_ids=torch.from_numpy(g["ids"]), attention_mask=torch.from_numpy(g["mask"])).last_hidden_state.numpy()
+    np.testing.assert_allclose(orc.meanpool(hidden, g["mask"]), g["out_mean_pooling"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(hidden[:, 0], g["out_cls"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(orc.layer_norm(hidden[:, 0]), g["out_mean_layer_norm"], rtol=0, atol=5e-6)

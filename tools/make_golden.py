@@ -32,6 +32,7 @@ import contextlib
 import importlib.abc
 import importlib.machinery
 import io
+import json
 import os
 import sys
 import types
@@ -210,6 +211,41 @@ def g_item_tower():
         for step in ["mean_pooling", "cls", "mean_layer_norm"]:
             out[step] = tower(**inputs, output_step=step).numpy()
     np.savez_compressed(f"{OUT}/g6_item_tower.npz", hidden=hidden.numpy(), mask=mask.numpy(), **out)
+
+
+def g_item_tower_bert():
+    """g16: the reference's NaiveItemTower around a REAL (local, seeded, random-init) transformers BertModel, fp32 on the CPU: the
+    three output steps on ragged right-padded token batches.  Pins tower + encoder together (g6 pins the pooling on a given hidden
+    state).  Weights are rounded to bf16-exact values and stored as their 16-bit patterns (half the bytes; and the kernel forward's bf16
+    weight copies are then exact, so only activation rounding separates it from these outputs)."""
+    from transformers import BertConfig, BertModel
+    from ccrec.models.item_tower import NaiveItemTower
+    torch.manual_seed(1234)
+    cfg = dict(vocab_size=64, hidden_size=256, num_hidden_layers=1, num_attention_heads=4, intermediate_size=256, max_position_embeddings=40)
+    model = BertModel(BertConfig(**cfg)).eval()
+    with torch.no_grad():
+        for name, prm in model.named_parameters():
+            if "attention.self.query.weight" in name or "attention.self.key.weight" in name:
+                prm.mul_(12.0)                      # the default init leaves every softmax uniform
+            if "LayerNorm.weight" in name:
+                prm.uniform_(0.6, 1.4)
+            if "bias" in name:
+                prm.normal_(0.0, 0.05)
+            prm.copy_(bf16_exact(prm))
+    lens = [32, 1, 17, 5, 24, 9]
+    g = torch.Generator().manual_seed(7)
+    ids = torch.zeros(len(lens), 32, dtype=torch.long)
+    mask = torch.zeros(len(lens), 32, dtype=torch.long)
+    for b, n in enumerate(lens):
+        ids[b, :n] = torch.randint(1, 64, (n,), generator=g)
+        mask[b, :n] = 1
+    tower = NaiveItemTower(model, torch.nn.LayerNorm(256, elementwise_affine=False))
+    out = {}
+    with torch.no_grad():
+        for step in ["mean_pooling", "cls", "mean_layer_norm"]:
+            out["out_" + step] = tower(input_ids=ids, attention_mask=mask, output_step=step).numpy()
+    state = {"w_" + k: v.to(torch.bfloat16).view(torch.int16).numpy() for k, v in model.state_dict().items() if v.dtype == torch.float32}
+    np.savez_compressed(f"{OUT}/g16_item_tower_bert.npz", ids=ids.numpy(), mask=mask.numpy(), config=np.array(json.dumps(cfg)), **state, **out)
 
 
 def g_contrastive():
@@ -478,7 +514,7 @@ def main():
     want = set(sys.argv[1:])
     groups = [("g1", lambda: g_ranking(_import_reference("dot"))), ("g6", g_item_tower), ("g7", g_contrastive),
               ("g8", g_assign_topk), ("g9", g_pack), ("g10", g_requests), ("g11", g_train_data), ("g12", g_bm25), ("g13", g_item_rec), ("g14", g_sparse_prior),
-              ("g15", g_assign_topk_odd_width)]
+              ("g15", g_assign_topk_odd_width), ("g16", lambda: (_import_reference("dot"), g_item_tower_bert())[1])]
     for name, fn in groups:
         if not want or name in want:
             fn()
