@@ -574,3 +574,27 @@ def test_golden_tower_on_a_real_encoder(golden_dir):
         torch.testing.assert_close(plain, ref, atol=1e-4, rtol=1e-4)
         assert torch.nn.functional.cosine_similarity(fast, ref, dim=1).min().item() >= 0.9995, step
         assert (fast - ref).abs().max().item() <= 2 * 2.0 ** -8 * ref.abs().max().item() + 1e-2, step
+
+
+def test_length_sorted_encoder_edge_cases_on_the_kernel_path():
+    """No texts, one text, one-token texts, a preallocated shard with a row offset, identical texts: the packed-array path keeps the
+    contract of the padded one (rows land at row_offset + i; equal texts give equal rows)."""
+    from ccrec_amd.encode import LengthSortedEncoder
+    from ccrec_amd.item_tower import NaiveItemTower
+    tower = NaiveItemTower(_bert(256, 4, 1, 512, seed=1), torch.nn.LayerNorm(256, elementwise_affine=False)).cuda()
+    enc = LengthSortedEncoder(tower, _WordTokenizer(), max_length=64, max_tokens=512, fused=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        empty = enc.encode([])
+        assert empty.shape[0] == 0
+        one = enc.encode(["w1 w2 w3"])
+        assert one.shape == (1, 256) and torch.isfinite(one.float()).all()
+        texts = ["w1 w2 w3", "", "w9", "w1 w2 w3", "w4 " * 100]
+        shard = torch.zeros(9, 256, dtype=torch.bfloat16, device="cuda")
+        bounds = torch.zeros(9, device="cuda")
+        out = enc.encode(texts, out=shard, row_offset=3, norm_bounds=bounds)
+    assert out.data_ptr() == shard.data_ptr()
+    assert (shard[:3] == 0).all() and (shard[8:] == 0).all()
+    assert torch.equal(shard[3], shard[6])                                          # the same text twice in a batch: the same row
+    assert torch.nn.functional.cosine_similarity(shard[3].float(), one[0].float(), dim=0).item() > 0.9999   # ... and (to GEMM order) in another batch
+    assert torch.isfinite(shard.float()).all() and (bounds[3:8] > 0).all()
+    assert (bounds[3:8] >= shard[3:8].float().norm(dim=1) * 0.999).all()
