@@ -21,6 +21,7 @@ EXPORTS = [
     "ccr_search_sparse_prior_workspace_bytes", "ccr_search_sparse_prior", "ccr_colsum_bf16", "ccr_meanpool_bwd", "ccr_bm25_index_create", "ccr_bm25_index_destroy", "ccr_bm25_search_workspace_bytes",
     "ccr_bm25_search", "ccr_pack_bf16_padded", "ccr_shard_message_bytes", "ccr_search_shard", "ccr_shard_message_fill", "ccr_merge_shard_messages",
     "ccr_attention_bf16", "ccr_add_layernorm", "ccr_meanpool_pack_bf16_packed", "ccr_embed_layernorm", "ccr_gelu_bf16",
+    "ccr_attention_half", "ccr_add_layernorm_half", "ccr_embed_layernorm_half", "ccr_gelu_half",
 ]
 
 SHARD_HEADER_BYTES = 32
@@ -105,6 +106,10 @@ def load():
     lib.ccr_add_layernorm.argtypes = [vp, vp, vp, vp, ctypes.c_float, vp, vp, i64, i32, vp]
     lib.ccr_embed_layernorm.argtypes = [vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, ctypes.c_float, vp, vp, i64, i32, vp]
     lib.ccr_gelu_bf16.argtypes = [vp, vp, i64, vp]
+    lib.ccr_attention_half.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, ctypes.c_float, i32, vp]
+    lib.ccr_add_layernorm_half.argtypes = [vp, vp, vp, vp, ctypes.c_float, vp, vp, i64, i32, i32, vp]
+    lib.ccr_embed_layernorm_half.argtypes = [vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, ctypes.c_float, vp, vp, i64, i32, i32, vp]
+    lib.ccr_gelu_half.argtypes = [vp, vp, i64, i32, vp]
     lib.ccr_meanpool_pack_bf16_packed.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
     lib.ccr_shard_message_bytes.argtypes = [i32, i32]
     lib.ccr_shard_message_bytes.restype = sz

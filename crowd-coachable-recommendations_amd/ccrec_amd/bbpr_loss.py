@@ -84,15 +84,3 @@ class BertMTStep(MultipleNrlStep):
         return (1 - self.alpha) / self.ct_cycles * 0.0 + self.alpha / self.ft_cycles * ft_loss.mean()
 
     training_and_validation_step = __call__
-
-
-def grouped_adamw(named_parameters, lr, weight_decay):
-    """configure_optimizers of _BertMT (bert_mt.py:115-134): AdamW with weight decay on everything but biases and LayerNorm
-    parameters."""
-    no_decay = ("bias", "LayerNorm.bias", "LayerNorm.weight")
-    named = list(named_parameters)
-    groups = [
-        {"params": [p for n, p in named if not any(nd in n for nd in no_decay)], "weight_decay": weight_decay},
-        {"params": [p for n, p in named if any(nd in n for nd in no_decay)], "weight_decay": 0.0},
-    ]
-    return torch.optim.AdamW(groups, lr=lr, weight_decay=weight_decay)

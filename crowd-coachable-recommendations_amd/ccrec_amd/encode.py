@@ -274,15 +274,16 @@ class LengthSortedEncoder:
         tower.eval()
         device = tower.cls_model.device
         from . import fused_bert
-        fused = self._fused if (self._fused is not None and fused_bert.wanted(self.fused)) else None
+        half = fused_bert.kernel_dtype(self.fused) if self._fused is not None else None   # the caller's autocast type (fp16 under the reference's autocast())
+        fused = self._fused if half is not None else None
         if fused is not None:
-            fused.refresh()     # bf16 weight copies follow the module (fine-tuning between two ranking steps)
+            fused.refresh(half)     # 16-bit weight copies follow the module (fine-tuning between two ranking steps)
         self._packed_batches = fused is not None     # the kernel forward takes packed token arrays: no padding row is ever computed
         texts = texts if isinstance(texts, (list, tuple)) else list(texts)
         n, chunk = len(texts), self.chunk_texts
         st = {"texts": n, "batches": 0, "real_tokens": 0, "padded_tokens": 0, "fixed_length_tokens": n * self.max_length,
               "chunks": (n + chunk - 1) // chunk, "host_prepare_s": 0.0, "gpu_wait_for_host_s": 0.0, "gpu_busy_s": 0.0,
-              "fused_layers": fused is not None}
+              "fused_layers": fused is not None, "layer_dtype": None if half is None else str(half).replace("torch.", "")}
         wall0 = time.perf_counter()
         spans = []          # (start, end) events of every chunk's GPU work
         if self.host_processes > 0 and self._workers is None and n > chunk:
@@ -323,7 +324,7 @@ class LengthSortedEncoder:
                         seq_start, seq_len = start_t.to(device, non_blocking=True), lens_t.to(device, non_blocking=True)
                         hidden = fused.forward_packed(ids_t.to(device, non_blocking=True), pos_t.to(device, non_blocking=True),
                                                       seq_start, seq_len, longest,                       # [T, dim] fp32, or the CLS rows [B, dim]
-                                                      cls_only=self.output_step != "mean_pooling")
+                                                      cls_only=self.output_step != "mean_pooling", dtype=half)
                         if out is None:
                             out = torch.empty(n + row_offset, hidden.shape[-1], dtype=torch.bfloat16, device=hidden.device)
                         if self.output_step == "mean_pooling":

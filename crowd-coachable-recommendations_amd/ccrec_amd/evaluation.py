@@ -9,8 +9,11 @@ import torch
 from . import _lib, ops
 
 
-def rank_metrics(ids, qrel_lists, k_values=(1, 5, 10, 100)):
-    """ids: [Q, k] int64 cuda (rank order, global ids); qrel_lists: per query iterable of relevant ids.
+def rank_metrics(ids, qrel_lists, k_values=(1, 5, 10, 100), n_qrels=None):
+    """ids: [Q, k] int64 cuda (rank order, global ids); qrel_lists: per query iterable of relevant ids (relevance > 0 only).
+    n_qrels: the number of queries in the caller's `qrels` -- BEIR's mrr sums over the queries of `results` and divides by len(qrels)
+    (the reference passes its full qrels, scripts/al_0_rank.py:130-133), so a profile that holds fewer queries than the qrels is
+    averaged over the qrels' count; None = the Q queries passed in.
     -> {"MRR@k": float, "Recall@k": float} per cut-off."""
     lib = ops.require_gpu()
     assert ids.is_cuda and ids.dtype == torch.int64 and ids.dim() == 2
@@ -37,7 +40,7 @@ def rank_metrics(ids, qrel_lists, k_values=(1, 5, 10, 100)):
     rec = (hits.cpu().double() / nrel[:, None])[has].mean(0) if bool(has.any()) else torch.zeros(len(kv), dtype=torch.float64)
     out = {}
     for j, kk in enumerate(k_values):
-        out[f"MRR@{kk}"] = round(float(rr_sum[j]) / max(1, n_q), 5)
+        out[f"MRR@{kk}"] = round(float(rr_sum[j]) / max(1, n_q if n_qrels is None else int(n_qrels)), 5)
         out[f"Recall@{kk}"] = round(float(rec[j]), 5)
     return out
 

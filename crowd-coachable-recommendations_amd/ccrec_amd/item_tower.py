@@ -103,7 +103,8 @@ class NaiveItemTower(ItemTowerBase):
         caller asks for reduced precision (autocast -- al_0_rank.py:125 -- or CCREC_FUSED_ENCODER=1), the encoder is a BertModel the
         kernels cover, and the batch is plain right-padded token ids.  None = run the module."""
         from . import fused_bert
-        if not fused_bert.wanted("auto") or torch.is_grad_enabled() or getattr(self.cls_model, "training", True):
+        dtype = fused_bert.kernel_dtype("auto")      # the caller's autocast type: fp16 under the reference's autocast(), al_0_rank.py:125
+        if dtype is None or torch.is_grad_enabled() or getattr(self.cls_model, "training", True):
             return None
         if not set(inputs) <= {"input_ids", "attention_mask", "token_type_ids"} or "input_ids" not in inputs or "attention_mask" not in inputs:
             return None
@@ -115,8 +116,8 @@ class NaiveItemTower(ItemTowerBase):
         lengths = fused_bert.prefix_lengths(inputs["attention_mask"])
         if lengths is None:
             return None
-        enc.refresh()
-        return enc.forward(inputs["input_ids"], lengths, inputs.get("token_type_ids"), cls_only=cls_only)
+        enc.refresh(dtype)      # the weight copies follow the module's parameters (fine-tuning between two ranking steps)
+        return enc.forward(inputs["input_ids"], lengths, inputs.get("token_type_ids"), cls_only=cls_only, dtype=dtype)
 
     def forward(self, cls=None, text=None, input_step="inputs", output_step="embedding", **inputs):
         if input_step == "text":

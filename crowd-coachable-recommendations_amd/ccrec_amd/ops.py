@@ -167,30 +167,41 @@ def meanpool(hidden, mask):
 MAX_QUERIES_PER_SEARCH = 16384   # larger batches are searched in pieces (last_stats() then describes the last piece)
 
 
+_HALF_DTYPES = {torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}
+
+
+def _half_code(dtype):
+    """CCR_DTYPE_* of one of the two 16-bit operand types of the encoder layer kernels."""
+    assert dtype in _HALF_DTYPES, f"{dtype}: the encoder layer kernels take torch.bfloat16 or torch.float16 operands"
+    return _HALF_DTYPES[dtype]
+
+
 def attention(qkv, seq_start, seq_len, n_heads, max_len, pad_len=0, scale=0.125, out=None):
-    """Multi-head self-attention of a token array (ccr_attention_bf16; head width 64): qkv [T, 3 * n_heads * 64] bf16 = the stacked
-    query | key | value projection of every token, seq_start / seq_len [n_seq] int32 = each sequence's first row and real tokens,
+    """Multi-head self-attention of a token array (ccr_attention_half; head width 64): qkv [T, 3 * n_heads * 64] bf16 or fp16 = the
+    stacked query | key | value projection of every token, seq_start / seq_len [n_seq] int32 = each sequence's first row and real tokens,
     max_len = the longest seq_len (host int, <= 512), pad_len = L for a right-padded [n_seq, L] batch (its padding rows get
-    zeros) or 0 for a packed array.  -> context rows [T, n_heads * 64] bf16."""
+    zeros) or 0 for a packed array.  -> context rows [T, n_heads * 64] of qkv's dtype."""
     lib = require_gpu()
-    assert qkv.is_cuda and qkv.dtype == torch.bfloat16 and qkv.dim() == 2 and qkv.is_contiguous()
+    code = _half_code(qkv.dtype)
+    assert qkv.is_cuda and qkv.dim() == 2 and qkv.is_contiguous()
     T, width = qkv.shape
     assert width == 3 * n_heads * 64, f"qkv rows are {width} wide, expected 3 x {n_heads} heads x 64"
     assert seq_start.dtype == torch.int32 and seq_len.dtype == torch.int32 and seq_start.is_cuda and seq_len.is_cuda
     assert seq_start.is_contiguous() and seq_len.is_contiguous() and seq_start.numel() == seq_len.numel()
     if out is None:
-        out = torch.empty(T, n_heads * 64, dtype=torch.bfloat16, device=qkv.device)
-    assert out.is_cuda and out.dtype == torch.bfloat16 and tuple(out.shape) == (T, n_heads * 64) and out.is_contiguous()
+        out = torch.empty(T, n_heads * 64, dtype=qkv.dtype, device=qkv.device)
+    assert out.is_cuda and out.dtype == qkv.dtype and tuple(out.shape) == (T, n_heads * 64) and out.is_contiguous()
     with _on(qkv):
-        _lib.check(lib.ccr_attention_bf16(_ptr(qkv), _ptr(seq_start), _ptr(seq_len), _ptr(out), seq_len.numel(), int(n_heads),
-                                          int(max_len), int(pad_len), float(scale), _stream(qkv)), "ccr_attention_bf16")
+        _lib.check(lib.ccr_attention_half(_ptr(qkv), _ptr(seq_start), _ptr(seq_len), _ptr(out), seq_len.numel(), int(n_heads),
+                                          int(max_len), int(pad_len), float(scale), code, _stream(qkv)), "ccr_attention_half")
     return out
 
 
-def embed_layernorm(word_table, position_table, type_table, token_ids, positions, token_types, gamma, beta, eps):
-    """LayerNorm((word_table[ids] + type_table[types]) + position_table[positions]) per token (ccr_embed_layernorm): fp32 tables
-    [n, dim], int64 index vectors [T] (token_types may be None = type 0).  -> (fp32 [T, dim], bf16 [T, dim])."""
+def embed_layernorm(word_table, position_table, type_table, token_ids, positions, token_types, gamma, beta, eps, dtype=torch.bfloat16):
+    """LayerNorm((word_table[ids] + type_table[types]) + position_table[positions]) per token (ccr_embed_layernorm_half): fp32 tables
+    [n, dim], int64 index vectors [T] (token_types may be None = type 0).  -> (fp32 [T, dim], its copy in `dtype` (bf16 / fp16) [T, dim])."""
     lib = require_gpu()
+    code = _half_code(dtype)
     dim = word_table.shape[1]
     for t in (word_table, position_table, type_table):
         assert t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.shape[1] == dim and t.is_contiguous()
@@ -200,29 +211,32 @@ def embed_layernorm(word_table, position_table, type_table, token_ids, positions
     for t in (token_ids, positions) + ((token_types,) if token_types is not None else ()):
         assert t.is_cuda and t.dtype == torch.int64 and t.dim() == 1 and t.numel() == T and t.is_contiguous()
     f32 = torch.empty(T, dim, dtype=torch.float32, device=word_table.device)
-    b16 = torch.empty(T, dim, dtype=torch.bfloat16, device=word_table.device)
+    b16 = torch.empty(T, dim, dtype=dtype, device=word_table.device)
     with _on(word_table):
-        _lib.check(lib.ccr_embed_layernorm(_ptr(word_table), word_table.shape[0], _ptr(position_table), position_table.shape[0],
-                                           _ptr(type_table), type_table.shape[0], _ptr(token_ids), _ptr(positions), _ptr(token_types),
-                                           _ptr(gamma), _ptr(beta), float(eps), _ptr(f32), _ptr(b16), T, dim, _stream(word_table)),
-                   "ccr_embed_layernorm")
+        _lib.check(lib.ccr_embed_layernorm_half(_ptr(word_table), word_table.shape[0], _ptr(position_table), position_table.shape[0],
+                                                _ptr(type_table), type_table.shape[0], _ptr(token_ids), _ptr(positions),
+                                                _ptr(token_types), _ptr(gamma), _ptr(beta), float(eps), _ptr(f32), _ptr(b16), T, dim,
+                                                code, _stream(word_table)), "ccr_embed_layernorm_half")
     return f32, b16
 
 
 def gelu_(x):
-    """Exact (erf) GELU of a contiguous bf16 cuda tensor, IN PLACE (ccr_gelu_bf16); returns x."""
+    """Exact (erf) GELU of a contiguous bf16 or fp16 cuda tensor, IN PLACE (ccr_gelu_half); returns x."""
     lib = require_gpu()
-    assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and x.numel() % 8 == 0
+    code = _half_code(x.dtype)
+    assert x.is_cuda and x.is_contiguous() and x.numel() % 8 == 0
     with _on(x):
-        _lib.check(lib.ccr_gelu_bf16(_ptr(x), _ptr(x), x.numel(), _stream(x)), "ccr_gelu_bf16")
+        _lib.check(lib.ccr_gelu_half(_ptr(x), _ptr(x), x.numel(), code, _stream(x)), "ccr_gelu_half")
     return x
 
 
 def add_layernorm(x, residual, gamma, beta, eps, want_f32=True, want_bf16=True):
-    """LayerNorm(x + residual) * gamma + beta per row (ccr_add_layernorm): x [rows, dim] bf16, residual [rows, dim] fp32 or None,
-    gamma / beta [dim] fp32, dim a multiple of 256 (<= 2048).  -> (fp32 rows or None, their bf16 copy or None)."""
+    """LayerNorm(x + residual) * gamma + beta per row (ccr_add_layernorm_half): x [rows, dim] bf16 or fp16, residual [rows, dim] fp32 or
+    None, gamma / beta [dim] fp32, dim a multiple of 256 (<= 2048).  -> (fp32 rows or None, their copy in x's dtype or None:
+    want_bf16 asks for that 16-bit copy whichever of the two types x has)."""
     lib = require_gpu()
-    assert x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2 and x.is_contiguous()
+    code = _half_code(x.dtype)
+    assert x.is_cuda and x.dim() == 2 and x.is_contiguous()
     rows, dim = x.shape
     if residual is not None:
         assert residual.is_cuda and residual.dtype == torch.float32 and tuple(residual.shape) == (rows, dim) and residual.is_contiguous()
@@ -230,10 +244,10 @@ def add_layernorm(x, residual, gamma, beta, eps, want_f32=True, want_bf16=True):
         assert t.is_cuda and t.dtype == torch.float32 and tuple(t.shape) == (dim,) and t.is_contiguous()
     assert want_f32 or want_bf16
     f32 = torch.empty(rows, dim, dtype=torch.float32, device=x.device) if want_f32 else None
-    b16 = torch.empty(rows, dim, dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    b16 = torch.empty(rows, dim, dtype=x.dtype, device=x.device) if want_bf16 else None
     with _on(x):
-        _lib.check(lib.ccr_add_layernorm(_ptr(x), _ptr(residual), _ptr(gamma), _ptr(beta), float(eps), _ptr(f32), _ptr(b16),
-                                         rows, dim, _stream(x)), "ccr_add_layernorm")
+        _lib.check(lib.ccr_add_layernorm_half(_ptr(x), _ptr(residual), _ptr(gamma), _ptr(beta), float(eps), _ptr(f32), _ptr(b16),
+                                              rows, dim, code, _stream(x)), "ccr_add_layernorm_half")
     return f32, b16
 
 

@@ -16,7 +16,61 @@
 namespace ccr {
 
 typedef __bf16 ebf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 ef16x8 __attribute__((ext_vector_type(8)));
 typedef float ef32x16 __attribute__((ext_vector_type(16)));
+
+// The layer's 16-bit operand type: bf16 or fp16 -- whichever the caller's autocast context names (the reference's
+// torch.cuda.amp.autocast() at scripts/al_0_rank.py:125 is fp16).  Same kernels, same MFMA rate (v_mfma_f32_32x32x16_f16 /
+// _bf16), fp32 scores / softmax / residual stream / LayerNorm either way; only the rounding of the 16-bit operands differs.
+template <int DT>
+struct Half16;
+template <>
+struct Half16<CCR_DTYPE_BF16> {
+    typedef __bf16 elem;
+    typedef ebf16x8 vec8;
+    static __device__ __forceinline__ ef32x16 mfma(vec8 a, vec8 b, ef32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float lo(uint32_t w) { return __uint_as_float(w << 16); }
+    static __device__ __forceinline__ float hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+};
+template <>
+struct Half16<CCR_DTYPE_F16> {
+    typedef _Float16 elem;
+    typedef ef16x8 vec8;
+    static __device__ __forceinline__ ef32x16 mfma(vec8 a, vec8 b, ef32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float lo(uint32_t w) {
+        union {
+            uint32_t u;
+            _Float16 h[2];
+        } x;
+        x.u = w;
+        return (float)x.h[0];
+    }
+    static __device__ __forceinline__ float hi(uint32_t w) {
+        union {
+            uint32_t u;
+            _Float16 h[2];
+        } x;
+        x.u = w;
+        return (float)x.h[1];
+    }
+};
+// four fp32 values -> four 16-bit values (round to nearest even; a NaN stays a NaN), 8 bytes
+template <class E>
+__device__ __forceinline__ uint2 round4(float a, float b, float c, float d) {
+    union {
+        E h[4];
+        uint2 u;
+    } w;
+    w.h[0] = (E)a;
+    w.h[1] = (E)b;
+    w.h[2] = (E)c;
+    w.h[3] = (E)d;
+    return w.u;
+}
 
 constexpr int ATT_MAX_THREADS = 512;   // up to 8 waves: one workgroup per (sequence, head) stages K / V once, wave w takes query blocks w, w + waves, ..
 constexpr int ATT_QW = 32;             // query rows per wave step (the N side of one 32x32 MFMA tile)
@@ -37,11 +91,15 @@ __host__ __device__ inline size_t attention_lds_bytes(int lk_pad) {
 // softmax row reductions are in-lane plus one exchange with lane ^ 32, and the probabilities, rounded to bf16, ARE the B
 // operand of O^T = V^T P^T (contraction index = key; the A operand V^T is read from the transposed LDS image with the
 // same key permutation: element j of lane half g <-> key 16 s + 4 g + (j & 3) + 8 (j >> 2)).
+template <int DT>
 __global__ __launch_bounds__(ATT_MAX_THREADS) void attention_kernel(const uint16_t *__restrict__ qkv,
                                                                   const int32_t *__restrict__ seq_start,
                                                                   const int32_t *__restrict__ seq_len,
                                                                   uint16_t *__restrict__ out, int H, int pad_len, int max_len,
                                                                   int lk_pad, float scale_log2e) {
+    typedef Half16<DT> HT;
+    typedef typename HT::vec8 vec8;
+    typedef typename HT::elem elem;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int nthreads = blockDim.x;
@@ -97,12 +155,12 @@ __global__ __launch_bounds__(ATT_MAX_THREADS) void attention_kernel(const uint16
         if (2 * p < len) va[u] = *reinterpret_cast<const uint4 *>(Vg + (int64_t)(2 * p) * stride + c * 8);
         if (2 * p + 1 < len) vb[u] = *reinterpret_cast<const uint4 *>(Vg + (int64_t)(2 * p + 1) * stride + c * 8);
     }
-    ebf16x8 qf[4];
+    vec8 qf[4];
     {
         const int q = wq * ATT_QW + ql;
         const int qr = q < len ? q : len - 1;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const ebf16x8 *>(Qg + (int64_t)qr * stride + 16 * s + 8 * g);
+        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const vec8 *>(Qg + (int64_t)qr * stride + 16 * s + 8 * g);
     }
 #pragma unroll
     for (int u = 0; u < ATT_KMAX; ++u) {
@@ -138,7 +196,7 @@ __global__ __launch_bounds__(ATT_MAX_THREADS) void attention_kernel(const uint16
         if (q0w != wq * ATT_QW) {   // the wave's next query block (sequences beyond 32 x waves tokens)
             const int qr = q < len ? q : len - 1;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const ebf16x8 *>(Qg + (int64_t)qr * stride + 16 * s + 8 * g);
+            for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const vec8 *>(Qg + (int64_t)qr * stride + 16 * s + 8 * g);
         }
 
         ef32x16 o0, o1;
@@ -153,10 +211,10 @@ __global__ __launch_bounds__(ATT_MAX_THREADS) void attention_kernel(const uint16
             const char *kp = Ks + (kb * ATT_KB + ql) * ATT_KROW + g * 16;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const ebf16x8 k0 = *reinterpret_cast<const ebf16x8 *>(kp + 32 * s);
-                const ebf16x8 k1 = *reinterpret_cast<const ebf16x8 *>(kp + 32 * ATT_KROW + 32 * s);
-                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[s], s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[s], s1, 0, 0, 0);
+                const vec8 k0 = *reinterpret_cast<const vec8 *>(kp + 32 * s);
+                const vec8 k1 = *reinterpret_cast<const vec8 *>(kp + 32 * ATT_KROW + 32 * s);
+                s0 = HT::mfma(k0, qf[s], s0);
+                s1 = HT::mfma(k1, qf[s], s1);
             }
             float x[32];
 #pragma unroll
@@ -195,21 +253,21 @@ __global__ __launch_bounds__(ATT_MAX_THREADS) void attention_kernel(const uint16
             for (int hb = 0; hb < 2; ++hb) {
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
-                    ebf16x8 pf;
+                    vec8 pf;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) pf[j] = (__bf16)x[hb * 16 + s2 * 8 + j];
+                    for (int j = 0; j < 8; ++j) pf[j] = (elem)x[hb * 16 + s2 * 8 + j];
                     const int kbase = kb * ATT_KB + hb * 32 + s2 * 16 + 4 * g;
                     const char *vp = Vt + (size_t)ql * VS + 2 * kbase;
                     union {
                         uint2 u[2];
-                        ebf16x8 v;
+                        vec8 v;
                     } a0, a1;
                     a0.u[0] = *reinterpret_cast<const uint2 *>(vp);
                     a0.u[1] = *reinterpret_cast<const uint2 *>(vp + 16);
                     a1.u[0] = *reinterpret_cast<const uint2 *>(vp + (size_t)32 * VS);
                     a1.u[1] = *reinterpret_cast<const uint2 *>(vp + (size_t)32 * VS + 16);
-                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.v, pf, o0, 0, 0, 0);
-                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, pf, o1, 0, 0, 0);
+                    o0 = HT::mfma(a0.v, pf, o0);
+                    o1 = HT::mfma(a1.v, pf, o1);
                 }
             }
         }
@@ -220,17 +278,10 @@ __global__ __launch_bounds__(ATT_MAX_THREADS) void attention_kernel(const uint16
             uint16_t *dst = Og + (int64_t)q * HD + 4 * g;
 #pragma unroll
             for (int c4 = 0; c4 < 4; ++c4) {
-                union {
-                    __bf16 hv[4];
-                    uint2 u;
-                } w0, w1;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    w0.hv[j] = (__bf16)(o0[4 * c4 + j] * inv);
-                    w1.hv[j] = (__bf16)(o1[4 * c4 + j] * inv);
-                }
-                *reinterpret_cast<uint2 *>(dst + 8 * c4) = w0.u;
-                *reinterpret_cast<uint2 *>(dst + 32 + 8 * c4) = w1.u;
+                *reinterpret_cast<uint2 *>(dst + 8 * c4) =
+                    round4<elem>(o0[4 * c4] * inv, o0[4 * c4 + 1] * inv, o0[4 * c4 + 2] * inv, o0[4 * c4 + 3] * inv);
+                *reinterpret_cast<uint2 *>(dst + 32 + 8 * c4) =
+                    round4<elem>(o1[4 * c4] * inv, o1[4 * c4 + 1] * inv, o1[4 * c4 + 2] * inv, o1[4 * c4 + 3] * inv);
             }
         } else if (q < rows) {
             uint2 *dst = reinterpret_cast<uint2 *>(Og + (int64_t)q * HD);
@@ -241,7 +292,7 @@ __global__ __launch_bounds__(ATT_MAX_THREADS) void attention_kernel(const uint16
 }
 
 // One wave per row of dim = 256 * C elements; lane owns elements 4 * (64 c + lane) .. + 3 of every 256-element slice.
-template <int C>
+template <int C, int DT>
 __global__ __launch_bounds__(256) void add_layernorm_kernel(const uint16_t *__restrict__ x, const float *__restrict__ res,
                                                            const float *__restrict__ gamma, const float *__restrict__ beta,
                                                            float eps, float *__restrict__ out_f32,
@@ -258,10 +309,10 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const uint16_t *__re
         const uint2 xb = *reinterpret_cast<const uint2 *>(x + row * DIM + col);
         float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
         if (res) r = *reinterpret_cast<const float4 *>(res + row * DIM + col);
-        v[c][0] = __uint_as_float(xb.x << 16) + r.x;
-        v[c][1] = __uint_as_float(xb.x & 0xffff0000u) + r.y;
-        v[c][2] = __uint_as_float(xb.y << 16) + r.z;
-        v[c][3] = __uint_as_float(xb.y & 0xffff0000u) + r.w;
+        v[c][0] = Half16<DT>::lo(xb.x) + r.x;
+        v[c][1] = Half16<DT>::hi(xb.x) + r.y;
+        v[c][2] = Half16<DT>::lo(xb.y) + r.z;
+        v[c][3] = Half16<DT>::hi(xb.y) + r.w;
         sum += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
     }
 #pragma unroll
@@ -289,23 +340,13 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const uint16_t *__re
         y.z = fmaf((v[c][2] - mean) * rstd, gm.z, bt.z);
         y.w = fmaf((v[c][3] - mean) * rstd, gm.w, bt.w);
         if (out_f32) *reinterpret_cast<float4 *>(out_f32 + row * DIM + col) = y;
-        if (out_bf16) {
-            union {
-                __bf16 hv[4];
-                uint2 u;
-            } w;
-            w.hv[0] = (__bf16)y.x;
-            w.hv[1] = (__bf16)y.y;
-            w.hv[2] = (__bf16)y.z;
-            w.hv[3] = (__bf16)y.w;
-            *reinterpret_cast<uint2 *>(out_bf16 + row * DIM + col) = w.u;
-        }
+        if (out_bf16) *reinterpret_cast<uint2 *>(out_bf16 + row * DIM + col) = round4<typename Half16<DT>::elem>(y.x, y.y, y.z, y.w);
     }
 }
 
 // The embedding block of the encoder (transformers BertEmbeddings.forward): (word[id] + type[t]) + position[p] in that order, fp32,
 // then LayerNorm -> the fp32 residual stream and its bf16 copy.  One wave per token; ids outside a table are clamped (memory safety).
-template <int C>
+template <int C, int DT>
 __global__ __launch_bounds__(256) void embed_layernorm_kernel(const float *__restrict__ word, int64_t vocab,
                                                              const float *__restrict__ pos_tab, int64_t n_pos,
                                                              const float *__restrict__ type_tab, int64_t n_types,
@@ -360,120 +401,65 @@ __global__ __launch_bounds__(256) void embed_layernorm_kernel(const float *__res
         y.z = fmaf((v[c][2] - mean) * rstd, gm.z, bt.z);
         y.w = fmaf((v[c][3] - mean) * rstd, gm.w, bt.w);
         if (out_f32) *reinterpret_cast<float4 *>(out_f32 + row * DIM + col) = y;
-        if (out_bf16) {
-            union {
-                __bf16 hv[4];
-                uint2 u;
-            } wv;
-            wv.hv[0] = (__bf16)y.x;
-            wv.hv[1] = (__bf16)y.y;
-            wv.hv[2] = (__bf16)y.z;
-            wv.hv[3] = (__bf16)y.w;
-            *reinterpret_cast<uint2 *>(out_bf16 + row * DIM + col) = wv.u;
-        }
+        if (out_bf16) *reinterpret_cast<uint2 *>(out_bf16 + row * DIM + col) = round4<typename Half16<DT>::elem>(y.x, y.y, y.z, y.w);
     }
 }
 
 // Exact (erf) GELU of a bf16 array, in place or out of place: 16 bytes per lane per access, grid-stride.  The same formula and fp32
 // arithmetic as torch's GELU kernel (0.5 x (1 + erf(x / sqrt 2)), rounded to bf16 once): a pass of its own between the two FFN
 // projections because the library's GEMM epilogue only offers the tanh form.
-__global__ __launch_bounds__(256) void gelu_bf16_kernel(const uint4 *__restrict__ x, uint4 *__restrict__ y, int64_t n16) {
+template <int DT>
+__global__ __launch_bounds__(256) void gelu_kernel(const uint4 *__restrict__ x, uint4 *__restrict__ y, int64_t n16) {
+    typedef Half16<DT> HT;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) {
         const uint4 v = x[i];
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-        uint32_t r[4];
+        float g[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float a = __uint_as_float(w[j] << 16), b = __uint_as_float(w[j] & 0xffff0000u);
-            const float ga = 0.5f * a * (1.f + erff(a * 0.70710678118654752440f));
-            const float gb = 0.5f * b * (1.f + erff(b * 0.70710678118654752440f));
-            union {
-                __bf16 h[2];
-                uint32_t u;
-            } o;
-            o.h[0] = (__bf16)ga;
-            o.h[1] = (__bf16)gb;
-            r[j] = o.u;
+            const float a = HT::lo(w[j]), b = HT::hi(w[j]);
+            g[2 * j] = 0.5f * a * (1.f + erff(a * 0.70710678118654752440f));
+            g[2 * j + 1] = 0.5f * b * (1.f + erff(b * 0.70710678118654752440f));
         }
-        y[i] = make_uint4(r[0], r[1], r[2], r[3]);
+        const uint2 r0 = round4<typename HT::elem>(g[0], g[1], g[2], g[3]), r1 = round4<typename HT::elem>(g[4], g[5], g[6], g[7]);
+        y[i] = make_uint4(r0.x, r0.y, r1.x, r1.y);
     }
 }
 
-template <int C>
+template <int C, int DT>
 static int launch_add_layernorm(const uint16_t *x, const float *res, const float *gamma, const float *beta, float eps,
-                                float *out_f32, uint16_t *out_bf16, int64_t rows, hipStream_t s) {
-    hipLaunchKernelGGL(add_layernorm_kernel<C>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, res, gamma, beta, eps,
-                       out_f32, out_bf16, rows);
+                                float *out_f32, uint16_t *out_half, int64_t rows, hipStream_t s) {
+    hipLaunchKernelGGL((add_layernorm_kernel<C, DT>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, res, gamma, beta, eps,
+                       out_f32, out_half, rows);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
 }
 
-}  // namespace ccr
-
-using namespace ccr;
-
-extern "C" int ccr_attention_bf16(const uint16_t *qkv, const int32_t *seq_start, const int32_t *seq_len, uint16_t *out,
-                                  int n_seq, int n_heads, int max_len, int pad_len, float scale, void *stream) {
-    CCR_REQUIRE(qkv && seq_start && seq_len && out, "ccr_attention_bf16: null pointer");
-    CCR_REQUIRE(n_seq >= 0 && n_seq <= 65535 && n_heads > 0 && n_heads <= 1024, "ccr_attention_bf16: bad shape n_seq=%d n_heads=%d",
-                n_seq, n_heads);
-    CCR_REQUIRE(max_len > 0 && max_len <= 512 && pad_len >= 0 && pad_len <= 512,
-                "ccr_attention_bf16: max_len=%d pad_len=%d (1..512 tokens per sequence)", max_len, pad_len);
-    CCR_REQUIRE(scale > 0.f, "ccr_attention_bf16: scale must be positive");
-    if (n_seq == 0) return CCR_OK;
-    const int lk_pad = (max_len + ATT_KB - 1) / ATT_KB * ATT_KB;
-    const size_t lds = attention_lds_bytes(lk_pad);
-    const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&attention_kernel), lds);
-    if (rc != CCR_OK) return rc;
-    int waves = (max_len + ATT_QW - 1) / ATT_QW;   // one wave per 32 query rows, at most 8 (longer sequences: the waves loop)
-    if (waves > ATT_MAX_THREADS / 64) waves = ATT_MAX_THREADS / 64;
-    // 129..192 tokens: the LDS image lets three workgroups share a CU, but workgroups of 5 or 6 waves do not pack three times into
-    // its four SIMDs' wave slots (measured residency ~1.5 workgroups); 4 waves, the fifth / sixth query block on a second round
-    // of a wave that rotates with the head: 134 -> 120 us at 136 tokens, 125 -> 111 at 160 (longer sequences: two workgroups
-    // fit either way and 7-8 waves are faster)
-    if (lk_pad == 192 && waves > 4) waves = 4;
-    CCR_REQUIRE(lk_pad * 8 <= ATT_KMAX * 64 * waves && lk_pad * 4 <= ATT_VMAX * 64 * waves, "ccr_attention_bf16: staging bound (internal)");
-    hipLaunchKernelGGL(attention_kernel, dim3(n_heads, n_seq), dim3(64 * waves), lds, (hipStream_t)stream, qkv, seq_start, seq_len,
-                       out, n_heads, pad_len, max_len, lk_pad, scale * 1.4426950408889634f);
-    CCR_LAUNCH_CHECK();
-    return CCR_OK;
-}
-
-extern "C" int ccr_add_layernorm(const uint16_t *x_bf16, const float *residual, const float *gamma, const float *beta, float eps,
-                                 float *out_f32, uint16_t *out_bf16, int64_t rows, int dim, void *stream) {
-    CCR_REQUIRE(x_bf16 && gamma && beta && (out_f32 || out_bf16), "ccr_add_layernorm: null pointer");
-    CCR_REQUIRE(rows >= 0 && dim > 0 && dim % 256 == 0 && dim <= 2048, "ccr_add_layernorm: rows=%lld dim=%d (dim %% 256 == 0, dim <= 2048)",
-                (long long)rows, dim);
-    if (rows == 0) return CCR_OK;
-    hipStream_t s = (hipStream_t)stream;
+template <int DT>
+static int add_layernorm_any(const uint16_t *x, const float *res, const float *gamma, const float *beta, float eps, float *out_f32,
+                             uint16_t *out_half, int64_t rows, int dim, hipStream_t s) {
     switch (dim / 256) {
-        case 1: return launch_add_layernorm<1>(x_bf16, residual, gamma, beta, eps, out_f32, out_bf16, rows, s);
-        case 2: return launch_add_layernorm<2>(x_bf16, residual, gamma, beta, eps, out_f32, out_bf16, rows, s);
-        case 3: return launch_add_layernorm<3>(x_bf16, residual, gamma, beta, eps, out_f32, out_bf16, rows, s);
-        case 4: return launch_add_layernorm<4>(x_bf16, residual, gamma, beta, eps, out_f32, out_bf16, rows, s);
-        case 5: return launch_add_layernorm<5>(x_bf16, residual, gamma, beta, eps, out_f32, out_bf16, rows, s);
-        case 6: return launch_add_layernorm<6>(x_bf16, residual, gamma, beta, eps, out_f32, out_bf16, rows, s);
-        case 7: return launch_add_layernorm<7>(x_bf16, residual, gamma, beta, eps, out_f32, out_bf16, rows, s);
-        default: return launch_add_layernorm<8>(x_bf16, residual, gamma, beta, eps, out_f32, out_bf16, rows, s);
+        case 1: return launch_add_layernorm<1, DT>(x, res, gamma, beta, eps, out_f32, out_half, rows, s);
+        case 2: return launch_add_layernorm<2, DT>(x, res, gamma, beta, eps, out_f32, out_half, rows, s);
+        case 3: return launch_add_layernorm<3, DT>(x, res, gamma, beta, eps, out_f32, out_half, rows, s);
+        case 4: return launch_add_layernorm<4, DT>(x, res, gamma, beta, eps, out_f32, out_half, rows, s);
+        case 5: return launch_add_layernorm<5, DT>(x, res, gamma, beta, eps, out_f32, out_half, rows, s);
+        case 6: return launch_add_layernorm<6, DT>(x, res, gamma, beta, eps, out_f32, out_half, rows, s);
+        case 7: return launch_add_layernorm<7, DT>(x, res, gamma, beta, eps, out_f32, out_half, rows, s);
+        default: return launch_add_layernorm<8, DT>(x, res, gamma, beta, eps, out_f32, out_half, rows, s);
     }
 }
 
-extern "C" int ccr_embed_layernorm(const float *word_table, int64_t vocab, const float *position_table, int64_t n_positions,
-                                   const float *type_table, int64_t n_types, const int64_t *token_ids, const int64_t *positions,
-                                   const int64_t *token_types, const float *gamma, const float *beta, float eps, float *out_f32,
-                                   uint16_t *out_bf16, int64_t rows, int dim, void *stream) {
-    CCR_REQUIRE(word_table && position_table && type_table && token_ids && positions && gamma && beta && (out_f32 || out_bf16),
-                "ccr_embed_layernorm: null pointer");
-    CCR_REQUIRE(vocab > 0 && n_positions > 0 && n_types > 0, "ccr_embed_layernorm: empty table");
-    CCR_REQUIRE(rows >= 0 && dim > 0 && dim % 256 == 0 && dim <= 2048, "ccr_embed_layernorm: rows=%lld dim=%d (dim %% 256 == 0, dim <= 2048)",
-                (long long)rows, dim);
-    if (rows == 0) return CCR_OK;
-    hipStream_t s = (hipStream_t)stream;
+template <int DT>
+static int embed_layernorm_any(const float *word_table, int64_t vocab, const float *position_table, int64_t n_positions,
+                               const float *type_table, int64_t n_types, const int64_t *token_ids, const int64_t *positions,
+                               const int64_t *token_types, const float *gamma, const float *beta, float eps, float *out_f32,
+                               uint16_t *out_half, int64_t rows, int dim, hipStream_t s) {
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-#define CCR_EMBED_CASE(C)                                                                                                             \
-    case C:                                                                                                                           \
-        hipLaunchKernelGGL(embed_layernorm_kernel<C>, grid, block, 0, s, word_table, vocab, position_table, n_positions, type_table,   \
-                           n_types, token_ids, positions, token_types, gamma, beta, eps, out_f32, out_bf16, rows);                     \
+#define CCR_EMBED_CASE(C)                                                                                                              \
+    case C:                                                                                                                            \
+        hipLaunchKernelGGL((embed_layernorm_kernel<C, DT>), grid, block, 0, s, word_table, vocab, position_table, n_positions,         \
+                           type_table, n_types, token_ids, positions, token_types, gamma, beta, eps, out_f32, out_half, rows);         \
         break;
     switch (dim / 256) {
         CCR_EMBED_CASE(1)
@@ -484,24 +470,129 @@ extern "C" int ccr_embed_layernorm(const float *word_table, int64_t vocab, const
         CCR_EMBED_CASE(6)
         CCR_EMBED_CASE(7)
         default:
-            hipLaunchKernelGGL(embed_layernorm_kernel<8>, grid, block, 0, s, word_table, vocab, position_table, n_positions, type_table,
-                               n_types, token_ids, positions, token_types, gamma, beta, eps, out_f32, out_bf16, rows);
+            hipLaunchKernelGGL((embed_layernorm_kernel<8, DT>), grid, block, 0, s, word_table, vocab, position_table, n_positions,
+                               type_table, n_types, token_ids, positions, token_types, gamma, beta, eps, out_f32, out_half, rows);
     }
 #undef CCR_EMBED_CASE
     CCR_LAUNCH_CHECK();
     return CCR_OK;
 }
 
-extern "C" int ccr_gelu_bf16(const uint16_t *x, uint16_t *y, int64_t n, void *stream) {
-    CCR_REQUIRE(x && y, "ccr_gelu_bf16: null pointer");
-    CCR_REQUIRE(n >= 0 && n % 8 == 0, "ccr_gelu_bf16: n=%lld (a multiple of 8 elements)", (long long)n);
-    CCR_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0, "ccr_gelu_bf16: 16-byte aligned arrays");
-    if (n == 0) return CCR_OK;
+template <int DT>
+static int attention_any(const uint16_t *qkv, const int32_t *seq_start, const int32_t *seq_len, uint16_t *out, int n_seq, int n_heads,
+                         int max_len, int pad_len, float scale, hipStream_t stream) {
+    const int lk_pad = (max_len + ATT_KB - 1) / ATT_KB * ATT_KB;
+    const size_t lds = attention_lds_bytes(lk_pad);
+    // the opt-in is cached per (kernel, device) whatever the size: ask for the kernel's maximum once (512 keys), not for this call's
+    // image -- length-sorted batches start with the shortest texts
+    const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&attention_kernel<DT>), attention_lds_bytes(512));
+    if (rc != CCR_OK) return rc;
+    int waves = (max_len + ATT_QW - 1) / ATT_QW;   // one wave per 32 query rows, at most 8 (longer sequences: the waves loop)
+    if (waves > ATT_MAX_THREADS / 64) waves = ATT_MAX_THREADS / 64;
+    // 129..192 tokens: the LDS image lets three workgroups share a CU, but workgroups of 5 or 6 waves do not pack three times into
+    // its four SIMDs' wave slots (measured residency ~1.5 workgroups); 4 waves, the fifth / sixth query block on a second round
+    // of a wave that rotates with the head: 134 -> 120 us at 136 tokens, 125 -> 111 at 160 (longer sequences: two workgroups
+    // fit either way and 7-8 waves are faster)
+    if (lk_pad == 192 && waves > 4) waves = 4;
+    CCR_REQUIRE(lk_pad * 8 <= ATT_KMAX * 64 * waves && lk_pad * 4 <= ATT_VMAX * 64 * waves, "ccr_attention: staging bound (internal)");
+    hipLaunchKernelGGL(attention_kernel<DT>, dim3(n_heads, n_seq), dim3(64 * waves), lds, stream, qkv, seq_start, seq_len, out,
+                       n_heads, pad_len, max_len, lk_pad, scale * 1.4426950408889634f);
+    CCR_LAUNCH_CHECK();
+    return CCR_OK;
+}
+
+template <int DT>
+static int gelu_any(const uint16_t *x, uint16_t *y, int64_t n, hipStream_t stream) {
     const int64_t n16 = n / 8;
     int64_t blocks = (n16 + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(gelu_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint4 *>(x),
+    hipLaunchKernelGGL(gelu_kernel<DT>, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<const uint4 *>(x),
                        reinterpret_cast<uint4 *>(y), n16);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
+}
+
+}  // namespace ccr
+
+using namespace ccr;
+
+#define CCR_REQUIRE_HALF(dtype, who) \
+    CCR_REQUIRE((dtype) == CCR_DTYPE_BF16 || (dtype) == CCR_DTYPE_F16, who ": half_dtype=%d (CCR_DTYPE_F16 or CCR_DTYPE_BF16)", (int)(dtype))
+
+extern "C" int ccr_attention_half(const uint16_t *qkv, const int32_t *seq_start, const int32_t *seq_len, uint16_t *out, int n_seq,
+                                  int n_heads, int max_len, int pad_len, float scale, int half_dtype, void *stream) {
+    CCR_REQUIRE(qkv && seq_start && seq_len && out, "ccr_attention_half: null pointer");
+    CCR_REQUIRE_HALF(half_dtype, "ccr_attention_half");
+    CCR_REQUIRE(n_seq >= 0 && n_seq <= 65535 && n_heads > 0 && n_heads <= 1024, "ccr_attention_half: bad shape n_seq=%d n_heads=%d",
+                n_seq, n_heads);
+    CCR_REQUIRE(max_len > 0 && max_len <= 512 && pad_len >= 0 && pad_len <= 512,
+                "ccr_attention_half: max_len=%d pad_len=%d (1..512 tokens per sequence)", max_len, pad_len);
+    CCR_REQUIRE(scale > 0.f, "ccr_attention_half: scale must be positive");
+    if (n_seq == 0) return CCR_OK;
+    return half_dtype == CCR_DTYPE_F16
+               ? attention_any<CCR_DTYPE_F16>(qkv, seq_start, seq_len, out, n_seq, n_heads, max_len, pad_len, scale, (hipStream_t)stream)
+               : attention_any<CCR_DTYPE_BF16>(qkv, seq_start, seq_len, out, n_seq, n_heads, max_len, pad_len, scale, (hipStream_t)stream);
+}
+
+extern "C" int ccr_attention_bf16(const uint16_t *qkv, const int32_t *seq_start, const int32_t *seq_len, uint16_t *out,
+                                  int n_seq, int n_heads, int max_len, int pad_len, float scale, void *stream) {
+    return ccr_attention_half(qkv, seq_start, seq_len, out, n_seq, n_heads, max_len, pad_len, scale, CCR_DTYPE_BF16, stream);
+}
+
+extern "C" int ccr_add_layernorm_half(const uint16_t *x_half, const float *residual, const float *gamma, const float *beta, float eps,
+                                      float *out_f32, uint16_t *out_half, int64_t rows, int dim, int half_dtype, void *stream) {
+    CCR_REQUIRE(x_half && gamma && beta && (out_f32 || out_half), "ccr_add_layernorm_half: null pointer");
+    CCR_REQUIRE_HALF(half_dtype, "ccr_add_layernorm_half");
+    CCR_REQUIRE(rows >= 0 && dim > 0 && dim % 256 == 0 && dim <= 2048,
+                "ccr_add_layernorm_half: rows=%lld dim=%d (dim %% 256 == 0, dim <= 2048)", (long long)rows, dim);
+    if (rows == 0) return CCR_OK;
+    hipStream_t s = (hipStream_t)stream;
+    return half_dtype == CCR_DTYPE_F16 ? add_layernorm_any<CCR_DTYPE_F16>(x_half, residual, gamma, beta, eps, out_f32, out_half, rows, dim, s)
+                                       : add_layernorm_any<CCR_DTYPE_BF16>(x_half, residual, gamma, beta, eps, out_f32, out_half, rows, dim, s);
+}
+
+extern "C" int ccr_add_layernorm(const uint16_t *x_bf16, const float *residual, const float *gamma, const float *beta, float eps,
+                                 float *out_f32, uint16_t *out_bf16, int64_t rows, int dim, void *stream) {
+    return ccr_add_layernorm_half(x_bf16, residual, gamma, beta, eps, out_f32, out_bf16, rows, dim, CCR_DTYPE_BF16, stream);
+}
+
+extern "C" int ccr_embed_layernorm_half(const float *word_table, int64_t vocab, const float *position_table, int64_t n_positions,
+                                        const float *type_table, int64_t n_types, const int64_t *token_ids, const int64_t *positions,
+                                        const int64_t *token_types, const float *gamma, const float *beta, float eps, float *out_f32,
+                                        uint16_t *out_half, int64_t rows, int dim, int half_dtype, void *stream) {
+    CCR_REQUIRE(word_table && position_table && type_table && token_ids && positions && gamma && beta && (out_f32 || out_half),
+                "ccr_embed_layernorm_half: null pointer");
+    CCR_REQUIRE_HALF(half_dtype, "ccr_embed_layernorm_half");
+    CCR_REQUIRE(vocab > 0 && n_positions > 0 && n_types > 0, "ccr_embed_layernorm_half: empty table");
+    CCR_REQUIRE(rows >= 0 && dim > 0 && dim % 256 == 0 && dim <= 2048,
+                "ccr_embed_layernorm_half: rows=%lld dim=%d (dim %% 256 == 0, dim <= 2048)", (long long)rows, dim);
+    if (rows == 0) return CCR_OK;
+    hipStream_t s = (hipStream_t)stream;
+    return half_dtype == CCR_DTYPE_F16
+               ? embed_layernorm_any<CCR_DTYPE_F16>(word_table, vocab, position_table, n_positions, type_table, n_types, token_ids,
+                                                    positions, token_types, gamma, beta, eps, out_f32, out_half, rows, dim, s)
+               : embed_layernorm_any<CCR_DTYPE_BF16>(word_table, vocab, position_table, n_positions, type_table, n_types, token_ids,
+                                                     positions, token_types, gamma, beta, eps, out_f32, out_half, rows, dim, s);
+}
+
+extern "C" int ccr_embed_layernorm(const float *word_table, int64_t vocab, const float *position_table, int64_t n_positions,
+                                   const float *type_table, int64_t n_types, const int64_t *token_ids, const int64_t *positions,
+                                   const int64_t *token_types, const float *gamma, const float *beta, float eps, float *out_f32,
+                                   uint16_t *out_bf16, int64_t rows, int dim, void *stream) {
+    return ccr_embed_layernorm_half(word_table, vocab, position_table, n_positions, type_table, n_types, token_ids, positions,
+                                    token_types, gamma, beta, eps, out_f32, out_bf16, rows, dim, CCR_DTYPE_BF16, stream);
+}
+
+extern "C" int ccr_gelu_half(const uint16_t *x, uint16_t *y, int64_t n, int half_dtype, void *stream) {
+    CCR_REQUIRE(x && y, "ccr_gelu_half: null pointer");
+    CCR_REQUIRE_HALF(half_dtype, "ccr_gelu_half");
+    CCR_REQUIRE(n >= 0 && n % 8 == 0, "ccr_gelu_half: n=%lld (a multiple of 8 elements)", (long long)n);
+    CCR_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0, "ccr_gelu_half: 16-byte aligned arrays");
+    if (n == 0) return CCR_OK;
+    return half_dtype == CCR_DTYPE_F16 ? gelu_any<CCR_DTYPE_F16>(x, y, n, (hipStream_t)stream)
+                                       : gelu_any<CCR_DTYPE_BF16>(x, y, n, (hipStream_t)stream);
+}
+
+extern "C" int ccr_gelu_bf16(const uint16_t *x, uint16_t *y, int64_t n, void *stream) {
+    return ccr_gelu_half(x, y, n, CCR_DTYPE_BF16, stream);
 }

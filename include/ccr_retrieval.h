@@ -170,6 +170,21 @@ int ccr_attention_bf16(const uint16_t *qkv, const int32_t *seq_start, const int3
                        int n_heads, int max_len, int pad_len, float scale, void *stream);
 int ccr_add_layernorm(const uint16_t *x_bf16, const float *residual, const float *gamma, const float *beta, float eps,
                       float *out_f32, uint16_t *out_bf16, int64_t rows, int dim, void *stream);
+/* The same four kernels on either 16-bit operand type: half_dtype = CCR_DTYPE_BF16 or CCR_DTYPE_F16, whichever the caller's autocast
+ * context names.  The reference encodes under torch.cuda.amp.autocast() (scripts/al_0_rank.py:8,125), whose CUDA default is fp16:
+ * fp16 operands and outputs for the projections, the attention call and the GELU, fp32 for the residual sum and LayerNorm
+ * (src/ccrec/models/item_tower.py:122 runs transformers' BertLayer under it).  Every "bf16" array above is then an fp16 array; scores,
+ * softmax, accumulation, residual stream and LayerNorm stay fp32 either way.  The *_bf16 / un-suffixed entry points above are these
+ * with half_dtype = CCR_DTYPE_BF16. */
+int ccr_attention_half(const uint16_t *qkv, const int32_t *seq_start, const int32_t *seq_len, uint16_t *out, int n_seq, int n_heads,
+                       int max_len, int pad_len, float scale, int half_dtype, void *stream);
+int ccr_add_layernorm_half(const uint16_t *x_half, const float *residual, const float *gamma, const float *beta, float eps,
+                           float *out_f32, uint16_t *out_half, int64_t rows, int dim, int half_dtype, void *stream);
+int ccr_embed_layernorm_half(const float *word_table, int64_t vocab, const float *position_table, int64_t n_positions,
+                             const float *type_table, int64_t n_types, const int64_t *token_ids, const int64_t *positions,
+                             const int64_t *token_types, const float *gamma, const float *beta, float eps, float *out_f32,
+                             uint16_t *out_half, int64_t rows, int dim, int half_dtype, void *stream);
+int ccr_gelu_half(const uint16_t *x, uint16_t *y, int64_t n, int half_dtype, void *stream);
 
 /*
  * Build a search index over a resident bf16 corpus shard (borrowed pointer, no copy).

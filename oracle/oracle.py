@@ -306,16 +306,36 @@ def recall_at_k(ids, ref_ids):
     return float(np.mean(hit))
 
 
-def mrr(ids, qrels, kmax):
-    """BEIR custom_metrics.mrr restated (parity unpinned: beir absent):
-    first relevant hit within kmax -> 1/rank, averaged over queries, rounded to 5 dp."""
+def mrr(ids, qrels, kmax, n_qrels=None):
+    """BEIR custom_metrics.mrr restated on id rows (parity unpinned: beir absent, the reference holds no MRR vectors):
+    first relevant hit within kmax -> 1/rank, summed over the result rows, divided by the number of queries in the qrels
+    (n_qrels; None = one qrel entry per row), rounded to 5 dp."""
     tot = 0.0
     for row, rel in zip(ids, qrels):
         for r, j in enumerate(row[:kmax]):
             if int(j) in rel:
                 tot += 1.0 / (r + 1)
                 break
-    return round(tot / max(1, len(qrels)), 5)
+    return round(tot / max(1, len(qrels) if n_qrels is None else n_qrels), 5)
+
+
+def mrr_beir(qrels, results, k_values):
+    """The dict-level form the reference calls: EvaluateRetrieval.evaluate_custom(qrels, results, k_values, metric="mrr")
+    (scripts/al_0_rank.py:130-133) -> beir.retrieval.custom_metrics.mrr, restated from BEIR's published source (pinned nowhere in the
+    reference: setup.py lists no version; parity unpinned): per query of `results`, the k_max best documents by score (Python's stable
+    sort, descending); relevant = documents of qrels[query] with relevance > 0; MRR@k += 1 / rank of the first relevant hit within k;
+    every sum is divided by len(qrels) -- ALL queries of the qrels, also those `results` does not hold -- and rounded to 5 decimals."""
+    out = {f"MRR@{k}": 0.0 for k in k_values}
+    k_max = max(k_values)
+    for qid, doc_scores in results.items():
+        top = sorted(doc_scores.items(), key=lambda item: item[1], reverse=True)[:k_max]
+        relevant = {d for d, r in qrels[qid].items() if r > 0}
+        for k in k_values:
+            for rank, (doc, _) in enumerate(top[:k]):
+                if doc in relevant:
+                    out[f"MRR@{k}"] += 1.0 / (rank + 1)
+                    break
+    return {name: round(v / len(qrels), 5) for name, v in out.items()}
 
 
 # ----------------------------------------------------------------------------- BM25 (lexical leg of the candidate builder)

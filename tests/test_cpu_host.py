@@ -313,9 +313,15 @@ def test_exchange_repeats_on_every_rank_when_one_rank_flags(tmp_path, world):
         assert open(tmp_path / f"rank{r}.txt").read() == "ok"
 
 def test_committed_bench_line_has_the_contract_fields():
-    """The bench line committed under profiles/ (a real MI355X run of `python bench.py`) carries every field the driver reads."""
+    """The NEWEST default bench line committed under profiles/ (a real MI355X run of `python bench.py`: profiles/rNN_bench<i>.json)
+    carries every field the driver reads."""
+    import glob
     import json
-    path = os.path.join(ROOT, "profiles", "r01_bench_n1.json")
+    import re
+    runs = [(tuple(int(v) for v in re.findall(r"r(\d+)_bench(\d+)\.json$", f)[0]), f)
+            for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench[0-9].json"))]
+    assert runs, "no committed default bench line"
+    path = max(runs)[1]
     line = json.loads(open(path).read().strip().splitlines()[-1])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):

@@ -235,6 +235,21 @@ def _rank_worker(rank, world, port, out_dir):
                         encoder_kw={"max_length": 32, "max_tokens": 4096}, autocast=False, rank=rank, world=world)
     res["requests"]["request_orig"].to_csv(os.path.join(out_dir, f"orig{rank}.csv"), index=False)
     torch.save(dict(res["mrr"]), os.path.join(out_dir, f"mrr{rank}.pt"))
+    # ... and with the BM25 ranking computed inside (ranking_profile_bm25=None): rank 0 alone runs it -- on ITS device, from a worker
+    # thread -- and builds the requests; the other rank returns the merged profile and MRR without them
+    import threading
+    from ccrec_amd import al_step
+    seen = []
+    real = al_step.ranking_bm25
+    al_step.ranking_bm25 = lambda *a, **k: (seen.append((threading.current_thread() is threading.main_thread(), torch.cuda.current_device())),
+                                            real(*a, **k))[1]
+    res2 = run_rank_step(tower, tok, big, queries, qrels, list(queries)[:3], 0, os.path.join(out_dir, "step_bm25"),
+                         encoder_kw={"max_length": 32, "max_tokens": 4096}, autocast=False, rank=rank, world=world)
+    al_step.ranking_bm25 = real
+    assert seen == ([(False, torch.cuda.current_device())] if rank == 0 else []), seen
+    assert (res2["requests"] is not None) == (rank == 0) and res2["mrr"] == res["mrr"]
+    if rank == 0:
+        res2["requests"]["request_orig"].to_csv(os.path.join(out_dir, "orig_bm25.csv"), index=False)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -251,6 +266,8 @@ def test_ranking_sharded_two_ranks_equal_one(tmp_path):
     assert open(tmp_path / "orig0.csv").read() == open(tmp_path / "orig1.csv").read() == open(tmp_path / "step" / "data_iteration_0" / "request_orig.csv").read()
     assert torch.load(tmp_path / "mrr0.pt") == torch.load(tmp_path / "mrr1.pt")
     assert sorted(os.listdir(tmp_path / "step" / "data_iteration_0")) == ["id_track.pt", "ranking_profile.pt", "request_orig.csv", "request_perm.csv"]
+    assert sorted(os.listdir(tmp_path / "step_bm25" / "data_iteration_0")) == ["id_track.pt", "ranking_profile.pt", "request_orig.csv", "request_perm.csv"]
+    assert (tmp_path / "orig_bm25.csv").is_file()
     os.environ["CCREC_SIM_TYPE"] = "dot"
     tower, tok = _tower(), ToyTokenizer()
     corpus = {f"p{j}": t for j, t in enumerate(_texts(901, 4))}

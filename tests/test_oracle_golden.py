@@ -175,3 +175,23 @@ def test_item_tower_on_a_real_encoder(golden_dir):
     np.testing.assert_allclose(orc.meanpool(hidden, g["mask"]), g["out_mean_pooling"], rtol=0, atol=2e-6)
     np.testing.assert_allclose(hidden[:, 0], g["out_cls"], rtol=0, atol=2e-6)
     np.testing.assert_allclose(orc.layer_norm(hidden[:, 0]), g["out_mean_layer_norm"], rtol=0, atol=5e-6)
+
+
+def test_mrr_beir_known_answers():
+    """oracle.mrr_beir restates BEIR's published custom_metrics.mrr (scripts/al_0_rank.py:130-133; beir is absent here and the
+    reference holds no MRR vectors: parity unpinned).  Hand-computed cases pin the restatement's own reading: first
+    relevant hit within k, relevance > 0 only, results re-sorted by score, the sum divided by len(qrels) (queries missing from
+    `results` count), 5 decimals."""
+    qrels = {"a": {"d1": 1, "d9": 0}, "b": {"d2": 2}, "c": {"d3": 1}, "d": {"d4": 1}}
+    results = {
+        "a": {"d9": 0.9, "d1": 0.8, "d5": 0.1},      # the relevance-0 document does not count: first hit at rank 2
+        "b": {"d7": 0.1, "d2": 0.7, "d8": 0.3},      # insertion order is not rank order: re-sorted by score -> rank 1
+        "c": {"d5": 0.5, "d6": 0.4, "d7": 0.3, "d3": 0.2},   # rank 4
+    }                                                  # "d" has no results: contributes 0 but counts in the denominator
+    got = orc.mrr_beir(qrels, results, [1, 3, 10])
+    assert got == {"MRR@1": round(1 / 4, 5), "MRR@3": round((0.5 + 1) / 4, 5), "MRR@10": round((0.5 + 1 + 0.25) / 4, 5)}
+    # the id-row form with the qrels' count agrees
+    ids = [[9, 1, 5, 0], [2, 8, 7, 0], [5, 6, 7, 3]]
+    rel = [{1}, {2}, {3}]
+    assert [orc.mrr(ids, rel, k, n_qrels=4) for k in (1, 3, 10)] == [got["MRR@1"], got["MRR@3"], got["MRR@10"]]
+    assert orc.mrr(ids, rel, 10) == round((0.5 + 1 + 0.25) / 3, 5)
