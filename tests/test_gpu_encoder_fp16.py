@@ -96,9 +96,9 @@ def _errors(x, ref):
 def test_tower_under_the_references_autocast_is_as_close_to_golden_g16_as_the_fp16_module(golden_dir, monkeypatch, step):
     """NaiveItemTower(**inputs, output_step) under `torch.autocast("cuda")` (fp16, the reference's context) on golden g16's weights
     and inputs: the kernel forward (fp16 instantiations) vs the module forward under the same context, both against g16's fp32
-    outputs (the reference's tower, CPU).  Bar: max and mean |error| <= 1.5 x the module's, cosine no lower than the module's - 1e-5,
-    and an absolute bound of 6 fp16 ulps of the largest output (one layer: projection, context, attention-out, FFN-in, GELU and
-    FFN-out roundings, 2^-11 relative each)."""
+    outputs (the reference's tower, CPU).  Bar: max and mean |error| <= 1.5 x the module's (+ 0.05 / 0.01 ulp), cosine no lower than
+    the module's - 1e-6, and an absolute bound of ONE fp16 ulp (2^-11 relative) of the largest output -- measured on MI355X:
+    0.09-0.16 ulp for both paths (the layer's roundings average out in the 256-wide sums behind them)."""
     from ccrec_amd import fused_bert
     monkeypatch.delenv("CCREC_FUSED_ENCODER", raising=False)
     g, tower = _g16_tower(golden_dir)
@@ -119,10 +119,10 @@ def test_tower_under_the_references_autocast_is_as_close_to_golden_g16_as_the_fp
     ulp = FP16_ULP * ref.abs().max().item()
     print(f"g16 {step}: kernels max {k_max / ulp:.2f} ulp mean {k_mean / ulp:.3f} ulp cos {k_cos:.7f} | "
           f"module max {m_max / ulp:.2f} ulp mean {m_mean / ulp:.3f} ulp cos {m_cos:.7f}")
-    assert k_max <= 1.5 * m_max + 0.25 * ulp, (k_max / ulp, m_max / ulp)
-    assert k_mean <= 1.5 * m_mean + 0.05 * ulp, (k_mean / ulp, m_mean / ulp)
-    assert k_cos >= m_cos - 1e-5 and k_cos >= 0.99999, (k_cos, m_cos)
-    assert k_max <= 6 * ulp, k_max / ulp
+    assert k_max <= 1.5 * m_max + 0.05 * ulp, (k_max / ulp, m_max / ulp)
+    assert k_mean <= 1.5 * m_mean + 0.01 * ulp, (k_mean / ulp, m_mean / ulp)
+    assert k_cos >= m_cos - 1e-6 and k_cos >= 0.999999, (k_cos, m_cos)
+    assert k_max <= 1.0 * ulp, k_max / ulp
 
 
 def test_length_sorted_encoder_under_the_references_autocast_runs_fp16_kernels(golden_dir, monkeypatch):
@@ -153,8 +153,9 @@ def test_length_sorted_encoder_under_the_references_autocast_runs_fp16_kernels(g
     ulp = FP16_ULP * ref.abs().max().item()
     print(f"length-sorted g16: kernels max {k_max / ulp:.2f} ulp mean {k_mean / ulp:.3f} cos {k_cos:.7f} | module max {m_max / ulp:.2f} "
           f"mean {m_mean / ulp:.3f} cos {m_cos:.7f}")
-    assert k_max <= 1.5 * m_max + 0.25 * ulp and k_mean <= 1.5 * m_mean + 0.05 * ulp, (k_max / ulp, m_max / ulp, k_mean / ulp, m_mean / ulp)
-    assert k_cos >= m_cos - 1e-5 and k_cos >= 0.99999, (k_cos, m_cos)
+    assert k_max <= 1.5 * m_max + 0.05 * ulp and k_mean <= 1.5 * m_mean + 0.01 * ulp, (k_max / ulp, m_max / ulp, k_mean / ulp, m_mean / ulp)
+    assert k_cos >= m_cos - 1e-6 and k_cos >= 0.999999, (k_cos, m_cos)
+    assert k_max <= 1.0 * ulp, k_max / ulp
 
 
 @pytest.mark.parametrize("hidden,heads,layers,scale", [(256, 4, 3, 25.0), (768, 12, 2, 12.0)])
@@ -188,10 +189,11 @@ def test_fp16_kernel_forward_is_as_close_to_fp32_as_the_fp16_autocast_module(hid
 
 def test_top_k_ids_from_kernel_embeddings_equal_the_module_paths_where_scores_are_separated(golden_dir, monkeypatch):
     """The ranking consequence.  3 000 passages + 64 queries through golden g16's tower under the reference's autocast(), once on the
-    layer kernels and once as torch modules, cosine scores (CCREC_SIM_TYPE=cos; O(1) scores, so the north-star's 1e-3 is meaningful)
-    in fp32 from the fp32 pooled rows, top-20 of each.  Bar: max |score difference| <= 5e-4, hence at every rank r where the module's
-    score is more than 1e-3 away from both neighbours (rank r - 1 and r + 1, rank 21 included) the kernel path holds the same passage
-    at the same rank; the top-20 SETS agree except for passages within 1e-3 of the 20th score."""
+    layer kernels and once as torch modules, cosine scores (CCREC_SIM_TYPE=cos: O(1) scores, so the north-star's 1e-3 is meaningful)
+    in fp32 from the fp32 pooled rows, top-20 of each.  Bar: max |score difference| <= 2e-5 (measured 2.9e-6), hence at every rank
+    where the module's score is more than 1e-3 -- and, ten times stricter, more than 1e-4 -- away from both neighbours (rank 21
+    included) the kernel path holds the same passage at the same rank; the top-20 SETS agree except for passages within 1e-4 of
+    the 20th score."""
     from ccrec_amd.encode import LengthSortedEncoder
     monkeypatch.delenv("CCREC_FUSED_ENCODER", raising=False)
     _, tower = _g16_tower(golden_dir)
@@ -209,22 +211,26 @@ def test_top_k_ids_from_kernel_embeddings_equal_the_module_paths_where_scores_ar
         emb[name] = (torch.nn.functional.normalize(q.double(), dim=1) @ torch.nn.functional.normalize(d.double(), dim=1).T).float()
     s_k, s_m = emb["kernels"], emb["modules"]
     diff = (s_k - s_m).abs().max().item()
-    print(f"max |cos score (kernels) - cos score (modules)| = {diff:.2e}")
-    assert diff <= 5e-4, diff
+    assert diff <= 2e-5, diff
     top_m, idx_m = s_m.topk(k + 1, dim=1)
     _, idx_k = s_k.topk(k + 1, dim=1)
     gap_next = top_m[:, :-1] - top_m[:, 1:]                                   # [Q, k]: score(r) - score(r + 1)
     gap_prev = torch.cat([torch.full_like(gap_next[:, :1], float("inf")), gap_next[:, :-1]], dim=1)
-    separated = (gap_next > 1e-3) & (gap_prev > 1e-3)
-    assert separated.float().mean().item() > 0.3, "the test must bind: too few separated ranks"
     same = idx_k[:, :k] == idx_m[:, :k]
-    assert bool(same[separated].all()), int((~same & separated).sum())
-    # set agreement: a passage of the module's top-k missing from the kernel path's top-k sits within 1e-3 of the cut
+    bound = {}
+    for tau in (1e-3, 1e-4):
+        separated = (gap_next > tau) & (gap_prev > tau)
+        bound[tau] = separated.float().mean().item()
+        assert bool(same[separated].all()), (tau, int((~same & separated).sum()))
+    print(f"max |cos score (kernels) - cos score (modules)| = {diff:.2e}; ranks separated by > 1e-3: {bound[1e-3]:.2f}, by > 1e-4: "
+          f"{bound[1e-4]:.2f}; identical ranks overall: {same.float().mean().item():.3f}")
+    assert bound[1e-3] > 0.05 and bound[1e-4] > 0.25, bound            # the test must bind
+    # set agreement: a passage of the module's top-k missing from the kernel path's top-k sits within 1e-4 of the cut
     cut = top_m[:, k - 1]
     for qi in range(len(queries)):
         missing = set(idx_m[qi, :k].tolist()) - set(idx_k[qi, :k].tolist())
         for p in missing:
-            assert s_m[qi, p].item() - cut[qi].item() <= 1e-3, (qi, p)
+            assert s_m[qi, p].item() - cut[qi].item() <= 1e-4, (qi, p)
 
 
 def test_fp16_weight_copies_follow_the_module_and_both_types_coexist():
@@ -238,10 +244,10 @@ def test_fp16_weight_copies_follow_the_module_and_both_types_coexist():
     assert enc.refresh() is False and set(enc._layers) == {torch.float16, torch.bfloat16}
     assert enc._layers[torch.float16][0].wqkv.dtype == torch.float16
     with torch.no_grad():
-        model.encoder.layer[0].output.dense.weight.add_(0.05)
+        model.encoder.layer[0].output.dense.weight.mul_(3.0)          # (a uniform shift would vanish in the LayerNorm behind it)
     assert enc.refresh() is True and not enc._layers                   # every set dropped; each is rebuilt on its next use
     b16 = enc.forward(ids, lengths, dtype=torch.float16)
-    assert (a16 - b16).abs().max().item() > 1e-3
+    assert (a16 - b16).abs().max().item() > 1e-2
     assert (a16 - abf).abs().max().item() < 5e-2
     with pytest.raises(AssertionError):
         enc.forward(ids, lengths, dtype=torch.float32)
