@@ -21,7 +21,7 @@ EXPORTS = [
     "ccr_search_sparse_prior_workspace_bytes", "ccr_search_sparse_prior", "ccr_colsum_bf16", "ccr_meanpool_bwd", "ccr_bm25_index_create", "ccr_bm25_index_destroy", "ccr_bm25_search_workspace_bytes",
     "ccr_bm25_search", "ccr_pack_bf16_padded", "ccr_shard_message_bytes", "ccr_search_shard", "ccr_shard_message_fill", "ccr_merge_shard_messages",
     "ccr_attention_bf16", "ccr_add_layernorm", "ccr_meanpool_pack_bf16_packed", "ccr_embed_layernorm", "ccr_gelu_bf16",
-    "ccr_attention_half", "ccr_add_layernorm_half", "ccr_embed_layernorm_half", "ccr_gelu_half",
+    "ccr_attention_half", "ccr_add_layernorm_half", "ccr_embed_layernorm_half", "ccr_gelu_half", "ccr_merge_short_lists",
 ]
 
 SHARD_HEADER_BYTES = 32
@@ -116,6 +116,7 @@ def load():
     lib.ccr_search_shard.argtypes = [vp, vp, i32, i32, vp, vp, sz, i32, vp]
     lib.ccr_shard_message_fill.argtypes = [vp, i32, i32, i32, vp, vp, i64, i64, vp]
     lib.ccr_merge_shard_messages.argtypes = [vp, i64, i32, i32, i32, vp, vp, vp]
+    lib.ccr_merge_short_lists.argtypes = [vp, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is ctypes.c_int and name not in ("ccr_version", "ccr_index_dim"):

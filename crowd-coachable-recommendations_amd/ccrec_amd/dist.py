@@ -10,8 +10,18 @@ No host round trip before the collective: the per-shard search is asynchronous (
 queries it flagged in the message HEADER, on the stream.  After the all-gather every rank holds every rank's header, so all
 ranks take the same branch: lists final (the usual case: no rank flagged a query) -> merge; otherwise every rank completes its
 search (ccr_search_finish: a no-op where nothing was flagged) and ALL ranks repeat the all-gather -- the second collective is
-matched by construction."""
+matched by construction.
+
+SHORT LISTS (large k: ranking() keeps 1001, scripts/ms_marco_eval.py:230).  The select / canonical re-score stage of a shard's search
+does not shrink with the shard -- every rank would return the top-k of ITS rows although a shard of exchangeable rows holds only
+k / R +- sqrt(k (1/R)(1 - 1/R)) of the global top-k.  So every rank searches and sends its canonical top-k_list, k_list =
+short_list_length(k, R) ~ k / R + 6 sigma (196 instead of 1001 at R = 8), and the merge VERIFIES the shortcut exactly: a shard's list is
+its exact top-k_list, hence if its last entry is not among the merged top-k none of its unsent rows is.  Queries for which some list was
+consumed to its end (a corpus in topical order can put most of a query's top-k into one shard) are repeated with full lists by all
+ranks together -- every rank derives the same query set from the same gathered bytes, so the repeat is a matched collective too."""
 import ctypes
+import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -27,6 +37,26 @@ def shard_bounds(n_rows, world_size, rank):
     base, rem = divmod(n_rows, world_size)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def short_list_length(k, world, sigmas=6.0):
+    """Entries per query a rank sends in the short-list exchange: the share of a global top-k that one of `world` equal shards of
+    exchangeable rows holds is Binomial(k, 1/world); mean + 6 sigma + 8 is exceeded by some shard with probability < 1e-8 per query."""
+    if world <= 1:
+        return int(k)
+    share = 1.0 / world
+    return int(min(k, math.ceil(k * share + sigmas * math.sqrt(k * share * (1.0 - share))) + 8))
+
+
+def short_lists_pay(k, world):
+    """Use the short-list exchange?  When it cuts the lists by at least a quarter and the R lists of a query fit the merge kernel's LDS.
+    CCREC_SHORT_LISTS=0 / 1 switches it off / forces it where it is possible (the A/B knob)."""
+    kl = short_list_length(k, world)
+    possible = world > 1 and kl < k and world * kl * 12 <= ops.SHORT_LIST_LDS_BYTES
+    env = os.environ.get("CCREC_SHORT_LISTS", "").strip()
+    if env in ("0", "1"):
+        return possible and env == "1"
+    return possible and 4 * kl <= 3 * k
 
 
 class ShardMessage:
@@ -117,15 +147,29 @@ class ShardMessage:
             return merge_fn(*self.decoded())
         return ops.merge_shard_messages(self.recv, self.world, self.n_q, self.k)
 
+    def merge_short(self, k_out, headers, short_merge_fn=None):
+        """Short-list exchange: the k_out best of the R x k entries per query + the verification flags (ops.merge_short_lists).
+        short_merge_fn: test hook (decoded scores, decoded ids, truncated [R] bools, k_out) -> (scores, ids, flags [n_q], count)."""
+        if short_merge_fn is not None:
+            truncated = [h["n_rows"] > h["k_valid"] for h in headers]
+            return short_merge_fn(*self.decoded(), truncated, k_out)
+        return ops.merge_short_lists(self.recv, self.world, self.n_q, self.k, k_out)
+
 
 class ShardExchange:
     """One exchange in flight: submit() starts it behind the (asynchronous) search, result() completes it.  Between the two the
-    caller may enqueue the next step's pack and search: nothing in here waits for work enqueued after the collective."""
+    caller may enqueue the next step's pack and search: nothing in here waits for work enqueued after the collective.
+    k_out > message.k: the message holds SHORT lists (module docstring); result() then verifies the merged lists and repeats the
+    queries that fail with full lists -- `queries` (this exchange's query rows) and `index` are needed for that."""
 
-    def __init__(self, message, index=None, group=None, merge_fn=None):
+    def __init__(self, message, index=None, group=None, merge_fn=None, k_out=None, queries=None, search_fn=None, short_merge_fn=None):
         self.message, self.index, self.group, self.merge_fn = message, index, group, merge_fn
+        self.k_out = message.k if k_out is None else int(k_out)
+        assert self.k_out >= message.k
+        self.queries, self.search_fn, self.short_merge_fn = queries, search_fn, short_merge_fn
         self.work = self.event = None
         self.repeated = False
+        self.fallback_queries = 0      # short lists: queries repeated with full lists
         self.headers = None
 
     def submit(self):
@@ -159,7 +203,18 @@ class ShardExchange:
             self.repeated = True
             m.header[1:2].zero_()
             m.gather(self.group)
-        return m.merge(self.merge_fn)
+        if self.k_out == m.k:
+            return m.merge(self.merge_fn)
+        scores, ids, flags, count = m.merge_short(self.k_out, self.headers, self.short_merge_fn)
+        self.fallback_queries = int(count.item())      # (the one host read of the short-list path: 4 bytes behind the merge)
+        if self.fallback_queries:
+            # a list was consumed to its end for these queries: all ranks (same flags from the same bytes) repeat them with full lists
+            which = flags.nonzero().squeeze(1)
+            again = self.queries[which].contiguous() if self.queries is not None else None
+            s2, i2 = sharded_search(self.index, again, self.k_out, self.group, merge_fn=self.merge_fn, search_fn=self.search_fn,
+                                    short_lists=False)
+            scores[which], ids[which] = s2, i2
+        return scores, ids
 
 
 _SIDE = {}
@@ -172,23 +227,34 @@ def _side_stream(device):
     return _SIDE[key]
 
 
-def submit_sharded_search(index, queries_bf16, k, group=None, message=None, merge_fn=None):
+def submit_sharded_search(index, queries_bf16, k, group=None, message=None, merge_fn=None, short_lists=None):
     """Asynchronous per-shard search straight into a packed message + the all-gather behind it -> ShardExchange (call
-    .result() for the merged lists).  Needs k <= index.n_rows (sharded_search handles tiny shards)."""
+    .result() for the merged lists).  short_lists: None = short_lists_pay(k, world) (and the shard holds k_list rows); a `message`
+    built for k_list < k entries selects the short-list exchange by itself.  Needs min(k, k_list) <= index.n_rows (sharded_search
+    handles tiny shards)."""
     world = dist.get_world_size(group)
-    if message is None:
-        message = ShardMessage(queries_bf16.shape[0], k, queries_bf16.device, world)
-    assert (message.n_q, message.k, message.world) == (queries_bf16.shape[0], k, world)
-    index.search_shard(queries_bf16, k, message.send, defer=True)
-    return ShardExchange(message, index, group, merge_fn).submit()
+    n_q = queries_bf16.shape[0]
+    if message is not None:
+        k_list = message.k
+    else:
+        short = short_lists_pay(k, world) if short_lists is None else (bool(short_lists) and short_list_length(k, world) < k)
+        k_list = short_list_length(k, world) if short else k
+        if k_list > index.n_rows:
+            k_list = k
+        message = ShardMessage(n_q, k_list, queries_bf16.device, world)
+    assert (message.n_q, message.world) == (n_q, world) and message.k <= k
+    index.search_shard(queries_bf16, message.k, message.send, defer=True)
+    return ShardExchange(message, index, group, merge_fn, k_out=k, queries=queries_bf16).submit()
 
 
-def sharded_search(index, queries_bf16, k, group=None, merge_fn=None, search_fn=None, message=None, block=None, n_total=None):
+def sharded_search(index, queries_bf16, k, group=None, merge_fn=None, search_fn=None, message=None, block=None, n_total=None,
+                   short_lists=None, short_merge_fn=None):
     """index: this rank's CorpusIndex (built with global_row_offset = its shard's first row).
-    message: optional reusable ShardMessage(n_q, k, device, world) -- the search then writes straight into it.
+    message: optional reusable ShardMessage(n_q, k or short_list_length(k, world), device, world) -- the search then writes straight into it.
     block: (ptr, idx) CSR of per-query blocked GLOBAL row ids (the same on every rank; each shard applies its own part).
     n_total: rows of the whole corpus; k is clamped to it (a corpus smaller than k cannot fill k ranks).
-    search_fn / merge_fn: test hooks (CPU stand-ins for the per-shard search and the merge)."""
+    short_lists: None = automatic (short_lists_pay), False = always full lists, True = short lists wherever k_list < k.
+    search_fn / merge_fn / short_merge_fn: test hooks (CPU stand-ins for the per-shard search and the merges)."""
     if n_total is not None:
         k = min(k, int(n_total))
     k_local = min(k, index.n_rows)
@@ -198,17 +264,28 @@ def sharded_search(index, queries_bf16, k, group=None, merge_fn=None, search_fn=
             return index.search_blocked(queries_bf16, k_local, block[0], block[1])
         return (search_fn or index.search)(queries_bf16, k_local)
     world = dist.get_world_size(group)
-    direct = block is None and search_fn is None and k_local == k and 0 < queries_bf16.shape[0] <= ops.MAX_QUERIES_PER_SEARCH
-    if direct:   # the kernel writes the exchange message itself, no host round trip (larger batches are searched in pieces below)
-        return submit_sharded_search(index, queries_bf16, k, group, message, merge_fn).result()
-    # blocked lists, tiny shards (k_local < k: the message pads with (-inf, distinct ids), so every output slot is written even
-    # when the whole corpus holds fewer than k rows -- pass n_total to clamp k instead) and test hooks: ordinary results -> message
-    if block is not None and search_fn is None:
-        scores, ids = index.search_blocked(queries_bf16, k_local, block[0], block[1])
+    n_q = queries_bf16.shape[0] if queries_bf16 is not None else -1     # (None: a test hook that ignores its query argument)
+    if message is not None:
+        k_list = message.k
     else:
-        scores, ids = (search_fn or index.search)(queries_bf16, k_local)
+        short = block is None and (short_lists_pay(k, world) if short_lists is None else
+                                   (bool(short_lists) and short_list_length(k, world) < k and world * short_list_length(k, world) * 12 <= ops.SHORT_LIST_LDS_BYTES))
+        k_list = short_list_length(k, world) if short else k
+    direct = block is None and search_fn is None and k_list <= index.n_rows and 0 < n_q <= ops.MAX_QUERIES_PER_SEARCH
+    if direct:   # the kernel writes the exchange message itself, no host round trip (larger batches are searched in pieces below)
+        if message is None:
+            message = ShardMessage(n_q, k_list, queries_bf16.device, world)
+        return submit_sharded_search(index, queries_bf16, k, group, message, merge_fn).result()
+    # blocked lists, tiny shards (fewer rows than entries asked for: the message pads with (-inf, distinct ids), so every output slot is
+    # written even when the whole corpus holds fewer than k rows -- pass n_total to clamp k instead) and test hooks: ordinary results -> message
+    k_search = min(k_list, index.n_rows)
+    if block is not None and search_fn is None:
+        scores, ids = index.search_blocked(queries_bf16, k_search, block[0], block[1])
+    else:
+        scores, ids = (search_fn or index.search)(queries_bf16, k_search)
     if message is None:
-        message = ShardMessage(scores.shape[0], k, scores.device, world)
+        message = ShardMessage(scores.shape[0], k_list, scores.device, world)
     lo = index.offset
     message.fill(scores, ids, lo, index.n_rows)
-    return ShardExchange(message, None, group, merge_fn).submit().result()
+    return ShardExchange(message, index, group, merge_fn, k_out=k, queries=queries_bf16, search_fn=search_fn,
+                         short_merge_fn=short_merge_fn).submit().result()

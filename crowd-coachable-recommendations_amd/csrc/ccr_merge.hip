@@ -31,9 +31,12 @@ __device__ __forceinline__ int lds_lower_bound(const float *os, const int64_t *o
     return lo;
 }
 
-__device__ __forceinline__ void merge_lists_lds(const float *s_sc, const int64_t *s_id, int R, int k, int *s_cut, int *s_lohi, int *s_cnt,
+// (lists of kl elements each, the ko best kept: kl == ko for the full-list exchange, kl < ko for the short-list exchange, whose caller
+//  reads the cuts back from s_cut afterwards -- a list consumed to its end may have had more to give)
+__device__ __forceinline__ void merge_lists_lds(const float *s_sc, const int64_t *s_id, int R, int kl, int ko, int *s_cut, int *s_lohi, int *s_cnt,
                                                 int64_t out_base, float *__restrict__ out_scores, int64_t *__restrict__ out_ids) {
     const int tid = threadIdx.x;
+    const int k = kl;   // list stride and bisection range
     // ---- phase 1: cuts (s_lohi[2r] / [2r+1] = the bisection interval of list r, s_cnt[r] = rank accumulator of its probe).
     // The whole workgroup takes part (uniform trip count, block barriers): the R (R - 1) searches of a step are spread over its threads.
     for (int r = tid; r < R; r += blockDim.x) {
@@ -59,7 +62,7 @@ __device__ __forceinline__ void merge_lists_lds(const float *s_sc, const int64_t
             const int lo = s_lohi[2 * r], hi = s_lohi[2 * r + 1];
             if (lo < hi) {
                 const int mid = (lo + hi) >> 1;
-                if (s_cnt[r] < k)
+                if (s_cnt[r] < ko)
                     s_lohi[2 * r] = mid + 1;
                 else
                     s_lohi[2 * r + 1] = mid;
@@ -71,7 +74,7 @@ __device__ __forceinline__ void merge_lists_lds(const float *s_sc, const int64_t
     for (int r = tid; r < R; r += blockDim.x) s_cut[r] = s_lohi[2 * r];
     __syncthreads();
     // ---- phase 2: the kept elements (sum of the cuts = k) find their ranks among the kept prefixes
-    for (int t = tid; t < k; t += blockDim.x) {
+    for (int t = tid; t < ko; t += blockDim.x) {
         int r = 0, p = t;
         while (r < R - 1 && p >= s_cut[r]) {
             p -= s_cut[r];
@@ -83,7 +86,7 @@ __device__ __forceinline__ void merge_lists_lds(const float *s_sc, const int64_t
         int rank = p;
         for (int o = 0; o < R; ++o)
             if (o != r) rank += lds_lower_bound(s_sc + o * k, s_id + o * k, s_cut[o], s, id);
-        if (rank < k) {
+        if (rank < ko) {
             out_scores[out_base + rank] = s;
             out_ids[out_base + rank] = id;
         }
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(1024) void merge_topk_lds_kernel(const float *__res
     if (R * k < 600)
         merge_lists_lds_all(s_sc, s_id, R, k, (int64_t)q * k, out_scores, out_ids);
     else
-        merge_lists_lds(s_sc, s_id, R, k, s_cut, s_lohi, s_cnt, (int64_t)q * k, out_scores, out_ids);
+        merge_lists_lds(s_sc, s_id, R, k, k, s_cut, s_lohi, s_cnt, (int64_t)q * k, out_scores, out_ids);
 }
 
 }  // namespace ccr
@@ -232,7 +235,52 @@ __global__ __launch_bounds__(1024) void merge_messages_lds_kernel(ShardSrc m, in
     if (R * k < 600)
         merge_lists_lds_all(s_sc, s_id, R, k, (int64_t)q * k, out_scores, out_ids);
     else
-        merge_lists_lds(s_sc, s_id, R, k, s_cut, s_lohi, s_cnt, (int64_t)q * k, out_scores, out_ids);
+        merge_lists_lds(s_sc, s_id, R, k, k, s_cut, s_lohi, s_cnt, (int64_t)q * k, out_scores, out_ids);
+}
+
+// Short-list exchange: every rank sent only the kl < ko best entries of each query (kl ~ ko / R + 6 sigma of the share a shard of
+// exchangeable rows holds of a global top-ko), the merge keeps ko of the R kl.  A shard's list is its EXACT canonical top-kl, so every
+// row it did not send ranks behind its last entry: if that entry is NOT among the kept ko (cut_r < kl), no unsent row of the shard
+// is either, and the merged list is the global top-ko, bit for bit.  A list consumed to its end (cut_r == kl) whose shard holds more
+// rows may have had more to give: the query is marked in flags[] (and counted) and the caller repeats it with full lists.
+__global__ __launch_bounds__(1024) void merge_short_lists_kernel(ShardSrc m, int R, int ko, float *__restrict__ out_scores,
+                                                               int64_t *__restrict__ out_ids, uint32_t *__restrict__ flags,
+                                                               uint32_t *__restrict__ n_flagged) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    const int kl = m.k, n = R * kl;
+    int64_t *s_id = reinterpret_cast<int64_t *>(sm);
+    float *s_sc = reinterpret_cast<float *>(sm + (size_t)n * 8);
+    const int q = blockIdx.x;
+    __shared__ int s_valid[64], s_more[64];
+    __shared__ int64_t s_off[64];
+    for (int r = threadIdx.x; r < R; r += blockDim.x) {
+        const ccr_shard_header *h = reinterpret_cast<const ccr_shard_header *>(m.base + (int64_t)r * m.stride);
+        s_valid[r] = (int)h->k_valid;
+        s_off[r] = h->row_offset;
+        s_more[r] = (h->n_rows > (int64_t)h->k_valid) ? 1 : 0;   // the shard holds rows it did not send
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        const int r = e / kl, p = e - r * kl;
+        const char *msg = m.base + (int64_t)r * m.stride;
+        if (p < s_valid[r]) {
+            s_sc[e] = reinterpret_cast<const float *>(msg + sizeof(ccr_shard_header))[(int64_t)q * kl + p];
+            s_id[e] = s_off[r] + (int64_t) reinterpret_cast<const uint32_t *>(msg + m.rows_at)[(int64_t)q * kl + p];
+        } else {   // padding slot: ranks last, distinct id
+            s_sc[e] = -INFINITY;
+            s_id[e] = INT64_MAX - ((int64_t)r * kl + p);
+        }
+    }
+    __syncthreads();
+    __shared__ int s_cut[64], s_lohi[128], s_cnt[64];
+    merge_lists_lds(s_sc, s_id, R, kl, ko, s_cut, s_lohi, s_cnt, (int64_t)q * ko, out_scores, out_ids);
+    // (s_cut was complete before phase 2 of the merge began; nothing writes it afterwards)
+    if (threadIdx.x == 0) {
+        int bad = 0;
+        for (int r = 0; r < R; ++r) bad |= (s_cut[r] >= s_valid[r] && s_more[r]) ? 1 : 0;   // every REAL entry of list r was kept
+        flags[q] = (uint32_t)bad;
+        if (bad) atomicAdd(n_flagged, 1u);
+    }
 }
 
 // lists too long for the LDS: every probe decodes its entry from the messages.  grid = (ceil(R*k/256), n_q)
@@ -331,6 +379,32 @@ extern "C" int ccr_merge_shard_messages(const void *messages, int64_t message_st
     }
     dim3 grid((unsigned)((R * k + 255) / 256), (unsigned)n_q);
     hipLaunchKernelGGL(merge_messages_kernel, grid, dim3(256), 0, (hipStream_t)stream, m, R, n_q, out_scores, out_ids);
+    CCR_LAUNCH_CHECK();
+    return CCR_OK;
+}
+
+extern "C" int ccr_merge_short_lists(const void *messages, int64_t message_stride_bytes, int R, int n_q, int k_list, int k_out,
+                                     float *out_scores, int64_t *out_ids, uint32_t *flags, uint32_t *n_flagged, void *stream) {
+    CCR_REQUIRE(messages && out_scores && out_ids && flags && n_flagged, "ccr_merge_short_lists: null pointer");
+    CCR_REQUIRE(R >= 1 && R <= 64 && n_q >= 0 && k_list >= 1 && k_out >= 1 && k_out <= MAX_K && k_list <= k_out,
+                "ccr_merge_short_lists: bad shape R=%d n_q=%d k_list=%d k_out=%d", R, n_q, k_list, k_out);
+    CCR_REQUIRE((int64_t)R * k_list >= k_out, "ccr_merge_short_lists: R * k_list = %lld entries cannot fill k_out = %d", (long long)R * k_list, k_out);
+    const size_t rows_at = shard_rows_at(n_q, k_list);
+    CCR_REQUIRE((uintptr_t)messages % 16 == 0 && message_stride_bytes % 16 == 0 &&
+                    (size_t)message_stride_bytes >= rows_at + (size_t)n_q * k_list * 4,
+                "ccr_merge_short_lists: message stride %lld shorter than one message or not 16-byte aligned", (long long)message_stride_bytes);
+    const size_t lds = (size_t)R * k_list * 12;
+    CCR_REQUIRE(lds <= 96 * 1024, "ccr_merge_short_lists: R * k_list * 12 = %zu bytes of lists do not fit the LDS (use the full-list exchange)", lds);
+    hipStream_t s = (hipStream_t)stream;
+    CCR_HIP_CHECK(hipMemsetAsync(n_flagged, 0, 4, s));
+    if (n_q == 0) return CCR_OK;
+    if (lds > 48 * 1024) {
+        const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&merge_short_lists_kernel), 96 * 1024);
+        if (rc != CCR_OK) return rc;
+    }
+    ShardSrc m = {reinterpret_cast<const char *>(messages), message_stride_bytes, rows_at, k_list};
+    const int threads = (R * k_list >= 2048 || k_out >= 1024) ? 1024 : 256;
+    hipLaunchKernelGGL(merge_short_lists_kernel, dim3((unsigned)n_q), dim3(threads), lds, s, m, R, k_out, out_scores, out_ids, flags, n_flagged);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
 }

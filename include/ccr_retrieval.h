@@ -321,6 +321,18 @@ int ccr_shard_message_fill(void *message, int n_q, int k, int k_valid, const flo
  * every output slot is written even when the whole corpus holds fewer than k rows.  k <= 4096, R <= 64. */
 int ccr_merge_shard_messages(const void *messages, int64_t message_stride_bytes, int R, int n_q, int k, float *out_scores,
                              int64_t *out_ids, void *stream);
+/* Short-list exchange (the k that scripts/ms_marco_eval.py:230 keeps -- 1001 -- over R shards).  A shard of exchangeable rows holds
+ * k / R +- sqrt(k (1/R)(1 - 1/R)) of a global top-k, so every rank searches and sends only its canonical top-k_list, k_list ~ k / R + 6 sigma
+ * (ccr_search_shard(..., k_list, ...): the select / re-score stage, which does not shrink with the shard, does k_list instead of k rows per
+ * query, and the message is k_list / k of the size).  This merge keeps the k_out best of the R k_list entries and VERIFIES the shortcut: a
+ * shard's list is its exact top-k_list, so if its last entry is not among the kept k_out, none of its unsent rows is either and the result
+ * is the global top-k_out, bit for bit.  flags[q] = 1 (and *n_flagged counts them; both device memory, n_flagged zeroed by the call) where some
+ * list was consumed to its end while its shard (header.n_rows > header.k_valid) holds more rows: the caller repeats THOSE queries with full
+ * lists (every rank computes the same flags from the same gathered bytes, so the repeat is a matched collective).
+ *   messages: R gathered messages of ccr_shard_message_bytes(n_q, k_list) layout; out_* [n_q][k_out]; k_list <= k_out <= R k_list;
+ *   R k_list 12 B <= 96 KiB (the lists of a query are merged in LDS). */
+int ccr_merge_short_lists(const void *messages, int64_t message_stride_bytes, int R, int n_q, int k_list, int k_out, float *out_scores,
+                          int64_t *out_ids, uint32_t *flags, uint32_t *n_flagged, void *stream);
 
 /*
  * Apply per-query blocked ids to an over-fetched result list.

@@ -172,6 +172,30 @@ def merge_topk(scores, ids):
     return os_, oi
 
 
+def merge_short_lists(scores, ids, truncated, k_out):
+    """Test-side restatement of the short-list merge (csrc/ccr_merge.hip: merge_short_lists_kernel): [R, nq, kl] per-shard lists, each a
+    shard's exact canonical top-kl (padding slots: -inf with ids above 2^62) -> the k_out best of the R kl entries per query in the
+    canonical order (score desc, id asc), and flags[q] = 1 where every REAL entry of some list r with truncated[r] (its shard holds rows
+    it did not send) is among the kept k_out -- then an unsent row of that shard may belong there too and the query must be repeated
+    with full lists; otherwise the kept k_out are the global top-k_out.  -> (scores [nq, k_out], ids [nq, k_out], flags [nq] int32)."""
+    scores = np.ascontiguousarray(scores, np.float32)
+    ids = np.ascontiguousarray(ids, np.int64)
+    R, nq, kl = scores.shape
+    assert R * kl >= k_out
+    os_ = np.empty((nq, k_out), np.float32)
+    oi = np.empty((nq, k_out), np.int64)
+    flags = np.zeros(nq, np.int32)
+    src = np.repeat(np.arange(R), kl)
+    for q in range(nq):
+        s, i = scores[:, q].reshape(-1), ids[:, q].reshape(-1)
+        order = np.lexsort((i, -s.astype(np.float64)))[:k_out]
+        os_[q], oi[q] = s[order], i[order]
+        kept = np.bincount(src[order], minlength=R)
+        real = (ids[:, q] < (1 << 62)).sum(axis=1)
+        flags[q] = int(any(truncated[r] and kept[r] >= real[r] for r in range(R)))
+    return os_, oi, flags
+
+
 def sparse_prior_search(Qb, Db, indptr, indices, data, k):
     """Top-k of (canonical low-rank score + sparse prior), the restatement of `_assign_topk(transform(D) + D.prior_score, k)`
     (src/rime_lite/util/__init__.py:117-155 over ElementWiseExpression(add, [dense, sparse]), score_array.py:300-318;

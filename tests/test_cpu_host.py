@@ -201,6 +201,108 @@ def test_sharded_search_gloo_world2(tmp_path, n, k):
         assert open(tmp_path / f"rank{r}.txt").read() == "ok"
 
 
+def _short_worker(rank, world, port, n, nq, k, skew, out_dir):
+    """Short-list exchange over gloo with CPU stand-ins (the oracle scores the local rows; numpy merges): every rank searches and
+    sends only short_list_length(k, world) entries per query; the merge verifies the cuts and the flagged queries are repeated with
+    full lists by all ranks together."""
+    import torch.distributed as dist
+    sys.path[:0] = [ROOT, PKG]
+    from ccrec_amd import dist as cdist
+    from oracle import oracle as orc
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(11)
+    D = torch.randn(n, 64, generator=g) / 8
+    Q = torch.linalg.qr(torch.randn(64, nq, generator=g))[0].T.contiguous()      # orthonormal query rows: a row built for one query is noise for the others
+    if skew:   # queries 0 and 3 find their whole top-k inside the LAST shard: its short list is consumed to its end
+        lo_last = cdist.shard_bounds(n, world, world - 1)[0]
+        for j, qi in enumerate((0, 3)):
+            rows = slice(lo_last + 5 + j * k, lo_last + 5 + (j + 1) * k)
+            D[rows] = 3.0 * Q[qi] + 0.2 * D[rows]
+    Db, Qb = orc.pack_bf16(D.numpy()), orc.pack_bf16(Q.numpy())
+    Db[n // 2 + 1] = Db[1]          # cross-shard exact tie
+    lo, hi = cdist.shard_bounds(n, world, rank)
+    calls = []
+
+    class Shard:
+        n_rows = hi - lo
+        offset = lo
+
+    def search_fn(q, kk):
+        rows = np.arange(nq) if q is None else q.numpy().astype(np.int64)     # the fallback hands over the flagged queries' rows
+        calls.append((len(rows), kk))
+        ids, sc = orc.canonical_search(Qb[rows], Db[lo:hi], kk)
+        return torch.from_numpy(sc), torch.from_numpy(ids + lo)
+
+    def merge_fn(gs, gi):
+        s, i = orc.merge_topk(gs.numpy(), gi.numpy())
+        return torch.from_numpy(s), torch.from_numpy(i)
+
+    def short_merge_fn(gs, gi, truncated, k_out):
+        s, i, flags = orc.merge_short_lists(gs.numpy(), gi.numpy(), truncated, k_out)
+        return torch.from_numpy(s), torch.from_numpy(i), torch.from_numpy(flags), torch.tensor([int(flags.sum())])
+
+    k_list = cdist.short_list_length(k, world)
+    ok = k_list < k
+    # queries as a tensor of their own row numbers, so that the fallback's `queries[which]` names the flagged rows for search_fn
+    qrows = torch.arange(nq)
+    index = Shard()
+    msg = cdist.ShardMessage(nq, k_list, "cpu", world)
+    scores, ids = search_fn(qrows, k_list)
+    msg.fill(scores, ids, lo, hi - lo)
+    ex = cdist.ShardExchange(msg, index, None, merge_fn, k_out=k, queries=qrows, search_fn=search_fn, short_merge_fn=short_merge_fn).submit()
+    s, i = ex.result()
+    ref_i, ref_s = orc.canonical_search(Qb, Db, k)
+    ok = ok and np.array_equal(i.numpy(), ref_i) and np.array_equal(s.numpy().view(np.uint32), ref_s.view(np.uint32))
+    if skew:
+        ok = ok and ex.fallback_queries == 2 and calls == [(nq, k_list), (2, k)]      # exactly the two skewed queries were repeated, with full lists
+    else:
+        ok = ok and ex.fallback_queries == 0 and calls == [(nq, k_list)]
+    # the same through sharded_search's own routing (short_lists=True), and switched off
+    calls.clear()
+    s2, i2 = cdist.sharded_search(index, qrows, k, merge_fn=merge_fn, search_fn=search_fn, short_lists=True, short_merge_fn=short_merge_fn)
+    ok = ok and np.array_equal(i2.numpy(), ref_i) and calls[0] == (nq, k_list)
+    calls.clear()
+    s3, i3 = cdist.sharded_search(index, qrows, k, merge_fn=merge_fn, search_fn=search_fn, short_lists=False)
+    ok = ok and np.array_equal(i3.numpy(), ref_i) and calls == [(nq, k)]
+    open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if ok else f"MISMATCH fallback={ex.fallback_queries} calls={calls}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,skew", [(2, False), (3, False), (2, True), (3, True)])
+def test_short_list_exchange_gloo(tmp_path, world, skew):
+    """Short-list exchange (ccrec_amd/dist.py): world 2 / 3 over gloo, k = 300 -> 210 / 157 entries per rank and query; iid rows need no
+    repeat; with two queries whose top-k sits in one shard exactly those two are repeated with full lists -- the merged lists equal
+    the single-index oracle search bit for bit either way (a cross-shard exact tie included)."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_short_worker, args=(world, port, 2400, 7, 300, skew, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert open(tmp_path / f"rank{r}.txt").read() == "ok"
+
+
+def test_short_list_length_and_policy(monkeypatch):
+    from ccrec_amd import dist as cdist
+    monkeypatch.delenv("CCREC_SHORT_LISTS", raising=False)
+    assert cdist.short_list_length(1001, 1) == 1001
+    assert cdist.short_list_length(1001, 8) == 196 and cdist.short_list_length(1001, 2) == 604 and cdist.short_list_length(100, 8) == 41
+    assert cdist.short_list_length(10, 8) == 10                       # never above k
+    for k in (1, 10, 100, 1001, 4096):
+        for world in (2, 3, 8, 64):
+            assert world * cdist.short_list_length(k, world) >= k      # the R lists can always fill k ranks
+    assert cdist.short_lists_pay(1001, 8) and cdist.short_lists_pay(1001, 2) and cdist.short_lists_pay(100, 8)
+    assert not cdist.short_lists_pay(100, 2) and not cdist.short_lists_pay(1001, 1) and not cdist.short_lists_pay(10, 8)
+    assert cdist.short_lists_pay(4096, 64) and cdist.short_lists_pay(4096, 3)
+    monkeypatch.setattr(cdist.ops, "SHORT_LIST_LDS_BYTES", 32 * 1024)
+    assert not cdist.short_lists_pay(4096, 3) and cdist.short_lists_pay(1001, 8)       # 3 x 1 555 x 12 B of lists would not fit the merge kernel's LDS
+    monkeypatch.undo()
+    monkeypatch.delenv("CCREC_SHORT_LISTS", raising=False)
+    monkeypatch.setenv("CCREC_SHORT_LISTS", "0")
+    assert not cdist.short_lists_pay(1001, 8)
+    monkeypatch.setenv("CCREC_SHORT_LISTS", "1")
+    assert cdist.short_lists_pay(100, 2) and not cdist.short_lists_pay(1001, 1)
+
+
 def test_plan_batches_covers_every_text_once_under_the_budget():
     """Host logic of the length-sorted encoder."""
     from ccrec_amd.encode import plan_batches

@@ -253,6 +253,93 @@ def test_shard_messages_merge_equals_single(n, nq, k, world):
     assert np.array_equal(mi.cpu().numpy(), oi) and np.array_equal(ms.cpu().numpy(), os_)
 
 
+@pytest.mark.parametrize("n,nq,k,world,skewed", [(40000, 21, 1001, 8, 0), (40000, 21, 1001, 8, 3), (30000, 9, 1001, 2, 1), (12000, 33, 100, 8, 2),
+                                                 (2400, 5, 300, 3, 0)])
+def test_short_shard_messages_merge_equals_single(n, nq, k, world, skewed):
+    """The SHORT-list exchange (ccr_merge_short_lists; ranking()'s k = 1001 over 8 shards sends 196 entries per query and rank instead of
+    1001): every shard searches and packs its canonical top-k_list (ccr_search_shard), the gathered buffer is emulated, the merge keeps k
+    of the R k_list entries and flags the queries for which a list was consumed to its end.  iid rows: nobody is flagged and ids and
+    score bits equal the single-index search (a cross-shard exact tie included).  `skewed` queries have their whole top-k in ONE shard
+    (a corpus in topical order): exactly those are flagged -- same flags as the oracle's restatement -- and after the full-list repeat
+    of THOSE queries every list is the single-index search's, bit for bit.  (2400 rows over 3 shards at k = 300: shards of 800 rows,
+    k_list = 157.)"""
+    from ccrec_amd import ops
+    from ccrec_amd.dist import shard_bounds, short_list_length, ShardMessage
+    d = 256
+    Db, Qb = _rand_bits(n, d, 133), _rand_bits(nq, d, 134)
+    Db[n // 2 + 1] = Db[1]                     # cross-shard exact tie: the lower global id wins
+    lo_last = shard_bounds(n, world, world - 1)[0]
+    if skewed:   # rows that score far above everything else for ONE query each, all inside the last shard
+        rs = np.random.RandomState(5)
+        Df = rs.randn(n, d).astype(np.float32) / 16
+        Qf = np.linalg.qr(rs.randn(d, nq))[0].T.astype(np.float32)
+        for j in range(skewed):
+            rows = slice(lo_last + 7 + j * k, lo_last + 7 + (j + 1) * k)
+            Df[rows] = 2.0 * Qf[2 * j] + 0.3 * Df[rows]
+        Db, Qb = orc.pack_bf16(Df), orc.pack_bf16(Qf)
+        Db[n // 2 + 1] = Db[1]
+    D, Q = _bf16(Db), _bf16(Qb)
+    s1, i1 = ops.CorpusIndex(D).search(Q, k)
+    kl = short_list_length(k, world)
+    assert kl < k and world * kl >= k
+    gathered = ShardMessage(nq, kl, D.device, world)
+    shards = []
+    for r in range(world):
+        lo, hi = shard_bounds(n, world, r)
+        m = ShardMessage(nq, kl, D.device, 1)
+        ix = ops.CorpusIndex(D[lo:hi].contiguous(), global_row_offset=lo)
+        ix.search_shard(Q, kl, m.send, defer=(r % 2 == 1))
+        if r % 2 == 1:
+            ix.finish()
+        gathered.recv.view(world, -1)[r].copy_(m.send)
+        shards.append(ix)
+    ms, mi, flags, count = ops.merge_short_lists(gathered.recv, world, nq, kl, k)
+    want = sorted(2 * j for j in range(skewed))
+    assert flags.nonzero().squeeze(1).tolist() == want and int(count) == len(want)
+    gs, gi = gathered.decoded()
+    hdrs = ShardMessage.parse_headers(gathered.all_headers.cpu())
+    os_, oi, oflags = orc.merge_short_lists(gs.cpu().numpy(), gi.cpu().numpy(), [h["n_rows"] > h["k_valid"] for h in hdrs], k)
+    assert np.array_equal(flags.cpu().numpy(), oflags)
+    assert np.array_equal(mi.cpu().numpy(), oi) and np.array_equal(ms.cpu().numpy().view(np.uint32), os_.view(np.uint32))
+    good = (flags == 0)
+    assert torch.equal(mi[good], i1[good]) and torch.equal(ms[good].view(torch.int32), s1[good].view(torch.int32))
+    if want:   # the repeat: full lists for the flagged queries only
+        which = flags.nonzero().squeeze(1)
+        full = ShardMessage(len(want), k, D.device, world)
+        for r, ix in enumerate(shards):
+            m = ShardMessage(len(want), k, D.device, 1)
+            ix.search_shard(Q[which].contiguous(), k, m.send)
+            full.recv.view(world, -1)[r].copy_(m.send)
+        fs, fi = full.merge()
+        ms[which], mi[which] = fs, fi
+    assert torch.equal(mi, i1) and torch.equal(ms.view(torch.int32), s1.view(torch.int32))
+
+
+def test_short_list_merge_flags_a_consumed_list_only_when_its_shard_holds_more():
+    """The verification rule at its edges: a list consumed to its end is harmless when its shard sent EVERY row it has (k_valid = n_rows:
+    nothing is unsent); padding slots never count as kept entries; a list whose LAST entry is kept is flagged even when the merged
+    result happens to be right (the rule is a sufficient condition, checked exactly)."""
+    from ccrec_amd import ops
+    from ccrec_amd.dist import ShardMessage
+    nq, kl, k, world = 2, 4, 6, 2
+    gathered = ShardMessage(nq, kl, "cuda", world)
+    # rank 0: a 4-row shard that sent all 4 rows (scores 9 8 7 6); rank 1: a 100-row shard that sent its top 4
+    for r, (sc, n_rows) in enumerate([([[9, 8, 7, 6], [9, 8, 7, 6]], 4), ([[5, 4, 3, 2], [10, 9.5, 8.5, 6.5]], 100)]):
+        m = ShardMessage(nq, kl, "cuda", 1)
+        m.fill(torch.tensor(sc, dtype=torch.float32, device="cuda"), torch.arange(kl, device="cuda").repeat(nq, 1) + r * 1000, r * 1000, n_rows)
+        gathered.recv.view(world, -1)[r].copy_(m.send)
+    ms, mi, flags, count = ops.merge_short_lists(gathered.recv, world, nq, kl, k)
+    # query 0: rank 0's list is consumed (all 4 kept) but the shard has no more rows; rank 1 keeps 2 of 4 -> final
+    # query 1: rank 1's four entries all rank within the top 6 (10 9.5 9 8.5 8 7 | 6.5 would be 7th: NOT kept) -> 3 kept of 4 -> final
+    assert flags.tolist() == [0, 0] and int(count) == 0
+    assert ms.tolist() == [[9, 8, 7, 6, 5, 4], [10, 9.5, 9, 8.5, 8, 7]]
+    assert mi.tolist() == [[0, 1, 2, 3, 1000, 1001], [1000, 1001, 0, 1002, 1, 2]]
+    ms, mi, flags, count = ops.merge_short_lists(gathered.recv, world, nq, kl, 7)
+    assert flags.tolist() == [0, 1] and int(count) == 1          # k = 7: rank 1's last entry (6.5) is kept -> its 5th row might outrank 6
+    with pytest.raises(Exception):
+        ops.merge_short_lists(gathered.recv, world, nq, kl, 9)   # 2 x 4 entries cannot fill 9 ranks
+
+
 def test_shard_messages_of_a_corpus_smaller_than_k_fill_every_slot():
     from ccrec_amd import ops
     from ccrec_amd.dist import shard_bounds, ShardMessage, PAD_ID
