@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU rehearsal of N > 1)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--dump-ids", default=None, help="rank 0 saves the final [queries, k] id tensor here (tests)")
+    ap.add_argument("--rehearse-secondary", type=int, default=0, metavar="D",
+                    help="tests: run the N > 1 side runs on a custom shape too, the configs[2] one on 1/D of its rows and queries")
     return ap.parse_args()
 
 
@@ -165,7 +167,7 @@ class Workload:
     are double-buffered: a step that had to re-do flagged queries after the fact still finds its operands."""
 
     def __init__(self, rows, queries, dim, k, data, dev, rank, world, backend, normalize=False):
-        from ccrec_amd.dist import shard_bounds, ShardMessage
+        from ccrec_amd.dist import shard_bounds
         self.rows, self.queries, self.dim, self.k, self.world, self.dev, self.backend = rows, queries, dim, k, world, dev, backend
         self.normalize = normalize
         self.lo, self.hi = shard_bounds(rows, world, rank)
@@ -182,13 +184,32 @@ class Workload:
                        "qpack": torch.empty(queries, pdim, dtype=torch.bfloat16, device=dev),
                        "bounds": torch.empty(n_local, dtype=torch.float32, device=dev),   # norm bound per packed row (pack kernel)
                        "ws": None,   # search workspace, handed from the slot's previous index to its next one
-                       "message": ShardMessage(queries, k, dev, world) if world > 1 else None} for _ in range(2)]
+                       "message": None} for _ in range(2)]
         self.shard, self.qpack = self.slots[0]["shard"], self.slots[0]["qpack"]
         self.prev = None        # the step whose search / exchange is still in flight
         self.nstep = 0
+        self.index = self.scores = self.ids = None
+        self.set_k(k)
+
+    def set_k(self, k):
+        """(Re)size the exchange for top-k: every rank sends k_list entries per query -- the short-list exchange (ccrec_amd/dist.py:
+        k / R + 6 sigma entries, the merge verifies the shortcut) where it pays, full lists otherwise."""
+        from ccrec_amd.dist import ShardMessage, short_list_length, short_lists_pay
+        self.drain()
+        self.k = k
+        self.k_local = min(k, self.hi - self.lo)
+        if self.world > 1:
+            assert self.k_local == k, "shard smaller than k"
+        self.k_list = short_list_length(k, self.world) if (self.world > 1 and short_lists_pay(k, self.world)) else k
+        for b in self.slots:
+            b["message"] = ShardMessage(self.queries, self.k_list, self.dev, self.world) if self.world > 1 else None
+        self.reset_counters()
+
+    def reset_counters(self):
         self.done_stats = []    # last_stats() of every completed step
         self.repeats = 0        # exchanges that had to be repeated (some rank's search had flagged queries: completed by finish(), gathered again)
-        self.index = self.scores = self.ids = None
+        self.fallback_queries = 0   # short lists: queries repeated with full lists (a list was consumed to its end)
+        self.wait_ms = []       # host-observed wait for each step's collective, at the time the step is completed (one step later)
 
     def step(self):
         from ccrec_amd import ops
@@ -200,7 +221,7 @@ class Workload:
         ops.pack_bf16(self.queries_f32, out=b["qpack"], normalize=self.normalize)
         if self.world > 1:
             # asynchronous search straight into the packed message, all-gather behind it on the communication stream
-            cur = (index, submit_sharded_search(index, b["qpack"], self.k_local, message=b["message"]), None, None)
+            cur = (index, submit_sharded_search(index, b["qpack"], self.k, message=b["message"]), None, None)
         else:
             s, i = index.search(b["qpack"], self.k_local, defer=True)
             cur = (index, None, s, i)
@@ -218,6 +239,8 @@ class Workload:
         if exchange is not None:
             s, i = exchange.result()
             self.repeats += int(exchange.repeated)
+            self.fallback_queries += exchange.fallback_queries
+            self.wait_ms.append(exchange.wait_ms)
         else:
             index.finish()
         self.index, self.scores, self.ids = index, s, i
@@ -235,7 +258,7 @@ class Workload:
         self.fence()
         if self.done_stats:
             log(f"{tag}: warmup step", self.done_stats[-1])
-        self.done_stats, self.repeats = [], 0
+        self.reset_counters()
         t0 = time.perf_counter()
         for _ in range(steps):
             self.step()
@@ -258,7 +281,10 @@ class Workload:
         achieved = flops / (avg_main * 1e-3) / 1e12 if avg_main > 0 else 0.0
         return {"qps": self.queries * steps / elapsed, "ms_per_step": ms_per_step, "stats": st, "avg_main": avg_main, "flops": flops,
                 "achieved_tflops": achieved, "n_fallback_max": max(m["n_fallback"] for m in stats),
-                "rank_ms_per_step": [e / steps * 1e3 for e in per_rank], "exchange_repeats": self.repeats}
+                "rank_ms_per_step": [e / steps * 1e3 for e in per_rank], "exchange_repeats": self.repeats,
+                "fallback_queries": self.fallback_queries, "search_ms": sum(m["ms_total"] for m in stats) / len(stats),
+                "exchange_wait_ms": (sum(self.wait_ms) / len(self.wait_ms)) if self.wait_ms else 0.0,
+                "exchange_wait_ms_max": max(self.wait_ms) if self.wait_ms else 0.0}
 
     def release(self):
         self.drain()
@@ -361,6 +387,25 @@ def roofline_obj(r, traffic=None, traffic_source=None):
 def phases_obj(st):
     return {"sample_pass": round(st["ms_sample"], 3), "threshold": round(st["ms_threshold"], 3), "main_pass": round(st["ms_main"], 3),
             "select_rescore": round(st["ms_select"], 3), "fallback": round(st["ms_fallback"], 3), "search_total": round(st["ms_total"], 3)}
+
+
+def exchange_obj(w, r):
+    """What one step moves between the ranks and what the host saw of it (N > 1)."""
+    from ccrec_amd.ops import shard_message_bytes
+    msg = shard_message_bytes(w.queries, w.k_list)
+    short = w.k_list < w.k
+    return {"n_ranks_seen": dist.get_world_size(), "backend": dist.get_backend(),
+            "collective": "one all_gather_into_tensor of the packed shard message per step (header + fp32 scores + u32 local rows)",
+            "lists": (f"short: every rank sends its canonical top-{w.k_list} of top-{w.k} (k / R + 6 sigma + 8); the merge verifies the cuts, "
+                      f"queries that fail are repeated with full lists" if short else f"full: every rank sends its canonical top-{w.k}"),
+            "entries_per_query_per_rank": w.k_list, "message_bytes_per_rank": msg, "gathered_bytes_per_rank_per_step": msg * w.world,
+            "full_list_message_bytes_per_rank": shard_message_bytes(w.queries, w.k),
+            "repeated_exchanges": r["exchange_repeats"], "queries_repeated_with_full_lists": r["fallback_queries"],
+            "rank_ms_per_step_min": round(min(r["rank_ms_per_step"]), 3), "rank_ms_per_step_max": round(max(r["rank_ms_per_step"]), 3),
+            # the per-shard search on this rank's stream (library events) vs. what the host waited for the collective of a step when it
+            # completed that step one step later (0 = it had long arrived behind the next step's pack and search)
+            "search_ms_per_step": round(r["search_ms"], 3), "host_wait_for_exchange_ms_per_step": round(r["exchange_wait_ms"], 3),
+            "host_wait_for_exchange_ms_max": round(r["exchange_wait_ms_max"], 3)}
 
 
 def launch_ranks(n):
@@ -484,14 +529,7 @@ def main():
                              candidates_per_query=round(st["n_candidates"] / max(1, args.queries), 1), n_fallback_max=r["n_fallback_max"]),
     }
     if world > 1:
-        from ccrec_amd.ops import shard_message_bytes
-        msg = shard_message_bytes(args.queries, args.k)
-        out["exchange"] = {"n_ranks_seen": dist.get_world_size(), "backend": dist.get_backend(),
-                           "collective": "one all_gather_into_tensor of the packed shard message per step (header + fp32 scores + u32 local rows)",
-                           "message_bytes_per_rank": msg, "gathered_bytes_per_rank_per_step": msg * world,
-                           "repeated_exchanges": r["exchange_repeats"],
-                           "rank_ms_per_step_min": round(min(r["rank_ms_per_step"]), 3),
-                           "rank_ms_per_step_max": round(max(r["rank_ms_per_step"]), 3)}
+        out["exchange"] = exchange_obj(w, r)
     if args.dump_ids and rank == 0:
         torch.save(w.ids.cpu(), args.dump_ids)
     if rank == 0 and world == 1 and args.cpu_queries > 0:
@@ -499,12 +537,12 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
 
-    # ---- side runs of the default N = 1 invocation (short; never part of `value`)
+    # ---- side runs of the default invocation (short; never part of `value`)
     if world == 1 and default_shape and not args.no_secondary:
         sec = {}
         side_steps, side_warm = min(args.steps, 5), min(args.warmup, 2)
         # (a) what ranking() asks for: the same corpus at k = 1001
-        w.k = w.k_local = 1001
+        w.set_k(1001)
         r2 = w.run(side_steps, max(1, side_warm), "k1001")
         sec["k1001"] = {"workload": "configs[1] corpus, top-1001 (the k of ranking(), ms_marco_eval.py:230)", "value": round(r2["qps"], 1),
                         "unit": "queries/s", "ms_per_step": round(r2["ms_per_step"], 3), "roofline": roofline_obj(r2, *offline_traffic("nq_k1001")),
@@ -530,6 +568,28 @@ def main():
             sec["encode_passages"] = encode_side_run(dev)
         except Exception as e:      # a side run must never cost the line its headline
             sec["encode_passages"] = {"skipped": f"{type(e).__name__}: {e}"}
+        out["secondary"] = sec
+    elif world > 1 and (default_shape or args.rehearse_secondary > 0) and not args.no_secondary:
+        # N > 1: the shapes the multi-GPU target is quoted on, each sharded over the same ranks with its own exchange record
+        sec = {}
+        side_steps, side_warm = min(args.steps, 5), max(1, min(args.warmup, 2))
+        # (a) ranking()'s own k on the NQ corpus (ms_marco_eval.py:230): the short-list exchange's shape
+        w.set_k(1001)
+        r2 = w.run(side_steps, side_warm, "k1001")
+        sec["k1001"] = {"workload": "configs[1] corpus, top-1001 (the k of ranking(), ms_marco_eval.py:230), corpus row-sharded over n_gpus",
+                        "value": round(r2["qps"], 1), "unit": "queries/s", "ms_per_step": round(r2["ms_per_step"], 3), "scaling": "strong",
+                        "roofline": roofline_obj(r2), "phases_ms": phases_obj(r2["stats"]), "n_fallback": r2["n_fallback_max"],
+                        "exchange": exchange_obj(w, r2)}
+        w.release()
+        # (b) configs[2]: MS-MARCO passages, 8,841,823 x 768, 6,980 queries, top-100 -- the shape ">= 6x at 8 GPUs" is quoted on
+        div = max(1, args.rehearse_secondary)
+        m = Workload(MSMARCO_ROWS // div, MSMARCO_Q // div, DIM, TOP_K, "gaussian", dev, rank, world, args.dist_backend)
+        r3 = m.run(side_steps, side_warm, "msmarco")
+        sec["msmarco"] = {"workload": "configs[2]: 8,841,823 x 768 corpus row-sharded over n_gpus, 6,980 queries, top-100" + (f" (REHEARSAL: 1/{div} of the rows and queries)" if div > 1 else ""),
+                          "value": round(r3["qps"], 1), "unit": "queries/s", "ms_per_step": round(r3["ms_per_step"], 3), "scaling": "strong",
+                          "roofline": roofline_obj(r3), "phases_ms": phases_obj(r3["stats"]), "n_fallback": r3["n_fallback_max"],
+                          "exchange": exchange_obj(m, r3)}
+        m.release()
         out["secondary"] = sec
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -171,6 +171,7 @@ class ShardExchange:
         self.repeated = False
         self.fallback_queries = 0      # short lists: queries repeated with full lists
         self.headers = None
+        self.wait_ms = 0.0             # host time result() spent waiting for the collective (+ the header copy) to arrive
 
     def submit(self):
         m = self.message
@@ -186,7 +187,9 @@ class ShardExchange:
         return self
 
     def result(self):
+        import time
         m = self.message
+        t0 = time.perf_counter()
         if self.event is not None:
             self.event.synchronize()                              # the collective + the header copy, nothing later
             torch.cuda.current_stream(m.send.device).wait_event(self.event)   # the merge reads `recv` behind the collective
@@ -194,6 +197,7 @@ class ShardExchange:
         else:
             self.work.wait()
             words = m.all_headers.cpu()
+        self.wait_ms = (time.perf_counter() - t0) * 1e3
         self.headers = m.parse_headers(words)
         if self.index is not None and getattr(self.index, "_deferred", None) is not None:
             self.index.finish()    # its own event is long complete: fills last_stats(); re-does the queries the search flagged (rare)

@@ -121,9 +121,46 @@ def test_bench_ranks_rehearsal_in_fresh_processes(tmp_path, world, rows, launche
     assert rec["roofline"]["launches_per_step"] >= 1 and rec["roofline"]["flops_per_step"] > 0
     ex = rec["exchange"]
     assert ex["n_ranks_seen"] == world and ex["backend"] == "gloo" and ex["repeated_exchanges"] == 0
-    assert ex["message_bytes_per_rank"] == 32 + 300 * 100 * 8 and ex["rank_ms_per_step_min"] <= ex["rank_ms_per_step_max"]
+    from ccrec_amd.dist import short_list_length, short_lists_pay
+    from ccrec_amd.ops import shard_message_bytes
+    entries = short_list_length(100, world) if short_lists_pay(100, world) else 100      # 3 ranks: 70 of 100 entries; 2 ranks: full lists
+    assert ex["entries_per_query_per_rank"] == entries and ex["message_bytes_per_rank"] == shard_message_bytes(300, entries)
+    assert ex["rank_ms_per_step_min"] <= ex["rank_ms_per_step_max"] and ex["queries_repeated_with_full_lists"] == 0
+    assert ex["search_ms_per_step"] > 0 and ex["host_wait_for_exchange_ms_per_step"] >= 0
     a, b = torch.load(tmp_path / "one.pt"), torch.load(tmp_path / "two.pt")
     assert a.shape == (300, 100) and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_ranks_rehearsal_records_the_multi_gpu_side_runs(tmp_path, world):
+    """One N > 1 invocation also measures the shapes the multi-GPU target is quoted on -- ranking()'s k = 1001 on the same corpus (the
+    short-list exchange) and configs[2] (here 1/40 of its rows and queries) -- each with its own `exchange` record: entries per query
+    and rank, message bytes, repeats, per-rank min / max step, and the host-observed wait for the collective split from the search time."""
+    bench = os.path.join(ROOT, "bench.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CCR_BENCH_WATCHDOG="200")
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    cmd = [sys.executable, bench, "--gpus", str(world), "--dist-backend", "gloo", "--same-device", "--steps", "2", "--warmup", "1", "--rows", "150000",
+           "--queries", "200", "--cpu-queries", "0", "--rehearse-secondary", "40"]
+    out, err = _run_child(cmd, env, tmp_path, "ranks")
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    rec = json.loads(lines[0])
+    from ccrec_amd.dist import short_list_length
+    from ccrec_amd.ops import shard_message_bytes
+    sec = rec["secondary"]
+    assert set(sec) == {"k1001", "msmarco"}
+    k1001, ms = sec["k1001"], sec["msmarco"]
+    kl = short_list_length(1001, world)
+    assert k1001["exchange"]["entries_per_query_per_rank"] == kl < 1001 and k1001["exchange"]["message_bytes_per_rank"] == shard_message_bytes(200, kl)
+    assert k1001["exchange"]["full_list_message_bytes_per_rank"] == shard_message_bytes(200, 1001)
+    assert "REHEARSAL" in ms["workload"] and ms["exchange"]["message_bytes_per_rank"] == shard_message_bytes(6980 // 40, ms["exchange"]["entries_per_query_per_rank"])
+    for side in (k1001, ms):
+        ex = side["exchange"]
+        assert side["value"] > 0 and side["scaling"] == "strong" and side["n_fallback"] == 0 and side["roofline"]["bound"] == "mfma"
+        assert ex["n_ranks_seen"] == world and ex["repeated_exchanges"] == 0 and ex["queries_repeated_with_full_lists"] == 0
+        assert 0 < ex["rank_ms_per_step_min"] <= ex["rank_ms_per_step_max"] and ex["search_ms_per_step"] > 0
+        assert ex["host_wait_for_exchange_ms_per_step"] >= 0 and ex["host_wait_for_exchange_ms_max"] >= ex["host_wait_for_exchange_ms_per_step"]
 
 
 def test_bench_refuses_a_world_size_that_contradicts_gpus(tmp_path):
