@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "ccr_index.h"
+#include "ccr_narrow.h"
 #include "ccr_topk_device.h"
 
 namespace ccr {
@@ -45,6 +46,9 @@ Knobs read_knobs() {
     kn.item_swap = env_int("CCR_ITEM_SWAP", 0);
     kn.optimistic = env_int("CCR_OPTIMISTIC", -1);
     kn.opt_rank = env_int("CCR_OPT_RANK", 0);
+    kn.narrow = env_int("CCR_NARROW", -1);
+    kn.narrow_nt = env_int("CCR_NARROW_NT", 1);
+    kn.narrow_grid = env_int("CCR_NARROW_GRID", 0);
     return kn;
 }
 
@@ -146,7 +150,8 @@ static int optimistic_rank(int k, int64_t sample, int64_t tiles, const Knobs &kn
     return r;
 }
 
-static MainPassChoice choose_main_pass(const Plan &p, int k, int64_t sample_a, int64_t sample_b, int64_t sample_c, const Knobs &kn) {
+static MainPassChoice choose_main_pass(const Plan &p, int k, int64_t sample_a, int64_t sample_b, int64_t sample_c, const Knobs &kn,
+                                       bool single_only = false) {
     const int nrc = NUM_XCD / p.qgroups, qb_per = p.qblocks / p.qgroups, per_x = p.grid / NUM_XCD;
     // the select stage walks ranges x sublists sub-lists per query: 1 024 with its 256-thread form, 2 048 with the 1 024-thread
     // form large k uses anyway (rescore_cap > 512)
@@ -157,7 +162,7 @@ static MainPassChoice choose_main_pass(const Plan &p, int k, int64_t sample_a, i
     if (kn.max_lists >= 64 && kn.max_lists < max_lists) max_lists = kn.max_lists;
     const int64_t r_hi = std::min<int64_t>(max_lists / p.sublists, round_up(std::max<int64_t>(1, p.tiles / 8), NUM_XCD));
     const int64_t target = std::min<int64_t>(r_hi, round_up(std::max<int64_t>(NUM_XCD, (int64_t)p.grid * 6 / p.qblocks), NUM_XCD));
-    const bool prog_on = kn.progressive != 0;   // 0: single launch
+    const bool prog_on = kn.progressive != 0 && !single_only;   // 0: single launch (the streaming kernel of small batches has no phases)
     const int max_phases = kn.max_phases;        // 2: at most one re-tightening
     const double qscale = (double)p.nq_pad / 3584.0;
     const double select_per_range = 0.1 * qscale, hit_w = 0.014 * qscale, phase_w = 3.0;
@@ -282,7 +287,11 @@ static Plan make_plan_for(int64_t n_rows, int dim, int n_q, int k, int flags, in
         const int64_t sample_alt = pinned ? sample : sample_for(2 * sample_div);
         int64_t sample_big = pinned ? sample : sample_for(sample_div / 2);
         if (sample_big * 4 > p.full_tiles) sample_big = sample;
-        const MainPassChoice choice = choose_main_pass(p, k, sample, sample_alt, sample_big, kn);
+        // small batches: the first main pass is the streaming kernel (ccr_narrow.hip) when the query rows fit its LDS image
+        int nqt = n_q <= 16 ? 1 : (n_q <= 32 ? 2 : 4);
+        const bool narrow = kn.narrow != 0 && n_q <= NARROW_MAX_Q && dim % TILE_K == 0 && narrow_lds_bytes(nqt, dim) <= (size_t)160 * 1024;
+        p.narrow = narrow ? nqt : 0;
+        const MainPassChoice choice = choose_main_pass(p, k, sample, sample_alt, sample_big, kn, narrow);
         sample = choice.sample;
         const int64_t R = choice.ranges;
         p.sample_tiles = (int)sample;
@@ -360,6 +369,24 @@ static Plan make_plan_for(int64_t n_rows, int dim, int n_q, int k, int flags, in
         const double want_opt = std::max(xr * std::max((double)p.opt_rank / fs, (double)k) + 512.0, k > 256 ? 18.0 * k : 0.0);   // (18 entries per re-scored row: the 128-byte slices, where the LDS budget allows)
         p.select_compact = select_compact_entries(dim, p.ranges * p.sublists, p.rescore_cap,
                                                   (int64_t)((p.opt_rank ? want_opt : (RA ? 16.0 * k + 512.0 : expect)) * 1.25));
+        // what the FIRST main pass fills: the tile kernels' (range, query) cells -- or, for the streaming kernel, one cell of two
+        // sub-lists per query with whatever the candidate area gives each of them (at least 8 x the model's expectation)
+        p.first_nsub = p.ranges * p.sublists;
+        p.first_sp = p.sublists;
+        p.first_lay = p.cand;
+        if (p.narrow) {
+            const double pass = p.opt_rank ? xr * std::max((double)p.opt_rank / fs, (double)k) : expect;
+            int64_t capn = std::max<int64_t>(recs / ((int64_t)NARROW_SUBLISTS * std::max(1, n_q)), (int64_t)(8.0 * pass) + 4096);
+            capn = std::min<int64_t>(capn, (int64_t)1 << 22) / 4 * 4;
+            recs = std::max<int64_t>(recs, capn * NARROW_SUBLISTS * n_q);
+            CandLayout &N = p.first_lay;
+            memset(&N, 0, sizeof(N));
+            N.nseg = 1;
+            N.seg_end[0] = N.seg_end[1] = N.seg_end[2] = INT32_MAX;
+            N.cap[0] = N.cap[1] = N.cap[2] = (int)capn;
+            p.first_nsub = NARROW_SUBLISTS;
+            p.first_sp = NARROW_SUBLISTS;
+        }
         p.off_qnorm = take((size_t)p.nq_pad * 4);
         p.off_thr = take((size_t)p.nq_pad * 4 * 2);  // thr then delta
         p.off_gmax = take((size_t)p.sample_tiles * GROUPS_PER_TILE * p.nq_pad * 4);
@@ -739,9 +766,9 @@ static int search_complete(ccr_index *ix) {
     ix->stats.path = 1;
     ix->stats.n_fallback = (int32_t)host.nflag;
     ix->stats.sample_tiles = p.sample_tiles;
-    ix->stats.ranges = p.ranges;
-    ix->stats.cap = p.cap;
-    ix->stats.sublists = p.sublists;
+    ix->stats.ranges = p.narrow ? 1 : p.ranges;                      // (streaming main pass of a small batch: one range, two sub-lists per query)
+    ix->stats.cap = p.narrow ? p.first_lay.cap[0] : p.cap;
+    ix->stats.sublists = p.narrow ? p.first_sp : p.sublists;
     ix->stats.main_launches = 1 + (p.item_a ? 1 : 0) + (p.item_b ? 1 : 0);
     ix->stats.opt_rank = p.opt_rank;
     ix->stats.n_candidates = (int64_t)host.ncand;
@@ -808,7 +835,7 @@ static int search_complete(ccr_index *ix) {
     } else if (n_retry > 0) {
         // thresholds re-tightened from everything the first attempt recorded (truncated lists included) -- for every flagged
         // query at once, before the candidate area is reused
-        rc = launch_threshold_update(cand, cnt, nsub_all, 0, 0, 0, 0, 0, 1, p.sublists, n_q, p.nq_pad, p.cand, k, delta, ix->tile_norm, nullptr, false,
+        rc = launch_threshold_update(cand, cnt, p.first_nsub, 0, 0, 0, 0, 0, 1, p.first_sp, n_q, p.nq_pad, p.first_lay, k, delta, ix->tile_norm, nullptr, false,
                                      false, thr, s);
         if (rc != CCR_OK) return rc;
         // The flagged queries are retried in GROUPS that get the whole candidate area to themselves: the fewer queries share
@@ -1085,7 +1112,32 @@ static int search_impl(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k, fl
         gm.store = reinterpret_cast<float *>(stamps);
     }
     CCR_HIP_CHECK(hipEventRecord(ix->ev[3], s));
-    rc = run_main_pass(ix, p, gm, cand, cnt, thr, delta, p.item_b ? (uint32_t *)(ws + p.off_top) : nullptr, n_q, k, true, s);
+    if (p.narrow) {
+        // small batch: the corpus is STREAMED past query rows resident in LDS (ccr_narrow.hip); two atomically filled sub-lists per query
+        CCR_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)n_q * NARROW_SUBLISTS * 4, s));
+        NarrowArgs na;
+        memset(&na, 0, sizeof(na));
+        na.D = ix->D;
+        na.n_rows = ix->n_rows;
+        na.dim = ix->dim;
+        na.Q = Q_bf16;
+        na.n_q = n_q;
+        na.q_stride = narrow_query_stride(ix->dim);
+        na.thr = thr;
+        na.cq = delta;
+        na.tile_norm = ix->tile_norm;
+        na.cand = cand;
+        na.cnt = cnt;
+        na.cap = p.first_lay.cap[0];
+        // one workgroup per CU holds the 96-KiB image of 64 queries; with 32 or 16 queries two or four fit and keep more loads in flight
+        int per_cu = (int)std::min<size_t>(4, ((size_t)160 * 1024) / narrow_lds_bytes(p.narrow, ix->dim));
+        int ngrid = ix->knobs.narrow_grid > 0 ? ix->knobs.narrow_grid : ix->num_cu * std::max(1, per_cu);
+        const int64_t blocks = (ix->n_rows + 16 * NARROW_WAVES - 1) / (16 * NARROW_WAVES);
+        if ((int64_t)ngrid > blocks) ngrid = (int)std::max<int64_t>(1, blocks);
+        rc = launch_narrow_filter(na, p.narrow, ngrid, ix->knobs.narrow_nt != 0, s);
+    } else {
+        rc = run_main_pass(ix, p, gm, cand, cnt, thr, delta, p.item_b ? (uint32_t *)(ws + p.off_top) : nullptr, n_q, k, true, s);
+    }
     if (rc != CCR_OK) return rc;
     CCR_HIP_CHECK(hipEventRecord(ix->ev[4], s));
     if (want_stamps) {
@@ -1108,7 +1160,7 @@ static int search_impl(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k, fl
         (void)hipFree(stamps);
     }
 
-    rc = launch_select_rescore(cand, cnt, p.ranges * p.sublists, p.sublists, n_q, p.nq_pad, p.cand, k, p.rescore_cap, p.select_compact, ix->n_rows, thr, delta,
+    rc = launch_select_rescore(cand, cnt, p.first_nsub, p.first_sp, n_q, p.nq_pad, p.first_lay, k, p.rescore_cap, p.select_compact, ix->n_rows, thr, delta,
                                ix->tile_norm, ix->row_norm, ix->dmax_bits, Q_bf16, ix->D, ix->dim,
                                ix->id_out, out_scores, out_ids, flag_count, flag_list, stat_cand, nullptr, s);
     if (rc != CCR_OK) return rc;

@@ -94,6 +94,12 @@ struct Plan {
     int select_compact;   // candidates per query the select kernel gathers into LDS
     int mfma16;           // 1: main pass on the 16x16x32 MFMA kernel
     int sublists;         // candidate sub-lists per (range, query): 4 (32x32x16 kernel) or 8 (16x16x32 kernel)
+    // small query batches (n_q <= 64, query rows resident in LDS): the FIRST main pass is the streaming kernel (ccr_narrow.hip) with
+    // its own list layout -- one range, two sub-lists per query; the retry pass of flagged queries keeps the tile kernels' layout above
+    int narrow;           // 0, or the query tiles of 16 the streaming kernel computes (1, 2, 4)
+    int first_nsub;       // sub-lists per query the first main pass fills (ranges * sublists, or 2) ...
+    int first_sp;         // ... per cell (sublists, or 2) ...
+    CandLayout first_lay; // ... and where they are (cand, or one segment of narrow capacity)
     // workspace layout (byte offsets)
     size_t off_qnorm, off_thr, off_gmax, off_cnt, off_cand, off_flag, off_dense, off_retry, off_top, off_safe, total;
     int64_t dense_rows_per_chunk;  // queries per dense chunk

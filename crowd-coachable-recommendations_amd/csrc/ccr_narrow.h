@@ -1,0 +1,38 @@
+// ccr_narrow.h -- the streaming main pass for small query batches (ccr_narrow.hip): arguments, geometry, launcher.
+#pragma once
+#include "ccr_common.h"
+
+namespace ccr {
+
+constexpr int NARROW_THREADS = 512;                 // 8 waves, each streaming its own 16-row groups
+constexpr int NARROW_WAVES = NARROW_THREADS / 64;
+constexpr int NARROW_MAX_Q = 64;                    // query rows resident in LDS (4 MFMA tiles of 16)
+constexpr int NARROW_LDS_CAP = 64;                  // records a workgroup stages per query before it flushes (overflow: straight to global)
+constexpr int NARROW_SUBLISTS = 2;                  // sub-lists per query in the candidate area: workgroups of even / odd index
+
+// LDS bytes per resident query row: >= the row, == 32 (mod 256): the 16 lanes of every ds_read_b128 group (rows l15, chunks lq) then
+// hit 16 distinct 16-byte slots of the 256-byte LDS line
+__host__ __device__ inline int narrow_query_stride(int dim) {
+    const int row = dim * 2;
+    return row + ((32 - row % 256) + 256) % 256;
+}
+size_t narrow_lds_bytes(int nqt, int dim);
+
+struct NarrowArgs {
+    const uint16_t *D;
+    int64_t n_rows;
+    int dim;
+    const uint16_t *Q;
+    int n_q;
+    int q_stride;            // narrow_query_stride(dim)
+    const float *thr;        // [>= n_q] tau_q
+    const float *cq;         // [>= n_q] gamma ||q||
+    const float *tile_norm;  // [ceil(n_rows / 256)]
+    uint2 *cand;             // candidate area: query q's cell = [cap][2] records {score bits, local row}, slot-major
+    uint32_t *cnt;           // [n_q][2], zeroed by the caller
+    int cap;                 // slots per sub-list
+};
+
+int launch_narrow_filter(const NarrowArgs &a, int nqt, int grid, bool nt, hipStream_t s);
+
+}  // namespace ccr

@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include "ccr_index.h"
+#include "ccr_narrow.h"
 
 using namespace ccr;
 
@@ -81,6 +82,38 @@ int main() {
                                "workspace %.2f GB\n", n, nq, k, p.ranges, p.sublists, items, (double)items / per_x, p.item_a, p.item_b, p.opt_rank, p.sample_tiles,
                                L.cap[0], L.cap[1], L.cap[2], (double)p.total / 1e9);
                 }
+    // small batches: the first main pass is the streaming kernel (ccr_narrow.hip) -- one launch, two sub-lists per query inside the
+    // candidate area, chosen exactly when the query rows fit its LDS image; the retry layout stays the tile kernels'
+    kn.narrow = -1;
+    kn.narrow_nt = 1;
+    int narrow = 0;
+    for (long long n : rows)
+        for (int d : dims)
+            for (int nq : {1, 16, 17, 33, 40, 64, 65, 300})
+                for (int k : ks) {
+                    if (k > n) continue;
+                    const Plan p = make_plan(n, d, nq, k, CCR_SEARCH_DEFAULT, 256, kn);
+                    if (!p.fused) {
+                        if (p.narrow) bad += fail("narrow without the fused path", n, d, nq, k);
+                        continue;
+                    }
+                    const int nqt = nq <= 16 ? 1 : (nq <= 32 ? 2 : 4);
+                    const bool want = nq <= NARROW_MAX_Q && narrow_lds_bytes(nqt, d) <= (size_t)160 * 1024;
+                    if ((p.narrow != 0) != want || (want && p.narrow != nqt)) bad += fail("narrow choice", n, d, nq, k);
+                    if (!p.narrow) {
+                        if (p.first_nsub != p.ranges * p.sublists || p.first_sp != p.sublists || memcmp(&p.first_lay, &p.cand, sizeof(CandLayout)))
+                            bad += fail("first-pass layout of a tile plan", n, d, nq, k);
+                        continue;
+                    }
+                    ++narrow;
+                    if (p.item_a || p.item_b) bad += fail("narrow plan with phases", n, d, nq, k);
+                    if (p.first_nsub != NARROW_SUBLISTS || p.first_sp != NARROW_SUBLISTS || p.first_lay.nseg != 1) bad += fail("narrow layout", n, d, nq, k);
+                    const long long capn = p.first_lay.cap[0];
+                    if (capn % 4 || capn < 4096 || p.off_cand + (size_t)capn * NARROW_SUBLISTS * nq * 8 > p.off_flag) bad += fail("narrow capacity", n, d, nq, k);
+                    if ((size_t)nq * NARROW_SUBLISTS * 4 > p.off_cand - p.off_cnt) bad += fail("narrow counters", n, d, nq, k);
+                    if (p.ranges % NUM_XCD || p.ranges * p.sublists > 2048) bad += fail("retry layout of a narrow plan", n, d, nq, k);
+                }
+    printf("%d narrow plans\n", narrow);
     printf("%d plans (%d fused), %d violations\n", total, fused, bad);
     return bad ? 1 : 0;
 }

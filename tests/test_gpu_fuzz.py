@@ -181,3 +181,60 @@ def test_estimated_thresholds_are_verified_and_exact(case, monkeypatch):
     s1, i1 = ref.search(Q[:64], k, 1)                     # fp64 dense
     assert torch.equal(i, i0) and torch.equal(s.view(torch.int32), s0.view(torch.int32))
     assert torch.equal(i[:64], i1) and torch.equal(s[:64].view(torch.int32), s1.view(torch.int32))
+
+
+@pytest.mark.parametrize("n,nq,d,k", [(70_001, 1, 768, 100), (70_001, 16, 768, 100), (70_001, 17, 768, 10), (300_007, 33, 768, 1001),
+                                      (300_007, 64, 768, 100), (40_000, 64, 1024, 300), (40_000, 5, 32, 7), (123_457, 40, 256, 64),
+                                      (9_000, 64, 768, 1)])
+def test_streaming_main_pass_of_small_batches(n, nq, d, k, monkeypatch):
+    """n_q <= 64: the first main pass is the streaming kernel (csrc/ccr_narrow.hip: query rows resident in LDS, the corpus straight
+    into the MFMA operand registers, no barrier; one range x two atomically filled sub-lists per query).  Same canonical bits as the
+    tile kernels (CCR_NARROW=0) and as the exact dense path; rows that are no multiple of 16 (tail group), every query-tile count
+    (16 / 32 / 64 rows resident), dim 32 ... 1024 (64 x 1 024-wide rows do not fit the LDS image: the planner keeps the tile kernels
+    there), exact ties, and a norm-outlier row (per-tile margins)."""
+    from ccrec_amd import ops
+    g = torch.Generator().manual_seed(n + nq + d)
+    D = torch.randn(n, d, generator=g) / d ** 0.5
+    Q = torch.randn(nq, d, generator=g) / d ** 0.5
+    D[n // 3] = D[5]                                 # exact tie: the lower row wins
+    D[n - 1] = D[n // 2]                             # ... with a row of the tail group
+    D[7] *= 40.0                                     # a row whose norm is far above its tile's others
+    Db, Qb = ops.pack_bf16(D.cuda()), ops.pack_bf16(Q.cuda())
+    monkeypatch.delenv("CCR_NARROW", raising=False)
+    index = ops.CorpusIndex(Db, global_row_offset=11)
+    s, i = index.search(Qb, k, 2)
+    st = index.last_stats()
+    expect_narrow = not (d == 1024 and nq > 32)
+    assert st["path"] == 1 and (st["ranges"], st["sublists"]) == ((1, 2) if expect_narrow else (st["ranges"], 8)), st
+    assert (st["ranges"] == 1) == expect_narrow and st["n_fallback"] == 0, st
+    s_ref, i_ref = index.search(Qb, k, 1)           # exact dense path
+    assert torch.equal(i, i_ref) and torch.equal(s.view(torch.int32), s_ref.view(torch.int32)), st
+    monkeypatch.setenv("CCR_NARROW", "0")
+    tiles = ops.CorpusIndex(Db, global_row_offset=11)
+    s2, i2 = tiles.search(Qb, k, 2)
+    assert tiles.last_stats()["sublists"] in (4, 8) and tiles.last_stats()["ranges"] >= 8
+    assert torch.equal(i2, i) and torch.equal(s2.view(torch.int32), s.view(torch.int32))
+    if n * nq <= 3_000_000:
+        bits = lambda t: t.view(torch.int16).cpu().numpy().view(np.uint16)   # noqa: E731
+        ref_i, ref_s = orc.canonical_search(bits(Qb), bits(Db), k)
+        assert np.array_equal(i.cpu().numpy() - 11, ref_i) and np.array_equal(s.cpu().numpy(), ref_s)
+
+
+def test_streaming_main_pass_overflowing_lists_fall_back_to_the_retry():
+    """A flooded small batch: 30 000 copies of one row that every query prefers -- the estimated / sampled threshold lets all of them
+    pass, a workgroup's 64-record staging list overflows (records then go straight to the candidate area) and the mass tie around the
+    cut sends the queries down the exact path: still the canonical bits."""
+    from ccrec_amd import ops
+    n, nq, d, k = 200_000, 8, 256, 50
+    g = torch.Generator().manual_seed(1)
+    D = torch.randn(n, d, generator=g) / d ** 0.5
+    Q = torch.randn(nq, d, generator=g) / d ** 0.5
+    D[50_000:80_000] = Q.sum(0) * 2.0
+    Db, Qb = ops.pack_bf16(D.cuda()), ops.pack_bf16(Q.cuda())
+    index = ops.CorpusIndex(Db)
+    s, i = index.search(Qb, k, 2)
+    st = index.last_stats()
+    assert st["ranges"] == 1 and st["sublists"] == 2
+    s_ref, i_ref = index.search(Qb, k, 1)
+    assert torch.equal(i, i_ref) and torch.equal(s.view(torch.int32), s_ref.view(torch.int32)), st
+    assert i[0, 0].item() == 50_000 and i[0, k - 1].item() == 50_000 + k - 1          # the tie is cut in row order
