@@ -47,7 +47,7 @@ Knobs read_knobs() {
     kn.optimistic = env_int("CCR_OPTIMISTIC", -1);
     kn.opt_rank = env_int("CCR_OPT_RANK", 0);
     kn.narrow = env_int("CCR_NARROW", -1);
-    kn.narrow_nt = env_int("CCR_NARROW_NT", 1);
+    kn.narrow_nt = env_int("CCR_NARROW_NT", 0);
     kn.narrow_grid = env_int("CCR_NARROW_GRID", 0);
     return kn;
 }
@@ -1129,9 +1129,9 @@ static int search_impl(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k, fl
         na.cand = cand;
         na.cnt = cnt;
         na.cap = p.first_lay.cap[0];
-        // one workgroup per CU holds the 96-KiB image of 64 queries; with 32 or 16 queries two or four fit and keep more loads in flight
-        int per_cu = (int)std::min<size_t>(4, ((size_t)160 * 1024) / narrow_lds_bytes(p.narrow, ix->dim));
-        int ngrid = ix->knobs.narrow_grid > 0 ? ix->knobs.narrow_grid : ix->num_cu * std::max(1, per_cu);
+        // one workgroup (8 waves x 12 KiB of loads in flight) per CU: measured at NQ 6.2 / 6.2 / 6.0 TB/s of corpus bytes at n_q = 1 / 16 / 64;
+        // two or four per CU -- the 16- and 32-query images would fit -- stream no faster (6.2 / 5.9 TB/s at 1 / 16)
+        int ngrid = ix->knobs.narrow_grid > 0 ? ix->knobs.narrow_grid : ix->num_cu;
         const int64_t blocks = (ix->n_rows + 16 * NARROW_WAVES - 1) / (16 * NARROW_WAVES);
         if ((int64_t)ngrid > blocks) ngrid = (int)std::max<int64_t>(1, blocks);
         rc = launch_narrow_filter(na, p.narrow, ngrid, ix->knobs.narrow_nt != 0, s);
