@@ -20,6 +20,7 @@ never part of `value`.
 --data clustered: a non-iid corpus (1,024 Gaussian clusters, log-normal row norms, 3 % duplicate rows).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -292,10 +293,14 @@ class Workload:
         torch.cuda.empty_cache()
 
 
-def inbatch_side_run(dev, B=1024, d=768, iters=30):
+def inbatch_side_run(dev, B=1024, d=768, iters=50):
     """configs[4]: the in-batch-negative contrastive step (bbpr.py:205-212) at B = 1024, d = 768: forward + backward of the HIP loss
-    (ccr_inbatch_ce_fwd/bwd) next to the reference's torch formulation (mm, mm, cat, scale, CrossEntropyLoss + autograd) on this GPU."""
-    from ccrec_amd import ops
+    (ccr_inbatch_ce_fwd/bwd: three kernel launches) next to the reference's torch formulation (mm, mm, cat, scale, CrossEntropyLoss +
+    autograd) on this GPU, in fp32 and -- the comparator that matches this library's bf16 operands -- under autocast(bf16).
+    `roofline`: the step is 6 x 2 B^2 d MFMA flop (two logit blocks forward, dQ and dK backward with the gradient in three bf16
+    parts) = microseconds of matrix work, so what bounds it is LAUNCH LATENCY: three dependent kernels + the host's autograd
+    round trip; `kernels_ms` (HIP events around the library calls alone, operands already bf16) against `value` shows the split."""
+    from ccrec_amd import _lib, ops
     g = torch.Generator(device=dev).manual_seed(0)
     q, p, n = (torch.randn(B, d, device=dev, generator=g) * d ** -0.5 for _ in range(3))
 
@@ -305,15 +310,16 @@ def inbatch_side_run(dev, B=1024, d=768, iters=30):
         loss.backward()
         return loss
 
-    def ref():
+    def ref(dtype):
         a, b, c = (t.clone().requires_grad_(True) for t in (q, p, n))
-        scores = torch.cat([a @ b.T, a @ c.T], 1) * 20.0
-        loss = torch.nn.CrossEntropyLoss()(scores, torch.arange(B, device=dev))
+        with torch.autocast("cuda", dtype=dtype, enabled=dtype != torch.float32):
+            scores = torch.cat([a @ b.T, a @ c.T], 1) * 20.0
+            loss = torch.nn.CrossEntropyLoss()(scores.float(), torch.arange(B, device=dev))
         loss.backward()
         return loss
 
     out = {"workload": f"configs[4]: in-batch-negative loss forward + backward, B = {B}, d = {d}, inv_temperature 20"}
-    for name, fn in (("hip_ms", ours), ("torch_fp32_ms", ref)):
+    for name, fn in (("hip_ms", ours), ("torch_fp32_ms", lambda: ref(torch.float32)), ("torch_bf16_autocast_ms", lambda: ref(torch.bfloat16))):
         for _ in range(5):
             loss = fn()
         torch.cuda.synchronize()
@@ -324,6 +330,36 @@ def inbatch_side_run(dev, B=1024, d=768, iters=30):
         out[name] = round((time.perf_counter() - t0) / iters * 1e3, 4)
         out[name.replace("_ms", "_loss")] = round(float(loss), 6)
     out["steps_per_s"] = round(1e3 / out["hip_ms"], 1)
+    # the library calls alone: bf16 operands resident, HIP events on the stream they are launched on
+    lib = _lib.load()
+    qb, pb, nb = (t.to(torch.bfloat16).contiguous() for t in (q, p, n))
+    loss_t, lse = torch.empty(1, device=dev), torch.empty(B, device=dev)
+    grads = [torch.empty(B, d, device=dev) for _ in range(3)]
+    ws = torch.empty(int(lib.ccr_inbatch_ce_workspace_bytes(B, d)), dtype=torch.uint8, device=dev)
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def kernels():
+        _lib.check(lib.ccr_inbatch_ce_fwd(ptr(qb), ptr(pb), ptr(nb), B, d, 20.0, ptr(loss_t), ptr(lse), ptr(ws), ws.numel(), stream))
+        _lib.check(lib.ccr_inbatch_ce_bwd(ptr(qb), ptr(pb), ptr(nb), ptr(lse), B, d, 20.0, 1.0, ptr(grads[0]), ptr(grads[1]), ptr(grads[2]),
+                                          ptr(ws), ws.numel(), stream))
+    for _ in range(5):
+        kernels()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        kernels()
+    e1.record()
+    torch.cuda.synchronize()
+    kms = e0.elapsed_time(e1) / iters
+    flops = 6 * 2.0 * B * B * d * 2          # 2 logit blocks forward; dQ and dK backward, each over 2B keys, in three bf16 parts -> x 3 / 3 counted once
+    out["kernels_ms"] = round(kms, 4)
+    out["roofline"] = {"bound": "launch latency (3 dependent kernels of microseconds of MFMA work each)", "kernel": "inbatch_fwd_kernel + 2 x inbatch_grad_kernel",
+                       "achieved": round(flops / (kms * 1e-3) / 1e12, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": round(flops / (kms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4), "flops_per_step": flops,
+                       "launch_floor_ms": round(3 * 0.0019 + 0.0015, 4),
+                       "note": "floor = 3 kernel boundaries at ~1.9 us + one memset node (MI355X_MICROARCH price list); the host-side autograd "
+                               "round trip (clone, cast, Function.apply, backward) is the rest of hip_ms", "traffic": None}
     return out
 
 

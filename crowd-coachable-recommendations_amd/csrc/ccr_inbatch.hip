@@ -6,10 +6,14 @@
 // accumulator rows, queries on the lanes), so a lane owns one query column and the softmax over keys
 // is an in-register online reduction.  B x 2B is small (the encoder dominates the step): operands are
 // read straight from L2 in fragment layout, no LDS staging.
-//   fwd : per (query tile, key split) partial (max, sum, diagonal) -> fixed-order combine -> lse, loss
-//   bwd : G[j][i] = (softmax - onehot) * inv_T * grad_out / B  (fp32, recomputed logits, MFMA)
-//         dQ = G^T K,  dK = G Q   on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 products of the fp32
-//         gradient matrix with the bf16 embeddings, fp32 accumulate; LDS-staged 64x64 tiles, deterministic, no atomics)
+//   fwd : ONE launch.  Per (query tile, key split) partial (max, sum, diagonal) and the scaled logits S[2B][B] (kept for the
+//         backward); the last split of a query tile to arrive (ticket) combines the tile's partials in split order -> lse, the
+//         tile's loss share; the last tile to arrive adds the shares in tile order -> loss.  Deterministic.
+//   bwd : TWO launches, no gradient matrix in memory: dQ = G^T K and dK = G Q with G[j][i] = (exp(S[j][i] - lse_i) - [j == i]) *
+//         inv_T * grad_out / B evaluated while the operand is staged, split into THREE bf16 parts (g = hi + mid + lo exactly to
+//         2^-24 relative) so that the products with the bf16 embeddings run on v_mfma_f32_32x32x16_bf16 (3 MFMAs of 32 cycles
+//         per 16 K instead of 8 fp32 MFMAs of 64): fp32-MFMA accuracy at a fifth of its time; LDS-staged 64x64 tiles,
+//         deterministic, no atomics.  (r3: a separate G kernel + two v_mfma_f32_32x32x2_f32 GEMMs, 139 of the step's 175 us.)
 #include "ccr_common.h"
 
 namespace ccr {
@@ -21,15 +25,29 @@ __device__ __forceinline__ const uint16_t *key_row(const uint16_t *P, const uint
     return (j < B) ? P + (int64_t)j * dim : N + (int64_t)(j - B) * dim;
 }
 
-// MODE 0: partial softmax statistics; MODE 1: gradient matrix G[2B][B]
-template <int MODE>
-__global__ __launch_bounds__(64) void inbatch_logits_kernel(const uint16_t *__restrict__ Q, const uint16_t *__restrict__ P,
-                                                           const uint16_t *__restrict__ N, int B, int dim, float inv_t,
-                                                           int splits, float *__restrict__ pm, float *__restrict__ pl,
-                                                           float *__restrict__ pd, const float *__restrict__ lse,
-                                                           float gscale, const float *__restrict__ gscale_dev, float *__restrict__ G) {
+// release / acquire around a ticket (MI355X_MICROARCH, 'Valid forms'): the publishing lane's stores -> vmcnt(0) -> agent release ->
+// vmcnt(0) (inline asm: hipcc may drop its own wait behind the fence) -> relaxed agent atomic; the last arriver: agent acquire -> vmcnt(0)
+__device__ __forceinline__ unsigned int publish_and_take_ticket(unsigned int *ticket) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void acquire_after_ticket() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// grid = (query tiles of 32, key splits), block = one wave.
+//   pm / pl / pd [splits][B]: partial max, sum, diagonal; S [2B][ldS]: the scaled logits (row = key, column = query)
+//   tile_ticket [query tiles] + loss_ticket [1] + tile_part [query tiles] doubles: zeroed by the caller's memset
+__global__ __launch_bounds__(64) void inbatch_fwd_kernel(const uint16_t *__restrict__ Q, const uint16_t *__restrict__ P,
+                                                        const uint16_t *__restrict__ N, int B, int dim, float inv_t, int splits,
+                                                        float *__restrict__ pm, float *__restrict__ pl, float *__restrict__ pd,
+                                                        float *__restrict__ S, int ldS, float *__restrict__ lse,
+                                                        float *__restrict__ loss, unsigned int *__restrict__ tile_ticket,
+                                                        unsigned int *__restrict__ loss_ticket, double *__restrict__ tile_part) {
     const int lane = threadIdx.x;
-    if (MODE == 1 && gscale_dev) gscale *= gscale_dev[0];   // upstream gradient read on the device: no host round trip
     const int l31 = lane & 31, h = lane >> 5;
     const int i0 = blockIdx.x * 32;
     const int s = blockIdx.y;
@@ -39,7 +57,6 @@ __global__ __launch_bounds__(64) void inbatch_logits_kernel(const uint16_t *__re
     const int iq = i < B ? i : B - 1;
     const uint16_t *qrow = Q + (int64_t)iq * dim + 8 * h;
     float m = -INFINITY, l = 0.f, dg = -INFINITY;
-    const float my_lse = (MODE == 1) ? lse[iq] : 0.f;
     for (int t = t_lo; t < t_hi; ++t) {
         int jr = t * 32 + l31;
         if (jr > 2 * B - 1) jr = 2 * B - 1;
@@ -64,38 +81,26 @@ __global__ __launch_bounds__(64) void inbatch_logits_kernel(const uint16_t *__re
             const bf16x8 b = *reinterpret_cast<const bf16x8 *>(qrow + k0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
         }
-        if (MODE == 0) {
-            float tm = -INFINITY;
+        float tm = -INFINITY;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int j = t * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                const float v = (j < 2 * B) ? acc[e] * inv_t : -INFINITY;
-                acc[e] = v;
-                tm = fmaxf(tm, v);
-                if (j == i) dg = v;
-            }
-            const float mn = fmaxf(m, tm);
-            if (mn > -INFINITY) {
-                float sum = 0.f;
+        for (int e = 0; e < 16; ++e) {
+            const int j = t * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const float v = (j < 2 * B) ? acc[e] * inv_t : -INFINITY;
+            acc[e] = v;
+            tm = fmaxf(tm, v);
+            if (j == i) dg = v;
+            if (j < 2 * B && i < B) S[(int64_t)j * ldS + i] = v;   // 32 consecutive queries of one key row per half wave: 128-byte segments
+        }
+        const float mn = fmaxf(m, tm);
+        if (mn > -INFINITY) {
+            float sum = 0.f;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) sum += __expf(acc[e] - mn);
-                l = l * __expf(m - mn) + sum;
-                m = mn;
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int j = t * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (j < 2 * B && i < B) {
-                    float g = __expf(acc[e] * inv_t - my_lse);
-                    if (j == i) g -= 1.f;
-                    G[(int64_t)j * B + i] = g * gscale;
-                }
-            }
+            for (int e = 0; e < 16; ++e) sum += __expf(acc[e] - mn);
+            l = l * __expf(m - mn) + sum;
+            m = mn;
         }
     }
-    if (MODE == 0) {
-        // the two lane halves hold different key rows of the same query column
+    {   // the two lane halves hold different key rows of the same query column
         const float m2 = __shfl_xor(m, 32, 64), l2 = __shfl_xor(l, 32, 64), d2 = __shfl_xor(dg, 32, 64);
         const float M = fmaxf(m, m2);
         float L = 0.f;
@@ -106,164 +111,191 @@ __global__ __launch_bounds__(64) void inbatch_logits_kernel(const uint16_t *__re
             pd[(int64_t)s * B + i] = fmaxf(dg, d2);
         }
     }
-}
-
-// combine the split partials in a fixed order: lse[i], loss = sum_i (lse_i - logit_ii) / B.
-// grid = ceil(B / 256) blocks of 256 queries; every block writes its fp64 partial, the block that draws the last ticket
-// adds the partials in block order (deterministic) and writes the loss.  `ticket` is zeroed by the caller's memset.
-__global__ __launch_bounds__(256) void inbatch_reduce_kernel(const float *__restrict__ pm, const float *__restrict__ pl,
-                                                            const float *__restrict__ pd, int B, int splits,
-                                                            float *__restrict__ lse, float *__restrict__ loss,
-                                                            double *__restrict__ block_part, unsigned int *__restrict__ ticket) {
-    __shared__ double s_sum[4];
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    // ---- the last split of this query tile combines the tile's partials in split order (the wave is the whole workgroup: the
+    // ticket is taken by lane 0 behind the wave's own stores, the result broadcast)
+    unsigned int t = 0;
+    if (lane == 0) t = publish_and_take_ticket(&tile_ticket[blockIdx.x]);
+    t = __shfl(t, 0, 64);
+    if (t != (unsigned int)splits - 1) return;
+    acquire_after_ticket();
     double part = 0.0;
-    if (i < B) {
-        float M = -INFINITY, dg = -INFINITY, L = 0.f;
+    if (h == 0 && i < B) {
+        float M = -INFINITY, dgc = -INFINITY, L = 0.f;
         for (int s0 = 0; s0 < splits; s0 += 16) {   // 3 x 16 independent loads per round
             float vm[16], vl[16], vd[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const bool in = s0 + u < splits;
                 const int64_t at = (int64_t)(in ? s0 + u : 0) * B + i;
-                vm[u] = in ? pm[at] : -INFINITY;
-                vl[u] = in ? pl[at] : 0.f;
-                vd[u] = in ? pd[at] : -INFINITY;
+                vm[u] = in ? __builtin_nontemporal_load(pm + at) : -INFINITY;
+                vl[u] = in ? __builtin_nontemporal_load(pl + at) : 0.f;
+                vd[u] = in ? __builtin_nontemporal_load(pd + at) : -INFINITY;
             }
 #pragma unroll
             for (int u = 0; u < 16; ++u) {   // online combine in split order
                 const float mn = fmaxf(M, vm[u]);
                 if (mn > -INFINITY) L = (M > -INFINITY ? L * __expf(M - mn) : 0.f) + (vm[u] > -INFINITY ? vl[u] * __expf(vm[u] - mn) : 0.f);
                 M = mn;
-                dg = fmaxf(dg, vd[u]);
+                dgc = fmaxf(dgc, vd[u]);
             }
         }
         const float v = M + __logf(L);
         lse[i] = v;
-        part = (double)(v - dg);
+        part = (double)(v - dgc);
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
-    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = part;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        // publish the partial (agent-scope release before the ticket), last arriver acquires and sums in block order
-        block_part[blockIdx.x] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == gridDim.x - 1) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            double tot = 0.0;
-            for (unsigned int b = 0; b < gridDim.x; ++b) tot += block_part[b];
-            loss[0] = (float)(tot / (double)B);
-        }
+    unsigned int t2 = 0;
+    if (lane == 0) {
+        tile_part[blockIdx.x] = part;
+        t2 = publish_and_take_ticket(loss_ticket);
+    }
+    t2 = __shfl(t2, 0, 64);
+    if (t2 != gridDim.x - 1) return;
+    acquire_after_ticket();
+    if (lane == 0) {   // the last tile adds the shares in tile order
+        double tot = 0.0;
+        for (unsigned int b = 0; b < gridDim.x; ++b) tot += __builtin_nontemporal_load(tile_part + b);
+        loss[0] = (float)(tot / (double)B);
     }
 }
 
-// C[M][Nc] (fp32) = sum_k A(k, m) * Bm(k, n) on v_mfma_f32_32x32x2_f32.
-//   A fp32: A_KMAJOR ? A[k*lda + m] : A[m*lda + k];  Bm rows are bf16 embedding rows selected by the mode:
-//   KEYS -> key_row(P, N, B, k), else Q + k*dim (widened to fp32 exactly).  Output row m goes to C0 (m < split) or C1.
-// Block = 4 waves, 64 x 64 output tile (32 x 32 per wave), K walked in chunks of 32 through two LDS buffers; the next
-// chunk's global loads are in flight while the current chunk's 16 MFMAs per wave run.  LDS rows are k-major with a
-// stride of 68 floats (16-byte aligned rows): the MFMA operand reads (32 consecutive floats per half wave) and both staging patterns
-// (m-fastest and k-fastest) are bank-conflict free.
-typedef float f32x16v __attribute__((ext_vector_type(16)));
-constexpr int GG_T = 64, GG_THREADS = 256, GG_KC = 32, GG_LD = 68;   // 64 x 64 block tile, 4 waves of 32 x 32, K chunk 32
-// VEC: 16-byte loads (needs lda % 4 == 0, M % 4 == 0, dim % 8 == 0, 16-byte aligned bases): 3 loads per thread and chunk
-// instead of 16 scalar ones.
-template <bool A_KMAJOR, bool B_KEYS, bool VEC>
-__global__ __launch_bounds__(GG_THREADS) void inbatch_grad_gemm_kernel(const float *__restrict__ A, int lda, const uint16_t *__restrict__ X0,
-                                                               const uint16_t *__restrict__ X1, int B, int M, int K, int dim,
-                                                               float *__restrict__ C0, float *__restrict__ C1, int split) {
-    __shared__ __attribute__((aligned(16))) float As[2][GG_KC][GG_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][GG_KC][GG_LD];
+// C[M][dim] (fp32) = sum_k A(k, m) X(k, :) with A = the gradient of the loss w.r.t. the scaled logits, evaluated from S and lse while
+// it is staged and split into three bf16 parts; X rows are bf16 embedding rows.
+//   FOR_Q:  m = query i, k = key j:   A(k, m) = g(S[k][m]),  X(k) = key_row(k)          -> dQ   (M = B, K = 2B)
+//   else :  m = key j,   k = query i: A(k, m) = g(S[m][k]),  X(k) = Q[k]                -> dP | dN (M = 2B, K = B; rows >= B go to C1)
+//   g(S[j][i]) = (exp(S[j][i] - lse[i]) - [j == i]) * gscale
+// Block = 4 waves, 64 x 64 output tile (32 x 32 per wave), K in chunks of 32 through two LDS buffers; the next chunk's global loads
+// are in flight while the current chunk's 6 MFMAs per wave run.  LDS images are [row][k] with 80-byte rows (5 x 16 B: the 16 lanes of
+// a ds_read_b128 group hit 16 distinct slots): the transposes the operand layout needs happen in the staging stores.
+constexpr int GG_T = 64, GG_THREADS = 256, GG_KC = 32, GG_KP = 40;   // 64 x 64 tile, K chunk 32, LDS row pitch 40 bf16
+__device__ __forceinline__ void split3(float g, uint16_t &hi, uint16_t &mid, uint16_t &lo) {
+    const __bf16 a = (__bf16)g;
+    const float r1 = g - (float)a;
+    const __bf16 b = (__bf16)r1;
+    const __bf16 c = (__bf16)(r1 - (float)b);
+    hi = __builtin_bit_cast(uint16_t, a);
+    mid = __builtin_bit_cast(uint16_t, b);
+    lo = __builtin_bit_cast(uint16_t, c);
+}
+
+template <bool FOR_Q>
+__global__ __launch_bounds__(GG_THREADS) void inbatch_grad_kernel(const float *__restrict__ S, int ldS, const float *__restrict__ lse,
+                                                                 const uint16_t *__restrict__ X0, const uint16_t *__restrict__ X1, int B,
+                                                                 int dim, float gscale, const float *__restrict__ gscale_dev,
+                                                                 float *__restrict__ C0, float *__restrict__ C1) {
+    __shared__ __attribute__((aligned(16))) uint16_t As[2][3][GG_T][GG_KP];
+    __shared__ __attribute__((aligned(16))) uint16_t Bs[2][GG_T][GG_KP];
+    if (gscale_dev) gscale *= gscale_dev[0];   // upstream gradient read on the device: no host round trip
+    const int M = FOR_Q ? B : 2 * B, K = FOR_Q ? 2 * B : B;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wv >> 1, wn = wv & 1;
     const int m0 = blockIdx.y * GG_T, n0 = blockIdx.x * GG_T;
-    f32x16v acc;
+    f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 
-    // Raw load results are only touched AFTER the MFMAs of the current chunk and out-of-range elements are zeroed
-    // arithmetically there (addresses are clamped): behind a select LLVM sinks each load into the select's branch and
-    // waits for it separately, one dependent round trip per element.
-    constexpr int NA = VEC ? 2 : 8;
-    float4 va[VEC ? 2 : 1];
-    uint4 vb;
-    float ra[VEC ? 1 : 8];
-    uint32_t rb[VEC ? 1 : 8];
-    auto fetch = [&](int k0) {
-        if constexpr (VEC) {
+    // staging roles.  A, FOR_Q (S rows are keys = k, columns = queries = m, m contiguous): thread -> 4 consecutive m (am) of the k pair
+    // (2 ak, 2 ak + 1): two float4 loads, 4 x 3 packed (k, k + 1) dword stores.  A, dK (rows = keys = m, columns = queries = k, k
+    // contiguous): thread -> 4 consecutive k (4 ak4) of rows am and am + 32: two float4 loads, 2 x 3 eight-byte stores.
+    // X (rows = k, 8 consecutive n per 16-byte load): threads 0..127 -> the k pair (2 bk, 2 bk + 1) x 8 columns: 8 dword stores.
+    const int am = FOR_Q ? (tid & 15) * 4 : (tid >> 3), ak = FOR_Q ? (tid >> 4) : (tid & 7);
+    const int bk = (tid >> 3) & 15, bn = (tid & 7) * 8;
+    float4 va[2];
+    uint4 vb[2];
+    float4 lse_m = make_float4(0.f, 0.f, 0.f, 0.f), lse_k = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (FOR_Q) {   // lse of the thread's 4 query columns: the same for every chunk
+        float t4[4];
 #pragma unroll
-            for (int r = 0; r < NA; ++r) {
-                const int v = r * GG_THREADS + tid;   // 512 float4 of the A chunk
-                const int kk = A_KMAJOR ? (v >> 4) : ((v & 7) * 4), mm = A_KMAJOR ? ((v & 15) * 4) : (v >> 3);
-                const int k = k0 + kk, mrow = m0 + mm;
-                // K and M are multiples of 4 here, so a 4-vector is entirely inside or entirely outside the matrix
-                const int kc = A_KMAJOR ? (k < K ? k : K - 1) : (k < K ? k : K - 4);
-                const int mc = A_KMAJOR ? (mrow < M ? mrow : M - 4) : (mrow < M ? mrow : M - 1);
-                va[r] = *reinterpret_cast<const float4 *>(A_KMAJOR ? A + (int64_t)kc * lda + mc : A + (int64_t)mc * lda + kc);
+        for (int u = 0; u < 4; ++u) {
+            const int i = m0 + am + u;
+            t4[u] = lse[i < B ? i : B - 1];
+        }
+        lse_m = make_float4(t4[0], t4[1], t4[2], t4[3]);
+    }
+    auto fetch = [&](int k0) {
+        if (FOR_Q) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                int k = k0 + 2 * ak + r;
+                if (k > K - 1) k = K - 1;
+                int mc = m0 + am;
+                if (mc > ldS - 4) mc = ldS - 4;           // (ldS is a multiple of 4: an aligned vector inside the row pitch)
+                va[r] = *reinterpret_cast<const float4 *>(S + (int64_t)k * ldS + mc);
             }
-            const int kb = tid >> 3, n8 = (tid & 7) * 8;   // 256 x 16 bytes of the B chunk
-            const int kr = k0 + kb, ncol = n0 + n8;
-            const int krc = kr < K ? kr : K - 1, ncc = ncol + 7 < dim ? ncol : dim - 8;
-            const uint16_t *row = B_KEYS ? key_row(X0, X1, B, krc, dim) : X0 + (int64_t)krc * dim;
-            vb = *reinterpret_cast<const uint4 *>(row + ncc);
         } else {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int idx = r * GG_THREADS + tid;
-                const int kk = A_KMAJOR ? (idx >> 6) : (idx & 31), mm = A_KMAJOR ? (idx & 63) : (idx >> 5);
-                const int k = k0 + kk, mrow = m0 + mm;
-                const int kc = k < K ? k : K - 1, mc = mrow < M ? mrow : M - 1;
-                ra[r] = A_KMAJOR ? A[(int64_t)kc * lda + mc] : A[(int64_t)mc * lda + kc];
-                const int kr = k0 + (idx >> 6), ncol = n0 + (idx & 63);
-                const int krc = kr < K ? kr : K - 1, ncc = ncol < dim ? ncol : dim - 1;
-                const uint16_t *row = B_KEYS ? key_row(X0, X1, B, krc, dim) : X0 + (int64_t)krc * dim;
-                rb[r] = row[ncc];
+            for (int r = 0; r < 2; ++r) {
+                int mrow = m0 + am + 32 * r;
+                if (mrow > M - 1) mrow = M - 1;
+                int kc = k0 + 4 * ak;
+                if (kc > ldS - 4) kc = ldS - 4;
+                va[r] = *reinterpret_cast<const float4 *>(S + (int64_t)mrow * ldS + kc);
+            }
+            float t4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = k0 + 4 * ak + u;
+                t4[u] = lse[i < B ? i : B - 1];
+            }
+            lse_k = make_float4(t4[0], t4[1], t4[2], t4[3]);
+        }
+        if (tid < 128) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                int kr = k0 + 2 * bk + r;
+                if (kr > K - 1) kr = K - 1;
+                int nc = n0 + bn;
+                if (nc > dim - 8) nc = dim - 8;
+                const uint16_t *row = FOR_Q ? key_row(X0, X1, B, kr, dim) : X0 + (int64_t)kr * dim;
+                vb[r] = *reinterpret_cast<const uint4 *>(row + nc);
             }
         }
     };
+    auto grad = [&](float sv, float lsev, int j, int i) -> float {
+        float g = __expf(sv - lsev);
+        if (j == i) g -= 1.f;
+        return (j < 2 * B && i < B) ? g * gscale : 0.f;   // (a select, not a product: staged positions outside the matrix may hold anything)
+    };
     auto stash = [&](int buf, int k0) {
-        if constexpr (VEC) {
+        if (FOR_Q) {
+            const float s0[4] = {va[0].x, va[0].y, va[0].z, va[0].w}, s1[4] = {va[1].x, va[1].y, va[1].z, va[1].w};
+            const float ls[4] = {lse_m.x, lse_m.y, lse_m.z, lse_m.w};
 #pragma unroll
-            for (int r = 0; r < NA; ++r) {
-                const int v = r * GG_THREADS + tid;
-                const int kk = A_KMAJOR ? (v >> 4) : ((v & 7) * 4), mm = A_KMAJOR ? ((v & 15) * 4) : (v >> 3);
-                const float e4[4] = {va[r].x, va[r].y, va[r].z, va[r].w};
-                if (A_KMAJOR) {   // 4 consecutive m of one k row; a row/vector is entirely in or out (M % 4 == 0)
-                    const float ok = (k0 + kk < K && m0 + mm < M) ? 1.f : 0.f;
-                    *reinterpret_cast<float4 *>(&As[buf][kk][mm]) = make_float4(e4[0] * ok, e4[1] * ok, e4[2] * ok, e4[3] * ok);
-                } else {          // 4 consecutive k of one m row
-                    const float ok = (k0 + kk < K && m0 + mm < M) ? 1.f : 0.f;
+            for (int u = 0; u < 4; ++u) {
+                const int i = m0 + am + u, j = k0 + 2 * ak;
+                uint16_t p0[3], p1[3];
+                split3(grad(s0[u], ls[u], j, i), p0[0], p0[1], p0[2]);
+                split3(grad(s1[u], ls[u], j + 1, i), p1[0], p1[1], p1[2]);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) As[buf][kk + j][mm] = e4[j] * ok;
-                }
+                for (int part = 0; part < 3; ++part)
+                    *reinterpret_cast<uint32_t *>(&As[buf][part][am + u][2 * ak]) = (uint32_t)p0[part] | ((uint32_t)p1[part] << 16);
             }
-            const int kb = tid >> 3, n8 = (tid & 7) * 8;
-            const uint32_t ok = (k0 + kb < K && n0 + n8 < dim) ? 0xffffffffu : 0u;
-            const uint32_t w[4] = {vb.x, vb.y, vb.z, vb.w};
-            float f[8];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                f[2 * e] = __uint_as_float((w[e] << 16) & ok);
-                f[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u & ok);
-            }
-            *reinterpret_cast<float4 *>(&Bs[buf][kb][n8]) = make_float4(f[0], f[1], f[2], f[3]);
-            *reinterpret_cast<float4 *>(&Bs[buf][kb][n8 + 4]) = make_float4(f[4], f[5], f[6], f[7]);
         } else {
+            const float lk[4] = {lse_k.x, lse_k.y, lse_k.z, lse_k.w};
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int idx = r * GG_THREADS + tid;
-                const int kk = A_KMAJOR ? (idx >> 6) : (idx & 31), mm = A_KMAJOR ? (idx & 63) : (idx >> 5);
-                As[buf][kk][mm] = ra[r] * ((k0 + kk < K && m0 + mm < M) ? 1.f : 0.f);
-                Bs[buf][idx >> 6][idx & 63] =
-                    __uint_as_float((rb[r] << 16) & ((k0 + (idx >> 6) < K && n0 + (idx & 63) < dim) ? 0xffffffffu : 0u));
+            for (int r = 0; r < 2; ++r) {
+                const float sv[4] = {va[r].x, va[r].y, va[r].z, va[r].w};
+                const int j = m0 + am + 32 * r;
+                uint16_t p[4][3];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) split3(grad(sv[u], lk[u], j, k0 + 4 * ak + u), p[u][0], p[u][1], p[u][2]);
+#pragma unroll
+                for (int part = 0; part < 3; ++part)
+                    *reinterpret_cast<uint2 *>(&As[buf][part][am + 32 * r][4 * ak]) =
+                        make_uint2((uint32_t)p[0][part] | ((uint32_t)p[1][part] << 16), (uint32_t)p[2][part] | ((uint32_t)p[3][part] << 16));
+            }
+        }
+        if (tid < 128) {
+            const uint32_t w0[4] = {vb[0].x, vb[0].y, vb[0].z, vb[0].w}, w1[4] = {vb[1].x, vb[1].y, vb[1].z, vb[1].w};
+            const uint32_t ok0 = (k0 + 2 * bk < K && n0 + bn < dim) ? 0xffffffffu : 0u, ok1 = (k0 + 2 * bk + 1 < K && n0 + bn < dim) ? 0xffffffffu : 0u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {   // columns bn + 2e (low halves) and bn + 2e + 1 (high halves) of the two k rows
+                const uint32_t a = w0[e] & ok0, b = w1[e] & ok1;
+                *reinterpret_cast<uint32_t *>(&Bs[buf][bn + 2 * e][2 * bk]) = (a & 0xffffu) | (b << 16);
+                *reinterpret_cast<uint32_t *>(&Bs[buf][bn + 2 * e + 1][2 * bk]) = (a >> 16) | (b & 0xffff0000u);
             }
         }
     };
@@ -275,22 +307,25 @@ __global__ __launch_bounds__(GG_THREADS) void inbatch_grad_gemm_kernel(const flo
         const bool more = k0 + GG_KC < K;
         if (more) fetch(k0 + GG_KC);                   // global loads of the next chunk stay in flight over the MFMAs
 #pragma unroll
-        for (int ks = 0; ks < GG_KC / 2; ++ks) {
-            const float a = As[buf][2 * ks + h][wm * 32 + l31];
-            const float b = Bs[buf][2 * ks + h][wn * 32 + l31];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        for (int ks = 0; ks < GG_KC / 16; ++ks) {
+            const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Bs[buf][wn * 32 + l31][ks * 16 + 8 * h]);
+#pragma unroll
+            for (int part = 0; part < 3; ++part) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&As[buf][part][wm * 32 + l31][ks * 16 + 8 * h]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+            }
         }
         if (more) stash(buf ^ 1, k0 + GG_KC);
         __syncthreads();
         buf ^= 1;
     }
-    // C layout of v_mfma_f32_32x32x2: column = lane & 31, register e -> row (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+    // C layout of v_mfma_f32_32x32x16: column = lane & 31, register e -> row (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
     const int ncol = n0 + wn * 32 + l31;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int mrow = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (mrow < M && ncol < dim) {
-            float *crow = (mrow < split) ? C0 + (int64_t)mrow * dim : C1 + (int64_t)(mrow - split) * dim;
+            float *crow = (FOR_Q || mrow < B) ? C0 + (int64_t)mrow * dim : C1 + (int64_t)(mrow - B) * dim;
             crow[ncol] = acc[e];
         }
     }
@@ -310,38 +345,60 @@ static int pick_splits(int B) {
 
 using namespace ccr;
 
+namespace {
+// workspace: [partials 3 x 64 x B floats][S: 2B rows of ldS floats][tickets: (query tiles + 1) u32, padded][tile shares: doubles]
+struct InbatchWs {
+    float *pm, *pl, *pd, *S;
+    int ldS;
+    unsigned int *tile_ticket, *loss_ticket;
+    double *tile_part;
+    size_t zero_bytes;   // tickets: zeroed before every forward
+    size_t total;
+};
+InbatchWs inbatch_ws(void *workspace, int B) {
+    InbatchWs w;
+    const size_t partial = (((size_t)3 * 64 * B * sizeof(float) + 255) / 256) * 256;
+    w.ldS = (B + 3) / 4 * 4;
+    const size_t sbytes = (((size_t)2 * B * w.ldS * sizeof(float) + 255) / 256) * 256;
+    const int qtiles = (B + 31) / 32;
+    w.zero_bytes = (((size_t)(qtiles + 1) * 4 + 255) / 256) * 256;
+    const size_t parts = (((size_t)qtiles * 8 + 255) / 256) * 256;
+    char *base = (char *)workspace;
+    w.pm = (float *)base;
+    w.pl = w.pm + (size_t)64 * B;
+    w.pd = w.pl + (size_t)64 * B;
+    w.S = (float *)(base + partial);
+    w.tile_ticket = (unsigned int *)(base + partial + sbytes);
+    w.loss_ticket = w.tile_ticket + qtiles;
+    w.tile_part = (double *)(base + partial + sbytes + w.zero_bytes);
+    w.total = partial + sbytes + w.zero_bytes + parts + 256;   // + 256: the caller's pointer need only be 16-byte aligned
+    return w;
+}
+char *align256(void *p) { return (char *)p + (256 - (uintptr_t)p % 256) % 256; }
+}  // namespace
+
 extern "C" size_t ccr_inbatch_ce_workspace_bytes(int B, int dim) {
     (void)dim;
     if (B <= 0) return 0;
-    const size_t partial = (size_t)3 * 64 * B * sizeof(float);
-    const size_t g = (size_t)2 * B * B * sizeof(float);
-    const size_t red = (size_t)((B + 255) / 256) * sizeof(double) + 256;   // block partials + ticket of the loss reduction
-    return ((partial + 255) / 256) * 256 + g + ((red + 255) / 256) * 256 + 256;
+    return inbatch_ws(nullptr, B).total;
 }
 
 extern "C" int ccr_inbatch_ce_fwd(const uint16_t *Qe, const uint16_t *Pe, const uint16_t *Ne, int B, int dim,
                                   float inv_temperature, float *loss, float *lse, void *workspace, size_t ws_bytes, void *stream) {
     CCR_REQUIRE(Qe && Pe && Ne && loss && lse, "ccr_inbatch_ce_fwd: null pointer");
     CCR_REQUIRE(B >= 1 && dim >= 16 && dim % 16 == 0, "ccr_inbatch_ce_fwd: B=%d dim=%d (dim %% 16 == 0)", B, dim);
+    CCR_REQUIRE(((uintptr_t)Qe | (uintptr_t)Pe | (uintptr_t)Ne) % 16 == 0, "ccr_inbatch_ce_fwd: embedding pointers must be 16-byte aligned");
     if (!workspace || ws_bytes < ccr_inbatch_ce_workspace_bytes(B, dim)) {
         set_error("ccr_inbatch_ce_fwd: workspace %zu bytes required, got %zu", ccr_inbatch_ce_workspace_bytes(B, dim), ws_bytes);
         return CCR_ERR_WORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
+    const InbatchWs w = inbatch_ws(align256(workspace), B);
     const int splits = pick_splits(B);
-    float *pm = (float *)workspace, *pl = pm + (size_t)64 * B, *pd = pl + (size_t)64 * B;
+    CCR_HIP_CHECK(hipMemsetAsync(w.tile_ticket, 0, w.zero_bytes, s));
     dim3 grid((B + 31) / 32, splits);
-    hipLaunchKernelGGL(inbatch_logits_kernel<0>, grid, dim3(64), 0, s, Qe, Pe, Ne, B, dim, inv_temperature, splits, pm, pl, pd,
-                       (const float *)nullptr, 0.f, (const float *)nullptr, (float *)nullptr);
-    CCR_LAUNCH_CHECK();
-    const size_t partial = (((size_t)3 * 64 * B * sizeof(float) + 255) / 256) * 256;
-    char *red = (char *)workspace + partial + (size_t)2 * B * B * sizeof(float);
-    red += (256 - (uintptr_t)red % 256) % 256;
-    unsigned int *ticket = (unsigned int *)red;
-    double *block_part = (double *)(red + 64);
-    CCR_HIP_CHECK(hipMemsetAsync(ticket, 0, 64, s));
-    hipLaunchKernelGGL(inbatch_reduce_kernel, dim3((B + 255) / 256), dim3(256), 0, s, pm, pl, pd, B, splits, lse, loss, block_part,
-                       ticket);
+    hipLaunchKernelGGL(inbatch_fwd_kernel, grid, dim3(64), 0, s, Qe, Pe, Ne, B, dim, inv_temperature, splits, w.pm, w.pl, w.pd, w.S, w.ldS,
+                       lse, loss, w.tile_ticket, w.loss_ticket, w.tile_part);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
 }
@@ -351,32 +408,19 @@ static int inbatch_bwd_impl(const uint16_t *Qe, const uint16_t *Pe, const uint16
                             void *workspace, size_t ws_bytes, void *stream) {
     CCR_REQUIRE(Qe && Pe && Ne && lse && dQ && dP && dN, "ccr_inbatch_ce_bwd: null pointer");
     CCR_REQUIRE(B >= 1 && dim >= 16 && dim % 16 == 0, "ccr_inbatch_ce_bwd: B=%d dim=%d (dim %% 16 == 0)", B, dim);
+    CCR_REQUIRE(((uintptr_t)Qe | (uintptr_t)Pe | (uintptr_t)Ne) % 16 == 0, "ccr_inbatch_ce_bwd: embedding pointers must be 16-byte aligned");
     if (!workspace || ws_bytes < ccr_inbatch_ce_workspace_bytes(B, dim)) {
         set_error("ccr_inbatch_ce_bwd: workspace %zu bytes required, got %zu", ccr_inbatch_ce_workspace_bytes(B, dim), ws_bytes);
         return CCR_ERR_WORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
-    const size_t partial = (((size_t)3 * 64 * B * sizeof(float) + 255) / 256) * 256;
-    float *G = (float *)((char *)workspace + partial);
-    const int splits = pick_splits(B);
-    dim3 grid((B + 31) / 32, splits);
-    hipLaunchKernelGGL(inbatch_logits_kernel<1>, grid, dim3(64), 0, s, Qe, Pe, Ne, B, dim, inv_temperature, splits,
-                       (float *)nullptr, (float *)nullptr, (float *)nullptr, lse, inv_temperature * grad_out / (float)B, grad_out_dev, G);
-    CCR_LAUNCH_CHECK();
-    // dQ[i][:] = sum_j G[j][i] K[j][:]      (A k-major: A[k=j][m=i])
-    // dK[j][:] = sum_i G[j][i] Q[i][:]      (A row-major [m=j][k=i]); rows < B -> dP, the rest -> dN
-    const bool vec = (B % 4 == 0) && B >= 4 && (dim % 8 == 0) && dim >= 8 && ((uintptr_t)Qe % 16 == 0) && ((uintptr_t)Pe % 16 == 0) &&
-                     ((uintptr_t)Ne % 16 == 0) && ((uintptr_t)G % 16 == 0);
+    const InbatchWs w = inbatch_ws(align256(workspace), B);   // the FORWARD's workspace: it holds the scaled logits S
+    const float gscale = inv_temperature * grad_out / (float)B;
+    // dQ[i][:] = sum_j G[j][i] K[j][:];   dK[j][:] = sum_i G[j][i] Q[i][:], rows < B -> dP, the rest -> dN
     const dim3 gq((dim + GG_T - 1) / GG_T, (B + GG_T - 1) / GG_T), gk((dim + GG_T - 1) / GG_T, (2 * B + GG_T - 1) / GG_T);
-    if (vec) {
-        hipLaunchKernelGGL((inbatch_grad_gemm_kernel<true, true, true>), gq, dim3(GG_THREADS), 0, s, G, B, Pe, Ne, B, B, 2 * B, dim, dQ, dQ, B);
-        CCR_LAUNCH_CHECK();
-        hipLaunchKernelGGL((inbatch_grad_gemm_kernel<false, false, true>), gk, dim3(GG_THREADS), 0, s, G, B, Qe, Qe, B, 2 * B, B, dim, dP, dN, B);
-    } else {
-        hipLaunchKernelGGL((inbatch_grad_gemm_kernel<true, true, false>), gq, dim3(GG_THREADS), 0, s, G, B, Pe, Ne, B, B, 2 * B, dim, dQ, dQ, B);
-        CCR_LAUNCH_CHECK();
-        hipLaunchKernelGGL((inbatch_grad_gemm_kernel<false, false, false>), gk, dim3(GG_THREADS), 0, s, G, B, Qe, Qe, B, 2 * B, B, dim, dP, dN, B);
-    }
+    hipLaunchKernelGGL((inbatch_grad_kernel<true>), gq, dim3(GG_THREADS), 0, s, w.S, w.ldS, lse, Pe, Ne, B, dim, gscale, grad_out_dev, dQ, dQ);
+    CCR_LAUNCH_CHECK();
+    hipLaunchKernelGGL((inbatch_grad_kernel<false>), gk, dim3(GG_THREADS), 0, s, w.S, w.ldS, lse, Qe, Qe, B, dim, gscale, grad_out_dev, dP, dN);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
 }

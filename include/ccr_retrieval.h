@@ -352,8 +352,11 @@ int ccr_apply_block(const float *in_scores, const int64_t *in_ids, int n_q, int 
  *   Qe, Pe, Ne [B][dim] bf16; logits = [Qe Pe^T | Qe Ne^T] * inv_temperature (fp32 accumulate)
  *   fwd: loss (1 float, mean CE with labels arange(B)), lse [B] (saved for bwd)
  *   bwd: dQ, dP, dN [B][dim] fp32 = grad_out * dloss/d(.)
- *   workspace: ccr_inbatch_ce_workspace_bytes(B, dim) bytes of device memory (split partials + the
- *   [2B][B] fp32 gradient-of-logits matrix); dim % 16 == 0.
+ *   workspace: ccr_inbatch_ce_workspace_bytes(B, dim) bytes of device memory (16-byte aligned); dim % 16 == 0; the embedding
+ *   pointers 16-byte aligned.  The FORWARD leaves the scaled logits ([2B][B] fp32) in it and the BACKWARD reads them there
+ *   instead of recomputing them: pass the backward the same, unmodified workspace its forward call used (the Python autograd
+ *   function saves it with the operands).  Launches: forward = one kernel (+ a memset of its tickets), backward = two kernels;
+ *   deterministic (fixed combine orders, no float atomics).
  */
 size_t ccr_inbatch_ce_workspace_bytes(int B, int dim);
 int ccr_inbatch_ce_fwd(const uint16_t *Qe, const uint16_t *Pe, const uint16_t *Ne, int B, int dim,
