@@ -13,7 +13,10 @@
 //         inv_T * grad_out / B evaluated while the operand is staged, split into THREE bf16 parts (g = hi + mid + lo exactly to
 //         2^-24 relative) so that the products with the bf16 embeddings run on v_mfma_f32_32x32x16_bf16 (3 MFMAs of 32 cycles
 //         per 16 K instead of 8 fp32 MFMAs of 64): fp32-MFMA accuracy at a fifth of its time; LDS-staged 64x64 tiles,
-//         deterministic, no atomics.  (r3: a separate G kernel + two v_mfma_f32_32x32x2_f32 GEMMs, 139 of the step's 175 us.)
+//         deterministic, no atomics.  (r3: a separate G kernel + two v_mfma_f32_32x32x2_f32 GEMMs, 139 of the step's 175 us; now
+//         61 + 40 us.  What bounds them now is the VALU work of evaluating and splitting the gradient while it is staged -- every
+//         element once per 64-column output tile, 12 times at dim 768 -- at one wave per SIMD: a variant with one 16-byte LDS store per
+//         operand part and thread, conflict free, but 16 scalar loads per thread and chunk, measured SLOWER: 85 + 53 us.)
 #include "ccr_common.h"
 
 namespace ccr {
@@ -25,17 +28,17 @@ __device__ __forceinline__ const uint16_t *key_row(const uint16_t *P, const uint
     return (j < B) ? P + (int64_t)j * dim : N + (int64_t)(j - B) * dim;
 }
 
-// release / acquire around a ticket (MI355X_MICROARCH, 'Valid forms'): the publishing lane's stores -> vmcnt(0) -> agent release ->
-// vmcnt(0) (inline asm: hipcc may drop its own wait behind the fence) -> relaxed agent atomic; the last arriver: agent acquire -> vmcnt(0)
-__device__ __forceinline__ unsigned int publish_and_take_ticket(unsigned int *ticket) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+// Hand-off of a wave's partials to the last arriver WITHOUT a release fence: a fence (buffer_wbl2) writes back every dirty line of
+// the XCD's L2, and this kernel keeps 8 MB of freshly written logits there -- measured 65 us for the fused forward with fences against
+// 52 us without.  MI355X_MICROARCH 'Valid forms', first row of its table: every handed-off byte is
+// stored sc1 (write-through: __hip_atomic_store relaxed / agent), the storing wave drains its stores (s_waitcnt vmcnt(0)), ONE lane
+// then adds to an agent-scope counter, and the wave whose add came last reads the bytes with sc1 loads (__hip_atomic_load relaxed /
+// agent) after its add has returned.  A workgroup here is one wave, so the signalling lane signals for its own wave's stores only.
+__device__ __forceinline__ void store_handoff(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float load_handoff(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned int drain_and_take_ticket(unsigned int *ticket) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     return __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void acquire_after_ticket() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // grid = (query tiles of 32, key splits), block = one wave.
@@ -106,18 +109,17 @@ __global__ __launch_bounds__(64) void inbatch_fwd_kernel(const uint16_t *__restr
         float L = 0.f;
         if (M > -INFINITY) L = (m > -INFINITY ? l * __expf(m - M) : 0.f) + (m2 > -INFINITY ? l2 * __expf(m2 - M) : 0.f);
         if (h == 0 && i < B) {
-            pm[(int64_t)s * B + i] = M;
-            pl[(int64_t)s * B + i] = L;
-            pd[(int64_t)s * B + i] = fmaxf(dg, d2);
+            store_handoff(pm + (int64_t)s * B + i, M);
+            store_handoff(pl + (int64_t)s * B + i, L);
+            store_handoff(pd + (int64_t)s * B + i, fmaxf(dg, d2));
         }
     }
     // ---- the last split of this query tile combines the tile's partials in split order (the wave is the whole workgroup: the
     // ticket is taken by lane 0 behind the wave's own stores, the result broadcast)
     unsigned int t = 0;
-    if (lane == 0) t = publish_and_take_ticket(&tile_ticket[blockIdx.x]);
+    if (lane == 0) t = drain_and_take_ticket(&tile_ticket[blockIdx.x]);   // (s_waitcnt is per wave: every lane's stores are drained)
     t = __shfl(t, 0, 64);
     if (t != (unsigned int)splits - 1) return;
-    acquire_after_ticket();
     double part = 0.0;
     if (h == 0 && i < B) {
         float M = -INFINITY, dgc = -INFINITY, L = 0.f;
@@ -127,9 +129,9 @@ __global__ __launch_bounds__(64) void inbatch_fwd_kernel(const uint16_t *__restr
             for (int u = 0; u < 16; ++u) {
                 const bool in = s0 + u < splits;
                 const int64_t at = (int64_t)(in ? s0 + u : 0) * B + i;
-                vm[u] = in ? __builtin_nontemporal_load(pm + at) : -INFINITY;
-                vl[u] = in ? __builtin_nontemporal_load(pl + at) : 0.f;
-                vd[u] = in ? __builtin_nontemporal_load(pd + at) : -INFINITY;
+                vm[u] = in ? load_handoff(pm + at) : -INFINITY;
+                vl[u] = in ? load_handoff(pl + at) : 0.f;
+                vd[u] = in ? load_handoff(pd + at) : -INFINITY;
             }
 #pragma unroll
             for (int u = 0; u < 16; ++u) {   // online combine in split order
@@ -147,15 +149,14 @@ __global__ __launch_bounds__(64) void inbatch_fwd_kernel(const uint16_t *__restr
     for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
     unsigned int t2 = 0;
     if (lane == 0) {
-        tile_part[blockIdx.x] = part;
-        t2 = publish_and_take_ticket(loss_ticket);
+        __hip_atomic_store(tile_part + blockIdx.x, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t2 = drain_and_take_ticket(loss_ticket);
     }
     t2 = __shfl(t2, 0, 64);
     if (t2 != gridDim.x - 1) return;
-    acquire_after_ticket();
     if (lane == 0) {   // the last tile adds the shares in tile order
         double tot = 0.0;
-        for (unsigned int b = 0; b < gridDim.x; ++b) tot += __builtin_nontemporal_load(tile_part + b);
+        for (unsigned int b = 0; b < gridDim.x; ++b) tot += __hip_atomic_load(tile_part + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         loss[0] = (float)(tot / (double)B);
     }
 }
@@ -203,9 +204,12 @@ __global__ __launch_bounds__(GG_THREADS) void inbatch_grad_kernel(const float *_
     // X (rows = k, 8 consecutive n per 16-byte load): threads 0..127 -> the k pair (2 bk, 2 bk + 1) x 8 columns: 8 dword stores.
     const int am = FOR_Q ? (tid & 15) * 4 : (tid >> 3), ak = FOR_Q ? (tid >> 4) : (tid & 7);
     const int bk = (tid >> 3) & 15, bn = (tid & 7) * 8;
-    float4 va[2];
-    uint4 vb[2];
-    float4 lse_m = make_float4(0.f, 0.f, 0.f, 0.f), lse_k = make_float4(0.f, 0.f, 0.f, 0.f);
+    // Three chunks of global loads in flight (register sets 0..2): a chunk is ~200 MFMA cycles per wave and less than one workgroup
+    // sits on a CU, so a single chunk of lookahead leaves every chunk waiting for an L2 round trip
+    constexpr int PF = 3;
+    float4 va[PF][2];
+    uint4 vb[PF][2];
+    float4 lse_m = make_float4(0.f, 0.f, 0.f, 0.f), lse_k[PF];
     if (FOR_Q) {   // lse of the thread's 4 query columns: the same for every chunk
         float t4[4];
 #pragma unroll
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(GG_THREADS) void inbatch_grad_kernel(const float *_
         }
         lse_m = make_float4(t4[0], t4[1], t4[2], t4[3]);
     }
-    auto fetch = [&](int k0) {
+    auto fetch = [&](int set, int k0) {
         if (FOR_Q) {
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(GG_THREADS) void inbatch_grad_kernel(const float *_
                 if (k > K - 1) k = K - 1;
                 int mc = m0 + am;
                 if (mc > ldS - 4) mc = ldS - 4;           // (ldS is a multiple of 4: an aligned vector inside the row pitch)
-                va[r] = *reinterpret_cast<const float4 *>(S + (int64_t)k * ldS + mc);
+                va[set][r] = *reinterpret_cast<const float4 *>(S + (int64_t)k * ldS + mc);
             }
         } else {
 #pragma unroll
@@ -232,7 +236,7 @@ __global__ __launch_bounds__(GG_THREADS) void inbatch_grad_kernel(const float *_
                 if (mrow > M - 1) mrow = M - 1;
                 int kc = k0 + 4 * ak;
                 if (kc > ldS - 4) kc = ldS - 4;
-                va[r] = *reinterpret_cast<const float4 *>(S + (int64_t)mrow * ldS + kc);
+                va[set][r] = *reinterpret_cast<const float4 *>(S + (int64_t)mrow * ldS + kc);
             }
             float t4[4];
 #pragma unroll
@@ -240,9 +244,10 @@ __global__ __launch_bounds__(GG_THREADS) void inbatch_grad_kernel(const float *_
                 const int i = k0 + 4 * ak + u;
                 t4[u] = lse[i < B ? i : B - 1];
             }
-            lse_k = make_float4(t4[0], t4[1], t4[2], t4[3]);
+            lse_k[set] = make_float4(t4[0], t4[1], t4[2], t4[3]);
         }
-        if (tid < 128) {
+        {   // (every thread loads -- 128..255 the same rows again -- so that the number of loads in flight is the same on every path:
+            // behind a branch hipcc counts vmcnt for the path without the loads and drains the prefetch window)
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 int kr = k0 + 2 * bk + r;
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(GG_THREADS) void inbatch_grad_kernel(const float *_
                 int nc = n0 + bn;
                 if (nc > dim - 8) nc = dim - 8;
                 const uint16_t *row = FOR_Q ? key_row(X0, X1, B, kr, dim) : X0 + (int64_t)kr * dim;
-                vb[r] = *reinterpret_cast<const uint4 *>(row + nc);
+                vb[set][r] = *reinterpret_cast<const uint4 *>(row + nc);
             }
         }
     };
@@ -259,9 +264,9 @@ __global__ __launch_bounds__(GG_THREADS) void inbatch_grad_kernel(const float *_
         if (j == i) g -= 1.f;
         return (j < 2 * B && i < B) ? g * gscale : 0.f;   // (a select, not a product: staged positions outside the matrix may hold anything)
     };
-    auto stash = [&](int buf, int k0) {
+    auto stash = [&](int buf, int set, int k0) {
         if (FOR_Q) {
-            const float s0[4] = {va[0].x, va[0].y, va[0].z, va[0].w}, s1[4] = {va[1].x, va[1].y, va[1].z, va[1].w};
+            const float s0[4] = {va[set][0].x, va[set][0].y, va[set][0].z, va[set][0].w}, s1[4] = {va[set][1].x, va[set][1].y, va[set][1].z, va[set][1].w};
             const float ls[4] = {lse_m.x, lse_m.y, lse_m.z, lse_m.w};
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -274,10 +279,10 @@ __global__ __launch_bounds__(GG_THREADS) void inbatch_grad_kernel(const float *_
                     *reinterpret_cast<uint32_t *>(&As[buf][part][am + u][2 * ak]) = (uint32_t)p0[part] | ((uint32_t)p1[part] << 16);
             }
         } else {
-            const float lk[4] = {lse_k.x, lse_k.y, lse_k.z, lse_k.w};
+            const float lk[4] = {lse_k[set].x, lse_k[set].y, lse_k[set].z, lse_k[set].w};
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                const float sv[4] = {va[r].x, va[r].y, va[r].z, va[r].w};
+                const float sv[4] = {va[set][r].x, va[set][r].y, va[set][r].z, va[set][r].w};
                 const int j = m0 + am + 32 * r;
                 uint16_t p[4][3];
 #pragma unroll
@@ -289,7 +294,7 @@ __global__ __launch_bounds__(GG_THREADS) void inbatch_grad_kernel(const float *_
             }
         }
         if (tid < 128) {
-            const uint32_t w0[4] = {vb[0].x, vb[0].y, vb[0].z, vb[0].w}, w1[4] = {vb[1].x, vb[1].y, vb[1].z, vb[1].w};
+            const uint32_t w0[4] = {vb[set][0].x, vb[set][0].y, vb[set][0].z, vb[set][0].w}, w1[4] = {vb[set][1].x, vb[set][1].y, vb[set][1].z, vb[set][1].w};
             const uint32_t ok0 = (k0 + 2 * bk < K && n0 + bn < dim) ? 0xffffffffu : 0u, ok1 = (k0 + 2 * bk + 1 < K && n0 + bn < dim) ? 0xffffffffu : 0u;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {   // columns bn + 2e (low halves) and bn + 2e + 1 (high halves) of the two k rows
@@ -299,25 +304,32 @@ __global__ __launch_bounds__(GG_THREADS) void inbatch_grad_kernel(const float *_
             }
         }
     };
-    fetch(0);
-    stash(0, 0);
+    // chunk c: LDS buffer c % 2, register set c % 3.  Iteration c: fetch chunk c + 3 into the set stash(c) has just freed | MFMAs of
+    // chunk c | stash chunk c + 1 | barrier.  Loads beyond K are clamped (never stashed), so neither the prologue nor the loop needs bounds.
+#pragma unroll
+    for (int u = 0; u < PF; ++u) fetch(u, u * GG_KC);
+    stash(0, 0, 0);
     __syncthreads();
-    int buf = 0;
-    for (int k0 = 0; k0 < K; k0 += GG_KC) {
-        const bool more = k0 + GG_KC < K;
-        if (more) fetch(k0 + GG_KC);                   // global loads of the next chunk stay in flight over the MFMAs
+    for (int k0 = 0; k0 < K; k0 += PF * GG_KC) {
 #pragma unroll
-        for (int ks = 0; ks < GG_KC / 16; ++ks) {
-            const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Bs[buf][wn * 32 + l31][ks * 16 + 8 * h]);
+        for (int u = 0; u < PF; ++u) {
+            const int kc = k0 + u * GG_KC;          // chunk c = kc / 32: buffer (c & 1), set u (k0 / 32 is a multiple of 3)
+            if (kc < K) {                           // block-uniform
+                const int buf = (kc / GG_KC) & 1;
+                fetch(u, kc + PF * GG_KC);
 #pragma unroll
-            for (int part = 0; part < 3; ++part) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&As[buf][part][wm * 32 + l31][ks * 16 + 8 * h]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+                for (int ks = 0; ks < GG_KC / 16; ++ks) {
+                    const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Bs[buf][wn * 32 + l31][ks * 16 + 8 * h]);
+#pragma unroll
+                    for (int part = 0; part < 3; ++part) {
+                        const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&As[buf][part][wm * 32 + l31][ks * 16 + 8 * h]);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+                    }
+                }
+                if (kc + GG_KC < K) stash(buf ^ 1, (u + 1) % PF, kc + GG_KC);
+                __syncthreads();
             }
         }
-        if (more) stash(buf ^ 1, k0 + GG_KC);
-        __syncthreads();
-        buf ^= 1;
     }
     // C layout of v_mfma_f32_32x32x16: column = lane & 31, register e -> row (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
     const int ncol = n0 + wn * 32 + l31;
