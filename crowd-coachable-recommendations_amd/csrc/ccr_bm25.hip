@@ -11,15 +11,21 @@
 // adds the postings of every query's r-th term (one launch per round: within a round a (query, doc) cell is touched at
 // most once, and the rounds run in stream order = ascending term order).  The accumulator is converted to fp32 and
 // re-zeroed in one pass, and the exact dense selection of the retrieval path picks the top-k.
+#include <stdlib.h>
+
 #include <algorithm>
 #include <vector>
 
+#include <math.h>
+
 #include "ccr_common.h"
+#include "ccr_topk_device.h"
 
 namespace ccr {
 int launch_dense_select(const float *scores, int64_t n_rows, int k, const uint32_t *out_rows, int q_begin, int nq_chunk,
                         const uint32_t *count_dev, int64_t id_offset, float *out_scores, int64_t *out_ids, hipStream_t s,
-                        bool aggregate);
+                        bool aggregate, const uint32_t *in_rows);
+int ensure_dynamic_lds(const void *kernel, size_t lds);
 
 struct Bm25Round {       // one (query row of the batch, term) pair of a round
     int64_t begin, end;  // posting range
@@ -72,6 +78,188 @@ __global__ __launch_bounds__(256) void bm25_finish_kernel(double *__restrict__ a
         acc[i] = 0.0;
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Batched selection of the top-k of a batch of finished fp32 score rows (r4).  The exact dense selection (one 256-thread
+// workgroup per query walking its whole row through four radix passes, every zero score landing in ONE histogram bin) took 70 %
+// of a BM25 search: 5.2 ms per batch of 256 queries x 500 k documents.  Instead, the retrieval path's estimate-and-verify filter:
+//   threshold : tau_row = the r-th largest score of a 1/64 SAMPLE of the row (contiguous 64-document pieces, one out of every 64),
+//               r = the rank for which fewer than k documents pass with probability < 1e-7 (r = 41 at k = 1001: ~2 600 pass);
+//   collect   : every (row, 16 K-document chunk) block streams its scores ONCE and appends the documents with score >= tau (and > 0
+//               when tau <= 0: a BM25 row is mostly exact zeros) to the row's candidate list -- wave ballot, one LDS atomic per
+//               wave, one global atomic per block;
+//   top-k     : per row, if k <= candidates <= capacity the k best of the list by (score desc, document asc) ARE the row's top-k
+//               (everything >= tau is in the list and at least k documents are >= tau): bitonic sort of 64-bit keys in LDS.
+//               Otherwise (an estimate that came out too high, a query whose terms match fewer than k documents, a flooded list)
+//               the row is put on a list for the exact dense selection, which runs for the listed rows only.
+// Exact for every input; the order rule is the same everywhere.
+constexpr int BM25_SAMPLE_PIECE = 64;        // documents per sampled piece (256 contiguous bytes)
+constexpr int BM25_SAMPLE_EVERY = 64;        // one piece out of this many
+constexpr int BM25_SAMPLE_MAX = 16384;       // sampled scores the threshold kernel holds in LDS
+constexpr int BM25_COLLECT_CHUNK = 16384;    // documents per collect block (64 per thread)
+constexpr int BM25_LIST_CAP = 16384;         // candidate records per row (128 KiB of keys in the top-k kernel)
+
+// grid = rows, block = 256.  tau[row] = the rank-th largest sampled score (0 if the sample holds fewer than `rank` scores).
+__global__ __launch_bounds__(256) void bm25_threshold_kernel(const float *__restrict__ scores, int64_t n_docs, int64_t piece_stride, int n_pieces,
+                                                            int rank, float *__restrict__ tau, uint32_t *__restrict__ list_cnt) {
+    extern __shared__ __attribute__((aligned(16))) float s_val[];
+    __shared__ uint32_t s_hist[256];
+    __shared__ uint32_t s_ctl[4];
+    const int tid = threadIdx.x;
+    const float *row = scores + (int64_t)blockIdx.x * n_docs;
+    const int n = n_pieces * BM25_SAMPLE_PIECE;
+    for (int i = tid; i < n; i += 256) {
+        const int64_t d = (int64_t)(i / BM25_SAMPLE_PIECE) * piece_stride + (i % BM25_SAMPLE_PIECE);
+        s_val[i] = d < n_docs ? row[d] : -INFINITY;
+    }
+    if (tid == 0) list_cnt[blockIdx.x] = 0u;
+    __syncthreads();
+    uint32_t kth = 0;
+    int need_eq = 0;
+    block_radix_select<true>(
+        [&](int64_t i, bool &skip) -> uint32_t {
+            (void)skip;
+            return f32_orderable(s_val[i]);
+        },
+        n, rank, s_hist, s_ctl, kth, need_eq);
+    if (tid == 0) tau[blockIdx.x] = orderable_to_f32(kth);
+}
+
+// grid = (chunks, rows), block = 256.  Records {score bits, document} of the documents that pass go to list[row][...]; odd_cnt[row]
+// counts the scores that are negative or NaN (a BM25 row has none: then every document that is not in the list of a row with tau <= 0
+// scores exactly zero).  No LDS, no barrier: a wave reserves room for its hits with ONE global atomic per 64-document step that
+// has any (about k hits per row in all), its 16 loads per lane are in flight together.
+__global__ __launch_bounds__(256) void bm25_collect_kernel(const float *__restrict__ scores, int64_t n_docs, const float *__restrict__ tau,
+                                                          uint2 *__restrict__ list, uint32_t *__restrict__ list_cnt, uint32_t *__restrict__ odd_cnt) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r = blockIdx.y;
+    const float t = tau[r];
+    const float *row = scores + (int64_t)r * n_docs;
+    uint2 *out = list + (int64_t)r * BM25_LIST_CAP;
+    // wave w of the block takes documents [lo, lo + 4096): 16 steps of 64 lanes x 4 consecutive documents
+    const int64_t lo = (int64_t)blockIdx.x * BM25_COLLECT_CHUNK + (int64_t)wv * (BM25_COLLECT_CHUNK / 4);
+    constexpr int STEPS = BM25_COLLECT_CHUNK / 4 / 256;
+    float v[STEPS][4];
+    const bool aligned = (reinterpret_cast<uintptr_t>(row) & 15) == 0;
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+        const int64_t d0 = lo + st * 256 + 4 * lane;
+        if (aligned && d0 + 3 < n_docs) {
+            const float4 q = *reinterpret_cast<const float4 *>(row + d0);
+            v[st][0] = q.x, v[st][1] = q.y, v[st][2] = q.z, v[st][3] = q.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[st][e] = d0 + e < n_docs ? row[d0 + e] : 0.f;   // (beyond the row: an exact zero, never collected)
+        }
+    }
+    uint32_t odd = 0;
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+        const int64_t d0 = lo + st * 256 + 4 * lane;
+        bool pass[4];
+        int mine = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x = v[st][e];
+            pass[e] = x >= t && (t > 0.f || x > 0.f) && d0 + e < n_docs;
+            mine += pass[e] ? 1 : 0;
+            odd += (x < 0.f || x != x) ? 1u : 0u;
+        }
+        if (__ballot(mine != 0) == 0ull) continue;   // wave-uniform: the usual case
+        // exclusive prefix of the lanes' hit counts (a hit step is rare: plain shuffles)
+        int incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
+        }
+        const int total = __shfl(incl, 63, 64);
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&list_cnt[r], (uint32_t)total);
+        base = (uint32_t)__shfl((int)base, 0, 64) + (uint32_t)(incl - mine);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (pass[e]) {
+                if (base < (uint32_t)BM25_LIST_CAP) out[base] = make_uint2(__float_as_uint(v[st][e]), (uint32_t)(d0 + e));
+                ++base;
+            }
+    }
+    const unsigned long long any_odd = __ballot(odd != 0u);
+    if (any_odd != 0ull && lane == 0) atomicAdd(&odd_cnt[r], 1u);
+}
+
+// grid = rows, block = 1024, dyn LDS = BM25_LIST_CAP keys.  Rows that cannot be finished here are appended to redo_list.
+__global__ __launch_bounds__(1024) void bm25_topk_kernel(const uint2 *__restrict__ list, const uint32_t *__restrict__ list_cnt,
+                                                        const uint32_t *__restrict__ odd_cnt, const float *__restrict__ tau, int64_t n_docs, int k,
+                                                        int q_begin, float *__restrict__ out_scores, int64_t *__restrict__ out_ids,
+                                                        uint32_t *__restrict__ redo_cnt, uint32_t *__restrict__ redo_list) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];
+    const int tid = threadIdx.x;
+    const int r = blockIdx.x;
+    const uint32_t n = list_cnt[r];
+    // Fewer than k documents passed.  With tau <= 0 and no negative / NaN score in the row the list holds EVERY non-zero document, all
+    // others score exactly zero, and the row's top-k is the sorted list followed by the k - n lowest-numbered documents outside it
+    // (a query whose terms match fewer than k documents: common for rare terms).  Anything else -- an estimate that came out too high,
+    // a flooded list -- goes to the exact dense selection.
+    const bool zero_fill = n < (uint32_t)k && tau[r] <= 0.f && odd_cnt[r] == 0u;
+    if ((n < (uint32_t)k && !zero_fill) || n > (uint32_t)BM25_LIST_CAP) {   // block-uniform
+        if (tid == 0) redo_list[atomicAdd(redo_cnt, 1u)] = (uint32_t)r;
+        return;
+    }
+    const int np2 = n ? pow2_ceil((int)n) : 1;
+    const uint2 *src = list + (int64_t)r * BM25_LIST_CAP;
+    for (int i = tid; i < np2; i += 1024) {
+        unsigned long long key = 0ull;
+        if (i < (int)n) {
+            const uint2 e = src[i];
+            key = make_key(__uint_as_float(e.x), e.y);
+        }
+        s_keys[i] = key;
+    }
+    block_bitonic_sort_desc(s_keys, np2);
+    const int64_t orow = (int64_t)(q_begin + r);
+    const int head = n < (uint32_t)k ? (int)n : k;
+    for (int i = tid; i < head; i += 1024) {
+        const unsigned long long key = s_keys[i];
+        out_scores[orow * k + i] = key_score(key);
+        out_ids[orow * k + i] = (int64_t)key_idx(key);
+    }
+    if (zero_fill) {
+        // the j-th lowest document that is NOT in the list (j = 0 .. k - n - 1) is document j + (number of listed documents <= it): at most
+        // n < k listed documents lie below it, so thread j walks candidates j, j + 1, ... and counts the listed ones below by scanning the
+        // list (n < k <= 8 192 entries in LDS; this path serves a few rare-term queries)
+        __syncthreads();
+        unsigned int *s_doc = reinterpret_cast<unsigned int *>(s_keys + np2);     // the listed documents, unsorted
+        for (int i = tid; i < (int)n; i += 1024) s_doc[i] = key_idx(s_keys[i]);
+        __syncthreads();
+        for (int j = tid; j < k - (int)n; j += 1024) {
+            // fixed point of d = j + #{listed < = d}: monotone, converges in at most n + 1 rounds (usually 1 - 2)
+            unsigned int d = (unsigned int)j;
+            for (;;) {
+                unsigned int below = 0;
+                for (int i = 0; i < (int)n; ++i) below += s_doc[i] <= d ? 1u : 0u;
+                const unsigned int nd = (unsigned int)j + below;
+                if (nd == d) break;
+                d = nd;
+            }
+            out_scores[orow * k + n + j] = 0.f;
+            out_ids[orow * k + n + j] = (int64_t)d;
+        }
+    }
+}
+
+// rank of the sample whose value at most k documents fail to reach with probability < 1e-7 (the planner's rule for estimated
+// thresholds, ccr_api.hip: Wilson-Hilferty lower quantile of Gamma(r) >= k x sample fraction; at least 40)
+static int bm25_sample_rank(int k, double fs) {
+    const double need = (double)k * fs;
+    int r = 40;
+    for (; r < 1 << 20; ++r) {
+        const double a = 1.0 / (9.0 * r), t = 1.0 - a - 5.2 * sqrt(a);
+        if (t > 0.0 && (double)r * t * t * t >= need) break;
+    }
+    return r;
+}
+
 }  // namespace ccr
 
 using namespace ccr;
@@ -119,7 +307,9 @@ static int bm25_batch_rows(const ccr_bm25_index *ix, int n_q) {
 extern "C" size_t ccr_bm25_search_workspace_bytes(const ccr_bm25_index *ix, int n_q, int max_terms_per_query) {
     if (!ix || n_q <= 0 || max_terms_per_query < 0) return 0;
     const int rows = bm25_batch_rows(ix, n_q);
-    return (size_t)rows * ix->n_docs * 12 + (size_t)rows * (size_t)std::max(1, max_terms_per_query) * sizeof(Bm25Round) + 1024;
+    // + the batched selection: candidate lists, thresholds, counters, redo list
+    const size_t sel = (size_t)rows * BM25_LIST_CAP * 8 + (size_t)rows * 20 + 256 * 4;
+    return (size_t)rows * ix->n_docs * 12 + (size_t)rows * (size_t)std::max(1, max_terms_per_query) * sizeof(Bm25Round) + 1024 + sel;
 }
 
 extern "C" int ccr_bm25_search(const ccr_bm25_index *ix, const int64_t *q_ptr_host, const int32_t *q_terms_host,
@@ -151,6 +341,28 @@ extern "C" int ccr_bm25_search(const ccr_bm25_index *ix, const int64_t *q_ptr_ho
     double *acc = (double *)ws;
     float *scores = (float *)(ws + (size_t)rows * ix->n_docs * 8);
     Bm25Round *d_pairs = (Bm25Round *)(ws + (size_t)rows * ix->n_docs * 12);
+    char *sel = ws + (((size_t)rows * ix->n_docs * 12 + (size_t)rows * (size_t)std::max(1, max_terms) * sizeof(Bm25Round) + 255) / 256) * 256;
+    uint2 *cand_list = (uint2 *)sel;
+    float *tau = (float *)(sel + (size_t)rows * BM25_LIST_CAP * 8);
+    uint32_t *list_cnt = (uint32_t *)(tau + rows);
+    uint32_t *odd_cnt = list_cnt + rows;           // [rows]: blocks that saw a negative / NaN score
+    uint32_t *redo_cnt = odd_cnt + rows;           // [1] + pad
+    uint32_t *redo_list = redo_cnt + 4;            // [rows]
+    // the sampled filter needs a sample that holds several times the rank; smaller corpora keep the exact dense selection
+    const int64_t all_pieces = (ix->n_docs + BM25_SAMPLE_PIECE - 1) / BM25_SAMPLE_PIECE;
+    int64_t every = BM25_SAMPLE_EVERY;
+    while ((all_pieces + every - 1) / every * BM25_SAMPLE_PIECE > BM25_SAMPLE_MAX) every *= 2;
+    const int n_pieces = (int)((all_pieces + every - 1) / every);
+    const double fs = (double)n_pieces * BM25_SAMPLE_PIECE / (double)ix->n_docs;
+    const int rank = bm25_sample_rank(k, fs);
+    const bool sampled = getenv("CCR_BM25_DENSE_SELECT") == nullptr && (int64_t)n_pieces * BM25_SAMPLE_PIECE >= 8 * (int64_t)rank &&
+                         (double)rank / fs * 2.0 + 1024.0 <= (double)BM25_LIST_CAP && k <= BM25_LIST_CAP / 2;
+    if (sampled) {
+        const int rc1 = ensure_dynamic_lds(reinterpret_cast<const void *>(&bm25_topk_kernel), (size_t)BM25_LIST_CAP * 8);
+        if (rc1 != CCR_OK) return rc1;
+        const int rc2 = ensure_dynamic_lds(reinterpret_cast<const void *>(&bm25_threshold_kernel), (size_t)BM25_SAMPLE_MAX * 4);
+        if (rc2 != CCR_OK) return rc2;
+    }
     const int64_t cells = (int64_t)rows * ix->n_docs;
     CCR_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)cells * 8, s));
     // One pair table per batch (all rounds back to back), uploaded once; the host tables stay alive until the
@@ -199,8 +411,24 @@ extern "C" int ccr_bm25_search(const ccr_bm25_index *ix, const int64_t *q_ptr_ho
         const int64_t n = (int64_t)m * ix->n_docs;
         hipLaunchKernelGGL(bm25_finish_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, (int64_t)1 << 30)), dim3(256), 0, s, acc, scores, n);   // one cell per thread: streams faster than a capped grid-stride loop
         CCR_LAUNCH_CHECK();
-        const int rc = launch_dense_select(scores, ix->n_docs, k, nullptr, q0, m, nullptr, 0, out_scores, out_ids, s, false);
-        if (rc != CCR_OK) return rc;
+        if (sampled) {
+            CCR_HIP_CHECK(hipMemsetAsync(odd_cnt, 0, (size_t)rows * 4 + 16, s));   // odd counts + the redo count behind them
+            hipLaunchKernelGGL(bm25_threshold_kernel, dim3((unsigned)m), dim3(256), (size_t)n_pieces * BM25_SAMPLE_PIECE * 4, s, scores, ix->n_docs,
+                               every * BM25_SAMPLE_PIECE, n_pieces, rank, tau, list_cnt);
+            CCR_LAUNCH_CHECK();
+            hipLaunchKernelGGL(bm25_collect_kernel, dim3((unsigned)((ix->n_docs + BM25_COLLECT_CHUNK - 1) / BM25_COLLECT_CHUNK), (unsigned)m), dim3(256), 0, s,
+                               scores, ix->n_docs, tau, cand_list, list_cnt, odd_cnt);
+            CCR_LAUNCH_CHECK();
+            hipLaunchKernelGGL(bm25_topk_kernel, dim3((unsigned)m), dim3(1024), (size_t)BM25_LIST_CAP * 8, s, cand_list, list_cnt, odd_cnt, tau,
+                               ix->n_docs, k, q0, out_scores, out_ids, redo_cnt, redo_list);
+            CCR_LAUNCH_CHECK();
+            // the rows the filter could not finish: exact dense selection for the listed rows only (blocks beyond the count exit at once)
+            const int rc = launch_dense_select(scores, ix->n_docs, k, nullptr, q0, m, redo_cnt, 0, out_scores, out_ids, s, false, redo_list);
+            if (rc != CCR_OK) return rc;
+        } else {
+            const int rc = launch_dense_select(scores, ix->n_docs, k, nullptr, q0, m, nullptr, 0, out_scores, out_ids, s, false, nullptr);
+            if (rc != CCR_OK) return rc;
+        }
     }
     CCR_HIP_CHECK(hipStreamSynchronize(s));
     return CCR_OK;

@@ -107,3 +107,37 @@ def test_parallel_analysis_builds_the_same_index():
     model = orc.bm25_fit(texts, 0.75, 1.2)
     ref_i, ref_s = orc.bm25_ranking(model, qtexts[:40], 100)
     assert np.array_equal(ib.cpu().numpy()[:40], ref_i) and np.array_equal(sb.cpu().numpy()[:40].view(np.uint32), ref_s.view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [1, 100, 1001])
+def test_hip_bm25_sampled_selection_equals_the_dense_selection(k, monkeypatch):
+    """The batched estimate-and-verify selection (csrc/ccr_bm25.hip: sample threshold -> one streaming collect pass -> in-LDS sort,
+    rows it cannot finish redone by the exact dense selection) against the exact dense selection of every row (CCR_BM25_DENSE_SELECT=1)
+    and, on a subsample, the oracle: 120 k documents (two accumulator batches), queries that match most of the corpus (common terms),
+    queries that match FEWER than k documents (rare terms: their top-k continues with zero scores in document order -- the redo path),
+    an out-of-vocabulary query (all zeros), and 3 000 duplicated documents (mass ties at the cut)."""
+    from ccrec_amd.bm25 import BM25
+    rs = np.random.RandomState(17)
+    words = np.array([f"t{i}" for i in range(6000)])
+    p = 1.0 / np.arange(1, 6001) ** 1.05
+    p /= p.sum()
+    texts = [" ".join(rs.choice(words, rs.randint(5, 50), p=p)) for _ in range(120_000)]
+    for j in range(3000):
+        texts[40_000 + j] = texts[7]                                   # identical documents: identical scores
+    qtexts = [" ".join(rs.choice(words, rs.randint(1, 12), p=p)) for _ in range(300)]
+    qtexts += [" ".join(rs.choice(words[4000:], 2)) for _ in range(30)]   # rare terms only: tens of matching documents
+    qtexts += ["zzzunknown qqqunknown", texts[7]]
+    hip = BM25(0.75, 1.2).fit(texts)
+    monkeypatch.delenv("CCR_BM25_DENSE_SELECT", raising=False)
+    s, i = hip.transform_topk(qtexts, k)
+    monkeypatch.setenv("CCR_BM25_DENSE_SELECT", "1")
+    s2, i2 = hip.transform_topk(qtexts, k)
+    assert torch.equal(i, i2) and torch.equal(s.view(torch.int32), s2.view(torch.int32))
+    assert (s[-2] == 0).all() and i[-2].tolist() == list(range(k))        # nothing matches: zeros in document order
+    if k > 1:
+        assert i[-1, 0].item() == 7 and s[-1, 0].item() == s[-1, 1].item()     # the duplicates tie, the lowest document id first
+    model = orc.bm25_fit(texts, 0.75, 1.2)
+    sub = [0, 5, 299, 300, 317, 329, 330, 331]
+    ref_i, ref_s = orc.bm25_ranking(model, [qtexts[j] for j in sub], k)
+    assert np.array_equal(i.cpu().numpy()[sub], ref_i) and np.array_equal(s.cpu().numpy()[sub].view(np.uint32), ref_s.view(np.uint32))
