@@ -140,33 +140,44 @@ __global__ __launch_bounds__(256) void bm25_collect_kernel(const float *__restri
     const int64_t lo = (int64_t)blockIdx.x * BM25_COLLECT_CHUNK + (int64_t)wv * (BM25_COLLECT_CHUNK / 4);
     constexpr int STEPS = BM25_COLLECT_CHUNK / 4 / 256;
     float v[STEPS][4];
-    const bool aligned = (reinterpret_cast<uintptr_t>(row) & 15) == 0;
+    // wave-uniform: the wave's 4 096 documents lie inside the row and the row is 16-byte aligned -> 16 unconditional vector loads, all in
+    // flight together (a bounds test per step puts a branch between the loads and serialises their latencies: 1.66 instead of 0.4 ms)
+    const bool whole = (reinterpret_cast<uintptr_t>(row) & 15) == 0 && lo + BM25_COLLECT_CHUNK / 4 <= n_docs;
+    if (whole) {
 #pragma unroll
-    for (int st = 0; st < STEPS; ++st) {
-        const int64_t d0 = lo + st * 256 + 4 * lane;
-        if (aligned && d0 + 3 < n_docs) {
-            const float4 q = *reinterpret_cast<const float4 *>(row + d0);
+        for (int st = 0; st < STEPS; ++st) {
+            const float4 q = *reinterpret_cast<const float4 *>(row + lo + st * 256 + 4 * lane);
             v[st][0] = q.x, v[st][1] = q.y, v[st][2] = q.z, v[st][3] = q.w;
-        } else {
+        }
+    } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[st][e] = d0 + e < n_docs ? row[d0 + e] : 0.f;   // (beyond the row: an exact zero, never collected)
+        for (int st = 0; st < STEPS; ++st) {
+            const int64_t d0 = lo + st * 256 + 4 * lane;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {   // clamped address, masked value: the loads stay unconditional here too
+                const int64_t d = d0 + e < n_docs ? d0 + e : n_docs - 1;
+                const float x = row[d];
+                v[st][e] = d0 + e < n_docs ? x : 0.f;   // (beyond the row: an exact zero, never collected)
+            }
         }
     }
+    // which of the lane's 64 documents pass: one bit each; ONE reservation per wave for all of them (a returning atomic per 256-document
+    // step made the wave wait for 10 - 16 dependent round trips: 1.85 instead of 0.2 ms per launch)
     uint32_t odd = 0;
+    unsigned long long mask = 0ull;
 #pragma unroll
     for (int st = 0; st < STEPS; ++st) {
         const int64_t d0 = lo + st * 256 + 4 * lane;
-        bool pass[4];
-        int mine = 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float x = v[st][e];
-            pass[e] = x >= t && (t > 0.f || x > 0.f) && d0 + e < n_docs;
-            mine += pass[e] ? 1 : 0;
+            const bool pass = x >= t && (t > 0.f || x > 0.f) && d0 + e < n_docs;
+            mask |= pass ? (1ull << (st * 4 + e)) : 0ull;
             odd += (x < 0.f || x != x) ? 1u : 0u;
         }
-        if (__ballot(mine != 0) == 0ull) continue;   // wave-uniform: the usual case
-        // exclusive prefix of the lanes' hit counts (a hit step is rare: plain shuffles)
+    }
+    const int mine = __popcll(mask);
+    if (__ballot(mine != 0) != 0ull) {   // wave-uniform
         int incl = mine;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -178,11 +189,15 @@ __global__ __launch_bounds__(256) void bm25_collect_kernel(const float *__restri
         if (lane == 0) base = atomicAdd(&list_cnt[r], (uint32_t)total);
         base = (uint32_t)__shfl((int)base, 0, 64) + (uint32_t)(incl - mine);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (pass[e]) {
-                if (base < (uint32_t)BM25_LIST_CAP) out[base] = make_uint2(__float_as_uint(v[st][e]), (uint32_t)(d0 + e));
-                ++base;
-            }
+        for (int st = 0; st < STEPS; ++st) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if ((mask >> (st * 4 + e)) & 1ull) {
+                    if (base < (uint32_t)BM25_LIST_CAP)
+                        out[base] = make_uint2(__float_as_uint(v[st][e]), (uint32_t)(lo + st * 256 + 4 * lane + e));
+                    ++base;
+                }
+        }
     }
     const unsigned long long any_odd = __ballot(odd != 0u);
     if (any_odd != 0ull && lane == 0) atomicAdd(&odd_cnt[r], 1u);
