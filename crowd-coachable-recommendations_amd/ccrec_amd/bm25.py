@@ -10,6 +10,7 @@ ccr_bm25_search: fp64 accumulation in ascending term order, one rounding to fp32
 """
 import ctypes
 import re
+import time
 
 import numpy as np
 import torch
@@ -69,14 +70,34 @@ class BM25:
         self.idf = np.log(n / np.diff(self.indptr).astype(np.float64))          # idf_ - 1 with smooth_idf=False
         doc_k = self.k1 * (1 - self.b + self.b * lengths / self.avdl)
         self.n_docs = n
-        self._doc_ids = torch.from_numpy(rows.astype(np.int32)).cuda()
-        self._tf = torch.from_numpy(counts.astype(np.float32)).cuda()
-        self._doc_k = torch.from_numpy(doc_k).cuda()
+        return self._upload(rows, counts, doc_k, V)
+
+    def _upload(self, rows, counts, doc_k, n_terms):
+        self._doc_ids = torch.from_numpy(np.ascontiguousarray(rows, np.int32)).cuda()
+        self._tf = torch.from_numpy(np.ascontiguousarray(counts, np.float32)).cuda()
+        self._doc_k = torch.from_numpy(np.ascontiguousarray(doc_k, np.float64)).cuda()
         self._h = ctypes.c_void_p()
         _lib.check(self._lib.ccr_bm25_index_create(self.indptr.ctypes.data_as(ctypes.c_void_p), self._doc_ids.data_ptr(),
-                                                   self._tf.data_ptr(), self._doc_k.data_ptr(), V, n, self.k1,
+                                                   self._tf.data_ptr(), self._doc_k.data_ptr(), n_terms, self.n_docs, self.k1,
                                                    ctypes.byref(self._h)), "ccr_bm25_index_create")
         return self
+
+    @classmethod
+    def from_postings(cls, indptr, rows, counts, doc_k, idf, k1=1.6, b=0.75):
+        """An index over ready-made term-major postings (CSC of the count matrix: documents strictly ascending inside a term) --
+        what fit() builds from text; search it with transform_terms_topk()."""
+        self = cls(b=b, k1=k1)
+        self._lib = require_gpu()
+        self.indptr = np.ascontiguousarray(indptr, np.int64)
+        self.idf = np.ascontiguousarray(idf, np.float64)
+        self.n_docs = len(doc_k)
+        rows = np.asarray(rows)
+        inner = np.ones(len(rows), bool)
+        inner[self.indptr[:-1][self.indptr[:-1] < len(rows)]] = False        # first posting of every term
+        assert len(self.indptr) == len(self.idf) + 1 and self.indptr[-1] == len(rows) == len(counts)
+        assert not len(rows) or (0 <= rows.min() and rows.max() < self.n_docs), "document id out of range"
+        assert (np.diff(rows.astype(np.int64))[inner[1:]] > 0).all(), "documents must ascend strictly inside a term"
+        return self._upload(rows, counts, doc_k, len(self.idf))
 
     @staticmethod
     def _analyse(texts):
@@ -146,8 +167,12 @@ class BM25:
     def transform_topk(self, queries, k):
         """queries: list of strings -> (scores [n_q, k] fp32, document rows [n_q, k] int64) on the device."""
         assert self._h, "fit() first"
+        return self.transform_terms_topk([self.query_terms(q) for q in queries], k)
+
+    def transform_terms_topk(self, terms, k):
+        """terms: per query, its distinct term ids in ascending order -> (scores [n_q, k] fp32, document rows [n_q, k] int64)."""
+        assert self._h, "fit() first"
         k = min(int(k), self.n_docs)
-        terms = [self.query_terms(q) for q in queries]
         n_q = len(terms)
         q_ptr = np.zeros(n_q + 1, np.int64)
         q_ptr[1:] = np.cumsum([len(t) for t in terms])
@@ -160,10 +185,12 @@ class BM25:
         need = int(self._lib.ccr_bm25_search_workspace_bytes(self._h, n_q, int(max(len(t) for t in terms))))
         ws = torch.empty(need, dtype=torch.uint8, device="cuda")
         vp = ctypes.c_void_p
+        t0 = time.perf_counter()
         _lib.check(self._lib.ccr_bm25_search(self._h, q_ptr.ctypes.data_as(vp), q_terms.ctypes.data_as(vp), q_idf.ctypes.data_as(vp),
                                              n_q, k, scores.data_ptr(), ids.data_ptr(), ws.data_ptr(), ws.numel(),
                                              vp(torch.cuda.current_stream().cuda_stream)), "ccr_bm25_search")
         torch.cuda.current_stream().synchronize()   # the host arrays above must outlive the stream work
+        self.last_search_seconds = time.perf_counter() - t0   # the library call alone (tables + kernels), without the text analysis
         return scores, ids
 
     def transform(self, q, X=None):

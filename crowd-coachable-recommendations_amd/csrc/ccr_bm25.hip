@@ -80,14 +80,137 @@ __global__ __launch_bounds__(256) void bm25_finish_kernel(double *__restrict__ a
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// The document-tile scorer (r4): the same sums without the fp64 rows in HBM.  A WAVE owns (query row, run of consecutive document
+// tiles); the fp64 accumulators of one tile live in the wave's slice of LDS; for every tile the wave walks the query's terms in
+// ascending order (the order of the adds of a cell = the round order above, so the bits are the same) and, per term, streams the
+// slice of the posting list that falls into the tile: lane r keeps term r's cursor and the next document at the cursor, so a term
+// with no posting in the tile costs nothing, and a posting list is read once per query from front to back (documents ascend inside
+// a term; the cursor of a run's first tile comes from a lane-parallel binary search).  A finished tile leaves as fp32 scores:
+// HBM traffic per posting 8 B (+ the K_d gather, L2-resident: 8 B x documents) instead of 32, per (query, document) cell 4 B
+// instead of 28.  No barrier, no atomic on the data path (one ticket per run of tiles).
+struct Bm25Term {        // one distinct term of a query row
+    int64_t begin, end;  // posting range
+    double idf;
+};
+constexpr int BM25_TILE_WAVES = 4;
+constexpr int BM25_MAX_TILE_TERMS = 64;      // lane r <-> term r; longer queries take the round kernels
+
+__device__ __forceinline__ int64_t readlane64(int64_t v, int l) {
+    const int lo = __builtin_amdgcn_readlane((int)(uint32_t)v, l), hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+
+// grid = any, block = 256 (four independent waves).  T documents per tile, U 64-posting chunks per step, run_tiles tiles per ticket.
+template <int T, int U>
+__global__ __launch_bounds__(256) void bm25_tile_kernel(const Bm25Term *__restrict__ terms, const int32_t *__restrict__ row_ptr, int n_rows,
+                                                       const int32_t *__restrict__ doc_ids, const float *__restrict__ tf,
+                                                       const double *__restrict__ doc_k, double k1p1, int64_t n_docs, int run_tiles, int n_runs,
+                                                       uint32_t *__restrict__ ticket, float *__restrict__ scores) {
+    __shared__ double s_acc[BM25_TILE_WAVES][T];
+    const int lane = threadIdx.x & 63;
+    double *acc = s_acc[threadIdx.x >> 6];
+#pragma unroll
+    for (int j = 0; j < T / 64; ++j) acc[j * 64 + lane] = 0.0;
+    const uint32_t n_items = (uint32_t)n_runs * (uint32_t)n_rows;
+    for (;;) {
+        uint32_t item = 0;
+        if (lane == 0) item = atomicAdd(ticket, 1u);
+        item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
+        if (item >= n_items) break;   // every wave reaches this: the ticket only grows
+        const int row = (int)(item % (uint32_t)n_rows), run = (int)(item / (uint32_t)n_rows);
+        const int t0 = row_ptr[row], nt = row_ptr[row + 1] - t0;
+        int64_t cur = 0, end = 0;
+        double idf = 0.0;
+        if (lane < nt) {
+            const Bm25Term t = terms[t0 + lane];
+            cur = t.begin, end = t.end, idf = t.idf;
+        }
+        const int64_t run_base = (int64_t)run * run_tiles * T;
+        const int64_t run_end = run_base + (int64_t)run_tiles * T < n_docs ? run_base + (int64_t)run_tiles * T : n_docs;
+        if (run > 0) {   // first posting of every term at or behind the run's first document
+            int64_t lo = cur, hi = end;
+            while (__ballot(lo < hi) != 0ull) {
+                const int64_t mid = lo + ((hi - lo) >> 1);
+                if (lo < hi) {
+                    if ((int64_t)doc_ids[mid] < run_base) lo = mid + 1;
+                    else hi = mid;
+                }
+            }
+            cur = lo;
+        }
+        int nd = cur < end ? doc_ids[cur] : 0x7fffffff;   // the next document of the lane's term
+        float *out_row = scores + (int64_t)row * n_docs;
+        for (int64_t tile_base = run_base; tile_base < run_end; tile_base += T) {
+            const int tile_end = (int)(tile_base + T < n_docs ? tile_base + T : n_docs);
+            unsigned long long act = __ballot(nd < tile_end);
+            while (act != 0ull) {   // wave-uniform: the terms with a posting in this tile, ascending
+                const int r = __builtin_amdgcn_readfirstlane(__builtin_ctzll(act));
+                act &= act - 1ull;
+                int64_t c = readlane64(cur, r);
+                const int64_t e = readlane64(end, r);
+                const double w = __longlong_as_double(readlane64(__double_as_longlong(idf), r));
+                int32_t d[U];
+                int cnt;
+                do {
+                    float f[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {   // clamped: every load is valid and unconditional
+                        const int64_t i = c + lane + 64 * u;
+                        const int64_t ic = i < e ? i : e - 1;
+                        d[u] = doc_ids[ic];
+                        f[u] = tf[ic];
+                    }
+                    double kd[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) kd[u] = doc_k[d[u]];
+                    cnt = 0;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const bool in = c + lane + 64 * u < e && d[u] < tile_end;
+                        const double fd = (double)f[u];
+                        const double numer = (fd * w) * k1p1;
+                        const double denom = fd + kd[u];
+                        if (in) {
+                            const int x = d[u] - (int)tile_base;
+                            acc[x] = acc[x] + numer / denom;
+                        }
+                        cnt += __popcll(__ballot(in));
+                    }
+                    c += cnt;
+                } while (cnt == 64 * U);
+                // the postings are in document order, so the `cnt` taken ones are a prefix of the step and element `cnt` is the next one
+                int next = 0x7fffffff;
+                if (c < e) {
+                    const int l = cnt & 63, u_sel = cnt >> 6;
+                    next = __builtin_amdgcn_readlane(d[0], l);
+#pragma unroll
+                    for (int u = 1; u < U; ++u) {
+                        const int v = __builtin_amdgcn_readlane(d[u], l);
+                        next = u_sel == u ? v : next;
+                    }
+                }
+                if (lane == r) cur = c, nd = next;
+            }
+#pragma unroll
+            for (int j = 0; j < T / 64; ++j) {
+                const int x = j * 64 + lane;
+                const double v = acc[x];
+                acc[x] = 0.0;
+                if (tile_base + x < n_docs) out_row[tile_base + x] = (float)v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // Batched selection of the top-k of a batch of finished fp32 score rows (r4).  The exact dense selection (one 256-thread
 // workgroup per query walking its whole row through four radix passes, every zero score landing in ONE histogram bin) took 70 %
 // of a BM25 search: 5.2 ms per batch of 256 queries x 500 k documents.  Instead, the retrieval path's estimate-and-verify filter:
 //   threshold : tau_row = the r-th largest score of a 1/64 SAMPLE of the row (contiguous 64-document pieces, one out of every 64),
 //               r = the rank for which fewer than k documents pass with probability < 1e-7 (r = 41 at k = 1001: ~2 600 pass);
 //   collect   : every (row, 16 K-document chunk) block streams its scores ONCE and appends the documents with score >= tau (and > 0
-//               when tau <= 0: a BM25 row is mostly exact zeros) to the row's candidate list -- wave ballot, one LDS atomic per
-//               wave, one global atomic per block;
+//               when tau <= 0: a BM25 row is mostly exact zeros) to the row's candidate list -- a 64-bit pass mask per lane, one
+//               list reservation per wave;
 //   top-k     : per row, if k <= candidates <= capacity the k best of the list by (score desc, document asc) ARE the row's top-k
 //               (everything >= tau is in the list and at least k documents are >= tau): bitonic sort of 64-bit keys in LDS.
 //               Otherwise (an estimate that came out too high, a query whose terms match fewer than k documents, a flooded list)
@@ -127,8 +250,8 @@ __global__ __launch_bounds__(256) void bm25_threshold_kernel(const float *__rest
 
 // grid = (chunks, rows), block = 256.  Records {score bits, document} of the documents that pass go to list[row][...]; odd_cnt[row]
 // counts the scores that are negative or NaN (a BM25 row has none: then every document that is not in the list of a row with tau <= 0
-// scores exactly zero).  No LDS, no barrier: a wave reserves room for its hits with ONE global atomic per 64-document step that
-// has any (about k hits per row in all), its 16 loads per lane are in flight together.
+// scores exactly zero).  No LDS, no barrier: a wave's 16 loads per lane are in flight together, and it reserves room for all of its
+// hits with ONE global atomic.
 __global__ __launch_bounds__(256) void bm25_collect_kernel(const float *__restrict__ scores, int64_t n_docs, const float *__restrict__ tau,
                                                           uint2 *__restrict__ list, uint32_t *__restrict__ list_cnt, uint32_t *__restrict__ odd_cnt) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -286,6 +409,8 @@ struct ccr_bm25_index {
     const double *doc_k;           // device, borrowed
     int64_t n_terms, n_docs;
     double k1;
+    int num_cu;
+    int tile_cfg;                  // CCR_BM25_TILE: -1 = round kernels only (the A/B knob), 0 = default tile shape (1024 documents, 128-posting steps), 1 = 1024/64, 2 = 512/128
 };
 
 extern "C" int ccr_bm25_index_create(const int64_t *indptr_host, const int32_t *doc_ids, const float *tf, const double *doc_k,
@@ -295,6 +420,9 @@ extern "C" int ccr_bm25_index_create(const int64_t *indptr_host, const int32_t *
                 (long long)n_terms, (long long)n_docs);
     for (int64_t t = 0; t < n_terms; ++t)
         CCR_REQUIRE(indptr_host[t] <= indptr_host[t + 1], "ccr_bm25_index_create: indptr not monotone at term %lld", (long long)t);
+    int dev = 0, num_cu = 0;
+    CCR_HIP_CHECK(hipGetDevice(&dev));
+    CCR_HIP_CHECK(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
     ccr_bm25_index *ix = new ccr_bm25_index();
     ix->indptr.assign(indptr_host, indptr_host + n_terms + 1);
     ix->doc_ids = doc_ids;
@@ -303,6 +431,9 @@ extern "C" int ccr_bm25_index_create(const int64_t *indptr_host, const int32_t *
     ix->n_terms = n_terms;
     ix->n_docs = n_docs;
     ix->k1 = k1;
+    ix->num_cu = num_cu > 0 ? num_cu : 256;
+    const char *cfg = getenv("CCR_BM25_TILE");
+    ix->tile_cfg = cfg ? atoi(cfg) : 0;
     *out = ix;
     return CCR_OK;
 }
@@ -312,19 +443,53 @@ extern "C" int ccr_bm25_index_destroy(ccr_bm25_index *ix) {
     return CCR_OK;
 }
 
-static int bm25_batch_rows(const ccr_bm25_index *ix, int n_q) {
-    const int64_t per_row = ix->n_docs * 12;                       // fp64 accumulator + fp32 score row
+namespace {
+// Workspace of one search.  Tile scorer: fp32 score rows only (up to 4 096 query rows per batch); round kernels (queries of more
+// than 64 distinct terms, CCR_BM25_TILE=-1): fp64 accumulator rows beside them (up to 256).
+struct Bm25Layout {
+    bool tile;
+    int rows;
+    size_t scores_off, table_off, sel_off, total;
+};
+Bm25Layout bm25_layout(const ccr_bm25_index *ix, int n_q, int max_terms) {
+    Bm25Layout L;
+    L.tile = ix->tile_cfg >= 0 && max_terms <= BM25_MAX_TILE_TERMS;
+    const int64_t per_row = ix->n_docs * (L.tile ? 4 : 12);
     int64_t rows = ((int64_t)8 << 30) / per_row;                   // ~8 GiB of score rows per batch
-    rows = std::min<int64_t>(std::max<int64_t>(rows, 1), 256);
-    return (int)std::min<int64_t>(rows, n_q);
+    rows = std::min<int64_t>(std::max<int64_t>(rows, 1), L.tile ? 4096 : 256);
+    L.rows = (int)std::min<int64_t>(rows, n_q);
+    const size_t terms = (size_t)std::max(1, max_terms);
+    L.scores_off = L.tile ? 0 : (size_t)L.rows * ix->n_docs * 8;
+    L.table_off = (L.scores_off + (size_t)L.rows * ix->n_docs * 4 + 255) / 256 * 256;
+    const size_t table = L.tile ? (size_t)L.rows * terms * sizeof(Bm25Term) + ((size_t)L.rows + 1) * 4 : (size_t)L.rows * terms * sizeof(Bm25Round);
+    L.sel_off = (L.table_off + table + 255) / 256 * 256;
+    // the batched selection: candidate lists, thresholds, counters, redo list
+    L.total = L.sel_off + (size_t)L.rows * BM25_LIST_CAP * 8 + (size_t)L.rows * 20 + 256 * 4;
+    return L;
 }
+
+template <int T, int U>
+int launch_bm25_tile(const ccr_bm25_index *ix, const Bm25Term *terms, const int32_t *row_ptr, int m, uint32_t *ticket, float *scores,
+                     hipStream_t s) {
+    const int64_t n_tiles = (ix->n_docs + T - 1) / T;
+    const int wgs_per_cu = std::max(1, std::min(8, (int)(160 * 1024 / (BM25_TILE_WAVES * T * 8))));
+    const int64_t waves = (int64_t)ix->num_cu * wgs_per_cu * BM25_TILE_WAVES;
+    // about eight tickets per wave: long runs keep a wave on one query's cursors, short ones balance the tail
+    int64_t runs = std::min<int64_t>(std::max<int64_t>((8 * waves + m - 1) / m, 1), n_tiles);
+    const int run_tiles = (int)((n_tiles + runs - 1) / runs);
+    runs = (n_tiles + run_tiles - 1) / run_tiles;
+    const int64_t items = runs * m;
+    const unsigned grid = (unsigned)std::min<int64_t>((items + BM25_TILE_WAVES - 1) / BM25_TILE_WAVES, (int64_t)ix->num_cu * wgs_per_cu);
+    hipLaunchKernelGGL((bm25_tile_kernel<T, U>), dim3(grid), dim3(64 * BM25_TILE_WAVES), 0, s, terms, row_ptr, m, ix->doc_ids, ix->tf, ix->doc_k,
+                       ix->k1 + 1.0, ix->n_docs, run_tiles, (int)runs, ticket, scores);
+    CCR_LAUNCH_CHECK();
+    return CCR_OK;
+}
+}  // namespace
 
 extern "C" size_t ccr_bm25_search_workspace_bytes(const ccr_bm25_index *ix, int n_q, int max_terms_per_query) {
     if (!ix || n_q <= 0 || max_terms_per_query < 0) return 0;
-    const int rows = bm25_batch_rows(ix, n_q);
-    // + the batched selection: candidate lists, thresholds, counters, redo list
-    const size_t sel = (size_t)rows * BM25_LIST_CAP * 8 + (size_t)rows * 20 + 256 * 4;
-    return (size_t)rows * ix->n_docs * 12 + (size_t)rows * (size_t)std::max(1, max_terms_per_query) * sizeof(Bm25Round) + 1024 + sel;
+    return bm25_layout(ix, n_q, max_terms_per_query).total;
 }
 
 extern "C" int ccr_bm25_search(const ccr_bm25_index *ix, const int64_t *q_ptr_host, const int32_t *q_terms_host,
@@ -345,23 +510,25 @@ extern "C" int ccr_bm25_search(const ccr_bm25_index *ix, const int64_t *q_ptr_ho
             CCR_REQUIRE(i == a || q_terms_host[i] > q_terms_host[i - 1], "ccr_bm25_search: terms of query %d not strictly ascending", q);
         }
     }
-    const size_t need = ccr_bm25_search_workspace_bytes(ix, n_q, max_terms);
-    if (!workspace || ws_bytes < need || (uintptr_t)workspace % 256 != 0) {
-        set_error("ccr_bm25_search: workspace %zu bytes (256-byte aligned) required, got %zu at %p", need, ws_bytes, workspace);
+    const Bm25Layout L = bm25_layout(ix, n_q, max_terms);
+    if (!workspace || ws_bytes < L.total || (uintptr_t)workspace % 256 != 0) {
+        set_error("ccr_bm25_search: workspace %zu bytes (256-byte aligned) required, got %zu at %p", L.total, ws_bytes, workspace);
         return CCR_ERR_WORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
-    const int rows = bm25_batch_rows(ix, n_q);
+    const int rows = L.rows;
     char *ws = (char *)workspace;
-    double *acc = (double *)ws;
-    float *scores = (float *)(ws + (size_t)rows * ix->n_docs * 8);
-    Bm25Round *d_pairs = (Bm25Round *)(ws + (size_t)rows * ix->n_docs * 12);
-    char *sel = ws + (((size_t)rows * ix->n_docs * 12 + (size_t)rows * (size_t)std::max(1, max_terms) * sizeof(Bm25Round) + 255) / 256) * 256;
+    double *acc = (double *)ws;                                  // round kernels only
+    float *scores = (float *)(ws + L.scores_off);
+    Bm25Round *d_pairs = (Bm25Round *)(ws + L.table_off);        // round kernels
+    Bm25Term *d_terms = (Bm25Term *)(ws + L.table_off);          // tile scorer: the batch's terms, then its row pointers
+    char *sel = ws + L.sel_off;
     uint2 *cand_list = (uint2 *)sel;
     float *tau = (float *)(sel + (size_t)rows * BM25_LIST_CAP * 8);
     uint32_t *list_cnt = (uint32_t *)(tau + rows);
     uint32_t *odd_cnt = list_cnt + rows;           // [rows]: blocks that saw a negative / NaN score
-    uint32_t *redo_cnt = odd_cnt + rows;           // [1] + pad
+    uint32_t *redo_cnt = odd_cnt + rows;           // [1], then the tile scorer's ticket [1], pad [2]
+    uint32_t *ticket = redo_cnt + 1;
     uint32_t *redo_list = redo_cnt + 4;            // [rows]
     // the sampled filter needs a sample that holds several times the rank; smaller corpora keep the exact dense selection
     const int64_t all_pieces = (ix->n_docs + BM25_SAMPLE_PIECE - 1) / BM25_SAMPLE_PIECE;
@@ -378,56 +545,84 @@ extern "C" int ccr_bm25_search(const ccr_bm25_index *ix, const int64_t *q_ptr_ho
         const int rc2 = ensure_dynamic_lds(reinterpret_cast<const void *>(&bm25_threshold_kernel), (size_t)BM25_SAMPLE_MAX * 4);
         if (rc2 != CCR_OK) return rc2;
     }
-    const int64_t cells = (int64_t)rows * ix->n_docs;
-    CCR_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)cells * 8, s));
-    // One pair table per batch (all rounds back to back), uploaded once; the host tables stay alive until the
-    // synchronisation at the end of the call.
+    if (!L.tile) CCR_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)rows * ix->n_docs * 8, s));
+    // One table per batch, uploaded once; the host tables stay alive until the synchronisation at the end of the call.
     struct Round {
         size_t first, count;
         int64_t longest;
     };
     std::vector<std::vector<Bm25Round>> tables;
+    std::vector<std::vector<char>> tile_tables;
     tables.reserve((size_t)(n_q + rows - 1) / rows);
+    tile_tables.reserve((size_t)(n_q + rows - 1) / rows);
     for (int q0 = 0; q0 < n_q; q0 += rows) {
         const int m = std::min(rows, n_q - q0);
-        int rounds = 0;
-        for (int q = q0; q < q0 + m; ++q) rounds = std::max<int>(rounds, (int)(q_ptr_host[q + 1] - q_ptr_host[q]));
-        tables.emplace_back();
-        std::vector<Bm25Round> &table = tables.back();
-        std::vector<Round> plan;
-        for (int r = 0; r < rounds; ++r) {
-            Round rd = {table.size(), 0, 0};
+        CCR_HIP_CHECK(hipMemsetAsync(odd_cnt, 0, (size_t)rows * 4 + 16, s));   // odd counts + the redo count and the ticket behind them
+        if (L.tile) {
+            // [terms of row 0 | row 1 | ...] with empty posting lists dropped, then int32 row pointers (16-byte aligned behind the terms)
+            const size_t n_terms_batch = (size_t)(q_ptr_host[q0 + m] - q_ptr_host[q0]);
+            const size_t ptr_off = n_terms_batch * sizeof(Bm25Term);
+            tile_tables.emplace_back(ptr_off + ((size_t)m + 1) * 4);
+            std::vector<char> &blob = tile_tables.back();
+            Bm25Term *tt = reinterpret_cast<Bm25Term *>(blob.data());
+            int32_t *rp = reinterpret_cast<int32_t *>(blob.data() + ptr_off);
+            int32_t n = 0;
             for (int q = q0; q < q0 + m; ++q) {
-                const int64_t i = q_ptr_host[q] + r;
-                if (i >= q_ptr_host[q + 1]) continue;
-                const int32_t t = q_terms_host[i];
-                Bm25Round pr;
-                pr.begin = ix->indptr[t];
-                pr.end = ix->indptr[t + 1];
-                pr.idf = q_idf_host[i];
-                pr.row = q - q0;
-                pr.pad = 0;
-                if (pr.end > pr.begin) {
-                    table.push_back(pr);
-                    rd.longest = std::max(rd.longest, pr.end - pr.begin);
+                rp[q - q0] = n;
+                for (int64_t i = q_ptr_host[q]; i < q_ptr_host[q + 1]; ++i) {
+                    const int32_t t = q_terms_host[i];
+                    if (ix->indptr[t + 1] > ix->indptr[t]) tt[n++] = Bm25Term{ix->indptr[t], ix->indptr[t + 1], q_idf_host[i]};
                 }
             }
-            rd.count = table.size() - rd.first;
-            if (rd.count) plan.push_back(rd);
-        }
-        if (!table.empty())   // stream-ordered behind the previous batch's kernels, which read the same device region
-            CCR_HIP_CHECK(hipMemcpyAsync(d_pairs, table.data(), table.size() * sizeof(Bm25Round), hipMemcpyHostToDevice, s));
-        for (const Round &rd : plan) {
-            dim3 grid((unsigned)((rd.longest + BM25_CHUNK - 1) / BM25_CHUNK), (unsigned)rd.count);
-            hipLaunchKernelGGL(bm25_round_kernel, grid, dim3(256), 0, s, d_pairs + rd.first, ix->doc_ids, ix->tf, ix->doc_k,
-                               ix->k1 + 1.0, ix->n_docs, acc);
+            rp[m] = n;
+            CCR_HIP_CHECK(hipMemcpyAsync(d_terms, blob.data(), blob.size(), hipMemcpyHostToDevice, s));
+            const int32_t *d_row_ptr = reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(d_terms) + ptr_off);
+            int rc;
+            switch (ix->tile_cfg) {   // measured at 500 k documents x 2 000 queries (tools/exp_bm25_tile.py): 1024/2 4.7 ms, 512/2 the same, wider steps slower
+                case 1: rc = launch_bm25_tile<1024, 1>(ix, d_terms, d_row_ptr, m, ticket, scores, s); break;
+                case 2: rc = launch_bm25_tile<512, 2>(ix, d_terms, d_row_ptr, m, ticket, scores, s); break;
+                default: rc = launch_bm25_tile<1024, 2>(ix, d_terms, d_row_ptr, m, ticket, scores, s); break;
+            }
+            if (rc != CCR_OK) return rc;
+        } else {
+            int rounds = 0;
+            for (int q = q0; q < q0 + m; ++q) rounds = std::max<int>(rounds, (int)(q_ptr_host[q + 1] - q_ptr_host[q]));
+            tables.emplace_back();
+            std::vector<Bm25Round> &table = tables.back();
+            std::vector<Round> plan;
+            for (int r = 0; r < rounds; ++r) {
+                Round rd = {table.size(), 0, 0};
+                for (int q = q0; q < q0 + m; ++q) {
+                    const int64_t i = q_ptr_host[q] + r;
+                    if (i >= q_ptr_host[q + 1]) continue;
+                    const int32_t t = q_terms_host[i];
+                    Bm25Round pr;
+                    pr.begin = ix->indptr[t];
+                    pr.end = ix->indptr[t + 1];
+                    pr.idf = q_idf_host[i];
+                    pr.row = q - q0;
+                    pr.pad = 0;
+                    if (pr.end > pr.begin) {
+                        table.push_back(pr);
+                        rd.longest = std::max(rd.longest, pr.end - pr.begin);
+                    }
+                }
+                rd.count = table.size() - rd.first;
+                if (rd.count) plan.push_back(rd);
+            }
+            if (!table.empty())   // stream-ordered behind the previous batch's kernels, which read the same device region
+                CCR_HIP_CHECK(hipMemcpyAsync(d_pairs, table.data(), table.size() * sizeof(Bm25Round), hipMemcpyHostToDevice, s));
+            for (const Round &rd : plan) {
+                dim3 grid((unsigned)((rd.longest + BM25_CHUNK - 1) / BM25_CHUNK), (unsigned)rd.count);
+                hipLaunchKernelGGL(bm25_round_kernel, grid, dim3(256), 0, s, d_pairs + rd.first, ix->doc_ids, ix->tf, ix->doc_k,
+                                   ix->k1 + 1.0, ix->n_docs, acc);
+                CCR_LAUNCH_CHECK();
+            }
+            const int64_t n = (int64_t)m * ix->n_docs;
+            hipLaunchKernelGGL(bm25_finish_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, (int64_t)1 << 30)), dim3(256), 0, s, acc, scores, n);   // one cell per thread: streams faster than a capped grid-stride loop
             CCR_LAUNCH_CHECK();
         }
-        const int64_t n = (int64_t)m * ix->n_docs;
-        hipLaunchKernelGGL(bm25_finish_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, (int64_t)1 << 30)), dim3(256), 0, s, acc, scores, n);   // one cell per thread: streams faster than a capped grid-stride loop
-        CCR_LAUNCH_CHECK();
         if (sampled) {
-            CCR_HIP_CHECK(hipMemsetAsync(odd_cnt, 0, (size_t)rows * 4 + 16, s));   // odd counts + the redo count behind them
             hipLaunchKernelGGL(bm25_threshold_kernel, dim3((unsigned)m), dim3(256), (size_t)n_pieces * BM25_SAMPLE_PIECE * 4, s, scores, ix->n_docs,
                                every * BM25_SAMPLE_PIECE, n_pieces, rank, tau, list_cnt);
             CCR_LAUNCH_CHECK();

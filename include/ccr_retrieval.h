@@ -384,12 +384,16 @@ int ccr_rank_metrics(const int64_t *ids, int n_q, int k, const int64_t *qrel_ptr
  * BM25 as a sparse scorer (the lexical leg of the candidate builder).
  * Replaces: BM25.transform, scripts/bm_25.py:31-52 (scipy on the host, one query at a time) and the per-query full
  * sort + keep 1001 of ranking_bm25, scripts/ms_marco_eval.py:165-186.
- *   index  = term-major postings of the count matrix: indptr [n_terms + 1] (HOST), doc_ids [nnz] int32 and
- *            tf [nnz] fp32 (DEVICE, borrowed), doc_k [n_docs] fp64 (DEVICE, borrowed) = k1 * (1 - b + b * len_d / avdl)
+ *   index  = term-major postings of the count matrix: indptr [n_terms + 1] (HOST), doc_ids [nnz] int32 -- STRICTLY ASCENDING
+ *            inside a term (scipy's sorted CSC), the scorer walks every list with a cursor -- and tf [nnz] fp32 (DEVICE,
+ *            borrowed), doc_k [n_docs] fp64 (DEVICE, borrowed) = k1 * (1 - b + b * len_d / avdl)
  *   query  = CSR on the HOST: q_ptr [n_q + 1], q_terms strictly ascending term ids, q_idf = ln(n / df_t) per entry
  *   score(q, d) = sum_t ascending (tf * idf_t) * (k1 + 1) / (tf + doc_k[d]) in fp64, rounded once to fp32;
  *   out_scores / out_ids [n_q][k] in the order (score desc, document index asc); documents without any query term
  *   score 0 and follow in index order, as a stable sort of the reference's dense score vector would leave them.
+ *   Queries of up to 64 distinct terms run the document-tile scorer (fp64 accumulators in LDS, fp32 score rows in the workspace);
+ *   a call with a longer query runs the round kernels (fp64 rows in the workspace): same bits.  The environment is read at
+ *   ccr_bm25_index_create: CCR_BM25_TILE=-1 forces the round kernels.
  */
 typedef struct ccr_bm25_index ccr_bm25_index;
 int ccr_bm25_index_create(const int64_t *indptr_host, const int32_t *doc_ids, const float *tf, const double *doc_k,

@@ -141,3 +141,65 @@ def test_hip_bm25_sampled_selection_equals_the_dense_selection(k, monkeypatch):
     sub = [0, 5, 299, 300, 317, 329, 330, 331]
     ref_i, ref_s = orc.bm25_ranking(model, [qtexts[j] for j in sub], k)
     assert np.array_equal(i.cpu().numpy()[sub], ref_i) and np.array_equal(s.cpu().numpy()[sub].view(np.uint32), ref_s.view(np.uint32))
+
+
+def _random_postings(rs, n_docs, n_terms, dense_terms):
+    """Term-major postings of a random count matrix: `dense_terms` terms in ~half of the documents, the others with Zipf-like
+    document frequencies down to a single posting and a few empty terms."""
+    indptr, rows, counts = [0], [], []
+    for t in range(n_terms):
+        if t < dense_terms:
+            df = int(n_docs * rs.uniform(0.3, 0.98))
+        elif t % 97 == 5:
+            df = 0
+        else:
+            df = max(1, int(n_docs * 0.2 / (t - dense_terms + 1) ** 1.1))
+        r = np.sort(rs.choice(n_docs, df, replace=False)) if df else np.zeros(0, np.int64)
+        rows.append(r)
+        counts.append(rs.randint(1, 6, df))
+        indptr.append(indptr[-1] + df)
+    idf = np.log(n_docs / np.maximum(np.diff(indptr), 1).astype(np.float64))
+    doc_k = 1.2 * (0.25 + 0.75 * rs.uniform(0.3, 2.5, n_docs))
+    return np.asarray(indptr, np.int64), np.concatenate(rows).astype(np.int32), np.concatenate(counts).astype(np.float32), doc_k, idf
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_docs,k", [(70_001, 100), (1024, 1024), (777, 50), (300_000, 1001)])
+def test_hip_bm25_tile_scorer_equals_the_round_kernels(n_docs, k, monkeypatch):
+    """The document-tile scorer (a wave per run of tiles, fp64 accumulators in LDS, cursors per term) against the round kernels with
+    their fp64 rows in HBM (CCR_BM25_TILE=-1), ids and score bits: corpora that are not a multiple of the tile, smaller than one tile,
+    exactly one tile; queries of 0, 1, 64 (the tile scorer's limit) and 65+ terms (round kernels); terms without postings; a single
+    query (every run is one tile: a binary search per tile and term); the other tile shapes."""
+    from ccrec_amd.bm25 import BM25
+    rs = np.random.RandomState(n_docs % 1000)
+    n_terms = 400
+    indptr, rows, counts, doc_k, idf = _random_postings(rs, n_docs, n_terms, dense_terms=6)
+    queries = [np.sort(rs.choice(n_terms, rs.randint(1, 12), replace=False)).astype(np.int32) for _ in range(150)]
+    queries += [np.zeros(0, np.int32), np.asarray([3], np.int32), np.asarray([5 + 97], np.int32),      # empty, one dense term, one empty term
+                np.sort(rs.choice(n_terms, 64, replace=False)).astype(np.int32), np.arange(0, 12, dtype=np.int32)]
+    results = {}
+    for cfg in ("-1", "0", "1", "2"):
+        monkeypatch.setenv("CCR_BM25_TILE", cfg)
+        model = BM25.from_postings(indptr, rows, counts, doc_k, idf, k1=1.2)
+        s, i = model.transform_terms_topk(queries, k)
+        s1, i1 = model.transform_terms_topk(queries[7:8], k)           # one query: one tile per ticket
+        assert torch.equal(i1[0], i[7]) and torch.equal(s1.view(torch.int32)[0], s.view(torch.int32)[7])
+        results[cfg] = (s.view(torch.int32).cpu(), i.cpu())
+    for cfg in ("0", "1", "2"):
+        assert torch.equal(results[cfg][1], results["-1"][1]) and torch.equal(results[cfg][0], results["-1"][0]), cfg
+    # 65 terms in one query of the batch: the whole call takes the round kernels, same results for the other queries
+    monkeypatch.setenv("CCR_BM25_TILE", "0")
+    model = BM25.from_postings(indptr, rows, counts, doc_k, idf, k1=1.2)
+    long_q = np.sort(rs.choice(n_terms, 65, replace=False)).astype(np.int32)
+    s, i = model.transform_terms_topk(queries[:20] + [long_q], k)
+    assert torch.equal(i[:20].cpu(), results["-1"][1][:20]) and torch.equal(s.view(torch.int32)[:20].cpu(), results["-1"][0][:20])
+    # the oracle's arithmetic on one row: fp64 sums in ascending term order, rounded once
+    q = queries[3]
+    acc = np.zeros(n_docs)
+    for t in q:
+        d = rows[indptr[t]:indptr[t + 1]]
+        f = counts[indptr[t]:indptr[t + 1]].astype(np.float64)
+        acc[d] = acc[d] + (f * idf[t]) * (1.2 + 1.0) / (f + doc_k[d])
+    sc = acc.astype(np.float32)
+    order = np.lexsort((np.arange(n_docs), -sc.astype(np.float64)))[:k]
+    assert np.array_equal(results["0"][1][3].numpy(), order) and np.array_equal(results["0"][0][3].numpy().view(np.float32), sc[order])
