@@ -37,6 +37,7 @@ import torch.distributed as dist  # noqa: E402
 
 N_ROWS, DIM, N_Q, TOP_K = 2_681_468, 768, 3_452, 100
 MSMARCO_ROWS, MSMARCO_Q = 8_841_823, 6_980
+C4_ROWS, C4_Q, C4_DIM, C4_K = 50_000_000, 10_000, 1024, 1000    # BASELINE.json configs[3]
 MFMA_PEAK_TFLOPS = 2500.0   # dense bf16, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_locality.json")   # tools/exp_locality.py: separate rocprofv3 --pmc passes per workload
@@ -626,6 +627,16 @@ def main():
                           "roofline": roofline_obj(r3), "phases_ms": phases_obj(r3["stats"]), "n_fallback": r3["n_fallback_max"],
                           "exchange": exchange_obj(m, r3)}
         m.release()
+        # (c) configs[3]: 50 M x 1024, 10 000 queries, top-1000 -- 12.8 GB of bf16 per GPU at 8 (fp32 inputs + two packed slots:
+        # 51 GB per rank at 8, 102 GB at 4; not run below 4 ranks, where the resident fp32 inputs alone pass 100 GB per GPU)
+        if world >= 4 or args.rehearse_secondary > 0:
+            c = Workload(C4_ROWS // div, C4_Q // div, C4_DIM, min(C4_K, C4_ROWS // div // world), "gaussian", dev, rank, world, args.dist_backend)
+            r4 = c.run(min(side_steps, 3), 1, "config4")
+            sec["config4"] = {"workload": "configs[3]: 50,000,000 x 1024 corpus row-sharded over n_gpus, 10,000 queries, top-1000" + (f" (REHEARSAL: 1/{div} of the rows and queries)" if div > 1 else ""),
+                              "value": round(r4["qps"], 1), "unit": "queries/s", "ms_per_step": round(r4["ms_per_step"], 3), "scaling": "strong",
+                              "roofline": roofline_obj(r4), "phases_ms": phases_obj(r4["stats"]), "n_fallback": r4["n_fallback_max"],
+                              "exchange": exchange_obj(c, r4)}
+            c.release()
         out["secondary"] = sec
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -134,7 +134,8 @@ def test_bench_ranks_rehearsal_in_fresh_processes(tmp_path, world, rows, launche
 @pytest.mark.parametrize("world", [2, 3])
 def test_bench_ranks_rehearsal_records_the_multi_gpu_side_runs(tmp_path, world):
     """One N > 1 invocation also measures the shapes the multi-GPU target is quoted on -- ranking()'s k = 1001 on the same corpus (the
-    short-list exchange) and configs[2] (here 1/40 of its rows and queries) -- each with its own `exchange` record: entries per query
+    short-list exchange), configs[2] and configs[3] (here 1/40 of their rows and queries; configs[3] runs from 4 ranks up outside a
+    rehearsal) -- each with its own `exchange` record: entries per query
     and rank, message bytes, repeats, per-rank min / max step, and the host-observed wait for the collective split from the search time."""
     bench = os.path.join(ROOT, "bench.py")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CCR_BENCH_WATCHDOG="200")
@@ -149,13 +150,17 @@ def test_bench_ranks_rehearsal_records_the_multi_gpu_side_runs(tmp_path, world):
     from ccrec_amd.dist import short_list_length
     from ccrec_amd.ops import shard_message_bytes
     sec = rec["secondary"]
-    assert set(sec) == {"k1001", "msmarco"}
-    k1001, ms = sec["k1001"], sec["msmarco"]
+    assert set(sec) == {"k1001", "msmarco", "config4"}
+    k1001, ms, c4 = sec["k1001"], sec["msmarco"], sec["config4"]
     kl = short_list_length(1001, world)
     assert k1001["exchange"]["entries_per_query_per_rank"] == kl < 1001 and k1001["exchange"]["message_bytes_per_rank"] == shard_message_bytes(200, kl)
     assert k1001["exchange"]["full_list_message_bytes_per_rank"] == shard_message_bytes(200, 1001)
     assert "REHEARSAL" in ms["workload"] and ms["exchange"]["message_bytes_per_rank"] == shard_message_bytes(6980 // 40, ms["exchange"]["entries_per_query_per_rank"])
-    for side in (k1001, ms):
+    from ccrec_amd.dist import short_lists_pay
+    k4 = short_list_length(1000, world) if short_lists_pay(1000, world) else 1000      # configs[3]: 50 M x 1024 / 40, 250 queries, top-1000
+    assert "REHEARSAL" in c4["workload"] and "50,000,000 x 1024" in c4["workload"]
+    assert c4["exchange"]["entries_per_query_per_rank"] == k4 and c4["exchange"]["message_bytes_per_rank"] == shard_message_bytes(10000 // 40, k4)
+    for side in (k1001, ms, c4):
         ex = side["exchange"]
         assert side["value"] > 0 and side["scaling"] == "strong" and side["n_fallback"] == 0 and side["roofline"]["bound"] == "mfma"
         assert ex["n_ranks_seen"] == world and ex["repeated_exchanges"] == 0 and ex["queries_repeated_with_full_lists"] == 0
