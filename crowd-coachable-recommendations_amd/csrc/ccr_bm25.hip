@@ -386,6 +386,26 @@ __global__ __launch_bounds__(1024) void bm25_topk_kernel(const uint2 *__restrict
     }
 }
 
+// Index validation (once, at ccr_bm25_index_create): the tile scorer walks every posting list with a cursor, so the documents of a
+// term must ascend strictly; both scorers gather doc_k[doc].  mark[i] = 1 where a term's list starts.
+__global__ __launch_bounds__(256) void bm25_mark_starts_kernel(const int64_t *__restrict__ indptr, int64_t n_terms, int64_t nnz,
+                                                              uint8_t *__restrict__ mark) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < n_terms && indptr[t] < nnz) mark[indptr[t]] = 1;
+}
+__global__ __launch_bounds__(256) void bm25_check_postings_kernel(const int32_t *__restrict__ doc_ids, const uint8_t *__restrict__ mark,
+                                                                 int64_t nnz, int64_t n_docs, unsigned long long *__restrict__ bad) {
+    // bad[0] = postings with a document outside [0, n_docs), bad[1] = neighbours inside a term that do not ascend, bad[2] = first such position + 1
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * 256) {
+        const int32_t d = doc_ids[i];
+        if (d < 0 || (int64_t)d >= n_docs) atomicAdd(&bad[0], 1ull);
+        if (i + 1 < nnz && !mark[i + 1] && doc_ids[i + 1] <= d) {
+            atomicAdd(&bad[1], 1ull);
+            atomicMin(&bad[2], (unsigned long long)i + 1ull);
+        }
+    }
+}
+
 // rank of the sample whose value at most k documents fail to reach with probability < 1e-7 (the planner's rule for estimated
 // thresholds, ccr_api.hip: Wilson-Hilferty lower quantile of Gamma(r) >= k x sample fraction; at least 40)
 static int bm25_sample_rank(int k, double fs) {
@@ -423,6 +443,35 @@ extern "C" int ccr_bm25_index_create(const int64_t *indptr_host, const int32_t *
     int dev = 0, num_cu = 0;
     CCR_HIP_CHECK(hipGetDevice(&dev));
     CCR_HIP_CHECK(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    const int64_t nnz = indptr_host[n_terms];
+    CCR_REQUIRE(indptr_host[0] == 0 && nnz >= 0, "ccr_bm25_index_create: indptr must start at 0");
+    if (nnz > 0) {   // one pass over the postings (a temporary of nnz bytes; index creation is not on the search path)
+        char *tmp = nullptr;
+        const size_t ptr_bytes = ((size_t)(n_terms + 1) * 8 + 255) / 256 * 256, mark_bytes = ((size_t)nnz + 255) / 256 * 256;
+        CCR_HIP_CHECK(hipMalloc((void **)&tmp, ptr_bytes + mark_bytes + 64));
+        int64_t *d_indptr = (int64_t *)tmp;
+        uint8_t *mark = (uint8_t *)(tmp + ptr_bytes);
+        unsigned long long *bad = (unsigned long long *)(tmp + ptr_bytes + mark_bytes);
+        unsigned long long h_bad[3] = {0ull, 0ull, ~0ull};
+        hipError_t e = hipMemcpy(d_indptr, indptr_host, (size_t)(n_terms + 1) * 8, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemset(mark, 0, mark_bytes);
+        if (e == hipSuccess) e = hipMemcpy(bad, h_bad, sizeof(h_bad), hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(bm25_mark_starts_kernel, dim3((unsigned)((n_terms + 255) / 256)), dim3(256), 0, 0, d_indptr, n_terms, nnz, mark);
+            hipLaunchKernelGGL(bm25_check_postings_kernel, dim3((unsigned)std::min<int64_t>((nnz + 255) / 256, 65536)), dim3(256), 0, 0, doc_ids, mark, nnz,
+                               n_docs, bad);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpy(h_bad, bad, sizeof(h_bad), hipMemcpyDeviceToHost);
+        (void)hipFree(tmp);
+        if (e != hipSuccess) {
+            set_error("ccr_bm25_index_create: validating the postings failed: %s", hipGetErrorString(e));
+            return CCR_ERR_HIP;
+        }
+        CCR_REQUIRE(h_bad[0] == 0, "ccr_bm25_index_create: %llu postings name a document outside [0, %lld)", h_bad[0], (long long)n_docs);
+        CCR_REQUIRE(h_bad[1] == 0, "ccr_bm25_index_create: documents must ascend strictly inside a term (%llu violations, first at posting %llu)",
+                    h_bad[1], h_bad[2] - 1ull);
+    }
     ccr_bm25_index *ix = new ccr_bm25_index();
     ix->indptr.assign(indptr_host, indptr_host + n_terms + 1);
     ix->doc_ids = doc_ids;

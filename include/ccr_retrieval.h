@@ -385,7 +385,8 @@ int ccr_rank_metrics(const int64_t *ids, int n_q, int k, const int64_t *qrel_ptr
  * Replaces: BM25.transform, scripts/bm_25.py:31-52 (scipy on the host, one query at a time) and the per-query full
  * sort + keep 1001 of ranking_bm25, scripts/ms_marco_eval.py:165-186.
  *   index  = term-major postings of the count matrix: indptr [n_terms + 1] (HOST), doc_ids [nnz] int32 -- STRICTLY ASCENDING
- *            inside a term (scipy's sorted CSC), the scorer walks every list with a cursor -- and tf [nnz] fp32 (DEVICE,
+ *            inside a term (scipy's sorted CSC; the scorer walks every list with a cursor) and inside [0, n_docs): checked by
+ *            ccr_bm25_index_create in one pass over the postings (CCR_ERR_INVALID names the first violation) -- and tf [nnz] fp32 (DEVICE,
  *            borrowed), doc_k [n_docs] fp64 (DEVICE, borrowed) = k1 * (1 - b + b * len_d / avdl)
  *   query  = CSR on the HOST: q_ptr [n_q + 1], q_terms strictly ascending term ids, q_idf = ln(n / df_t) per entry
  *   score(q, d) = sum_t ascending (tf * idf_t) * (k1 + 1) / (tf + doc_k[d]) in fp64, rounded once to fp32;

@@ -203,3 +203,36 @@ def test_hip_bm25_tile_scorer_equals_the_round_kernels(n_docs, k, monkeypatch):
     sc = acc.astype(np.float32)
     order = np.lexsort((np.arange(n_docs), -sc.astype(np.float64)))[:k]
     assert np.array_equal(results["0"][1][3].numpy(), order) and np.array_equal(results["0"][0][3].numpy().view(np.float32), sc[order])
+
+
+@pytest.mark.gpu
+def test_hip_bm25_index_create_rejects_unsorted_or_out_of_range_postings():
+    """ccr_bm25_index_create validates what the tile scorer relies on (documents strictly ascending inside a term, ids inside the
+    corpus) in one pass over the postings: a violation is CCR_ERR_INVALID with the position, not a silently wrong ranking."""
+    from ccrec_amd import _lib
+    from ccrec_amd.bm25 import BM25
+    from ccrec_amd.ops import require_gpu
+    rs = np.random.RandomState(3)
+    indptr, rows, counts, doc_k, idf = _random_postings(rs, 5000, 40, dense_terms=2)
+
+    def create(r):
+        m = BM25(k1=1.2)
+        m._lib, m.indptr, m.idf, m.n_docs = require_gpu(), indptr, idf, len(doc_k)
+        return m._upload(r, counts, doc_k, len(idf))
+
+    create(rows).transform_terms_topk([np.asarray([0, 3], np.int32)], 10)          # the valid index works
+    swapped = rows.copy()
+    p = int(indptr[1]) + 7                                                          # inside term 1
+    swapped[p], swapped[p + 1] = swapped[p + 1], swapped[p]
+    with pytest.raises(_lib.CcrError, match="ascend strictly inside a term .*first at posting %d" % p):
+        create(swapped)
+    dup = rows.copy()
+    dup[p + 1] = dup[p]
+    with pytest.raises(_lib.CcrError, match="ascend strictly"):
+        create(dup)
+    far = rows.copy()
+    far[3] = 5000
+    with pytest.raises(_lib.CcrError, match="outside \\[0, 5000\\)"):
+        create(far)
+    # a descent ACROSS a term boundary is the normal case and must pass (every list starts again at a low document)
+    assert rows[indptr[1]] < rows[indptr[1] - 1]
