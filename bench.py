@@ -366,7 +366,8 @@ def inbatch_side_run(dev, B=1024, d=768, iters=50):
 
 def encode_side_run(dev, texts=16384):
     """SURVEY 8 f2 beside the search: `texts` synthetic passages (mean 136 tokens, pre-tokenised ids) through a random-init BERT-base
-    under bf16 autocast with the length-sorted encoder -- the encoder layers as torch modules, then on the library's attention /
+    under the reference's own `torch.autocast("cuda")` (fp16, scripts/al_0_rank.py:8,125) with the length-sorted encoder -- the encoder
+    layers as torch modules, then on the library's attention /
     add + LayerNorm kernels (ccrec_amd/fused_bert.py).  GPU seconds from events around the batches; host tokenisation excluded
     (one chunk, prepared before the GPU starts).  Bounded: ~10 s with the model construction."""
     import numpy as np
@@ -389,18 +390,18 @@ def encode_side_run(dev, texts=16384):
     corpus = [" ".join(map(str, rs.randint(1000, 30000, n))) for n in lens]
     torch.manual_seed(0)
     tower = NaiveItemTower(BertModel(BertConfig(vocab_size=30522)).eval(), torch.nn.LayerNorm(768, elementwise_affine=False)).to(dev)
-    out = {"workload": f"{texts} synthetic passages (mean {float(lens.mean()) + 2:.0f} tokens), random-init BERT-base, bf16 autocast, "
+    out = {"workload": f"{texts} synthetic passages (mean {float(lens.mean()) + 2:.0f} tokens), random-init BERT-base, fp16 autocast (the reference's torch.cuda.amp.autocast()), "
                        "length-sorted batches of <= 65,536 tokens, masked mean pooling + bf16 pack into the shard", "unit": "passages/s (GPU time of the batches)"}
     rows = {}
     for name, fused in (("torch_modules", False), ("layer_kernels", True)):
         enc = LengthSortedEncoder(tower, IdTokenizer(), max_length=200, max_tokens=65536, max_batch=2048, chunk_texts=10 ** 9, fused=fused)
-        with torch.autocast("cuda", dtype=torch.bfloat16):
+        with torch.autocast("cuda"):                  # the CUDA default: fp16 -- the layer kernels run in the caller's autocast type
             enc.encode(corpus[:2048])                 # GEMM shapes, library load: untimed
             f32 = torch.empty(texts, 768, dtype=torch.float32, device=dev)
             enc.encode(corpus, out_f32=f32)
         rows[name] = f32
         out[name] = {"value": round(texts / enc.stats["gpu_busy_s"], 1), "gpu_busy_s": round(enc.stats["gpu_busy_s"], 3),
-                     "batches": enc.stats["batches"], "padded_tokens": enc.stats["padded_tokens"]}
+                     "batches": enc.stats["batches"], "padded_tokens": enc.stats["padded_tokens"], "layer_dtype": str(enc.stats.get("layer_dtype"))}
     cos = torch.nn.functional.cosine_similarity(rows["torch_modules"], rows["layer_kernels"], dim=1)
     out["speedup"] = round(out["layer_kernels"]["value"] / out["torch_modules"]["value"], 3)
     out["cosine_of_pooled_rows_min"] = round(float(cos.min()), 6)
