@@ -410,6 +410,66 @@ def encode_side_run(dev, texts=16384):
     return out
 
 
+def bm25_side_run(dev, docs=500_000, queries=2000, vocab=50_000, k=1001, cpu_queries=10):
+    """SURVEY 8 f4 beside the search: the lexical leg of the candidate builder (scripts/bm_25.py, ranking_bm25) on the device --
+    `queries` Zipf queries of 3-11 words against `docs` synthetic documents (20-79 words, Zipf 1.07 over `vocab` terms), top-1001 =
+    ranking_bm25's KEEP.  The postings are built with numpy (the text analysis is host work and not what is measured); `value` is
+    the library call (tables + kernels, ccr_bm25_search); the reference formulation (scipy column slice + dense divide + row sum +
+    full sort per query, bm_25.py:31-52 + ms_marco_eval.py:177-185) runs on the same host for `cpu_queries` queries.  ~10 s."""
+    import numpy as np
+    from ccrec_amd.bm25 import BM25
+    rs = np.random.RandomState(0)
+    p = 1.0 / np.arange(1, vocab + 1) ** 1.07
+    p /= p.sum()
+    lens = rs.randint(20, 80, docs)
+    doc_of = np.repeat(np.arange(docs, dtype=np.int64), lens)
+    term_of = rs.choice(vocab, int(lens.sum()), p=p).astype(np.int64)
+    key, counts = np.unique(term_of * docs + doc_of, return_counts=True)        # term-major, documents ascending inside a term
+    terms, rows = key // docs, (key % docs).astype(np.int32)
+    indptr = np.zeros(vocab + 1, np.int64)
+    np.cumsum(np.bincount(terms, minlength=vocab), out=indptr[1:])
+    df = np.diff(indptr)
+    idf = np.log(docs / np.maximum(df, 1).astype(np.float64))
+    k1, b = 1.2, 0.75
+    doc_k = k1 * (1 - b + b * lens / lens.mean())
+    qs = [np.unique(rs.choice(vocab, rs.randint(3, 12), p=p)).astype(np.int32) for _ in range(queries)]
+    qs = [q[df[q] > 0] for q in qs]
+    model = BM25.from_postings(indptr, rows, counts.astype(np.float32), doc_k, idf, k1=k1, b=b)
+    model.transform_terms_topk(qs[:64], k)
+    best = 1e9
+    for _ in range(3):
+        s, i = model.transform_terms_topk(qs, k)
+        best = min(best, model.last_search_seconds)
+    postings = int(sum(int(df[q].sum()) for q in qs))
+    out = {"workload": f"BM25 (k1 1.2, b 0.75): {queries} queries of 3-11 Zipf words x {docs:,} synthetic documents ({len(rows):,} postings, "
+                       f"{postings:,} touched), top-{k} (ranking_bm25's KEEP)", "value": round(queries / best, 1), "unit": "queries/s (library call: tables + kernels)",
+           "ms_per_call": round(best * 1e3, 3),
+           "roofline": {"bound": "on-chip posting traffic (the 153-MB index is re-read once per query from L2 / Infinity Cache; HBM sees the index once + the fp32 score rows)",
+                        "kernel": "bm25_tile_kernel<1024,2> + threshold / collect / top-k", "achieved": round((postings * 8 + queries * docs * 8) / best / 1e9, 1),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round((postings * 8 + queries * docs * 8) / best / 1e9 / HBM_PEAK_GBS, 4),
+                        "bytes_per_unit": "8 per posting touched + 8 per (query, document) cell (fp32 score written once, read once)", "traffic": None}}
+    if cpu_queries > 0:
+        import scipy.sparse as sp
+        X = sp.csc_matrix((counts.astype(np.float64), rows, indptr), shape=(docs, vocab))
+        t0 = time.perf_counter()
+        rec = 0.0
+        for qi in range(cpu_queries):
+            t = qs[qi]
+            Xq = X[:, t]
+            denom = Xq + doc_k[:, None]
+            numer = Xq.multiply(np.broadcast_to(idf[None, t], Xq.shape)) * (k1 + 1)
+            sol = torch.Tensor(np.asarray((numer / denom).sum(1)).ravel())
+            _, order = sol.sort(descending=True)
+            rec += len(set(order[:k].tolist()) & set(i[qi].tolist())) / k
+        cdt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(cpu_queries / cdt, 2), "unit": "queries/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"{cpu_queries} queries, scipy column slice + dense divide + row sum + full sort", "recall_of_gpu_ids": round(rec / cpu_queries, 4)}
+        out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
 def roofline_obj(r, traffic=None, traffic_source=None):
     """`achieved` = algorithmic flops of one step's main pass (2 n_q n_rows dim: every launch of the pass covers its share of the
     corpus, together exactly once) / the main pass's duration per step from the library's HIP events on the search stream."""
@@ -606,6 +666,10 @@ def main():
             sec["encode_passages"] = encode_side_run(dev)
         except Exception as e:      # a side run must never cost the line its headline
             sec["encode_passages"] = {"skipped": f"{type(e).__name__}: {e}"}
+        try:
+            sec["bm25"] = bm25_side_run(dev, cpu_queries=10 if args.cpu_queries > 0 else 0)
+        except Exception as e:
+            sec["bm25"] = {"skipped": f"{type(e).__name__}: {e}"}
         out["secondary"] = sec
     elif world > 1 and (default_shape or args.rehearse_secondary > 0) and not args.no_secondary:
         # N > 1: the shapes the multi-GPU target is quoted on, each sharded over the same ranks with its own exchange record
