@@ -84,6 +84,19 @@ def test_ranking_api_block_dict(golden_dir):
         ranking({"p0": 0, "p1": 1}, {"q0": 0}, _table_func(torch.from_numpy(g["Ed"][:2])), 8, {"q0": ["nope"]})
 
 
+def test_ranking_api_cos_block_dict_and_truncation_together(golden_dir):
+    """Golden g17 through ranking(): cos + block lists long enough to reach into the kept 1001 of 1 100 passages (and one short, one
+    empty list) -- bit-exact against the oracle, within the bf16 tolerance of the reference's own output."""
+    g = np.load(os.path.join(golden_dir, "g17_ranking_cos_block_trunc.npz"))
+    ptr, idx = g["block_ptr"], g["block_idx"]
+    block = [idx[ptr[i]:ptr[i + 1]].tolist() for i in range(len(ptr) - 1)]
+    ids, sc = _ranking_via_api(g, "cos", block)
+    ref_i, ref_s = orc.canonical_ranking(g["Eq"], g["Ed"], "cos", block=block)
+    assert np.array_equal(ids, ref_i) and np.array_equal(sc.view(np.uint32), ref_s.view(np.uint32))
+    assert_rank_close(ids, sc, g["ids"], g["scores"], tol=1e-3, truncated=True)
+    os.environ["CCREC_SIM_TYPE"] = "dot"
+
+
 def test_exact_arithmetic_ties_golden(golden_dir):
     g = np.load(os.path.join(golden_dir, "g5_ranking_exact_ties.npz"))
     ids, sc = _ranking_via_api(g, "dot")

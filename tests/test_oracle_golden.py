@@ -67,6 +67,24 @@ def test_block_dict(golden_dir):
         orc.canonical_ranking(g["Eq"][:1], g["Ed"], "dot", block=[[10 ** 6]])
 
 
+def test_cos_block_dict_and_truncation_together(golden_dir):
+    """Golden g17 (the reference's ranking() with CCREC_SIM_TYPE=cos, block lists of 0 / 40 / 120-200 ids and an 1 100-passage corpus):
+    blocked passages score -1e6 and are KEPT -- those that fit fill the tail of the 1001 entries; with 40 blocked ids (< N - 1001) none
+    is kept; cos scores within the bf16 tolerance of the reference's fp32 values."""
+    g = _load(golden_dir, "g17_ranking_cos_block_trunc.npz")
+    block = _block_list(g)
+    ids, sc = orc.canonical_ranking(g["Eq"], g["Ed"], "cos", block=block)
+    ref_i, ref_s = g["ids"], g["scores"]
+    assert ids.shape == ref_i.shape == (9, 1001)
+    for q, b in enumerate(block):
+        kept = max(0, 1001 - (1100 - len(b)))                      # blocked entries inside the kept list
+        assert int((ref_s[q] == np.float32(-1e6)).sum()) == kept == int((sc[q] == np.float32(-1e6)).sum())
+        assert set(ids[q, 1001 - kept:].tolist()) <= set(b) and set(ref_i[q, 1001 - kept:].tolist()) <= set(b)
+        assert ids[q, 1001 - kept:].tolist() == sorted(b)[:kept]   # the canonical tie rule among the -1e6 entries: ascending id
+        assert not set(ids[q, :1001 - kept].tolist()) & set(b)
+    assert_rank_close(ids, sc, ref_i, ref_s, tol=1e-3, truncated=True)
+
+
 def test_exact_arithmetic_ties(golden_dir):
     g = _load(golden_dir, "g5_ranking_exact_ties.npz")
     ids, sc = orc.canonical_ranking(g["Eq"], g["Ed"], "dot")

@@ -187,6 +187,25 @@ def g_ranking(mod):
     np.savez_compressed(f"{OUT}/g5_ranking_exact_ties.npz", Eq=Eq5, Ed=Ed5, ids=ids, scores=sc, batch_size=128)
 
 
+def g_ranking_cos_block(mod):
+    """G17: the three switches of ranking() together -- CCREC_SIM_TYPE=cos on raw (un-normalised) embeddings, a block_dict whose lists
+    are long enough that blocked passages (score -1e6) sit INSIDE the kept 1001 of an 1 100-passage corpus, and the 1001 truncation."""
+    g = torch.Generator().manual_seed(1717)
+    d = 768
+    Ed = bf16_exact(torch.randn(1100, d, generator=g) / d ** 0.5 * (0.5 + torch.rand(1100, 1, generator=g) * 3))
+    Eq = bf16_exact(torch.randn(9, d, generator=g) / d ** 0.5 * (0.5 + torch.rand(9, 1, generator=g) * 3))
+    rs = np.random.RandomState(17)
+    block = [sorted(rs.choice(1100, int(rs.randint(120, 201)), replace=False).tolist()) for _ in range(9)]
+    block[3] = []                      # a query without blocked passages
+    block[5] = list(range(40))         # fewer than N - 1001 = 99 blocked: none of them is kept
+    ids, sc = _run_ranking(mod, Eq, Ed, 256, "cos", block=block)
+    flat = np.concatenate([np.asarray(b, np.int64) for b in block])
+    ptr = np.cumsum([0] + [len(b) for b in block]).astype(np.int64)
+    np.savez_compressed(f"{OUT}/g17_ranking_cos_block_trunc.npz", Eq=Eq.numpy(), Ed=Ed.numpy(), ids=ids, scores=sc, block_ptr=ptr, block_idx=flat,
+                        batch_size=256)
+    os.environ["CCREC_SIM_TYPE"] = "dot"
+
+
 def g_item_tower():
     from ccrec.models.item_tower import NaiveItemTower
 
@@ -514,7 +533,8 @@ def main():
     want = set(sys.argv[1:])
     groups = [("g1", lambda: g_ranking(_import_reference("dot"))), ("g6", g_item_tower), ("g7", g_contrastive),
               ("g8", g_assign_topk), ("g9", g_pack), ("g10", g_requests), ("g11", g_train_data), ("g12", g_bm25), ("g13", g_item_rec), ("g14", g_sparse_prior),
-              ("g15", g_assign_topk_odd_width), ("g16", lambda: (_import_reference("dot"), g_item_tower_bert())[1])]
+              ("g15", g_assign_topk_odd_width), ("g16", lambda: (_import_reference("dot"), g_item_tower_bert())[1]),
+              ("g17", lambda: g_ranking_cos_block(_import_reference("dot")))]
     for name, fn in groups:
         if not want or name in want:
             fn()
