@@ -430,6 +430,7 @@ struct ccr_bm25_index {
     int64_t n_terms, n_docs;
     double k1;
     int num_cu;
+    int run_tiles_knob;            // CCR_BM25_RUN_TILES: 0 = planner's choice, else tiles per ticket (tuning)
     int tile_cfg;                  // CCR_BM25_TILE: -1 = round kernels only (the A/B knob), 0 = default tile shape (1024 documents, 128-posting steps), 1 = 1024/64, 2 = 512/128
 };
 
@@ -483,6 +484,8 @@ extern "C" int ccr_bm25_index_create(const int64_t *indptr_host, const int32_t *
     ix->num_cu = num_cu > 0 ? num_cu : 256;
     const char *cfg = getenv("CCR_BM25_TILE");
     ix->tile_cfg = cfg ? atoi(cfg) : 0;
+    const char *rt = getenv("CCR_BM25_RUN_TILES");
+    ix->run_tiles_knob = rt ? atoi(rt) : 0;
     *out = ix;
     return CCR_OK;
 }
@@ -523,9 +526,14 @@ int launch_bm25_tile(const ccr_bm25_index *ix, const Bm25Term *terms, const int3
     const int64_t n_tiles = (ix->n_docs + T - 1) / T;
     const int wgs_per_cu = std::max(1, std::min(8, (int)(160 * 1024 / (BM25_TILE_WAVES * T * 8))));
     const int64_t waves = (int64_t)ix->num_cu * wgs_per_cu * BM25_TILE_WAVES;
-    // about eight tickets per wave: long runs keep a wave on one query's cursors, short ones balance the tail
-    int64_t runs = std::min<int64_t>(std::max<int64_t>((8 * waves + m - 1) / m, 1), n_tiles);
-    const int run_tiles = (int)((n_tiles + runs - 1) / runs);
+    // Tiles per ticket.  Consecutive tickets are consecutive query rows on the SAME run of documents, so the waves in flight read the
+    // same slices of the common terms' posting lists: short runs keep those slices (and their doc_k) inside the XCDs' L2 -- 4 to 12 tiles
+    // per ticket measured 10 % faster end to end than 24 or 48 (L2 hit rate of the kernel 81 % at 24), 2 slower again (a binary search
+    // per term and ticket).  About 24 tickets per wave, at most 12 tiles, at least 4 where that still leaves two tickets per wave.
+    int64_t runs = std::min<int64_t>(std::max<int64_t>((24 * waves + m - 1) / m, 1), n_tiles);
+    int run_tiles = (int)std::min<int64_t>((n_tiles + runs - 1) / runs, 12);
+    if (run_tiles < 4 && (n_tiles / 4) * (int64_t)m >= 2 * waves) run_tiles = 4;
+    if (ix->run_tiles_knob > 0) run_tiles = (int)std::min<int64_t>(ix->run_tiles_knob, n_tiles);
     runs = (n_tiles + run_tiles - 1) / run_tiles;
     const int64_t items = runs * m;
     const unsigned grid = (unsigned)std::min<int64_t>((items + BM25_TILE_WAVES - 1) / BM25_TILE_WAVES, (int64_t)ix->num_cu * wgs_per_cu);

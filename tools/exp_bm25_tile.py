@@ -2,7 +2,7 @@
 """A/B of the BM25 scorers on one fitted index: CCR_BM25_TILE = -1 (round kernels + fp64 rows) against the document-tile
 scorer's shapes; every shape must return the round kernels' ids and score bits.
 
-  python tools/exp_bm25_tile.py [--docs 500000] [--queries 2000] [--cfgs -1,0,1,2]"""
+  python tools/exp_bm25_tile.py [--docs 500000] [--queries 2000] [--cfgs=-1,0,1,2]"""
 import argparse
 import ctypes
 import os
