@@ -410,12 +410,9 @@ def encode_side_run(dev, texts=16384):
     return out
 
 
-def bm25_side_run(dev, docs=500_000, queries=2000, vocab=50_000, k=1001, cpu_queries=10):
-    """SURVEY 8 f4 beside the search: the lexical leg of the candidate builder (scripts/bm_25.py, ranking_bm25) on the device --
-    `queries` Zipf queries of 3-11 words against `docs` synthetic documents (20-79 words, Zipf 1.07 over `vocab` terms), top-1001 =
-    ranking_bm25's KEEP.  The postings are built with numpy (the text analysis is host work and not what is measured); `value` is
-    the library call (tables + kernels, ccr_bm25_search); the reference formulation (scipy column slice + dense divide + row sum +
-    full sort per query, bm_25.py:31-52 + ms_marco_eval.py:177-185) runs on the same host for `cpu_queries` queries.  ~10 s."""
+def bm25_workload(docs=500_000, queries=2000, vocab=50_000, k1=1.2, b=0.75):
+    """The synthetic BM25 workload of the bench line (also tools/one_bm25.py): postings of `docs` documents of 20-79 Zipf(1.07) words
+    over `vocab` terms built with numpy, `queries` queries of 3-11 Zipf words -> (model, query term arrays, df, raw arrays)."""
     import numpy as np
     from ccrec_amd.bm25 import BM25
     rs = np.random.RandomState(0)
@@ -430,11 +427,21 @@ def bm25_side_run(dev, docs=500_000, queries=2000, vocab=50_000, k=1001, cpu_que
     np.cumsum(np.bincount(terms, minlength=vocab), out=indptr[1:])
     df = np.diff(indptr)
     idf = np.log(docs / np.maximum(df, 1).astype(np.float64))
-    k1, b = 1.2, 0.75
     doc_k = k1 * (1 - b + b * lens / lens.mean())
     qs = [np.unique(rs.choice(vocab, rs.randint(3, 12), p=p)).astype(np.int32) for _ in range(queries)]
     qs = [q[df[q] > 0] for q in qs]
     model = BM25.from_postings(indptr, rows, counts.astype(np.float32), doc_k, idf, k1=k1, b=b)
+    return model, qs, df, (indptr, rows, counts, doc_k, idf, k1)
+
+
+def bm25_side_run(dev, docs=500_000, queries=2000, vocab=50_000, k=1001, cpu_queries=10):
+    """SURVEY 8 f4 beside the search: the lexical leg of the candidate builder (scripts/bm_25.py, ranking_bm25) on the device --
+    `queries` Zipf queries of 3-11 words against `docs` synthetic documents (20-79 words, Zipf 1.07 over `vocab` terms), top-1001 =
+    ranking_bm25's KEEP.  The postings are built with numpy (the text analysis is host work and not what is measured); `value` is
+    the library call (tables + kernels, ccr_bm25_search); the reference formulation (scipy column slice + dense divide + row sum +
+    full sort per query, bm_25.py:31-52 + ms_marco_eval.py:177-185) runs on the same host for `cpu_queries` queries.  ~10 s."""
+    import numpy as np
+    model, qs, df, (indptr, rows, counts, doc_k, idf, k1) = bm25_workload(docs, queries, vocab)
     model.transform_terms_topk(qs[:64], k)
     best = 1e9
     for _ in range(3):

@@ -22,6 +22,7 @@ EXPORTS = [
     "ccr_bm25_search", "ccr_pack_bf16_padded", "ccr_shard_message_bytes", "ccr_search_shard", "ccr_shard_message_fill", "ccr_merge_shard_messages",
     "ccr_attention_bf16", "ccr_add_layernorm", "ccr_meanpool_pack_bf16_packed", "ccr_embed_layernorm", "ccr_gelu_bf16",
     "ccr_attention_half", "ccr_add_layernorm_half", "ccr_embed_layernorm_half", "ccr_gelu_half", "ccr_merge_short_lists",
+    "ccr_bm25_search_workspace_bytes_k", "ccr_bm25_search_last_stats", "ccr_bm25_index_set_idf",
 ]
 
 SHARD_HEADER_BYTES = 32
@@ -100,6 +101,10 @@ def load():
     lib.ccr_bm25_index_destroy.argtypes = [vp]
     lib.ccr_bm25_search_workspace_bytes.argtypes = [vp, i32, i32]
     lib.ccr_bm25_search_workspace_bytes.restype = sz
+    lib.ccr_bm25_search_workspace_bytes_k.argtypes = [vp, i32, i32, i32]
+    lib.ccr_bm25_search_workspace_bytes_k.restype = sz
+    lib.ccr_bm25_search_last_stats.argtypes = [vp, vp]
+    lib.ccr_bm25_index_set_idf.argtypes = [vp, vp, vp, vp]
     lib.ccr_bm25_search.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp, sz, vp]
     lib.ccr_pack_bf16_padded.argtypes = [vp, i64, i32, vp, i32, vp, vp, i32, vp]
     lib.ccr_attention_bf16.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, ctypes.c_float, vp]

@@ -80,6 +80,11 @@ class BM25:
         _lib.check(self._lib.ccr_bm25_index_create(self.indptr.ctypes.data_as(ctypes.c_void_p), self._doc_ids.data_ptr(),
                                                    self._tf.data_ptr(), self._doc_k.data_ptr(), n_terms, self.n_docs, self.k1,
                                                    ctypes.byref(self._h)), "ccr_bm25_index_create")
+        # every query this class builds weighs a term with self.idf: the postings' finished contributions, once (8 B per posting)
+        idf = np.ascontiguousarray(self.idf, np.float64)
+        self._contrib = torch.empty(max(1, len(rows)), dtype=torch.float64, device="cuda")
+        _lib.check(self._lib.ccr_bm25_index_set_idf(self._h, idf.ctypes.data_as(ctypes.c_void_p), self._contrib.data_ptr(),
+                                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "ccr_bm25_index_set_idf")
         return self
 
     @classmethod
@@ -182,7 +187,7 @@ class BM25:
         ids = torch.empty(n_q, k, dtype=torch.int64, device="cuda")
         if n_q == 0:
             return scores, ids
-        need = int(self._lib.ccr_bm25_search_workspace_bytes(self._h, n_q, int(max(len(t) for t in terms))))
+        need = int(self._lib.ccr_bm25_search_workspace_bytes_k(self._h, n_q, int(max(len(t) for t in terms)), k))
         ws = torch.empty(need, dtype=torch.uint8, device="cuda")
         vp = ctypes.c_void_p
         t0 = time.perf_counter()
@@ -192,6 +197,13 @@ class BM25:
         torch.cuda.current_stream().synchronize()   # the host arrays above must outlive the stream work
         self.last_search_seconds = time.perf_counter() - t0   # the library call alone (tables + kernels), without the text analysis
         return scores, ids
+
+    def last_stats(self):
+        """Of the last search: which path ran, how many rows the fused filter could not finish, batches, the sampled threshold's rank."""
+        out = np.zeros(4, np.int64)
+        _lib.check(self._lib.ccr_bm25_search_last_stats(self._h, out.ctypes.data_as(ctypes.c_void_p)), "ccr_bm25_search_last_stats")
+        return {"path": ("rounds+stored_rows", "tile+stored_rows", "tile+fused_filter")[int(out[0]) & 3], "contribution_table": bool(int(out[0]) & 4),
+                "rows_redone": int(out[1]), "batches": int(out[2]), "sample_rank": int(out[3])}
 
     def transform(self, q, X=None):
         """bm_25.py:31-52: dense [n_docs] score vector of one query (small corpora / tests: reads back k = n_docs)."""

@@ -12,6 +12,7 @@
 // most once, and the rounds run in stream order = ascending term order).  The accumulator is converted to fp32 and
 // re-zeroed in one pass, and the exact dense selection of the retrieval path picks the top-k.
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <vector>
@@ -24,7 +25,7 @@
 namespace ccr {
 int launch_dense_select(const float *scores, int64_t n_rows, int k, const uint32_t *out_rows, int q_begin, int nq_chunk,
                         const uint32_t *count_dev, int64_t id_offset, float *out_scores, int64_t *out_ids, hipStream_t s,
-                        bool aggregate, const uint32_t *in_rows);
+                        bool aggregate, const uint32_t *in_rows, bool in_rows_compact);
 int ensure_dynamic_lds(const void *kernel, size_t lds);
 
 struct Bm25Round {       // one (query row of the batch, term) pair of a round
@@ -100,12 +101,29 @@ __device__ __forceinline__ int64_t readlane64(int64_t v, int l) {
     return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
 }
 
+// What a finished tile becomes (r5).  STORE: fp32 scores of every document into the row's score row (the exact dense selection reads
+// them: small corpora, k beyond the candidate lists, and the rows the filter could not finish).  SAMPLE: a "run" is ONE piece of T
+// documents out of every `run_stride_docs`; its scores go to a compact [rows][n_runs * T] sample the threshold kernel ranks.  FILTER:
+// the tile is compared against the row's tau while it is still in the wave's registers and only the documents that pass leave the
+// chip, as {score bits, document} records of the row's candidate list -- ONE list reservation per wave and tile that has a hit (about
+// five hits per tile at k = 1001 of 500 k documents) -- so the [rows][n_docs] fp32 score rows (written once and read once by a separate
+// collect pass in r4: 8 of the call's 13.6 GB of fabric traffic) never exist.
+enum { BM25_STORE = 0, BM25_SAMPLE = 1, BM25_FILTER = 2 };
+constexpr int BM25_LIST_CAP = 16384;         // candidate records per row (128 KiB of keys in the top-k kernel)
+
 // grid = any, block = 256 (four independent waves).  T documents per tile, U 64-posting chunks per step, run_tiles tiles per ticket.
-template <int T, int U>
+// row_map (STORE only, may be null): the launch scores table rows row_map[0 .. n_rows) into score rows 0 .. n_rows (the redo list).
+// TABLE: the index holds the FINISHED contribution of every posting (ccr_bm25_index_set_idf: (tf idf_t)(k1 + 1) / (tf + K_d) evaluated once, by
+// the same fp64 operations in the same order, so the same bits) and the queries use the index's idf: a posting is 4 + 8 coalesced bytes and
+// one add -- no K_d gather (64 scattered 8-byte requests per wave and step), no fp64 division (~30 instructions per posting).
+template <int T, int U, int MODE, bool TABLE>
 __global__ __launch_bounds__(256) void bm25_tile_kernel(const Bm25Term *__restrict__ terms, const int32_t *__restrict__ row_ptr, int n_rows,
                                                        const int32_t *__restrict__ doc_ids, const float *__restrict__ tf,
-                                                       const double *__restrict__ doc_k, double k1p1, int64_t n_docs, int run_tiles, int n_runs,
-                                                       uint32_t *__restrict__ ticket, float *__restrict__ scores) {
+                                                       const double *__restrict__ doc_k, const double *__restrict__ contrib, double k1p1,
+                                                       int64_t n_docs, int run_tiles, int n_runs,
+                                                       int64_t run_stride_docs, uint32_t *__restrict__ ticket, float *__restrict__ scores,
+                                                       const uint32_t *__restrict__ row_map, const float *__restrict__ tau,
+                                                       uint2 *__restrict__ list, uint32_t *__restrict__ list_cnt, uint32_t *__restrict__ odd_cnt) {
     __shared__ double s_acc[BM25_TILE_WAVES][T];
     const int lane = threadIdx.x & 63;
     double *acc = s_acc[threadIdx.x >> 6];
@@ -118,14 +136,15 @@ __global__ __launch_bounds__(256) void bm25_tile_kernel(const Bm25Term *__restri
         item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
         if (item >= n_items) break;   // every wave reaches this: the ticket only grows
         const int row = (int)(item % (uint32_t)n_rows), run = (int)(item / (uint32_t)n_rows);
-        const int t0 = row_ptr[row], nt = row_ptr[row + 1] - t0;
+        const int trow = row_map ? (int)row_map[row] : row;   // the row of the term table
+        const int t0 = row_ptr[trow], nt = row_ptr[trow + 1] - t0;
         int64_t cur = 0, end = 0;
         double idf = 0.0;
         if (lane < nt) {
             const Bm25Term t = terms[t0 + lane];
             cur = t.begin, end = t.end, idf = t.idf;
         }
-        const int64_t run_base = (int64_t)run * run_tiles * T;
+        const int64_t run_base = (int64_t)run * run_stride_docs;
         const int64_t run_end = run_base + (int64_t)run_tiles * T < n_docs ? run_base + (int64_t)run_tiles * T : n_docs;
         if (run > 0) {   // first posting of every term at or behind the run's first document
             int64_t lo = cur, hi = end;
@@ -139,7 +158,10 @@ __global__ __launch_bounds__(256) void bm25_tile_kernel(const Bm25Term *__restri
             cur = lo;
         }
         int nd = cur < end ? doc_ids[cur] : 0x7fffffff;   // the next document of the lane's term
-        float *out_row = scores + (int64_t)row * n_docs;
+        float *out_row = MODE == BM25_SAMPLE ? scores + ((int64_t)row * n_runs + run) * T : scores + (int64_t)row * n_docs;
+        float thr = 0.f;
+        bool odd = false;
+        if (MODE == BM25_FILTER) thr = tau[row];
         for (int64_t tile_base = run_base; tile_base < run_end; tile_base += T) {
             const int tile_end = (int)(tile_base + T < n_docs ? tile_base + T : n_docs);
             unsigned long long act = __ballot(nd < tile_end);
@@ -152,29 +174,49 @@ __global__ __launch_bounds__(256) void bm25_tile_kernel(const Bm25Term *__restri
                 int32_t d[U];
                 int cnt;
                 do {
-                    float f[U];
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {   // clamped: every load is valid and unconditional
-                        const int64_t i = c + lane + 64 * u;
-                        const int64_t ic = i < e ? i : e - 1;
-                        d[u] = doc_ids[ic];
-                        f[u] = tf[ic];
-                    }
-                    double kd[U];
-#pragma unroll
-                    for (int u = 0; u < U; ++u) kd[u] = doc_k[d[u]];
                     cnt = 0;
+                    if (TABLE) {
+                        double cv[U];
 #pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const bool in = c + lane + 64 * u < e && d[u] < tile_end;
-                        const double fd = (double)f[u];
-                        const double numer = (fd * w) * k1p1;
-                        const double denom = fd + kd[u];
-                        if (in) {
-                            const int x = d[u] - (int)tile_base;
-                            acc[x] = acc[x] + numer / denom;
+                        for (int u = 0; u < U; ++u) {   // clamped: every load is valid and unconditional
+                            const int64_t i = c + lane + 64 * u;
+                            const int64_t ic = i < e ? i : e - 1;
+                            d[u] = doc_ids[ic];
+                            cv[u] = contrib[ic];
                         }
-                        cnt += __popcll(__ballot(in));
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const bool in = c + lane + 64 * u < e && d[u] < tile_end;
+                            if (in) {
+                                const int x = d[u] - (int)tile_base;
+                                acc[x] = acc[x] + cv[u];
+                            }
+                            cnt += __popcll(__ballot(in));
+                        }
+                    } else {
+                        float f[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {   // clamped: every load is valid and unconditional
+                            const int64_t i = c + lane + 64 * u;
+                            const int64_t ic = i < e ? i : e - 1;
+                            d[u] = doc_ids[ic];
+                            f[u] = tf[ic];
+                        }
+                        double kd[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) kd[u] = doc_k[d[u]];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const bool in = c + lane + 64 * u < e && d[u] < tile_end;
+                            const double fd = (double)f[u];
+                            const double numer = (fd * w) * k1p1;
+                            const double denom = fd + kd[u];
+                            if (in) {
+                                const int x = d[u] - (int)tile_base;
+                                acc[x] = acc[x] + numer / denom;
+                            }
+                            cnt += __popcll(__ballot(in));
+                        }
                     }
                     c += cnt;
                 } while (cnt == 64 * U);
@@ -191,50 +233,107 @@ __global__ __launch_bounds__(256) void bm25_tile_kernel(const Bm25Term *__restri
                 }
                 if (lane == r) cur = c, nd = next;
             }
+            if (MODE == BM25_FILTER) {
+                // the tile against tau: the same test as the r4 collect pass (score >= tau, and > 0 when tau <= 0: a BM25 row is mostly
+                // exact zeros).  Two walks over the tile's LDS image -- count, then write -- instead of 16 live scores per lane: the
+                // registers of the second form cost a wave of occupancy per SIMD (117 against 72 VGPRs)
+                int hits = 0;
+#pragma unroll 4
+                for (int j = 0; j < T / 64; ++j) {
+                    const int x = j * 64 + lane;
+                    const float v = (float)acc[x];
+                    const bool in = tile_base + x < n_docs;
+                    odd = odd || (in && (v < 0.f || v != v));
+                    hits += __popcll(__ballot(in && v >= thr && (thr > 0.f || v > 0.f)));
+                }
+                if (hits != 0) {   // wave-uniform
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&list_cnt[row], (uint32_t)hits);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    uint2 *out = list + (int64_t)row * BM25_LIST_CAP;
+#pragma unroll 4
+                    for (int j = 0; j < T / 64; ++j) {
+                        const int x = j * 64 + lane;
+                        const float v = (float)acc[x];
+                        acc[x] = 0.0;
+                        const bool pass = tile_base + x < n_docs && v >= thr && (thr > 0.f || v > 0.f);
+                        const unsigned long long m = __ballot(pass);
+                        const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                        if (pass && at < (uint32_t)BM25_LIST_CAP) out[at] = make_uint2(__float_as_uint(v), (uint32_t)(tile_base + x));
+                        base += (uint32_t)__popcll(m);
+                    }
+                } else {
 #pragma unroll
-            for (int j = 0; j < T / 64; ++j) {
-                const int x = j * 64 + lane;
-                const double v = acc[x];
-                acc[x] = 0.0;
-                if (tile_base + x < n_docs) out_row[tile_base + x] = (float)v;
+                    for (int j = 0; j < T / 64; ++j) acc[j * 64 + lane] = 0.0;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < T / 64; ++j) {
+                    const int x = j * 64 + lane;
+                    const double v = acc[x];
+                    acc[x] = 0.0;
+                    if (MODE == BM25_SAMPLE) out_row[x] = tile_base + x < n_docs ? (float)v : -INFINITY;   // one tile per run
+                    else if (tile_base + x < n_docs) out_row[tile_base + x] = (float)v;
+                }
             }
         }
+        if (MODE == BM25_FILTER && __ballot(odd) != 0ull && lane == 0) atomicAdd(&odd_cnt[row], 1u);
+    }
+}
+
+// contrib[p] = the posting's finished contribution under the index's idf: the expression of the scorers, operation for operation.
+// grid = (chunks, 1), block = 256; term_of[p] is found by a binary search of indptr (device copy) per posting.
+__global__ __launch_bounds__(256) void bm25_contrib_kernel(const int64_t *__restrict__ indptr, int64_t n_terms, int64_t nnz,
+                                                          const int32_t *__restrict__ doc_ids, const float *__restrict__ tf,
+                                                          const double *__restrict__ doc_k, const double *__restrict__ idf, double k1p1,
+                                                          double *__restrict__ contrib) {
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < nnz; p += (int64_t)gridDim.x * 256) {
+        int64_t lo = 0, hi = n_terms;   // the last term t with indptr[t] <= p
+        while (hi - lo > 1) {
+            const int64_t mid = lo + ((hi - lo) >> 1);
+            if (indptr[mid] <= p) lo = mid;
+            else hi = mid;
+        }
+        const double w = idf[lo];
+        const double fd = (double)tf[p];
+        const double numer = (fd * w) * k1p1;
+        const double denom = fd + doc_k[doc_ids[p]];
+        contrib[p] = numer / denom;
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// Batched selection of the top-k of a batch of finished fp32 score rows (r4).  The exact dense selection (one 256-thread
+// Batched selection of the top-k of a batch of rows (r4; r5: fused into the tile scorer).  The exact dense selection (one 256-thread
 // workgroup per query walking its whole row through four radix passes, every zero score landing in ONE histogram bin) took 70 %
 // of a BM25 search: 5.2 ms per batch of 256 queries x 500 k documents.  Instead, the retrieval path's estimate-and-verify filter:
-//   threshold : tau_row = the r-th largest score of a 1/64 SAMPLE of the row (contiguous 64-document pieces, one out of every 64),
-//               r = the rank for which fewer than k documents pass with probability < 1e-7 (r = 41 at k = 1001: ~2 600 pass);
-//   collect   : every (row, 16 K-document chunk) block streams its scores ONCE and appends the documents with score >= tau (and > 0
-//               when tau <= 0: a BM25 row is mostly exact zeros) to the row's candidate list -- a 64-bit pass mask per lane, one
-//               list reservation per wave;
+//   sample    : bm25_tile_kernel<.., BM25_SAMPLE> scores one 1 024-document piece out of every 64 of each row (a wave per (row, piece))
+//               into a compact [rows][pieces * 1024] sample -- 1/64 of the scoring work, but a pass of dependent round trips (a binary
+//               search per term, then ids -> K_d -> LDS per term): 256-document pieces, four times as many items, took 0.80 ms against
+//               4.6 ms for the whole filter pass;
+//   threshold : tau_row = the r-th largest score of the row's sample, r = the rank for which fewer than k documents pass with
+//               probability < 1e-7 (r = 41 at k = 1001: ~2 600 pass);
+//   filter    : bm25_tile_kernel<.., BM25_FILTER> scores every tile and appends the documents with score >= tau (and > 0 when
+//               tau <= 0: a BM25 row is mostly exact zeros) to the row's candidate list straight from the tile's registers;
 //   top-k     : per row, if k <= candidates <= capacity the k best of the list by (score desc, document asc) ARE the row's top-k
 //               (everything >= tau is in the list and at least k documents are >= tau): bitonic sort of 64-bit keys in LDS.
 //               Otherwise (an estimate that came out too high, a query whose terms match fewer than k documents, a flooded list)
-//               the row is put on a list for the exact dense selection, which runs for the listed rows only.
+//               the row is put on a list; the listed rows are scored again with their fp32 rows stored (BM25_STORE) and go through
+//               the exact dense selection.
 // Exact for every input; the order rule is the same everywhere.
-constexpr int BM25_SAMPLE_PIECE = 64;        // documents per sampled piece (256 contiguous bytes)
+constexpr int BM25_SAMPLE_PIECE = 1024;      // documents per sampled piece (the SAMPLE instantiation's tile)
 constexpr int BM25_SAMPLE_EVERY = 64;        // one piece out of this many
 constexpr int BM25_SAMPLE_MAX = 16384;       // sampled scores the threshold kernel holds in LDS
-constexpr int BM25_COLLECT_CHUNK = 16384;    // documents per collect block (64 per thread)
-constexpr int BM25_LIST_CAP = 16384;         // candidate records per row (128 KiB of keys in the top-k kernel)
 
-// grid = rows, block = 256.  tau[row] = the rank-th largest sampled score (0 if the sample holds fewer than `rank` scores).
-__global__ __launch_bounds__(256) void bm25_threshold_kernel(const float *__restrict__ scores, int64_t n_docs, int64_t piece_stride, int n_pieces,
-                                                            int rank, float *__restrict__ tau, uint32_t *__restrict__ list_cnt) {
+// grid = rows, block = 256.  tau[row] = the rank-th largest of the row's n sampled scores (sample rows are contiguous; pieces that
+// reach beyond the corpus were filled with -inf).  Also zeroes the row's list counter.
+__global__ __launch_bounds__(256) void bm25_threshold_kernel(const float *__restrict__ sample, int n, int rank, float *__restrict__ tau,
+                                                            uint32_t *__restrict__ list_cnt) {
     extern __shared__ __attribute__((aligned(16))) float s_val[];
     __shared__ uint32_t s_hist[256];
     __shared__ uint32_t s_ctl[4];
     const int tid = threadIdx.x;
-    const float *row = scores + (int64_t)blockIdx.x * n_docs;
-    const int n = n_pieces * BM25_SAMPLE_PIECE;
-    for (int i = tid; i < n; i += 256) {
-        const int64_t d = (int64_t)(i / BM25_SAMPLE_PIECE) * piece_stride + (i % BM25_SAMPLE_PIECE);
-        s_val[i] = d < n_docs ? row[d] : -INFINITY;
-    }
+    const float *row = sample + (int64_t)blockIdx.x * n;
+    for (int i = tid; i < n; i += 256) s_val[i] = row[i];
     if (tid == 0) list_cnt[blockIdx.x] = 0u;
     __syncthreads();
     uint32_t kth = 0;
@@ -248,93 +347,21 @@ __global__ __launch_bounds__(256) void bm25_threshold_kernel(const float *__rest
     if (tid == 0) tau[blockIdx.x] = orderable_to_f32(kth);
 }
 
-// grid = (chunks, rows), block = 256.  Records {score bits, document} of the documents that pass go to list[row][...]; odd_cnt[row]
-// counts the scores that are negative or NaN (a BM25 row has none: then every document that is not in the list of a row with tau <= 0
-// scores exactly zero).  No LDS, no barrier: a wave's 16 loads per lane are in flight together, and it reserves room for all of its
-// hits with ONE global atomic.
-__global__ __launch_bounds__(256) void bm25_collect_kernel(const float *__restrict__ scores, int64_t n_docs, const float *__restrict__ tau,
-                                                          uint2 *__restrict__ list, uint32_t *__restrict__ list_cnt, uint32_t *__restrict__ odd_cnt) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int r = blockIdx.y;
-    const float t = tau[r];
-    const float *row = scores + (int64_t)r * n_docs;
-    uint2 *out = list + (int64_t)r * BM25_LIST_CAP;
-    // wave w of the block takes documents [lo, lo + 4096): 16 steps of 64 lanes x 4 consecutive documents
-    const int64_t lo = (int64_t)blockIdx.x * BM25_COLLECT_CHUNK + (int64_t)wv * (BM25_COLLECT_CHUNK / 4);
-    constexpr int STEPS = BM25_COLLECT_CHUNK / 4 / 256;
-    float v[STEPS][4];
-    // wave-uniform: the wave's 4 096 documents lie inside the row and the row is 16-byte aligned -> 16 unconditional vector loads, all in
-    // flight together (a bounds test per step puts a branch between the loads and serialises their latencies: 1.66 instead of 0.4 ms)
-    const bool whole = (reinterpret_cast<uintptr_t>(row) & 15) == 0 && lo + BM25_COLLECT_CHUNK / 4 <= n_docs;
-    if (whole) {
-#pragma unroll
-        for (int st = 0; st < STEPS; ++st) {
-            const float4 q = *reinterpret_cast<const float4 *>(row + lo + st * 256 + 4 * lane);
-            v[st][0] = q.x, v[st][1] = q.y, v[st][2] = q.z, v[st][3] = q.w;
-        }
-    } else {
-#pragma unroll
-        for (int st = 0; st < STEPS; ++st) {
-            const int64_t d0 = lo + st * 256 + 4 * lane;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {   // clamped address, masked value: the loads stay unconditional here too
-                const int64_t d = d0 + e < n_docs ? d0 + e : n_docs - 1;
-                const float x = row[d];
-                v[st][e] = d0 + e < n_docs ? x : 0.f;   // (beyond the row: an exact zero, never collected)
-            }
-        }
-    }
-    // which of the lane's 64 documents pass: one bit each; ONE reservation per wave for all of them (a returning atomic per 256-document
-    // step made the wave wait for 10 - 16 dependent round trips: 1.85 instead of 0.2 ms per launch)
-    uint32_t odd = 0;
-    unsigned long long mask = 0ull;
-#pragma unroll
-    for (int st = 0; st < STEPS; ++st) {
-        const int64_t d0 = lo + st * 256 + 4 * lane;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float x = v[st][e];
-            const bool pass = x >= t && (t > 0.f || x > 0.f) && d0 + e < n_docs;
-            mask |= pass ? (1ull << (st * 4 + e)) : 0ull;
-            odd += (x < 0.f || x != x) ? 1u : 0u;
-        }
-    }
-    const int mine = __popcll(mask);
-    if (__ballot(mine != 0) != 0ull) {   // wave-uniform
-        int incl = mine;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int up = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += up;
-        }
-        const int total = __shfl(incl, 63, 64);
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&list_cnt[r], (uint32_t)total);
-        base = (uint32_t)__shfl((int)base, 0, 64) + (uint32_t)(incl - mine);
-#pragma unroll
-        for (int st = 0; st < STEPS; ++st) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if ((mask >> (st * 4 + e)) & 1ull) {
-                    if (base < (uint32_t)BM25_LIST_CAP)
-                        out[base] = make_uint2(__float_as_uint(v[st][e]), (uint32_t)(lo + st * 256 + 4 * lane + e));
-                    ++base;
-                }
-        }
-    }
-    const unsigned long long any_odd = __ballot(odd != 0u);
-    if (any_odd != 0ull && lane == 0) atomicAdd(&odd_cnt[r], 1u);
-}
-
-// grid = rows, block = 1024, dyn LDS = BM25_LIST_CAP keys.  Rows that cannot be finished here are appended to redo_list.
-__global__ __launch_bounds__(1024) void bm25_topk_kernel(const uint2 *__restrict__ list, const uint32_t *__restrict__ list_cnt,
-                                                        const uint32_t *__restrict__ odd_cnt, const float *__restrict__ tau, int64_t n_docs, int k,
-                                                        int q_begin, float *__restrict__ out_scores, int64_t *__restrict__ out_ids,
-                                                        uint32_t *__restrict__ redo_cnt, uint32_t *__restrict__ redo_list) {
+// grid = rows, block = NT, dyn LDS = 12 bytes x the class's key capacity.  Two launches share the rows: the SMALL class (lists of up to
+// BM25_TOPK_SMALL records, 48 KiB of LDS, three 512-thread workgroups per CU -- nearly every row: ~2 600 records are expected at k = 1001)
+// and the rest (up to BM25_LIST_CAP, 128 KiB + , one 1024-thread workgroup per CU); a block whose row belongs to the other class
+// exits.  Rows that cannot be finished here are appended to redo_list.
+constexpr int BM25_TOPK_SMALL = 4096;
+template <int NT, bool SMALL>
+__global__ __launch_bounds__(NT) void bm25_topk_kernel(const uint2 *__restrict__ list, const uint32_t *__restrict__ list_cnt,
+                                                      const uint32_t *__restrict__ odd_cnt, const float *__restrict__ tau, int64_t n_docs, int k,
+                                                      int q_begin, float *__restrict__ out_scores, int64_t *__restrict__ out_ids,
+                                                      uint32_t *__restrict__ redo_cnt, uint32_t *__restrict__ redo_list) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];
     const int tid = threadIdx.x;
     const int r = blockIdx.x;
     const uint32_t n = list_cnt[r];
+    if ((n <= (uint32_t)BM25_TOPK_SMALL) != SMALL) return;   // block-uniform: the other launch's row
     // Fewer than k documents passed.  With tau <= 0 and no negative / NaN score in the row the list holds EVERY non-zero document, all
     // others score exactly zero, and the row's top-k is the sorted list followed by the k - n lowest-numbered documents outside it
     // (a query whose terms match fewer than k documents: common for rare terms).  Anything else -- an estimate that came out too high,
@@ -346,7 +373,7 @@ __global__ __launch_bounds__(1024) void bm25_topk_kernel(const uint2 *__restrict
     }
     const int np2 = n ? pow2_ceil((int)n) : 1;
     const uint2 *src = list + (int64_t)r * BM25_LIST_CAP;
-    for (int i = tid; i < np2; i += 1024) {
+    for (int i = tid; i < np2; i += NT) {
         unsigned long long key = 0ull;
         if (i < (int)n) {
             const uint2 e = src[i];
@@ -357,7 +384,7 @@ __global__ __launch_bounds__(1024) void bm25_topk_kernel(const uint2 *__restrict
     block_bitonic_sort_desc(s_keys, np2);
     const int64_t orow = (int64_t)(q_begin + r);
     const int head = n < (uint32_t)k ? (int)n : k;
-    for (int i = tid; i < head; i += 1024) {
+    for (int i = tid; i < head; i += NT) {
         const unsigned long long key = s_keys[i];
         out_scores[orow * k + i] = key_score(key);
         out_ids[orow * k + i] = (int64_t)key_idx(key);
@@ -368,9 +395,9 @@ __global__ __launch_bounds__(1024) void bm25_topk_kernel(const uint2 *__restrict
         // list (n < k <= 8 192 entries in LDS; this path serves a few rare-term queries)
         __syncthreads();
         unsigned int *s_doc = reinterpret_cast<unsigned int *>(s_keys + np2);     // the listed documents, unsorted
-        for (int i = tid; i < (int)n; i += 1024) s_doc[i] = key_idx(s_keys[i]);
+        for (int i = tid; i < (int)n; i += NT) s_doc[i] = key_idx(s_keys[i]);
         __syncthreads();
-        for (int j = tid; j < k - (int)n; j += 1024) {
+        for (int j = tid; j < k - (int)n; j += NT) {
             // fixed point of d = j + #{listed < = d}: monotone, converges in at most n + 1 rounds (usually 1 - 2)
             unsigned int d = (unsigned int)j;
             for (;;) {
@@ -427,11 +454,15 @@ struct ccr_bm25_index {
     const int32_t *doc_ids;        // device, borrowed
     const float *tf;               // device, borrowed
     const double *doc_k;           // device, borrowed
+    const double *contrib;         // device, borrowed: finished contributions under `idf` (ccr_bm25_index_set_idf), or null
+    std::vector<double> idf;       // host copy of the idf the table was built with
     int64_t n_terms, n_docs;
     double k1;
     int num_cu;
     int run_tiles_knob;            // CCR_BM25_RUN_TILES: 0 = planner's choice, else tiles per ticket (tuning)
-    int tile_cfg;                  // CCR_BM25_TILE: -1 = round kernels only (the A/B knob), 0 = default tile shape (1024 documents, 128-posting steps), 1 = 1024/64, 2 = 512/128
+    mutable int64_t stats[4];      // of the last search: path (0 rounds + stored rows, 1 tile scorer + stored rows, 2 fused filter; + 4: contribution table), rows redone, batches, sample rank
+    int redo_rows_knob;            // CCR_BM25_REDO_ROWS: rows of the fused path's redo area (tests: forces several redo chunks)
+    int tile_cfg;                  // CCR_BM25_TILE: -1 = round kernels only (the A/B knob), 0 = default tile shape (1024 documents, 128-posting steps), 1 = 1024/64, 2 = 512/128, 3 = 1024/256
 };
 
 extern "C" int ccr_bm25_index_create(const int64_t *indptr_host, const int32_t *doc_ids, const float *tf, const double *doc_k,
@@ -478,6 +509,7 @@ extern "C" int ccr_bm25_index_create(const int64_t *indptr_host, const int32_t *
     ix->doc_ids = doc_ids;
     ix->tf = tf;
     ix->doc_k = doc_k;
+    ix->contrib = nullptr;
     ix->n_terms = n_terms;
     ix->n_docs = n_docs;
     ix->k1 = k1;
@@ -486,7 +518,44 @@ extern "C" int ccr_bm25_index_create(const int64_t *indptr_host, const int32_t *
     ix->tile_cfg = cfg ? atoi(cfg) : 0;
     const char *rt = getenv("CCR_BM25_RUN_TILES");
     ix->run_tiles_knob = rt ? atoi(rt) : 0;
+    const char *rr = getenv("CCR_BM25_REDO_ROWS");
+    ix->redo_rows_knob = rr ? atoi(rr) : 0;
+    ix->stats[0] = ix->stats[1] = ix->stats[2] = ix->stats[3] = 0;
     *out = ix;
+    return CCR_OK;
+}
+
+extern "C" int ccr_bm25_index_set_idf(ccr_bm25_index *ix, const double *idf_host, double *contrib, void *stream) {
+    CCR_REQUIRE(ix && idf_host && contrib, "ccr_bm25_index_set_idf: null pointer");
+    const int64_t nnz = ix->indptr[ix->n_terms];
+    ix->contrib = nullptr;
+    ix->idf.assign(idf_host, idf_host + ix->n_terms);
+    if (nnz == 0) return CCR_OK;
+    hipStream_t s = (hipStream_t)stream;
+    char *tmp = nullptr;
+    const size_t ptr_bytes = ((size_t)(ix->n_terms + 1) * 8 + 255) / 256 * 256;
+    CCR_HIP_CHECK(hipMalloc((void **)&tmp, ptr_bytes + (size_t)ix->n_terms * 8));
+    hipError_t e = hipMemcpyAsync(tmp, ix->indptr.data(), (size_t)(ix->n_terms + 1) * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(tmp + ptr_bytes, idf_host, (size_t)ix->n_terms * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(bm25_contrib_kernel, dim3((unsigned)std::min<int64_t>((nnz + 255) / 256, 1 << 20)), dim3(256), 0, s, (const int64_t *)tmp,
+                           ix->n_terms, nnz, ix->doc_ids, ix->tf, ix->doc_k, (const double *)(tmp + ptr_bytes), ix->k1 + 1.0, contrib);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) {
+        set_error("ccr_bm25_index_set_idf: %s", hipGetErrorString(e));
+        return CCR_ERR_HIP;
+    }
+    const char *off = getenv("CCR_BM25_TABLE");
+    if (!(off && atoi(off) == 0)) ix->contrib = contrib;   // CCR_BM25_TABLE=0: build it, never use it (the A/B knob)
+    return CCR_OK;
+}
+
+extern "C" int ccr_bm25_search_last_stats(const ccr_bm25_index *ix, int64_t *out4) {
+    CCR_REQUIRE(ix && out4, "ccr_bm25_search_last_stats: null pointer");
+    for (int i = 0; i < 4; ++i) out4[i] = ix->stats[i];
     return CCR_OK;
 }
 
@@ -496,57 +565,140 @@ extern "C" int ccr_bm25_index_destroy(ccr_bm25_index *ix) {
 }
 
 namespace {
-// Workspace of one search.  Tile scorer: fp32 score rows only (up to 4 096 query rows per batch); round kernels (queries of more
-// than 64 distinct terms, CCR_BM25_TILE=-1): fp64 accumulator rows beside them (up to 256).
-struct Bm25Layout {
-    bool tile;
-    int rows;
-    size_t scores_off, table_off, sel_off, total;
+// The sample of the estimate-and-verify selection: one BM25_SAMPLE_PIECE-document piece out of every `every`.
+struct Bm25Sample {
+    int64_t every;
+    int n_pieces, rank;
+    bool ok;     // the corpus is large enough for the sampled filter at this k
 };
-Bm25Layout bm25_layout(const ccr_bm25_index *ix, int n_q, int max_terms) {
+Bm25Sample bm25_sample_plan(const ccr_bm25_index *ix, int k) {
+    Bm25Sample S;
+    const int64_t all_pieces = (ix->n_docs + BM25_SAMPLE_PIECE - 1) / BM25_SAMPLE_PIECE;
+    S.every = BM25_SAMPLE_EVERY;
+    while ((all_pieces + S.every - 1) / S.every * BM25_SAMPLE_PIECE > BM25_SAMPLE_MAX) S.every *= 2;
+    S.n_pieces = (int)((all_pieces + S.every - 1) / S.every);
+    const double fs = (double)S.n_pieces * BM25_SAMPLE_PIECE / (double)ix->n_docs;
+    S.rank = bm25_sample_rank(k, fs);
+    // the sampled filter needs a sample that holds several times the rank; smaller corpora keep the exact dense selection
+    S.ok = getenv("CCR_BM25_DENSE_SELECT") == nullptr && (int64_t)S.n_pieces * BM25_SAMPLE_PIECE >= 8 * (int64_t)S.rank &&
+           (double)S.rank / fs * 2.0 + 1024.0 <= (double)BM25_LIST_CAP && k <= BM25_LIST_CAP / 2;
+    return S;
+}
+
+// Workspace of one search.
+//   fused (tile scorer + sampled filter, the default from ~30 k documents up): no score rows at all -- per row of the batch (up to
+//     4 096) a 128-KiB candidate list and a sample row, plus fp32 score rows for `redo_rows` rows at a time (the rows the filter could
+//     not finish; ~1 GiB);
+//   stored (small corpora, k beyond the candidate lists, CCR_BM25_DENSE_SELECT): fp32 score rows of the whole batch (~8 GiB of them),
+//     exact dense selection of every row; the round kernels (queries of more than 64 distinct terms, CCR_BM25_TILE=-1) keep their fp64
+//     accumulator rows beside them (up to 256 rows).
+struct Bm25Layout {
+    bool tile, fused;
+    int rows, redo_rows;
+    Bm25Sample sample;
+    size_t scores_off, table_off, sel_off, sample_off, total;
+};
+Bm25Layout bm25_layout(const ccr_bm25_index *ix, int n_q, int max_terms, int k) {
     Bm25Layout L;
     L.tile = ix->tile_cfg >= 0 && max_terms <= BM25_MAX_TILE_TERMS;
-    const int64_t per_row = ix->n_docs * (L.tile ? 4 : 12);
-    int64_t rows = ((int64_t)8 << 30) / per_row;                   // ~8 GiB of score rows per batch
-    rows = std::min<int64_t>(std::max<int64_t>(rows, 1), L.tile ? 4096 : 256);
-    L.rows = (int)std::min<int64_t>(rows, n_q);
+    L.sample = bm25_sample_plan(ix, k > 0 ? k : 1);
+    L.fused = L.tile && k > 0 && L.sample.ok;
     const size_t terms = (size_t)std::max(1, max_terms);
-    L.scores_off = L.tile ? 0 : (size_t)L.rows * ix->n_docs * 8;
-    L.table_off = (L.scores_off + (size_t)L.rows * ix->n_docs * 4 + 255) / 256 * 256;
+    if (L.fused) {
+        L.rows = std::min(n_q, 4096);
+        L.redo_rows = (int)std::min<int64_t>(std::max<int64_t>(((int64_t)1 << 30) / (ix->n_docs * 4), 4), L.rows);
+        if (ix->redo_rows_knob > 0) L.redo_rows = std::min(ix->redo_rows_knob, L.rows);
+        L.scores_off = 0;
+        L.table_off = ((size_t)L.redo_rows * ix->n_docs * 4 + 255) / 256 * 256;
+    } else {
+        const int64_t per_row = ix->n_docs * (L.tile ? 4 : 12);
+        int64_t rows = ((int64_t)8 << 30) / per_row;                   // ~8 GiB of score rows per batch
+        rows = std::min<int64_t>(std::max<int64_t>(rows, 1), L.tile ? 4096 : 256);
+        L.rows = (int)std::min<int64_t>(rows, n_q);
+        L.redo_rows = 0;
+        L.scores_off = L.tile ? 0 : (size_t)L.rows * ix->n_docs * 8;
+        L.table_off = (L.scores_off + (size_t)L.rows * ix->n_docs * 4 + 255) / 256 * 256;
+    }
     const size_t table = L.tile ? (size_t)L.rows * terms * sizeof(Bm25Term) + ((size_t)L.rows + 1) * 4 : (size_t)L.rows * terms * sizeof(Bm25Round);
     L.sel_off = (L.table_off + table + 255) / 256 * 256;
-    // the batched selection: candidate lists, thresholds, counters, redo list
-    L.total = L.sel_off + (size_t)L.rows * BM25_LIST_CAP * 8 + (size_t)L.rows * 20 + 256 * 4;
+    // the fused selection: candidate lists, thresholds, counters, redo list, then the sample rows
+    const size_t sel = L.fused ? (size_t)L.rows * BM25_LIST_CAP * 8 + (size_t)L.rows * 20 + 256 * 4 : 256;
+    L.sample_off = (L.sel_off + sel + 255) / 256 * 256;
+    L.total = L.sample_off + (L.fused ? (size_t)L.rows * L.sample.n_pieces * BM25_SAMPLE_PIECE * 4 : 0);
     return L;
 }
 
-template <int T, int U>
-int launch_bm25_tile(const ccr_bm25_index *ix, const Bm25Term *terms, const int32_t *row_ptr, int m, uint32_t *ticket, float *scores,
-                     hipStream_t s) {
+struct Bm25TileArgs {
+    const Bm25Term *terms;
+    const int32_t *row_ptr;
+    int m;                      // rows of this launch
+    uint32_t *ticket;
+    float *scores;              // STORE: [m][n_docs]; SAMPLE: [m][n_pieces * T]
+    const uint32_t *row_map;    // STORE of listed rows
+    const float *tau;           // FILTER
+    uint2 *list;
+    uint32_t *list_cnt, *odd_cnt;
+    int64_t sample_every;       // SAMPLE: one piece of T documents out of this many
+    int sample_pieces;
+    bool table;                 // the queries use the index's idf: finished contributions instead of tf / K_d
+};
+
+template <int T, int U, int MODE>
+int launch_bm25_tile(const ccr_bm25_index *ix, const Bm25TileArgs &a, hipStream_t s) {
     const int64_t n_tiles = (ix->n_docs + T - 1) / T;
+    const int m = a.m;
     const int wgs_per_cu = std::max(1, std::min(8, (int)(160 * 1024 / (BM25_TILE_WAVES * T * 8))));
     const int64_t waves = (int64_t)ix->num_cu * wgs_per_cu * BM25_TILE_WAVES;
-    // Tiles per ticket.  Consecutive tickets are consecutive query rows on the SAME run of documents, so the waves in flight read the
-    // same slices of the common terms' posting lists: short runs keep those slices (and their doc_k) inside the XCDs' L2 -- 4 to 12 tiles
-    // per ticket measured 10 % faster end to end than 24 or 48 (L2 hit rate of the kernel 81 % at 24), 2 slower again (a binary search
-    // per term and ticket).  About 24 tickets per wave, at most 12 tiles, at least 4 where that still leaves two tickets per wave.
-    int64_t runs = std::min<int64_t>(std::max<int64_t>((24 * waves + m - 1) / m, 1), n_tiles);
-    int run_tiles = (int)std::min<int64_t>((n_tiles + runs - 1) / runs, 12);
-    if (run_tiles < 4 && (n_tiles / 4) * (int64_t)m >= 2 * waves) run_tiles = 4;
-    if (ix->run_tiles_knob > 0) run_tiles = (int)std::min<int64_t>(ix->run_tiles_knob, n_tiles);
-    runs = (n_tiles + run_tiles - 1) / run_tiles;
+    int64_t runs, stride;
+    int run_tiles;
+    if (MODE == BM25_SAMPLE) {
+        runs = a.sample_pieces, run_tiles = 1, stride = a.sample_every * T;
+    } else {
+        // Tiles per ticket.  Consecutive tickets are consecutive query rows on the SAME run of documents, so the waves in flight read the
+        // same slices of the common terms' posting lists: short runs keep those slices (and their doc_k) inside the XCDs' L2 -- 4 to 12 tiles
+        // per ticket measured 10 % faster end to end than 24 or 48 (L2 hit rate of the kernel 81 % at 24), 2 slower again (a binary search
+        // per term and ticket).  About 24 tickets per wave, at most 12 tiles, at least 4 where that still leaves two tickets per wave.
+        runs = std::min<int64_t>(std::max<int64_t>((24 * waves + m - 1) / m, 1), n_tiles);
+        run_tiles = (int)std::min<int64_t>((n_tiles + runs - 1) / runs, 12);
+        if (run_tiles < 4 && (n_tiles / 4) * (int64_t)m >= 2 * waves) run_tiles = 4;
+        if (ix->run_tiles_knob > 0) run_tiles = (int)std::min<int64_t>(ix->run_tiles_knob, n_tiles);
+        runs = (n_tiles + run_tiles - 1) / run_tiles;
+        stride = (int64_t)run_tiles * T;
+    }
     const int64_t items = runs * m;
     const unsigned grid = (unsigned)std::min<int64_t>((items + BM25_TILE_WAVES - 1) / BM25_TILE_WAVES, (int64_t)ix->num_cu * wgs_per_cu);
-    hipLaunchKernelGGL((bm25_tile_kernel<T, U>), dim3(grid), dim3(64 * BM25_TILE_WAVES), 0, s, terms, row_ptr, m, ix->doc_ids, ix->tf, ix->doc_k,
-                       ix->k1 + 1.0, ix->n_docs, run_tiles, (int)runs, ticket, scores);
+    if (a.table)
+        hipLaunchKernelGGL((bm25_tile_kernel<T, U, MODE, true>), dim3(grid), dim3(64 * BM25_TILE_WAVES), 0, s, a.terms, a.row_ptr, m, ix->doc_ids, ix->tf,
+                           ix->doc_k, ix->contrib, ix->k1 + 1.0, ix->n_docs, run_tiles, (int)runs, stride, a.ticket, a.scores, a.row_map, a.tau, a.list,
+                           a.list_cnt, a.odd_cnt);
+    else
+        hipLaunchKernelGGL((bm25_tile_kernel<T, U, MODE, false>), dim3(grid), dim3(64 * BM25_TILE_WAVES), 0, s, a.terms, a.row_ptr, m, ix->doc_ids, ix->tf,
+                           ix->doc_k, ix->contrib, ix->k1 + 1.0, ix->n_docs, run_tiles, (int)runs, stride, a.ticket, a.scores, a.row_map, a.tau, a.list,
+                           a.list_cnt, a.odd_cnt);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
 }
+
+template <int MODE>
+int launch_bm25_tile_cfg(const ccr_bm25_index *ix, const Bm25TileArgs &a, hipStream_t s) {
+    switch (ix->tile_cfg) {   // measured at 500 k documents x 2 000 queries (tools/exp_bm25_tile.py): 1024/2 4.7 ms, 512/2 the same, wider steps slower
+        case 1: return launch_bm25_tile<1024, 1, MODE>(ix, a, s);
+        case 2: return launch_bm25_tile<512, 2, MODE>(ix, a, s);
+        case 3: return launch_bm25_tile<1024, 4, MODE>(ix, a, s);
+        default: return launch_bm25_tile<1024, 2, MODE>(ix, a, s);
+    }
+}
 }  // namespace
 
+extern "C" size_t ccr_bm25_search_workspace_bytes_k(const ccr_bm25_index *ix, int n_q, int max_terms_per_query, int k) {
+    if (!ix || n_q <= 0 || max_terms_per_query < 0 || k < 1) return 0;
+    return bm25_layout(ix, n_q, max_terms_per_query, k).total;
+}
+
+// k unknown: the larger of the two layouts (a workspace of this size serves every k)
 extern "C" size_t ccr_bm25_search_workspace_bytes(const ccr_bm25_index *ix, int n_q, int max_terms_per_query) {
     if (!ix || n_q <= 0 || max_terms_per_query < 0) return 0;
-    return bm25_layout(ix, n_q, max_terms_per_query).total;
+    return std::max(bm25_layout(ix, n_q, max_terms_per_query, 0).total, bm25_layout(ix, n_q, max_terms_per_query, 1).total);
 }
 
 extern "C" int ccr_bm25_search(const ccr_bm25_index *ix, const int64_t *q_ptr_host, const int32_t *q_terms_host,
@@ -557,6 +709,7 @@ extern "C" int ccr_bm25_search(const ccr_bm25_index *ix, const int64_t *q_ptr_ho
                 MAX_K);
     if (n_q == 0) return CCR_OK;
     int max_terms = 0;
+    bool table = ix->contrib != nullptr;   // ... and every query weight is the index's idf of that term, bit for bit
     for (int q = 0; q < n_q; ++q) {
         const int64_t a = q_ptr_host[q], b = q_ptr_host[q + 1];
         CCR_REQUIRE(a <= b, "ccr_bm25_search: q_ptr not monotone at query %d", q);
@@ -565,45 +718,41 @@ extern "C" int ccr_bm25_search(const ccr_bm25_index *ix, const int64_t *q_ptr_ho
             CCR_REQUIRE(q_terms_host && q_idf_host, "ccr_bm25_search: null term arrays");
             CCR_REQUIRE(q_terms_host[i] >= 0 && q_terms_host[i] < ix->n_terms, "ccr_bm25_search: term id %d out of range", q_terms_host[i]);
             CCR_REQUIRE(i == a || q_terms_host[i] > q_terms_host[i - 1], "ccr_bm25_search: terms of query %d not strictly ascending", q);
+            if (table && memcmp(&q_idf_host[i], &ix->idf[q_terms_host[i]], 8) != 0) table = false;
         }
     }
-    const Bm25Layout L = bm25_layout(ix, n_q, max_terms);
+    const Bm25Layout L = bm25_layout(ix, n_q, max_terms, k);
     if (!workspace || ws_bytes < L.total || (uintptr_t)workspace % 256 != 0) {
         set_error("ccr_bm25_search: workspace %zu bytes (256-byte aligned) required, got %zu at %p", L.total, ws_bytes, workspace);
         return CCR_ERR_WORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
     const int rows = L.rows;
+    ix->stats[0] = (L.fused ? 2 : (L.tile ? 1 : 0)) + (L.tile && table ? 4 : 0), ix->stats[1] = 0, ix->stats[2] = (n_q + rows - 1) / rows, ix->stats[3] = L.fused ? L.sample.rank : 0;
     char *ws = (char *)workspace;
     double *acc = (double *)ws;                                  // round kernels only
-    float *scores = (float *)(ws + L.scores_off);
+    float *scores = (float *)(ws + L.scores_off);                // stored: [rows][n_docs]; fused: [redo_rows][n_docs]
     Bm25Round *d_pairs = (Bm25Round *)(ws + L.table_off);        // round kernels
     Bm25Term *d_terms = (Bm25Term *)(ws + L.table_off);          // tile scorer: the batch's terms, then its row pointers
     char *sel = ws + L.sel_off;
-    uint2 *cand_list = (uint2 *)sel;
+    uint2 *cand_list = (uint2 *)sel;                             // fused only from here on
     float *tau = (float *)(sel + (size_t)rows * BM25_LIST_CAP * 8);
     uint32_t *list_cnt = (uint32_t *)(tau + rows);
-    uint32_t *odd_cnt = list_cnt + rows;           // [rows]: blocks that saw a negative / NaN score
-    uint32_t *redo_cnt = odd_cnt + rows;           // [1], then the tile scorer's ticket [1], pad [2]
-    uint32_t *ticket = redo_cnt + 1;
-    uint32_t *redo_list = redo_cnt + 4;            // [rows]
-    // the sampled filter needs a sample that holds several times the rank; smaller corpora keep the exact dense selection
-    const int64_t all_pieces = (ix->n_docs + BM25_SAMPLE_PIECE - 1) / BM25_SAMPLE_PIECE;
-    int64_t every = BM25_SAMPLE_EVERY;
-    while ((all_pieces + every - 1) / every * BM25_SAMPLE_PIECE > BM25_SAMPLE_MAX) every *= 2;
-    const int n_pieces = (int)((all_pieces + every - 1) / every);
-    const double fs = (double)n_pieces * BM25_SAMPLE_PIECE / (double)ix->n_docs;
-    const int rank = bm25_sample_rank(k, fs);
-    const bool sampled = getenv("CCR_BM25_DENSE_SELECT") == nullptr && (int64_t)n_pieces * BM25_SAMPLE_PIECE >= 8 * (int64_t)rank &&
-                         (double)rank / fs * 2.0 + 1024.0 <= (double)BM25_LIST_CAP && k <= BM25_LIST_CAP / 2;
-    if (sampled) {
-        const int rc1 = ensure_dynamic_lds(reinterpret_cast<const void *>(&bm25_topk_kernel), (size_t)BM25_LIST_CAP * 8);
+    uint32_t *odd_cnt = list_cnt + rows;           // [rows]: waves that saw a negative / NaN score
+    uint32_t *ctl = L.fused ? odd_cnt + rows : (uint32_t *)sel;   // [0] redo count, [1..3] tickets of the sample / filter / store launches
+    uint32_t *redo_list = ctl + 4;                 // [rows]
+    float *sample = (float *)(ws + L.sample_off);
+    const Bm25Sample &S = L.sample;
+    if (L.fused) {
+        const int rc1 = ensure_dynamic_lds(reinterpret_cast<const void *>(&bm25_topk_kernel<1024, false>), (size_t)BM25_LIST_CAP * 8);
         if (rc1 != CCR_OK) return rc1;
+        const int rc3 = ensure_dynamic_lds(reinterpret_cast<const void *>(&bm25_topk_kernel<512, true>), (size_t)BM25_TOPK_SMALL * 12);
+        if (rc3 != CCR_OK) return rc3;
         const int rc2 = ensure_dynamic_lds(reinterpret_cast<const void *>(&bm25_threshold_kernel), (size_t)BM25_SAMPLE_MAX * 4);
         if (rc2 != CCR_OK) return rc2;
     }
     if (!L.tile) CCR_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)rows * ix->n_docs * 8, s));
-    // One table per batch, uploaded once; the host tables stay alive until the synchronisation at the end of the call.
+    // One table per batch, uploaded once; the host tables stay alive until the synchronisation at the end of the batch.
     struct Round {
         size_t first, count;
         int64_t longest;
@@ -614,7 +763,8 @@ extern "C" int ccr_bm25_search(const ccr_bm25_index *ix, const int64_t *q_ptr_ho
     tile_tables.reserve((size_t)(n_q + rows - 1) / rows);
     for (int q0 = 0; q0 < n_q; q0 += rows) {
         const int m = std::min(rows, n_q - q0);
-        CCR_HIP_CHECK(hipMemsetAsync(odd_cnt, 0, (size_t)rows * 4 + 16, s));   // odd counts + the redo count and the ticket behind them
+        if (L.fused) CCR_HIP_CHECK(hipMemsetAsync(odd_cnt, 0, (size_t)rows * 4 + 16, s));   // odd counts + the redo count and the tickets behind them
+        else CCR_HIP_CHECK(hipMemsetAsync(ctl, 0, 16, s));
         if (L.tile) {
             // [terms of row 0 | row 1 | ...] with empty posting lists dropped, then int32 row pointers (16-byte aligned behind the terms)
             const size_t n_terms_batch = (size_t)(q_ptr_host[q0 + m] - q_ptr_host[q0]);
@@ -634,12 +784,43 @@ extern "C" int ccr_bm25_search(const ccr_bm25_index *ix, const int64_t *q_ptr_ho
             rp[m] = n;
             CCR_HIP_CHECK(hipMemcpyAsync(d_terms, blob.data(), blob.size(), hipMemcpyHostToDevice, s));
             const int32_t *d_row_ptr = reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(d_terms) + ptr_off);
-            int rc;
-            switch (ix->tile_cfg) {   // measured at 500 k documents x 2 000 queries (tools/exp_bm25_tile.py): 1024/2 4.7 ms, 512/2 the same, wider steps slower
-                case 1: rc = launch_bm25_tile<1024, 1>(ix, d_terms, d_row_ptr, m, ticket, scores, s); break;
-                case 2: rc = launch_bm25_tile<512, 2>(ix, d_terms, d_row_ptr, m, ticket, scores, s); break;
-                default: rc = launch_bm25_tile<1024, 2>(ix, d_terms, d_row_ptr, m, ticket, scores, s); break;
+            Bm25TileArgs a = {d_terms, d_row_ptr, m, ctl + 1, scores, nullptr, tau, cand_list, list_cnt, odd_cnt, S.every, S.n_pieces, table};
+            if (L.fused) {
+                // sample pieces -> tau per row -> every tile against tau -> sort the lists
+                a.scores = sample;
+                int rc = launch_bm25_tile<BM25_SAMPLE_PIECE, 2, BM25_SAMPLE>(ix, a, s);   // (this instantiation whatever CCR_BM25_TILE says)
+                if (rc != CCR_OK) return rc;
+                const int n_sample = S.n_pieces * BM25_SAMPLE_PIECE;
+                hipLaunchKernelGGL(bm25_threshold_kernel, dim3((unsigned)m), dim3(256), (size_t)n_sample * 4, s, sample, n_sample, S.rank, tau, list_cnt);
+                CCR_LAUNCH_CHECK();
+                a.scores = nullptr, a.ticket = ctl + 2;
+                rc = launch_bm25_tile_cfg<BM25_FILTER>(ix, a, s);
+                if (rc != CCR_OK) return rc;
+                hipLaunchKernelGGL((bm25_topk_kernel<512, true>), dim3((unsigned)m), dim3(512), (size_t)BM25_TOPK_SMALL * 12, s, cand_list, list_cnt, odd_cnt,
+                                   tau, ix->n_docs, k, q0, out_scores, out_ids, ctl, redo_list);
+                CCR_LAUNCH_CHECK();
+                hipLaunchKernelGGL((bm25_topk_kernel<1024, false>), dim3((unsigned)m), dim3(1024), (size_t)BM25_LIST_CAP * 8, s, cand_list, list_cnt, odd_cnt,
+                                   tau, ix->n_docs, k, q0, out_scores, out_ids, ctl, redo_list);
+                CCR_LAUNCH_CHECK();
+                // the rows the filter could not finish (usually none or a few rare-term queries): scored again with their rows stored,
+                // `redo_rows` at a time, exact dense selection
+                uint32_t n_redo = 0;
+                CCR_HIP_CHECK(hipMemcpyAsync(&n_redo, ctl, 4, hipMemcpyDeviceToHost, s));
+                CCR_HIP_CHECK(hipStreamSynchronize(s));
+                ix->stats[1] += n_redo;
+                for (uint32_t r0 = 0; r0 < n_redo; r0 += (uint32_t)L.redo_rows) {
+                    const int mr = (int)std::min<uint32_t>((uint32_t)L.redo_rows, n_redo - r0);
+                    CCR_HIP_CHECK(hipMemsetAsync(ctl + 3, 0, 4, s));
+                    Bm25TileArgs b = a;
+                    b.m = mr, b.ticket = ctl + 3, b.scores = scores, b.row_map = redo_list + r0;
+                    rc = launch_bm25_tile_cfg<BM25_STORE>(ix, b, s);
+                    if (rc != CCR_OK) return rc;
+                    rc = launch_dense_select(scores, ix->n_docs, k, nullptr, q0, mr, nullptr, 0, out_scores, out_ids, s, false, redo_list + r0, true);
+                    if (rc != CCR_OK) return rc;
+                }
+                continue;
             }
+            const int rc = launch_bm25_tile_cfg<BM25_STORE>(ix, a, s);
             if (rc != CCR_OK) return rc;
         } else {
             int rounds = 0;
@@ -679,23 +860,8 @@ extern "C" int ccr_bm25_search(const ccr_bm25_index *ix, const int64_t *q_ptr_ho
             hipLaunchKernelGGL(bm25_finish_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, (int64_t)1 << 30)), dim3(256), 0, s, acc, scores, n);   // one cell per thread: streams faster than a capped grid-stride loop
             CCR_LAUNCH_CHECK();
         }
-        if (sampled) {
-            hipLaunchKernelGGL(bm25_threshold_kernel, dim3((unsigned)m), dim3(256), (size_t)n_pieces * BM25_SAMPLE_PIECE * 4, s, scores, ix->n_docs,
-                               every * BM25_SAMPLE_PIECE, n_pieces, rank, tau, list_cnt);
-            CCR_LAUNCH_CHECK();
-            hipLaunchKernelGGL(bm25_collect_kernel, dim3((unsigned)((ix->n_docs + BM25_COLLECT_CHUNK - 1) / BM25_COLLECT_CHUNK), (unsigned)m), dim3(256), 0, s,
-                               scores, ix->n_docs, tau, cand_list, list_cnt, odd_cnt);
-            CCR_LAUNCH_CHECK();
-            hipLaunchKernelGGL(bm25_topk_kernel, dim3((unsigned)m), dim3(1024), (size_t)BM25_LIST_CAP * 8, s, cand_list, list_cnt, odd_cnt, tau,
-                               ix->n_docs, k, q0, out_scores, out_ids, redo_cnt, redo_list);
-            CCR_LAUNCH_CHECK();
-            // the rows the filter could not finish: exact dense selection for the listed rows only (blocks beyond the count exit at once)
-            const int rc = launch_dense_select(scores, ix->n_docs, k, nullptr, q0, m, redo_cnt, 0, out_scores, out_ids, s, false, redo_list);
-            if (rc != CCR_OK) return rc;
-        } else {
-            const int rc = launch_dense_select(scores, ix->n_docs, k, nullptr, q0, m, nullptr, 0, out_scores, out_ids, s, false, nullptr);
-            if (rc != CCR_OK) return rc;
-        }
+        const int rc = launch_dense_select(scores, ix->n_docs, k, nullptr, q0, m, nullptr, 0, out_scores, out_ids, s, false, nullptr, false);
+        if (rc != CCR_OK) return rc;
     }
     CCR_HIP_CHECK(hipStreamSynchronize(s));
     return CCR_OK;

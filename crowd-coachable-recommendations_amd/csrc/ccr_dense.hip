@@ -96,11 +96,13 @@ __global__ __launch_bounds__(256) void dense_select_kernel(const float *__restri
                                                           const uint32_t *__restrict__ out_rows, int q_begin,
                                                           const uint32_t *__restrict__ count_dev,
                                                           int64_t id_offset, float *__restrict__ out_scores,
-                                                          int64_t *__restrict__ out_ids, const uint32_t *__restrict__ in_rows) {
-    // in_rows (with count_dev): block b serves score row in_rows[b] of the chunk and writes output row q_begin + in_rows[b]; blocks
-    // beyond *count_dev exit (the listed-rows form: the BM25 filter's redo list)
+                                                          int64_t *__restrict__ out_ids, const uint32_t *__restrict__ in_rows,
+                                                          bool in_rows_compact) {
+    // in_rows: block b serves score row in_rows[b] of the chunk (in_rows_compact: score row b -- the listed rows were scored into
+    // consecutive rows) and writes output row q_begin + in_rows[b]; with count_dev, blocks beyond *count_dev exit (the listed-rows
+    // form: the BM25 filter's redo list)
     if (in_rows) {
-        if (blockIdx.x >= *count_dev) return;
+        if (count_dev && blockIdx.x >= *count_dev) return;
     } else if (count_dev && (int)blockIdx.x >= (int)*count_dev - q_begin) {
         return;
     }
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(256) void dense_select_kernel(const float *__restri
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int qi = in_rows ? (int)in_rows[blockIdx.x] : (int)blockIdx.x;
-    const float *row = scores + (int64_t)qi * n_rows;
+    const float *row = scores + (int64_t)(in_rows_compact ? (int)blockIdx.x : qi) * n_rows;
     const int kp2 = pow2_ceil(k);
 
     uint32_t kth;
@@ -184,17 +186,17 @@ int launch_dense_scores(const uint16_t *D, int64_t n_rows, int dim, const uint16
 
 int launch_dense_select(const float *scores, int64_t n_rows, int k, const uint32_t *out_rows, int q_begin, int nq_chunk,
                         const uint32_t *count_dev, int64_t id_offset, float *out_scores, int64_t *out_ids, hipStream_t s,
-                        bool aggregate, const uint32_t *in_rows) {
+                        bool aggregate, const uint32_t *in_rows, bool in_rows_compact) {
     // aggregate: wave-aggregated histogram updates in the radix passes.  Inner-product score rows sit in a handful of top-byte
     // bins (2.8 x faster per NQ-sized row: 0.65 vs 1.8 ms per query); BM25 score rows do not gain (24 k vs 29 k queries/s), so
     // that caller keeps plain atomics.
     const size_t lds = (size_t)pow2_ceil(k) * 8;
     if (aggregate)
         hipLaunchKernelGGL(dense_select_kernel<true>, dim3(nq_chunk), dim3(256), lds, s, scores, n_rows, k, out_rows, q_begin, count_dev,
-                           id_offset, out_scores, out_ids, in_rows);
+                           id_offset, out_scores, out_ids, in_rows, in_rows_compact);
     else
         hipLaunchKernelGGL(dense_select_kernel<false>, dim3(nq_chunk), dim3(256), lds, s, scores, n_rows, k, out_rows, q_begin, count_dev,
-                           id_offset, out_scores, out_ids, in_rows);
+                           id_offset, out_scores, out_ids, in_rows, in_rows_compact);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
 }

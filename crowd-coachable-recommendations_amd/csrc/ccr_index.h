@@ -73,7 +73,9 @@ int launch_dense_scores(const uint16_t *D, int64_t n_rows, int dim, const uint16
                         int q_begin, int nq_chunk, const uint32_t *count_dev, float *out, hipStream_t s);
 int launch_dense_select(const float *scores, int64_t n_rows, int k, const uint32_t *out_rows, int q_begin, int nq_chunk,
                         const uint32_t *count_dev, int64_t id_offset, float *out_scores, int64_t *out_ids, hipStream_t s,
-                        bool aggregate = true, const uint32_t *in_rows = nullptr);   // in_rows + count_dev: only the listed rows of the chunk
+                        bool aggregate = true, const uint32_t *in_rows = nullptr, bool in_rows_compact = false);
+// in_rows: block b ranks the score row in_rows[b] (in_rows_compact: score row b) and writes output row q_begin + in_rows[b]; with count_dev
+// only the first *count_dev blocks
 
 // Exact top-k from MFMA score rows [nq_chunk][pitch] + error margins (ccr_dense.hip); the chunk's query rows are contiguous at Q.
 // hint (per chunk query, or null): a valid lower bound of its k-th largest score -- one scan of the row instead of five.

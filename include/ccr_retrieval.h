@@ -392,15 +392,29 @@ int ccr_rank_metrics(const int64_t *ids, int n_q, int k, const int64_t *qrel_ptr
  *   score(q, d) = sum_t ascending (tf * idf_t) * (k1 + 1) / (tf + doc_k[d]) in fp64, rounded once to fp32;
  *   out_scores / out_ids [n_q][k] in the order (score desc, document index asc); documents without any query term
  *   score 0 and follow in index order, as a stable sort of the reference's dense score vector would leave them.
- *   Queries of up to 64 distinct terms run the document-tile scorer (fp64 accumulators in LDS, fp32 score rows in the workspace);
- *   a call with a longer query runs the round kernels (fp64 rows in the workspace): same bits.  The environment is read at
- *   ccr_bm25_index_create: CCR_BM25_TILE=-1 forces the round kernels.
+ *   Queries of up to 64 distinct terms run the document-tile scorer (fp64 accumulators in LDS); from ~30 k documents up the top-k
+ *   filter is fused into it (a sampled threshold per query, the documents that pass leave the tile's registers as candidate records,
+ *   verified; rows the filter cannot finish are scored again with their fp32 rows stored and ranked exactly), so no [n_q][n_docs]
+ *   score row exists and the workspace is ~130 KiB per query + 1 GiB.  Smaller corpora and CCR_BM25_DENSE_SELECT=1 store the fp32 rows
+ *   (~8 GiB per batch) and rank them exactly; a call with a longer query runs the round kernels (fp64 rows in the workspace): same
+ *   bits on every path.  CCR_BM25_TILE=-1 (read at ccr_bm25_index_create) forces the round kernels.
+ *   ccr_bm25_search_workspace_bytes_k sizes the workspace for one k; ccr_bm25_search_workspace_bytes for any k (the larger layout).
  */
 typedef struct ccr_bm25_index ccr_bm25_index;
 int ccr_bm25_index_create(const int64_t *indptr_host, const int32_t *doc_ids, const float *tf, const double *doc_k,
                           int64_t n_terms, int64_t n_docs, double k1, ccr_bm25_index **out);
 int ccr_bm25_index_destroy(ccr_bm25_index *index);
+/* Optional, once per index: the idf of every term (HOST, [n_terms]; BM25.fit's ln(n / df), scripts/bm_25.py:21-29) -> a table of the
+ * FINISHED contribution of every posting, contrib [nnz] fp64 (DEVICE, caller-owned, filled here; must outlive the index):
+ * (tf idf_t)(k1 + 1) / (tf + doc_k[d]) by the scorer's own operations, so the same bits.  A search whose q_idf entries all equal this
+ * idf bit for bit streams 12 bytes per posting and adds -- no doc_k gather, no fp64 division; any other search runs as before. */
+int ccr_bm25_index_set_idf(ccr_bm25_index *index, const double *idf_host, double *contrib, void *stream);
 size_t ccr_bm25_search_workspace_bytes(const ccr_bm25_index *index, int n_q, int max_terms_per_query);
+size_t ccr_bm25_search_workspace_bytes_k(const ccr_bm25_index *index, int n_q, int max_terms_per_query, int k);
+/* of the index's last search: out4 = {path: 0 round kernels + stored rows, 1 tile scorer + stored rows, 2 tile scorer + fused filter, + 4 if
+ * the contribution table was used;
+ * rows the filter could not finish (scored again and ranked exactly); batches; rank of the sampled threshold} */
+int ccr_bm25_search_last_stats(const ccr_bm25_index *index, int64_t *out4);
 int ccr_bm25_search(const ccr_bm25_index *index, const int64_t *q_ptr_host, const int32_t *q_terms_host,
                     const double *q_idf_host, int n_q, int k, float *out_scores, int64_t *out_ids, void *workspace,
                     size_t ws_bytes, void *stream);

@@ -112,11 +112,12 @@ def test_parallel_analysis_builds_the_same_index():
 @pytest.mark.gpu
 @pytest.mark.parametrize("k", [1, 100, 1001])
 def test_hip_bm25_sampled_selection_equals_the_dense_selection(k, monkeypatch):
-    """The batched estimate-and-verify selection (csrc/ccr_bm25.hip: sample threshold -> one streaming collect pass -> in-LDS sort,
-    rows it cannot finish redone by the exact dense selection) against the exact dense selection of every row (CCR_BM25_DENSE_SELECT=1)
-    and, on a subsample, the oracle: 120 k documents (two accumulator batches), queries that match most of the corpus (common terms),
-    queries that match FEWER than k documents (rare terms: their top-k continues with zero scores in document order -- the redo path),
-    an out-of-vocabulary query (all zeros), and 3 000 duplicated documents (mass ties at the cut)."""
+    """The fused estimate-and-verify selection (csrc/ccr_bm25.hip: sampled pieces -> tau per row -> every tile filtered against tau in
+    the scorer's registers -> in-LDS sort; rows it cannot finish are scored again with their fp32 rows stored and ranked by the exact
+    dense selection, CCR_BM25_REDO_ROWS at a time) against the stored-rows path (CCR_BM25_DENSE_SELECT=1: every row stored and ranked
+    exactly) and, on a subsample, the oracle: 120 k documents, queries that match most of the corpus (common terms), queries that
+    match FEWER than k documents (rare terms: their top-k continues with zero scores in document order), an out-of-vocabulary query
+    (all zeros), and 3 000 duplicated documents (mass ties at the cut -> the list floods -> the redo path)."""
     from ccrec_amd.bm25 import BM25
     rs = np.random.RandomState(17)
     words = np.array([f"t{i}" for i in range(6000)])
@@ -131,9 +132,11 @@ def test_hip_bm25_sampled_selection_equals_the_dense_selection(k, monkeypatch):
     hip = BM25(0.75, 1.2).fit(texts)
     monkeypatch.delenv("CCR_BM25_DENSE_SELECT", raising=False)
     s, i = hip.transform_topk(qtexts, k)
+    assert hip.last_stats()["path"] == "tile+fused_filter"
     monkeypatch.setenv("CCR_BM25_DENSE_SELECT", "1")
     s2, i2 = hip.transform_topk(qtexts, k)
     assert torch.equal(i, i2) and torch.equal(s.view(torch.int32), s2.view(torch.int32))
+    assert hip.last_stats()["path"] == "tile+stored_rows"
     assert (s[-2] == 0).all() and i[-2].tolist() == list(range(k))        # nothing matches: zeros in document order
     if k > 1:
         assert i[-1, 0].item() == 7 and s[-1, 0].item() == s[-1, 1].item()     # the duplicates tie, the lowest document id first
@@ -141,6 +144,47 @@ def test_hip_bm25_sampled_selection_equals_the_dense_selection(k, monkeypatch):
     sub = [0, 5, 299, 300, 317, 329, 330, 331]
     ref_i, ref_s = orc.bm25_ranking(model, [qtexts[j] for j in sub], k)
     assert np.array_equal(i.cpu().numpy()[sub], ref_i) and np.array_equal(s.cpu().numpy()[sub].view(np.uint32), ref_s.view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [10, 1001])
+def test_hip_bm25_rows_the_filter_cannot_finish_are_redone_exactly(k, monkeypatch):
+    """Estimates that fail, on purpose.  The sampled pieces of a 150 k-document corpus are documents [p * 65536, p * 65536 + 1024):
+    term A occurs in every document OUTSIDE the pieces (the sample holds zeros only -> tau <= 0 -> 147 k positive scores flood the
+    16 K-entry list), term B ONLY inside the pieces (tau far above what the other documents reach -> fewer than k pass at tau > 0).
+    Both kinds of row must come back through the redo path -- scored again with their fp32 rows stored, CCR_BM25_REDO_ROWS = 3 rows
+    at a time, exact dense selection -- with the bits of the stored-rows path; rows between them finish in the filter."""
+    from ccrec_amd.bm25 import BM25
+    n_docs, n_terms = 150_000, 300
+    rs = np.random.RandomState(k)
+    indptr, rows, counts, doc_k, idf = _random_postings(rs, n_docs, n_terms, dense_terms=3)
+    docs = np.arange(n_docs)
+    in_piece = (docs % 65536) < 1024
+    extra_rows = [docs[~in_piece], docs[in_piece]]
+    extra = [(r.astype(np.int32), rs.randint(1, 6, len(r)).astype(np.float32)) for r in extra_rows]
+    indptr = np.concatenate([indptr, indptr[-1] + np.cumsum([len(r) for r, _ in extra])])
+    rows = np.concatenate([rows] + [r for r, _ in extra])
+    counts = np.concatenate([counts] + [c for _, c in extra])
+    idf = np.concatenate([idf, [0.7, 2.5]])
+    A, B = n_terms, n_terms + 1
+    queries = []
+    for j in range(40):
+        # A / B rows: rare companions only (<= 125 postings each), so that the sampled rank is decided by A / B alone
+        q = list(rs.choice(np.arange(150 if j % 4 < 2 else 6, n_terms), rs.randint(1, 6), replace=False))
+        if j % 4 == 0:
+            q.append(A)
+        if j % 4 == 1:
+            q.append(B)
+        queries.append(np.sort(np.asarray(q)).astype(np.int32))
+    monkeypatch.setenv("CCR_BM25_REDO_ROWS", "3")
+    model = BM25.from_postings(indptr, rows, counts, doc_k, idf, k1=1.2)
+    s, i = model.transform_terms_topk(queries, k)
+    st = model.last_stats()
+    assert st["path"] == "tile+fused_filter" and 10 <= st["rows_redone"] < 40, st      # the A rows always; the B rows when k > their hits
+    monkeypatch.setenv("CCR_BM25_DENSE_SELECT", "1")
+    s2, i2 = model.transform_terms_topk(queries, k)
+    assert model.last_stats()["path"] == "tile+stored_rows"
+    assert torch.equal(i, i2) and torch.equal(s.view(torch.int32), s2.view(torch.int32))
 
 
 def _random_postings(rs, n_docs, n_terms, dense_terms):
@@ -187,6 +231,23 @@ def test_hip_bm25_tile_scorer_equals_the_round_kernels(n_docs, k, monkeypatch):
         results[cfg] = (s.view(torch.int32).cpu(), i.cpu())
     for cfg in ("0", "1", "2"):
         assert torch.equal(results[cfg][1], results["-1"][1]) and torch.equal(results[cfg][0], results["-1"][0]), cfg
+    # the tile scorers above streamed the table of finished contributions (ccr_bm25_index_set_idf); without it (CCR_BM25_TABLE=0: tf and
+    # K_d per posting, the division in the kernel) and with query weights that are not the index's idf (generic path): the same bits
+    assert model.last_stats()["contribution_table"]
+    monkeypatch.setenv("CCR_BM25_TILE", "0")
+    monkeypatch.setenv("CCR_BM25_TABLE", "0")
+    plain = BM25.from_postings(indptr, rows, counts, doc_k, idf, k1=1.2)
+    monkeypatch.delenv("CCR_BM25_TABLE")
+    s, i = plain.transform_terms_topk(queries, k)
+    assert not plain.last_stats()["contribution_table"]
+    assert torch.equal(i.cpu(), results["-1"][1]) and torch.equal(s.view(torch.int32).cpu(), results["-1"][0])
+    other = BM25.from_postings(indptr, rows, counts, doc_k, idf, k1=1.2)
+    other.idf = idf * 1.25                                              # the table holds idf, the queries ask for 1.25 idf
+    s, i = other.transform_terms_topk(queries[:30], k)
+    assert not other.last_stats()["contribution_table"]
+    plain.idf = idf * 1.25
+    s2, i2 = plain.transform_terms_topk(queries[:30], k)
+    assert torch.equal(i, i2) and torch.equal(s.view(torch.int32), s2.view(torch.int32))
     # 65 terms in one query of the batch: the whole call takes the round kernels, same results for the other queries
     monkeypatch.setenv("CCR_BM25_TILE", "0")
     model = BM25.from_postings(indptr, rows, counts, doc_k, idf, k1=1.2)
