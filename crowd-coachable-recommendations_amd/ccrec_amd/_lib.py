@@ -22,7 +22,7 @@ EXPORTS = [
     "ccr_bm25_search", "ccr_pack_bf16_padded", "ccr_shard_message_bytes", "ccr_search_shard", "ccr_shard_message_fill", "ccr_merge_shard_messages",
     "ccr_attention_bf16", "ccr_add_layernorm", "ccr_meanpool_pack_bf16_packed", "ccr_embed_layernorm", "ccr_gelu_bf16",
     "ccr_attention_half", "ccr_add_layernorm_half", "ccr_embed_layernorm_half", "ccr_gelu_half", "ccr_merge_short_lists",
-    "ccr_bm25_search_workspace_bytes_k", "ccr_bm25_search_last_stats", "ccr_bm25_index_set_idf",
+    "ccr_bm25_search_workspace_bytes_k", "ccr_bm25_search_last_stats", "ccr_bm25_index_set_idf", "ccr_inbatch_pack3_bf16", "ccr_inbatch_ce_fwd_f32",
 ]
 
 SHARD_HEADER_BYTES = 32
@@ -86,6 +86,8 @@ def load():
     lib.ccr_inbatch_ce_fwd.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp, vp, sz, vp]
     lib.ccr_inbatch_ce_bwd.argtypes = [vp, vp, vp, vp, i32, i32, f32, f32, vp, vp, vp, vp, sz, vp]
     lib.ccr_inbatch_ce_bwd_dev.argtypes = [vp, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp, vp, sz, vp]
+    lib.ccr_inbatch_pack3_bf16.argtypes = [vp, vp, vp, i32, i32, vp, vp]
+    lib.ccr_inbatch_ce_fwd_f32.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp, vp, vp, sz, vp]
     lib.ccr_rank_metrics.argtypes = [vp, i32, i32, vp, vp, vp, i32, vp, vp, vp]
     lib.ccr_search_finish.argtypes = [vp]
     lib.ccr_scores.argtypes = [vp, vp, i32, i32, vp, vp]

@@ -566,37 +566,69 @@ def colsum_bf16(x):
     return out
 
 
+_INBATCH_LAYOUT = {}   # (B, dim) -> (bytes of the packed blocks padded to 256, workspace bytes, total bytes)
+
+
 class _InBatchCE(torch.autograd.Function):
-    """loss = CE([Q P^T | Q N^T] * inv_T, arange(B)).mean()   (bbpr.py:205-212), bf16 operands, fp32 accumulate."""
+    """loss = CE([Q P^T | Q N^T] * inv_T, arange(B)).mean()   (bbpr.py:205-212), bf16 operands, fp32 accumulate.
+
+    The step is ~0.12 ms of kernels, so the host path is kept to a handful of Python operations: ONE allocation per forward holds the
+    packed bf16 operands, the library's workspace and lse (addresses by integer arithmetic, no tensor views), ONE library call rounds
+    the three fp32 blocks to bf16 (torch's .to(bfloat16) bits) and runs the forward; the backward is one allocation and one call.
+    The buffer belongs to THIS forward until its backward has run (the backward reads the forward's logits there; the library checks
+    the workspace's stamp on the device)."""
 
     @staticmethod
     def forward(ctx, q, p, n, inv_temperature):
         lib = require_gpu()
-        qb, pb, nb = (t.detach().to(torch.bfloat16).contiguous() for t in (q, p, n))
-        B, dim = qb.shape
-        loss = torch.empty(1, dtype=torch.float32, device=q.device)
-        lse = torch.empty(B, dtype=torch.float32, device=q.device)
-        ws = torch.empty(int(lib.ccr_inbatch_ce_workspace_bytes(B, dim)), dtype=torch.uint8, device=q.device)
-        with _on(qb):
-            _lib.check(lib.ccr_inbatch_ce_fwd(_ptr(qb), _ptr(pb), _ptr(nb), B, dim, float(inv_temperature), _ptr(loss),
-                                              _ptr(lse), _ptr(ws), ws.numel(), _stream(qb)), "ccr_inbatch_ce_fwd")
-        ctx.save_for_backward(qb, pb, nb, lse, ws)
-        ctx.inv_t = float(inv_temperature)
-        ctx.dtypes = (q.dtype, p.dtype, n.dtype)
-        return loss[0]
+        B, dim = q.shape
+        lay = _INBATCH_LAYOUT.get((B, dim))
+        if lay is None:
+            ws_bytes = int(lib.ccr_inbatch_ce_workspace_bytes(B, dim))
+            head = (3 * B * dim * 2 + 255) // 256 * 256
+            lay = _INBATCH_LAYOUT[(B, dim)] = (head, ws_bytes, head + (ws_bytes + 255) // 256 * 256 + B * 4)
+        head, ws_bytes, total = lay
+        dev = q.device
+        buf = torch.empty(total, dtype=torch.uint8, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        base = buf.data_ptr()
+        lse_ptr = base + total - B * 4
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        fast = (q.dtype == p.dtype == n.dtype == torch.float32 and q.is_contiguous() and p.is_contiguous() and n.is_contiguous()
+                and dim % 8 == 0 and (q.data_ptr() | p.data_ptr() | n.data_ptr()) % 16 == 0)
+        with _on(q):
+            if fast:
+                _lib.check(lib.ccr_inbatch_ce_fwd_f32(q.data_ptr(), p.data_ptr(), n.data_ptr(), B, dim, float(inv_temperature), base,
+                                                      loss.data_ptr(), lse_ptr, base + head, ws_bytes, stream), "ccr_inbatch_ce_fwd_f32")
+            else:   # other dtypes / strided inputs: torch copies round to bf16, then the forward on the packed blocks
+                packed = buf[:3 * B * dim * 2].view(torch.bfloat16).view(3, B, dim)
+                for dst, t in zip(packed, (q, p, n)):
+                    dst.copy_(t.detach())
+                blk = B * dim * 2
+                _lib.check(lib.ccr_inbatch_ce_fwd(base, base + blk, base + 2 * blk, B, dim, float(inv_temperature), loss.data_ptr(), lse_ptr,
+                                                  base + head, ws_bytes, stream), "ccr_inbatch_ce_fwd")
+        ctx.save_for_backward(buf)
+        ctx.lay = (B, dim, head, ws_bytes, total, float(inv_temperature), q.dtype, p.dtype, n.dtype)
+        return loss
 
     @staticmethod
     def backward(ctx, grad_out):
         lib = require_gpu()
-        qb, pb, nb, lse, ws = ctx.saved_tensors
-        B, dim = qb.shape
-        dq, dp, dn = (torch.empty(B, dim, dtype=torch.float32, device=qb.device) for _ in range(3))
-        g = grad_out.detach().to(device=qb.device, dtype=torch.float32).reshape(1).contiguous()   # stays on the device
-        with _on(qb):
-            _lib.check(lib.ccr_inbatch_ce_bwd_dev(_ptr(qb), _ptr(pb), _ptr(nb), _ptr(lse), B, dim, ctx.inv_t, _ptr(g),
-                                                  _ptr(dq), _ptr(dp), _ptr(dn), _ptr(ws), ws.numel(), _stream(qb)),
+        (buf,) = ctx.saved_tensors
+        B, dim, head, ws_bytes, total, inv_t, tq, tp, tn = ctx.lay
+        dev = buf.device
+        grads = torch.empty(3, B, dim, dtype=torch.float32, device=dev)
+        g = grad_out
+        if g.dtype != torch.float32 or g.device != dev or not g.is_contiguous():
+            g = g.detach().to(device=dev, dtype=torch.float32).contiguous()   # stays on the device either way
+        base, gp, blk = buf.data_ptr(), grads.data_ptr(), B * dim
+        with _on(buf):
+            _lib.check(lib.ccr_inbatch_ce_bwd_dev(base, base + 2 * blk, base + 4 * blk, base + total - B * 4, B, dim, inv_t, g.data_ptr(),
+                                                  gp, gp + 4 * blk, gp + 8 * blk, base + head, ws_bytes, torch.cuda.current_stream(dev).cuda_stream),
                        "ccr_inbatch_ce_bwd")
-        return dq.to(ctx.dtypes[0]), dp.to(ctx.dtypes[1]), dn.to(ctx.dtypes[2]), None
+        dq, dp, dn = grads.unbind(0)
+        f32 = torch.float32
+        return (dq if tq == f32 else dq.to(tq)), (dp if tp == f32 else dp.to(tp)), (dn if tn == f32 else dn.to(tn)), None
 
 
 def inbatch_ce(q, p, n, inv_temperature):

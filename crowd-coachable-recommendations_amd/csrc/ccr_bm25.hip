@@ -94,6 +94,7 @@ struct Bm25Term {        // one distinct term of a query row
     double idf;
 };
 constexpr int BM25_TILE_WAVES = 4;
+constexpr int BM25_TILE_GROUP = 4;           // terms whose first steps are in flight together
 constexpr int BM25_MAX_TILE_TERMS = 64;      // lane r <-> term r; longer queries take the round kernels
 
 __device__ __forceinline__ int64_t readlane64(int64_t v, int l) {
@@ -164,74 +165,102 @@ __global__ __launch_bounds__(256) void bm25_tile_kernel(const Bm25Term *__restri
         if (MODE == BM25_FILTER) thr = tau[row];
         for (int64_t tile_base = run_base; tile_base < run_end; tile_base += T) {
             const int tile_end = (int)(tile_base + T < n_docs ? tile_base + T : n_docs);
+            // The terms with a posting in this tile, ascending (wave-uniform), in groups of NB: the first steps of a group's terms (ids +
+            // values of up to 64 U postings each) are fetched TOGETHER, then consumed in term order -- one global round trip per group
+            // instead of one per term (at five waves per SIMD the chain "load -> LDS add -> count -> next term's load", ~8 links per tile,
+            // was the whole kernel).  A slot without a term repeats slot 0's addresses: every wave issues the same number of loads, so
+            // the wait in front of slot b is a plain count.  The values are pinned behind the loads: left alone, hipcc sinks the load of
+            // a value into the `if (in)` that uses it -- a second dependent round trip per step.
             unsigned long long act = __ballot(nd < tile_end);
-            while (act != 0ull) {   // wave-uniform: the terms with a posting in this tile, ascending
-                const int r = __builtin_amdgcn_readfirstlane(__builtin_ctzll(act));
-                act &= act - 1ull;
-                int64_t c = readlane64(cur, r);
-                const int64_t e = readlane64(end, r);
-                const double w = __longlong_as_double(readlane64(__double_as_longlong(idf), r));
-                int32_t d[U];
-                int cnt;
-                do {
-                    cnt = 0;
-                    if (TABLE) {
-                        double cv[U];
+            constexpr int NB = BM25_TILE_GROUP;
+            // (addresses = a wave-uniform 64-bit base + a 32-bit lane offset: the loads take the scalar-base form, no 64-bit lane arithmetic)
+            auto fetch = [&](int32_t(&dd)[U], double(&cc)[U], float(&ff)[U], int64_t c0, int64_t e0) {
+                const int last = (int)(e0 - c0 < (int64_t)(64 * U) ? e0 - c0 : (int64_t)(64 * U)) - 1;   // >= 0: c0 < e0
+                const int32_t *pd = doc_ids + c0;
+                const double *pc = contrib + c0;
+                const float *pf = tf + c0;
 #pragma unroll
-                        for (int u = 0; u < U; ++u) {   // clamped: every load is valid and unconditional
-                            const int64_t i = c + lane + 64 * u;
-                            const int64_t ic = i < e ? i : e - 1;
-                            d[u] = doc_ids[ic];
-                            cv[u] = contrib[ic];
-                        }
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            const bool in = c + lane + 64 * u < e && d[u] < tile_end;
-                            if (in) {
-                                const int x = d[u] - (int)tile_base;
-                                acc[x] = acc[x] + cv[u];
-                            }
-                            cnt += __popcll(__ballot(in));
-                        }
-                    } else {
-                        float f[U];
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {   // clamped: every load is valid and unconditional
-                            const int64_t i = c + lane + 64 * u;
-                            const int64_t ic = i < e ? i : e - 1;
-                            d[u] = doc_ids[ic];
-                            f[u] = tf[ic];
-                        }
-                        double kd[U];
-#pragma unroll
-                        for (int u = 0; u < U; ++u) kd[u] = doc_k[d[u]];
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            const bool in = c + lane + 64 * u < e && d[u] < tile_end;
-                            const double fd = (double)f[u];
-                            const double numer = (fd * w) * k1p1;
-                            const double denom = fd + kd[u];
-                            if (in) {
-                                const int x = d[u] - (int)tile_base;
-                                acc[x] = acc[x] + numer / denom;
-                            }
-                            cnt += __popcll(__ballot(in));
-                        }
-                    }
-                    c += cnt;
-                } while (cnt == 64 * U);
-                // the postings are in document order, so the `cnt` taken ones are a prefix of the step and element `cnt` is the next one
-                int next = 0x7fffffff;
-                if (c < e) {
-                    const int l = cnt & 63, u_sel = cnt >> 6;
-                    next = __builtin_amdgcn_readlane(d[0], l);
-#pragma unroll
-                    for (int u = 1; u < U; ++u) {
-                        const int v = __builtin_amdgcn_readlane(d[u], l);
-                        next = u_sel == u ? v : next;
-                    }
+                for (int u = 0; u < U; ++u) {   // clamped: every load is valid and unconditional
+                    const int o = lane + 64 * u < last ? lane + 64 * u : last;
+                    dd[u] = pd[o];
+                    if (TABLE) cc[u] = pc[o];
+                    else ff[u] = pf[o];
                 }
-                if (lane == r) cur = c, nd = next;
+            };
+            while (act != 0ull) {
+                int32_t d[NB][U];
+                double cv[NB][U];
+                float f[NB][U];
+                int rr[NB];
+                int64_t cc[NB], ee[NB];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    rr[b] = -1;
+                    if (b > 0) cc[b] = cc[0], ee[b] = ee[0];
+                    if (act != 0ull) {
+                        rr[b] = __builtin_amdgcn_readfirstlane(__builtin_ctzll(act));
+                        act &= act - 1ull;
+                        cc[b] = readlane64(cur, rr[b]), ee[b] = readlane64(end, rr[b]);
+                    }
+                    fetch(d[b], cv[b], f[b], cc[b], ee[b]);
+                }
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    if (rr[b] < 0) break;
+                    const int r = rr[b];
+                    int64_t c = cc[b];
+                    const int64_t e = ee[b];
+                    const double w = __longlong_as_double(readlane64(__double_as_longlong(idf), r));
+                    int cnt;
+                    for (;;) {
+                        cnt = 0;
+                        const int have = (int)(e - c < (int64_t)(64 * U) ? e - c : (int64_t)(64 * U));   // real postings of this step
+                        if (TABLE) {
+#pragma unroll
+                            for (int u = 0; u < U; ++u) asm volatile("" : "+v"(cv[b][u]));
+#pragma unroll
+                            for (int u = 0; u < U; ++u) {
+                                const bool in = lane + 64 * u < have && d[b][u] < tile_end;
+                                if (in) {
+                                    const int x = d[b][u] - (int)tile_base;
+                                    acc[x] = acc[x] + cv[b][u];
+                                }
+                                cnt += __popcll(__ballot(in));
+                            }
+                        } else {
+                            double kd[U];
+#pragma unroll
+                            for (int u = 0; u < U; ++u) kd[u] = doc_k[d[b][u]];
+#pragma unroll
+                            for (int u = 0; u < U; ++u) {
+                                const bool in = lane + 64 * u < have && d[b][u] < tile_end;
+                                const double fd = (double)f[b][u];
+                                const double numer = (fd * w) * k1p1;
+                                const double denom = fd + kd[u];
+                                if (in) {
+                                    const int x = d[b][u] - (int)tile_base;
+                                    acc[x] = acc[x] + numer / denom;
+                                }
+                                cnt += __popcll(__ballot(in));
+                            }
+                        }
+                        c += cnt;
+                        if (cnt != 64 * U) break;
+                        fetch(d[b], cv[b], f[b], c, e);   // a list that fills the whole step goes on (c < e: a full step took real postings only)
+                    }
+                    // the postings are in document order, so the `cnt` taken ones are a prefix of the step and element `cnt` is the next one
+                    int next = 0x7fffffff;
+                    if (c < e) {
+                        const int l = cnt & 63, u_sel = cnt >> 6;
+                        next = __builtin_amdgcn_readlane(d[b][0], l);
+#pragma unroll
+                        for (int u = 1; u < U; ++u) {
+                            const int v = __builtin_amdgcn_readlane(d[b][u], l);
+                            next = u_sel == u ? v : next;
+                        }
+                    }
+                    if (lane == r) cur = c, nd = next;
+                }
             }
             if (MODE == BM25_FILTER) {
                 // the tile against tau: the same test as the r4 collect pass (score >= tau, and > 0 when tau <= 0: a BM25 row is mostly
@@ -355,13 +384,15 @@ constexpr int BM25_TOPK_SMALL = 4096;
 template <int NT, bool SMALL>
 __global__ __launch_bounds__(NT) void bm25_topk_kernel(const uint2 *__restrict__ list, const uint32_t *__restrict__ list_cnt,
                                                       const uint32_t *__restrict__ odd_cnt, const float *__restrict__ tau, int64_t n_docs, int k,
-                                                      int q_begin, float *__restrict__ out_scores, int64_t *__restrict__ out_ids,
+                                                      int q_begin, int n_rows, float *__restrict__ out_scores, int64_t *__restrict__ out_ids,
                                                       uint32_t *__restrict__ redo_cnt, uint32_t *__restrict__ redo_list) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];
     const int tid = threadIdx.x;
-    const int r = blockIdx.x;
+    // SMALL: a block per row.  Large: a few blocks walk all rows and take the large ones (2 000 blocks of 128 KiB that only exit cost 70 us)
+    for (int r = blockIdx.x; r < n_rows; r += gridDim.x) {
     const uint32_t n = list_cnt[r];
-    if ((n <= (uint32_t)BM25_TOPK_SMALL) != SMALL) return;   // block-uniform: the other launch's row
+    if ((n <= (uint32_t)BM25_TOPK_SMALL) != SMALL) continue;   // block-uniform: the other launch's row
+    __syncthreads();   // the previous row's keys are done with
     // Fewer than k documents passed.  With tau <= 0 and no negative / NaN score in the row the list holds EVERY non-zero document, all
     // others score exactly zero, and the row's top-k is the sorted list followed by the k - n lowest-numbered documents outside it
     // (a query whose terms match fewer than k documents: common for rare terms).  Anything else -- an estimate that came out too high,
@@ -369,7 +400,7 @@ __global__ __launch_bounds__(NT) void bm25_topk_kernel(const uint2 *__restrict__
     const bool zero_fill = n < (uint32_t)k && tau[r] <= 0.f && odd_cnt[r] == 0u;
     if ((n < (uint32_t)k && !zero_fill) || n > (uint32_t)BM25_LIST_CAP) {   // block-uniform
         if (tid == 0) redo_list[atomicAdd(redo_cnt, 1u)] = (uint32_t)r;
-        return;
+        continue;
     }
     const int np2 = n ? pow2_ceil((int)n) : 1;
     const uint2 *src = list + (int64_t)r * BM25_LIST_CAP;
@@ -410,6 +441,7 @@ __global__ __launch_bounds__(NT) void bm25_topk_kernel(const uint2 *__restrict__
             out_scores[orow * k + n + j] = 0.f;
             out_ids[orow * k + n + j] = (int64_t)d;
         }
+    }
     }
 }
 
@@ -685,6 +717,7 @@ int launch_bm25_tile_cfg(const ccr_bm25_index *ix, const Bm25TileArgs &a, hipStr
         case 1: return launch_bm25_tile<1024, 1, MODE>(ix, a, s);
         case 2: return launch_bm25_tile<512, 2, MODE>(ix, a, s);
         case 3: return launch_bm25_tile<1024, 4, MODE>(ix, a, s);
+        case 4: return launch_bm25_tile<512, 4, MODE>(ix, a, s);
         default: return launch_bm25_tile<1024, 2, MODE>(ix, a, s);
     }
 }
@@ -797,10 +830,10 @@ extern "C" int ccr_bm25_search(const ccr_bm25_index *ix, const int64_t *q_ptr_ho
                 rc = launch_bm25_tile_cfg<BM25_FILTER>(ix, a, s);
                 if (rc != CCR_OK) return rc;
                 hipLaunchKernelGGL((bm25_topk_kernel<512, true>), dim3((unsigned)m), dim3(512), (size_t)BM25_TOPK_SMALL * 12, s, cand_list, list_cnt, odd_cnt,
-                                   tau, ix->n_docs, k, q0, out_scores, out_ids, ctl, redo_list);
+                                   tau, ix->n_docs, k, q0, m, out_scores, out_ids, ctl, redo_list);
                 CCR_LAUNCH_CHECK();
-                hipLaunchKernelGGL((bm25_topk_kernel<1024, false>), dim3((unsigned)m), dim3(1024), (size_t)BM25_LIST_CAP * 8, s, cand_list, list_cnt, odd_cnt,
-                                   tau, ix->n_docs, k, q0, out_scores, out_ids, ctl, redo_list);
+                hipLaunchKernelGGL((bm25_topk_kernel<1024, false>), dim3((unsigned)std::min(m, 128)), dim3(1024), (size_t)BM25_LIST_CAP * 8, s, cand_list,
+                                   list_cnt, odd_cnt, tau, ix->n_docs, k, q0, m, out_scores, out_ids, ctl, redo_list);
                 CCR_LAUNCH_CHECK();
                 // the rows the filter could not finish (usually none or a few rare-term queries): scored again with their rows stored,
                 // `redo_rows` at a time, exact dense selection

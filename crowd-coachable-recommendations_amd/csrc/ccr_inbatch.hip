@@ -9,14 +9,17 @@
 //   fwd : ONE launch.  Per (query tile, key split) partial (max, sum, diagonal) and the scaled logits S[2B][B] (kept for the
 //         backward); the last split of a query tile to arrive (ticket) combines the tile's partials in split order -> lse, the
 //         tile's loss share; the last tile to arrive adds the shares in tile order -> loss.  Deterministic.
-//   bwd : TWO launches, no gradient matrix in memory: dQ = G^T K and dK = G Q with G[j][i] = (exp(S[j][i] - lse_i) - [j == i]) *
-//         inv_T * grad_out / B evaluated while the operand is staged, split into THREE bf16 parts (g = hi + mid + lo exactly to
-//         2^-24 relative) so that the products with the bf16 embeddings run on v_mfma_f32_32x32x16_bf16 (3 MFMAs of 32 cycles
-//         per 16 K instead of 8 fp32 MFMAs of 64): fp32-MFMA accuracy at a fifth of its time; LDS-staged 64x64 tiles,
-//         deterministic, no atomics.  (r3: a separate G kernel + two v_mfma_f32_32x32x2_f32 GEMMs, 139 of the step's 175 us; now
-//         61 + 40 us.  What bounds them now is the VALU work of evaluating and splitting the gradient while it is staged -- every
-//         element once per 64-column output tile, 12 times at dim 768 -- at one wave per SIMD: a variant with one 16-byte LDS store per
-//         operand part and thread, conflict free, but 16 scalar loads per thread and chunk, measured SLOWER: 85 + 53 us.)
+//   bwd : TWO launches.  dQ = G^T K and dK = G Q with G[j][i] = (exp(S[j][i] - lse_i) - [j == i]) * inv_T * grad_out / B, split into
+//         THREE bf16 parts (g = hi + mid + lo exactly to 2^-24 relative) so that the products with the bf16 embeddings run on
+//         v_mfma_f32_32x32x16_bf16 (3 MFMAs of 32 cycles per 16 K instead of 8 fp32 MFMAs of 64): fp32-MFMA accuracy at a fifth of
+//         its time.  r5: (1) inbatch_prep_kernel evaluates and splits every G element ONCE (r4 did it while staging, once per
+//         64-column output tile = 12 times at dim 768, which bounded the kernels: 61 + 41 us) and leaves the parts in BOTH
+//         orientations (keys x queries and queries x keys, 6 bytes each) plus the transposes of the embeddings, all with the
+//         contraction index contiguous; (2) inbatch_gemm3_kernel then reads every MFMA fragment straight from L2 -- no LDS staging,
+//         no barrier inside the K loop -- one workgroup per 32 x 64 output tile, its four waves taking a quarter of K each and
+//         adding their partial tiles through LDS in wave order.  Deterministic, no atomics.
+#include <algorithm>
+
 #include "ccr_common.h"
 
 namespace ccr {
@@ -49,7 +52,8 @@ __global__ __launch_bounds__(64) void inbatch_fwd_kernel(const uint16_t *__restr
                                                         float *__restrict__ pm, float *__restrict__ pl, float *__restrict__ pd,
                                                         float *__restrict__ S, int ldS, float *__restrict__ lse,
                                                         float *__restrict__ loss, unsigned int *__restrict__ tile_ticket,
-                                                        unsigned int *__restrict__ loss_ticket, double *__restrict__ tile_part) {
+                                                        unsigned int *__restrict__ loss_ticket, double *__restrict__ tile_part,
+                                                        uint32_t *__restrict__ stamp) {
     const int lane = threadIdx.x;
     const int l31 = lane & 31, h = lane >> 5;
     const int i0 = blockIdx.x * 32;
@@ -67,18 +71,33 @@ __global__ __launch_bounds__(64) void inbatch_fwd_kernel(const uint16_t *__restr
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        // operands come straight from L2 in fragment layout: 8 K steps (16 loads) are issued before the first MFMA
-        int k0 = 0;
-        for (; k0 + 128 <= dim; k0 += 128) {
-            bf16x8 a[8], b[8];
+        // operands come straight from L2 in fragment layout, in chunks of 8 K steps (16 loads); the NEXT chunk's loads are issued before
+        // the current chunk's 8 MFMAs (two register sets; the last prefetch repeats the last chunk -- unconditional loads keep the
+        // wait counts exact), so a tile costs ~dim / 256 + 1 L2 round trips instead of dim / 128
+        const int nfull = dim / 128;
+        bf16x8 a[2][8], b[2][8];
+        auto load = [&](int set, int c) {
+            const int kk = (c < nfull ? c : nfull - 1) * 128;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                a[u] = *reinterpret_cast<const bf16x8 *>(krow + k0 + 16 * u);
-                b[u] = *reinterpret_cast<const bf16x8 *>(qrow + k0 + 16 * u);
+                a[set][u] = *reinterpret_cast<const bf16x8 *>(krow + kk + 16 * u);
+                b[set][u] = *reinterpret_cast<const bf16x8 *>(qrow + kk + 16 * u);
             }
+        };
+        if (nfull > 0) {
+            load(0, 0);
+            for (int c = 0; c < nfull; c += 2) {
+                load(1, c + 1);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u], b[u], acc, 0, 0, 0);
+                for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][u], b[0][u], acc, 0, 0, 0);
+                load(0, c + 2);
+                if (c + 1 < nfull) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][u], b[1][u], acc, 0, 0, 0);
+                }
+            }
         }
+        int k0 = nfull * 128;
         for (; k0 < dim; k0 += 16) {
             const bf16x8 a = *reinterpret_cast<const bf16x8 *>(krow + k0);
             const bf16x8 b = *reinterpret_cast<const bf16x8 *>(qrow + k0);
@@ -158,18 +177,12 @@ __global__ __launch_bounds__(64) void inbatch_fwd_kernel(const uint16_t *__restr
         double tot = 0.0;
         for (unsigned int b = 0; b < gridDim.x; ++b) tot += __hip_atomic_load(tile_part + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         loss[0] = (float)(tot / (double)B);
+        // every logit of this forward is in the workspace now: the stamp the backward checks (InbatchStamp below)
+        stamp[0] = 0x43434942u, stamp[1] = (uint32_t)B, stamp[2] = (uint32_t)dim, stamp[3] = __float_as_uint(inv_t);
     }
 }
 
-// C[M][dim] (fp32) = sum_k A(k, m) X(k, :) with A = the gradient of the loss w.r.t. the scaled logits, evaluated from S and lse while
-// it is staged and split into three bf16 parts; X rows are bf16 embedding rows.
-//   FOR_Q:  m = query i, k = key j:   A(k, m) = g(S[k][m]),  X(k) = key_row(k)          -> dQ   (M = B, K = 2B)
-//   else :  m = key j,   k = query i: A(k, m) = g(S[m][k]),  X(k) = Q[k]                -> dP | dN (M = 2B, K = B; rows >= B go to C1)
-//   g(S[j][i]) = (exp(S[j][i] - lse[i]) - [j == i]) * gscale
-// Block = 4 waves, 64 x 64 output tile (32 x 32 per wave), K in chunks of 32 through two LDS buffers; the next chunk's global loads
-// are in flight while the current chunk's 6 MFMAs per wave run.  LDS images are [row][k] with 80-byte rows (5 x 16 B: the 16 lanes of
-// a ds_read_b128 group hit 16 distinct slots): the transposes the operand layout needs happen in the staging stores.
-constexpr int GG_T = 64, GG_THREADS = 256, GG_KC = 32, GG_KP = 40;   // 64 x 64 tile, K chunk 32, LDS row pitch 40 bf16
+// ---- backward -------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void split3(float g, uint16_t &hi, uint16_t &mid, uint16_t &lo) {
     const __bf16 a = (__bf16)g;
     const float r1 = g - (float)a;
@@ -180,166 +193,220 @@ __device__ __forceinline__ void split3(float g, uint16_t &hi, uint16_t &mid, uin
     lo = __builtin_bit_cast(uint16_t, c);
 }
 
-template <bool FOR_Q>
-__global__ __launch_bounds__(GG_THREADS) void inbatch_grad_kernel(const float *__restrict__ S, int ldS, const float *__restrict__ lse,
-                                                                 const uint16_t *__restrict__ X0, const uint16_t *__restrict__ X1, int B,
-                                                                 int dim, float gscale, const float *__restrict__ gscale_dev,
-                                                                 float *__restrict__ C0, float *__restrict__ C1) {
-    __shared__ __attribute__((aligned(16))) uint16_t As[2][3][GG_T][GG_KP];
-    __shared__ __attribute__((aligned(16))) uint16_t Bs[2][GG_T][GG_KP];
-    if (gscale_dev) gscale *= gscale_dev[0];   // upstream gradient read on the device: no host round trip
-    const int M = FOR_Q ? B : 2 * B, K = FOR_Q ? 2 * B : B;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wv = tid >> 6;
-    const int l31 = lane & 31, h = lane >> 5;
-    const int wm = wv >> 1, wn = wv & 1;
-    const int m0 = blockIdx.y * GG_T, n0 = blockIdx.x * GG_T;
-    f32x16 acc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+// Stamp the forward leaves in the workspace and the backward checks ON THE DEVICE (a mismatch -- a workspace another forward has
+// used in between, or none -- poisons the gradients with NaN instead of returning plausible garbage; no host round trip).
+struct InbatchStamp {
+    uint32_t magic, B, dim, inv_t_bits;
+};
+constexpr uint32_t INBATCH_MAGIC = 0x43434942u;   // 'CCIB'
 
-    // staging roles.  A, FOR_Q (S rows are keys = k, columns = queries = m, m contiguous): thread -> 4 consecutive m (am) of the k pair
-    // (2 ak, 2 ak + 1): two float4 loads, 4 x 3 packed (k, k + 1) dword stores.  A, dK (rows = keys = m, columns = queries = k, k
-    // contiguous): thread -> 4 consecutive k (4 ak4) of rows am and am + 32: two float4 loads, 2 x 3 eight-byte stores.
-    // X (rows = k, 8 consecutive n per 16-byte load): threads 0..127 -> the k pair (2 bk, 2 bk + 1) x 8 columns: 8 dword stores.
-    const int am = FOR_Q ? (tid & 15) * 4 : (tid >> 3), ak = FOR_Q ? (tid >> 4) : (tid & 7);
-    const int bk = (tid >> 3) & 15, bn = (tid & 7) * 8;
-    // Three chunks of global loads in flight (register sets 0..2): a chunk is ~200 MFMA cycles per wave and less than one workgroup
-    // sits on a CU, so a single chunk of lookahead leaves every chunk waiting for an L2 round trip
-    constexpr int PF = 3;
-    float4 va[PF][2];
-    uint4 vb[PF][2];
-    float4 lse_m = make_float4(0.f, 0.f, 0.f, 0.f), lse_k[PF];
-    if (FOR_Q) {   // lse of the thread's 4 query columns: the same for every chunk
-        float t4[4];
+// Operands of the backward's GEMMs, written here in FRAGMENT-MAJOR tiles: a matrix [rows][K] (K = the contraction index; rows and K
+// padded to multiples of 64 with zeros) is stored as [rows / 32][K / 64][4 k-steps][2 halves][32 rows][8 elements], i.e. the 16 bytes
+// lane (half h, row l) of a v_mfma_f32_32x32x16_bf16 operand wants for k-step ks of a 64-wide K chunk sit at byte
+// ((ks 2 + h) 32 + l) 16 of the chunk's 4-KiB block: one 16-byte load per lane fetches the whole fragment as ONE contiguous KiB.
+// (Row-major rows with 16 bytes per lane from 32 different rows touch 32 cache lines per load instruction: the first form of the
+// GEMM below ran at 5 TB/s of fragment loads, 91 us.)
+//   Gk [3] x (keys x queries)   parts of G[j][i]      (dK: m = key j,   k = query i),  ldk = round_up(B, 64)
+//   Gq [3] x (queries x keys)   parts of G[j][i]^T    (dQ: m = query i, k = key j),    ldq = round_up(2B, 64)
+//   QT (dim x queries) = Q^T    (dK's second operand),   KT (dim x keys) = [P ; N]^T   (dQ's)
+// grid.x = G tiles (64 keys x 64 queries) + Q tiles + K tiles (64 rows x 64 columns each), block = 256.
+constexpr int PREP_T = 64, PREP_P = PREP_T + 8;   // LDS pitch 72 bf16 = 144 B: 16-byte aligned rows, rows 4 banks apart
+__device__ __forceinline__ int64_t frag_major(int r, int k, int nchunks) {   // element offset of (row r, contraction index k), k % 8 == 0
+    return ((((int64_t)(r >> 5) * nchunks + (k >> 6)) * 8 + ((k >> 3) & 7)) * 32 + (r & 31)) * 8;
+}
+__global__ __launch_bounds__(256) void inbatch_prep_kernel(const float *__restrict__ S, int ldS, const float *__restrict__ lse,
+                                                          const uint16_t *__restrict__ Q, const uint16_t *__restrict__ P,
+                                                          const uint16_t *__restrict__ N, int B, int dim, float gscale,
+                                                          const float *__restrict__ gscale_dev, const InbatchStamp *__restrict__ stamp,
+                                                          uint32_t inv_t_bits, uint16_t *__restrict__ Gk, uint16_t *__restrict__ Gq,
+                                                          uint16_t *__restrict__ QT, uint16_t *__restrict__ KT, int ldk, int ldq) {
+    __shared__ __attribute__((aligned(16))) uint16_t s_t[3][PREP_T][PREP_P];
+    const int tid = threadIdx.x;
+    const int gi = (B + PREP_T - 1) / PREP_T, gj = (2 * B + PREP_T - 1) / PREP_T, gd = (dim + PREP_T - 1) / PREP_T;
+    int b = blockIdx.x;
+    if (b < gi * gj) {
+        // ---- G tile: rows j0 .. j0 + 63 (keys), columns i0 .. i0 + 63 (queries); thread -> row tid / 4, 16 consecutive columns
+        if (gscale_dev) gscale *= gscale_dev[0];   // upstream gradient read on the device: no host round trip
+        const InbatchStamp st = *stamp;
+        if (st.magic != INBATCH_MAGIC || st.B != (uint32_t)B || st.dim != (uint32_t)dim || st.inv_t_bits != inv_t_bits) gscale = __builtin_nanf("");
+        const int j0 = (b / gi) * PREP_T, i0 = (b % gi) * PREP_T;
+        const int r = tid >> 2, c0 = (tid & 3) * 16;
+        const int j = j0 + r;
+        uint16_t part[3][16];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = m0 + am + u;
-            t4[u] = lse[i < B ? i : B - 1];
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const int ic = i0 + c0 + 4 * q4;
+            float sv[4] = {0.f, 0.f, 0.f, 0.f}, lv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (j < 2 * B && ic < ldS) {   // ldS is a multiple of 4: an aligned vector inside the row pitch
+                const float4 v = *reinterpret_cast<const float4 *>(S + (int64_t)j * ldS + ic);
+                sv[0] = v.x, sv[1] = v.y, sv[2] = v.z, sv[3] = v.w;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) lv[u] = lse[ic + u < B ? ic + u : B - 1];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = ic + u;
+                float g = __expf(sv[u] - lv[u]);
+                if (j == i) g -= 1.f;
+                g = (j < 2 * B && i < B) ? g * gscale : 0.f;   // (a select, not a product: positions outside the matrix may hold anything)
+                split3(g, part[0][4 * q4 + u], part[1][4 * q4 + u], part[2][4 * q4 + u]);
+            }
         }
-        lse_m = make_float4(t4[0], t4[1], t4[2], t4[3]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            uint32_t w[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] = (uint32_t)part[p][2 * e] | ((uint32_t)part[p][2 * e + 1] << 16);
+            {   // rows up to the padded height are written (zeros beyond the matrix)
+                uint16_t *base = Gk + (int64_t)p * gj * PREP_T * ldk;
+                *reinterpret_cast<uint4 *>(base + frag_major(j, i0 + c0, ldk / 64)) = make_uint4(w[0], w[1], w[2], w[3]);
+                *reinterpret_cast<uint4 *>(base + frag_major(j, i0 + c0 + 8, ldk / 64)) = make_uint4(w[4], w[5], w[6], w[7]);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s_t[p][c0 + e][r] = part[p][e];   // transposed: [query][key]
+        }
+        __syncthreads();
+        const int i = i0 + r;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(&s_t[p][r][c0]);
+            uint16_t *base = Gq + (int64_t)p * gi * PREP_T * ldq;
+            *reinterpret_cast<uint4 *>(base + frag_major(i, j0 + c0, ldq / 64)) = src[0];
+            *reinterpret_cast<uint4 *>(base + frag_major(i, j0 + c0 + 8, ldq / 64)) = src[1];
+        }
+        return;
     }
-    auto fetch = [&](int set, int k0) {
-        if (FOR_Q) {
+    // ---- transposes of the embeddings: X [rows][dim] -> XT [dim][ld], rows beyond the matrix zero
+    b -= gi * gj;
+    const bool isq = b < gi * gd;
+    if (!isq) b -= gi * gd;
+    const int rows = isq ? B : 2 * B, ld = isq ? ldk : ldq;
+    uint16_t *XT = isq ? QT : KT;
+    const int r0 = (b / gd) * PREP_T, d0 = (b % gd) * PREP_T;
+    {
+        const int r = tid >> 2, c0 = (tid & 3) * 16;   // row r0 + r, columns d0 + c0 .. + 16
+        const int row = r0 + r;
+        uint16_t v[16];
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                int k = k0 + 2 * ak + r;
-                if (k > K - 1) k = K - 1;
-                int mc = m0 + am;
-                if (mc > ldS - 4) mc = ldS - 4;           // (ldS is a multiple of 4: an aligned vector inside the row pitch)
-                va[set][r] = *reinterpret_cast<const float4 *>(S + (int64_t)k * ldS + mc);
-            }
-        } else {
+        for (int e = 0; e < 16; ++e) v[e] = 0;
+        if (row < rows) {
+            const uint16_t *src = isq ? Q + (int64_t)row * dim : key_row(P, N, B, row, dim);
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                int mrow = m0 + am + 32 * r;
-                if (mrow > M - 1) mrow = M - 1;
-                int kc = k0 + 4 * ak;
-                if (kc > ldS - 4) kc = ldS - 4;
-                va[set][r] = *reinterpret_cast<const float4 *>(S + (int64_t)mrow * ldS + kc);
-            }
-            float t4[4];
+            for (int h8 = 0; h8 < 2; ++h8) {
+                const int dc = d0 + c0 + 8 * h8;
+                if (dc < dim) {   // dim % 16 == 0 and dc % 8 == 0: whole 16-byte vectors
+                    const uint4 q = *reinterpret_cast<const uint4 *>(src + dc);
+                    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = k0 + 4 * ak + u;
-                t4[u] = lse[i < B ? i : B - 1];
-            }
-            lse_k[set] = make_float4(t4[0], t4[1], t4[2], t4[3]);
-        }
-        {   // (every thread loads -- 128..255 the same rows again -- so that the number of loads in flight is the same on every path:
-            // behind a branch hipcc counts vmcnt for the path without the loads and drains the prefetch window)
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                int kr = k0 + 2 * bk + r;
-                if (kr > K - 1) kr = K - 1;
-                int nc = n0 + bn;
-                if (nc > dim - 8) nc = dim - 8;
-                const uint16_t *row = FOR_Q ? key_row(X0, X1, B, kr, dim) : X0 + (int64_t)kr * dim;
-                vb[set][r] = *reinterpret_cast<const uint4 *>(row + nc);
-            }
-        }
-    };
-    auto grad = [&](float sv, float lsev, int j, int i) -> float {
-        float g = __expf(sv - lsev);
-        if (j == i) g -= 1.f;
-        return (j < 2 * B && i < B) ? g * gscale : 0.f;   // (a select, not a product: staged positions outside the matrix may hold anything)
-    };
-    auto stash = [&](int buf, int set, int k0) {
-        if (FOR_Q) {
-            const float s0[4] = {va[set][0].x, va[set][0].y, va[set][0].z, va[set][0].w}, s1[4] = {va[set][1].x, va[set][1].y, va[set][1].z, va[set][1].w};
-            const float ls[4] = {lse_m.x, lse_m.y, lse_m.z, lse_m.w};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = m0 + am + u, j = k0 + 2 * ak;
-                uint16_t p0[3], p1[3];
-                split3(grad(s0[u], ls[u], j, i), p0[0], p0[1], p0[2]);
-                split3(grad(s1[u], ls[u], j + 1, i), p1[0], p1[1], p1[2]);
-#pragma unroll
-                for (int part = 0; part < 3; ++part)
-                    *reinterpret_cast<uint32_t *>(&As[buf][part][am + u][2 * ak]) = (uint32_t)p0[part] | ((uint32_t)p1[part] << 16);
-            }
-        } else {
-            const float lk[4] = {lse_k[set].x, lse_k[set].y, lse_k[set].z, lse_k[set].w};
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const float sv[4] = {va[set][r].x, va[set][r].y, va[set][r].z, va[set][r].w};
-                const int j = m0 + am + 32 * r;
-                uint16_t p[4][3];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) split3(grad(sv[u], lk[u], j, k0 + 4 * ak + u), p[u][0], p[u][1], p[u][2]);
-#pragma unroll
-                for (int part = 0; part < 3; ++part)
-                    *reinterpret_cast<uint2 *>(&As[buf][part][am + 32 * r][4 * ak]) =
-                        make_uint2((uint32_t)p[0][part] | ((uint32_t)p[1][part] << 16), (uint32_t)p[2][part] | ((uint32_t)p[3][part] << 16));
-            }
-        }
-        if (tid < 128) {
-            const uint32_t w0[4] = {vb[set][0].x, vb[set][0].y, vb[set][0].z, vb[set][0].w}, w1[4] = {vb[set][1].x, vb[set][1].y, vb[set][1].z, vb[set][1].w};
-            const uint32_t ok0 = (k0 + 2 * bk < K && n0 + bn < dim) ? 0xffffffffu : 0u, ok1 = (k0 + 2 * bk + 1 < K && n0 + bn < dim) ? 0xffffffffu : 0u;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {   // columns bn + 2e (low halves) and bn + 2e + 1 (high halves) of the two k rows
-                const uint32_t a = w0[e] & ok0, b = w1[e] & ok1;
-                *reinterpret_cast<uint32_t *>(&Bs[buf][bn + 2 * e][2 * bk]) = (a & 0xffffu) | (b << 16);
-                *reinterpret_cast<uint32_t *>(&Bs[buf][bn + 2 * e + 1][2 * bk]) = (a >> 16) | (b & 0xffff0000u);
-            }
-        }
-    };
-    // chunk c: LDS buffer c % 2, register set c % 3.  Iteration c: fetch chunk c + 3 into the set stash(c) has just freed | MFMAs of
-    // chunk c | stash chunk c + 1 | barrier.  Loads beyond K are clamped (never stashed), so neither the prologue nor the loop needs bounds.
-#pragma unroll
-    for (int u = 0; u < PF; ++u) fetch(u, u * GG_KC);
-    stash(0, 0, 0);
-    __syncthreads();
-    for (int k0 = 0; k0 < K; k0 += PF * GG_KC) {
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            const int kc = k0 + u * GG_KC;          // chunk c = kc / 32: buffer (c & 1), set u (k0 / 32 is a multiple of 3)
-            if (kc < K) {                           // block-uniform
-                const int buf = (kc / GG_KC) & 1;
-                fetch(u, kc + PF * GG_KC);
-#pragma unroll
-                for (int ks = 0; ks < GG_KC / 16; ++ks) {
-                    const bf16x8 b = *reinterpret_cast<const bf16x8 *>(&Bs[buf][wn * 32 + l31][ks * 16 + 8 * h]);
-#pragma unroll
-                    for (int part = 0; part < 3; ++part) {
-                        const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&As[buf][part][wm * 32 + l31][ks * 16 + 8 * h]);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
-                    }
+                    for (int e = 0; e < 4; ++e) v[8 * h8 + 2 * e] = (uint16_t)(w[e] & 0xffffu), v[8 * h8 + 2 * e + 1] = (uint16_t)(w[e] >> 16);
                 }
-                if (kc + GG_KC < K) stash(buf ^ 1, (u + 1) % PF, kc + GG_KC);
-                __syncthreads();
             }
         }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s_t[0][c0 + e][r] = v[e];
+    }
+    __syncthreads();
+    {
+        const int r = tid >> 2, c0 = (tid & 3) * 16;   // column d0 + r of X = row of XT, 16 consecutive source rows
+        const int d = d0 + r;   // (rows d >= dim of the padded height: zeros)
+        const uint4 *src = reinterpret_cast<const uint4 *>(&s_t[0][r][c0]);
+        *reinterpret_cast<uint4 *>(XT + frag_major(d, r0 + c0, ld / 64)) = src[0];
+        *reinterpret_cast<uint4 *>(XT + frag_major(d, r0 + c0 + 8, ld / 64)) = src[1];
+    }
+}
+
+// C[M][dim] fp32 = sum over the three parts and over k of A_part[m][k] * BT[n][k], every operand fragment read straight from L2.
+//   blocks [0, nq): dQ  (A = Gq parts, M = B,  K = ldq, BT = KT, C = dQ);   blocks [nq, ...): dK (A = Gk parts, M = 2B, K = ldk,
+//   BT = QT, rows < B -> dP, the rest -> dN).  Workgroup = 4 waves on one 32 (m) x 64 (n) output tile; wave w contracts the w-th quarter
+//   of K (in 64-element chunks: 12 + 8 sixteen-byte loads per lane, the next chunk's loads issued before the 24 MFMAs of the current
+//   one) and the four partial tiles are added through LDS in wave order.
+constexpr int G3_TM = 32, G3_TN = 64, G3_KC = 64;
+__global__ __launch_bounds__(256) void inbatch_gemm3_kernel(const uint16_t *__restrict__ Gq, const uint16_t *__restrict__ Gk,
+                                                           const uint16_t *__restrict__ KT, const uint16_t *__restrict__ QT, int B, int dim,
+                                                           int ldq, int ldk, int nq_blocks, float *__restrict__ dQ, float *__restrict__ dP,
+                                                           float *__restrict__ dN) {
+    __shared__ float s_part[4][32][64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    (void)0;
+    const int ntn = (dim + G3_TN - 1) / G3_TN;
+    int b = blockIdx.x;
+    const bool for_q = b < nq_blocks;
+    if (!for_q) b -= nq_blocks;
+    const int M = for_q ? B : 2 * B, K = for_q ? ldq : ldk;
+    const uint16_t *A = for_q ? Gq : Gk, *BT = for_q ? KT : QT;
+    const int m0 = (b / ntn) * G3_TM, n0 = (b % ntn) * G3_TN;
+    const int chunks = K / G3_KC, per = (chunks + 3) / 4;
+    const int c_lo = wv * per, c_hi = c_lo + per < chunks ? c_lo + per : chunks;
+    // fragment-major blocks: [row block of 32][chunk of 64 k] = 2 048 elements, the lane's 16 bytes of k-step ks at ks 512 + lane 8
+    const int64_t part_stride = (int64_t)((M + 63) / 64 * 64) * K;
+    const uint16_t *arow[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) arow[p] = A + p * part_stride + (int64_t)(m0 >> 5) * chunks * 2048 + lane * 8;
+    const uint16_t *brow[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) brow[t] = BT + (int64_t)((n0 >> 5) + t) * chunks * 2048 + lane * 8;   // (the padded height of BT covers n0 + 63)
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    bf16x8 a[2][3][4], bb[2][2][4];
+    auto fetch = [&](int set, int c) {
+        const int k0 = (c < chunks ? c : chunks - 1) * 2048;   // clamped: loads beyond the wave's range are never used
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) a[set][p][ks] = *reinterpret_cast<const bf16x8 *>(arow[p] + k0 + 512 * ks);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) bb[set][t][ks] = *reinterpret_cast<const bf16x8 *>(brow[t] + k0 + 512 * ks);
+        }
+    };
+    auto mma = [&](int set) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[set][p][ks], bb[set][t][ks], acc[t], 0, 0, 0);
+    };
+    fetch(0, c_lo);
+    for (int c = c_lo; c < c_hi; c += 2) {   // wave-uniform
+        fetch(1, c + 1);
+        mma(0);
+        fetch(0, c + 2);
+        if (c + 1 < c_hi) mma(1);
     }
     // C layout of v_mfma_f32_32x32x16: column = lane & 31, register e -> row (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
-    const int ncol = n0 + wn * 32 + l31;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int mrow = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s_part[wv][t * 16 + e][lane] = acc[t][e];
+    __syncthreads();
+    for (int idx = tid; idx < 32 * 64; idx += 256) {
+        const int r = idx >> 6, ln = idx & 63;
+        const float v = ((s_part[0][r][ln] + s_part[1][r][ln]) + s_part[2][r][ln]) + s_part[3][r][ln];
+        const int t = r >> 4, e = r & 15;
+        const int mrow = m0 + (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5), ncol = n0 + 32 * t + (ln & 31);
         if (mrow < M && ncol < dim) {
-            float *crow = (FOR_Q || mrow < B) ? C0 + (int64_t)mrow * dim : C1 + (int64_t)(mrow - B) * dim;
-            crow[ncol] = acc[e];
+            float *crow = for_q ? dQ + (int64_t)mrow * dim : (mrow < B ? dP + (int64_t)mrow * dim : dN + (int64_t)(mrow - B) * dim);
+            crow[ncol] = v;
         }
+    }
+}
+
+// fp32 -> bf16 (RNE: torch's .to(bfloat16) bits) of the step's three embedding blocks in ONE launch.  grid = (chunks, 3), block = 256.
+__global__ __launch_bounds__(256) void inbatch_pack3_kernel(const float *__restrict__ q, const float *__restrict__ p, const float *__restrict__ n,
+                                                           int64_t count, uint16_t *__restrict__ out) {
+    const float *src = blockIdx.y == 0 ? q : (blockIdx.y == 1 ? p : n);
+    uint16_t *dst = out + (int64_t)blockIdx.y * count;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; i < count; i += (int64_t)gridDim.x * 256 * 8) {   // count % 8 == 0
+        const float4 v0 = *reinterpret_cast<const float4 *>(src + i), v1 = *reinterpret_cast<const float4 *>(src + i + 4);
+        const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        uint32_t w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            w[e] = (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)f[2 * e]) | ((uint32_t)__builtin_bit_cast(uint16_t, (__bf16)f[2 * e + 1]) << 16);
+        *reinterpret_cast<uint4 *>(dst + i) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
 
@@ -359,22 +426,29 @@ using namespace ccr;
 
 namespace {
 // workspace: [partials 3 x 64 x B floats][S: 2B rows of ldS floats][tickets: (query tiles + 1) u32, padded][tile shares: doubles]
+//            [stamp][backward: Gk | Gq (three bf16 parts each) | QT | KT]
 struct InbatchWs {
     float *pm, *pl, *pd, *S;
-    int ldS;
+    int ldS, ldk, ldq;
     unsigned int *tile_ticket, *loss_ticket;
     double *tile_part;
-    size_t zero_bytes;   // tickets: zeroed before every forward
+    uint32_t *stamp;
+    uint16_t *Gk, *Gq, *QT, *KT;
+    size_t zero_bytes;   // tickets + stamp: zeroed before every forward
     size_t total;
 };
-InbatchWs inbatch_ws(void *workspace, int B) {
+size_t up256(size_t n) { return (n + 255) / 256 * 256; }
+InbatchWs inbatch_ws(void *workspace, int B, int dim) {
     InbatchWs w;
-    const size_t partial = (((size_t)3 * 64 * B * sizeof(float) + 255) / 256) * 256;
+    const size_t partial = up256((size_t)3 * 64 * B * sizeof(float));
     w.ldS = (B + 3) / 4 * 4;
-    const size_t sbytes = (((size_t)2 * B * w.ldS * sizeof(float) + 255) / 256) * 256;
+    w.ldk = (B + 63) / 64 * 64;
+    w.ldq = (2 * B + 63) / 64 * 64;
+    const size_t sbytes = up256((size_t)2 * B * w.ldS * sizeof(float));
     const int qtiles = (B + 31) / 32;
-    w.zero_bytes = (((size_t)(qtiles + 1) * 4 + 255) / 256) * 256;
-    const size_t parts = (((size_t)qtiles * 8 + 255) / 256) * 256;
+    const size_t tickets = up256((size_t)(qtiles + 1) * 4);
+    w.zero_bytes = tickets + 256;
+    const size_t parts = up256((size_t)qtiles * 8);
     char *base = (char *)workspace;
     w.pm = (float *)base;
     w.pl = w.pm + (size_t)64 * B;
@@ -382,17 +456,25 @@ InbatchWs inbatch_ws(void *workspace, int B) {
     w.S = (float *)(base + partial);
     w.tile_ticket = (unsigned int *)(base + partial + sbytes);
     w.loss_ticket = w.tile_ticket + qtiles;
+    w.stamp = (uint32_t *)(base + partial + sbytes + tickets);
     w.tile_part = (double *)(base + partial + sbytes + w.zero_bytes);
-    w.total = partial + sbytes + w.zero_bytes + parts + 256;   // + 256: the caller's pointer need only be 16-byte aligned
+    size_t off = partial + sbytes + w.zero_bytes + parts;
+    const size_t dimp = (size_t)(dim + 63) / 64 * 64;   // every operand height and width is padded to a multiple of 64
+    w.Gk = (uint16_t *)(base + off), off += up256((size_t)3 * w.ldq * w.ldk * 2);
+    w.Gq = (uint16_t *)(base + off), off += up256((size_t)3 * w.ldk * w.ldq * 2);
+    w.QT = (uint16_t *)(base + off), off += up256(dimp * w.ldk * 2);
+    w.KT = (uint16_t *)(base + off), off += up256(dimp * w.ldq * 2);
+    w.total = off + 256;   // + 256: the caller's pointer need only be 16-byte aligned
     return w;
 }
 char *align256(void *p) { return (char *)p + (256 - (uintptr_t)p % 256) % 256; }
 }  // namespace
 
+extern "C" int ccr_inbatch_pack3_bf16(const float *q, const float *p, const float *n, int B, int dim, uint16_t *out, void *stream);
+
 extern "C" size_t ccr_inbatch_ce_workspace_bytes(int B, int dim) {
-    (void)dim;
-    if (B <= 0) return 0;
-    return inbatch_ws(nullptr, B).total;
+    if (B <= 0 || dim <= 0) return 0;
+    return inbatch_ws(nullptr, B, dim).total;
 }
 
 extern "C" int ccr_inbatch_ce_fwd(const uint16_t *Qe, const uint16_t *Pe, const uint16_t *Ne, int B, int dim,
@@ -405,14 +487,23 @@ extern "C" int ccr_inbatch_ce_fwd(const uint16_t *Qe, const uint16_t *Pe, const 
         return CCR_ERR_WORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
-    const InbatchWs w = inbatch_ws(align256(workspace), B);
+    const InbatchWs w = inbatch_ws(align256(workspace), B, dim);
     const int splits = pick_splits(B);
-    CCR_HIP_CHECK(hipMemsetAsync(w.tile_ticket, 0, w.zero_bytes, s));
+    CCR_HIP_CHECK(hipMemsetAsync(w.tile_ticket, 0, w.zero_bytes, s));   // tickets, and the stamp: no longer this workspace's logits
     dim3 grid((B + 31) / 32, splits);
     hipLaunchKernelGGL(inbatch_fwd_kernel, grid, dim3(64), 0, s, Qe, Pe, Ne, B, dim, inv_temperature, splits, w.pm, w.pl, w.pd, w.S, w.ldS,
-                       lse, loss, w.tile_ticket, w.loss_ticket, w.tile_part);
+                       lse, loss, w.tile_ticket, w.loss_ticket, w.tile_part, w.stamp);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
+}
+
+// pack + forward in one call (the autograd function's host path: one crossing of the C boundary per forward)
+extern "C" int ccr_inbatch_ce_fwd_f32(const float *q, const float *p, const float *n, int B, int dim, float inv_temperature,
+                                      uint16_t *packed, float *loss, float *lse, void *workspace, size_t ws_bytes, void *stream) {
+    const int rc = ccr_inbatch_pack3_bf16(q, p, n, B, dim, packed, stream);
+    if (rc != CCR_OK) return rc;
+    const size_t blk = (size_t)B * dim;
+    return ccr_inbatch_ce_fwd(packed, packed + blk, packed + 2 * blk, B, dim, inv_temperature, loss, lse, workspace, ws_bytes, stream);
 }
 
 static int inbatch_bwd_impl(const uint16_t *Qe, const uint16_t *Pe, const uint16_t *Ne, const float *lse, int B, int dim,
@@ -426,13 +517,29 @@ static int inbatch_bwd_impl(const uint16_t *Qe, const uint16_t *Pe, const uint16
         return CCR_ERR_WORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
-    const InbatchWs w = inbatch_ws(align256(workspace), B);   // the FORWARD's workspace: it holds the scaled logits S
+    const InbatchWs w = inbatch_ws(align256(workspace), B, dim);   // the FORWARD's workspace: it holds the scaled logits S and the stamp
     const float gscale = inv_temperature * grad_out / (float)B;
     // dQ[i][:] = sum_j G[j][i] K[j][:];   dK[j][:] = sum_i G[j][i] Q[i][:], rows < B -> dP, the rest -> dN
-    const dim3 gq((dim + GG_T - 1) / GG_T, (B + GG_T - 1) / GG_T), gk((dim + GG_T - 1) / GG_T, (2 * B + GG_T - 1) / GG_T);
-    hipLaunchKernelGGL((inbatch_grad_kernel<true>), gq, dim3(GG_THREADS), 0, s, w.S, w.ldS, lse, Pe, Ne, B, dim, gscale, grad_out_dev, dQ, dQ);
+    const int gi = (B + PREP_T - 1) / PREP_T, gj = (2 * B + PREP_T - 1) / PREP_T, gd = (dim + PREP_T - 1) / PREP_T;
+    hipLaunchKernelGGL(inbatch_prep_kernel, dim3((unsigned)(gi * gj + gi * gd + gj * gd)), dim3(256), 0, s, w.S, w.ldS, lse, Qe, Pe, Ne, B, dim, gscale,
+                       grad_out_dev, reinterpret_cast<const InbatchStamp *>(w.stamp), __builtin_bit_cast(uint32_t, inv_temperature), w.Gk, w.Gq, w.QT,
+                       w.KT, w.ldk, w.ldq);
     CCR_LAUNCH_CHECK();
-    hipLaunchKernelGGL((inbatch_grad_kernel<false>), gk, dim3(GG_THREADS), 0, s, w.S, w.ldS, lse, Qe, Qe, B, dim, gscale, grad_out_dev, dP, dN);
+    const int ntn = (dim + G3_TN - 1) / G3_TN;
+    const int nq_blocks = (B + G3_TM - 1) / G3_TM * ntn, nk_blocks = (2 * B + G3_TM - 1) / G3_TM * ntn;
+    hipLaunchKernelGGL(inbatch_gemm3_kernel, dim3((unsigned)(nq_blocks + nk_blocks)), dim3(256), 0, s, w.Gq, w.Gk, w.KT, w.QT, B, dim, w.ldq, w.ldk,
+                       nq_blocks, dQ, dP, dN);
+    CCR_LAUNCH_CHECK();
+    return CCR_OK;
+}
+
+extern "C" int ccr_inbatch_pack3_bf16(const float *q, const float *p, const float *n, int B, int dim, uint16_t *out, void *stream) {
+    CCR_REQUIRE(q && p && n && out, "ccr_inbatch_pack3_bf16: null pointer");
+    CCR_REQUIRE(B >= 1 && dim >= 8 && dim % 8 == 0, "ccr_inbatch_pack3_bf16: B=%d dim=%d (dim %% 8 == 0)", B, dim);
+    CCR_REQUIRE(((uintptr_t)q | (uintptr_t)p | (uintptr_t)n | (uintptr_t)out) % 16 == 0, "ccr_inbatch_pack3_bf16: pointers must be 16-byte aligned");
+    const int64_t count = (int64_t)B * dim;
+    hipLaunchKernelGGL(inbatch_pack3_kernel, dim3((unsigned)std::min<int64_t>((count / 8 + 255) / 256, 4096), 3), dim3(256), 0, (hipStream_t)stream, q, p, n,
+                       count, out);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
 }

@@ -355,10 +355,20 @@ int ccr_apply_block(const float *in_scores, const int64_t *in_ids, int n_q, int 
  *   workspace: ccr_inbatch_ce_workspace_bytes(B, dim) bytes of device memory (16-byte aligned); dim % 16 == 0; the embedding
  *   pointers 16-byte aligned.  The FORWARD leaves the scaled logits ([2B][B] fp32) in it and the BACKWARD reads them there
  *   instead of recomputing them: pass the backward the same, unmodified workspace its forward call used (the Python autograd
- *   function saves it with the operands).  Launches: forward = one kernel (+ a memset of its tickets), backward = two kernels;
- *   deterministic (fixed combine orders, no float atomics).
+ *   function saves it with the operands).  The forward also leaves a stamp {magic, B, dim, inv_temperature} behind its logits and
+ *   the backward checks it ON THE DEVICE: a workspace that is not this (B, dim, inv_temperature) forward's -- scratch memory, or one
+ *   another forward has started on since -- yields NaN gradients, not plausible garbage (no host round trip, so no error code).
+ *   Launches: forward = one kernel (+ a memset of its tickets and stamp), backward = two kernels (the gradient of the logits evaluated
+ *   and split into three bf16 parts once, in both orientations, + the embeddings' transposes; then one launch for dQ and dP | dN with
+ *   every MFMA fragment read straight from L2); deterministic (fixed combine orders, no float atomics).
+ *   ccr_inbatch_pack3_bf16: the step's three fp32 blocks [B][dim] -> out [3][B][dim] bf16 (RNE, torch's .to(bfloat16) bits) in ONE
+ *   launch (dim % 8 == 0, 16-byte aligned pointers); ccr_inbatch_ce_fwd_f32 = that pack into `packed` + the forward on the packed
+ *   blocks in one call (the autograd function's host path: the backward takes packed, packed + B dim, packed + 2 B dim).
  */
 size_t ccr_inbatch_ce_workspace_bytes(int B, int dim);
+int ccr_inbatch_pack3_bf16(const float *q, const float *p, const float *n, int B, int dim, uint16_t *out, void *stream);
+int ccr_inbatch_ce_fwd_f32(const float *q, const float *p, const float *n, int B, int dim, float inv_temperature, uint16_t *packed,
+                           float *loss, float *lse, void *workspace, size_t ws_bytes, void *stream);
 int ccr_inbatch_ce_fwd(const uint16_t *Qe, const uint16_t *Pe, const uint16_t *Ne, int B, int dim,
                        float inv_temperature, float *loss, float *lse, void *workspace, size_t ws_bytes, void *stream);
 int ccr_inbatch_ce_bwd(const uint16_t *Qe, const uint16_t *Pe, const uint16_t *Ne, const float *lse, int B, int dim,

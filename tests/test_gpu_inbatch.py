@@ -102,3 +102,71 @@ def test_bert_mt_step_weighting_and_one_optimizer_step():
     mt.backward()
     opt.step()
     assert float((table.weight - before).abs().max()) > 0
+
+
+def test_pack3_bits_gradient_determinism_and_odd_inputs():
+    """ccr_inbatch_pack3_bf16 = torch's .to(bfloat16) bits for the three blocks in one launch (incl. NaN, inf, denormals, ties to even);
+    two backward passes of the same step give the same gradient bits; inputs the one-launch pack cannot take (fp16 / non-contiguous)
+    go through the copy path and agree with the fp32 contiguous call on the same values."""
+    import ctypes
+    from ccrec_amd import _lib, ops
+    lib = ops.require_gpu()
+    B, dim = 70, 48
+    g = torch.Generator().manual_seed(1)
+    blocks = [torch.randn(B, dim, generator=g) for _ in range(3)]
+    blocks[0][0, :6] = torch.tensor([float("nan"), float("inf"), -float("inf"), 1e-40, 1.00390625, 1.01171875])   # the last two: ties
+    dev = [b.cuda().contiguous() for b in blocks]
+    out = torch.empty(3, B, dim, dtype=torch.bfloat16, device="cuda")
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
+    _lib.check(lib.ccr_inbatch_pack3_bf16(vp(dev[0]), vp(dev[1]), vp(dev[2]), B, dim, vp(out), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "pack3")
+    ref = torch.stack([d.to(torch.bfloat16) for d in dev])
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+
+    q, p, n = (torch.randn(B, dim, generator=g).cuda() * dim ** -0.5 for _ in range(3))
+    grads = []
+    for _ in range(2):
+        a, b, c = (t.clone().requires_grad_(True) for t in (q, p, n))
+        ops.inbatch_ce(a, b, c, 20.0).backward()
+        grads.append(torch.stack([a.grad, b.grad, c.grad]))
+    assert torch.equal(grads[0].view(torch.int32), grads[1].view(torch.int32))
+    # fp16 inputs / a transposed view: the same rounded operands through the copy path
+    qh = q.to(torch.bfloat16).float()
+    a, b, c = qh.half().requires_grad_(True), p.t().contiguous().t().requires_grad_(True), n.clone().requires_grad_(True)
+    assert not b.is_contiguous()
+    ops.inbatch_ce(a, b, c, 20.0).backward()
+    a2, b2, c2 = (t.clone().requires_grad_(True) for t in (qh.half().float(), p, n))
+    ops.inbatch_ce(a2, b2, c2, 20.0).backward()
+    assert a.grad.dtype == torch.float16 and torch.allclose(a.grad.float(), a2.grad, rtol=1e-2, atol=1e-6)
+    assert torch.equal(b.grad, b2.grad) and torch.equal(c.grad, c2.grad)
+
+
+def test_backward_rejects_a_workspace_that_is_not_its_forwards():
+    """The backward reads the forward's logits from the workspace.  A workspace no forward (or another shape's / temperature's forward)
+    has filled carries no matching stamp: the gradients come back NaN -- loudly wrong, not plausible garbage -- and a matching one works."""
+    import ctypes
+    from ccrec_amd import _lib, ops
+    lib = ops.require_gpu()
+    B, dim = 64, 32
+    g = torch.Generator().manual_seed(2)
+    qb, pb, nb = (torch.randn(B, dim, generator=g).cuda().to(torch.bfloat16) for _ in range(3))
+    loss, lse = torch.empty(1, device="cuda"), torch.empty(B, device="cuda")
+    grads = torch.empty(3, B, dim, device="cuda")
+    need = int(lib.ccr_inbatch_ce_workspace_bytes(B, dim))
+    ws, scratch = (torch.zeros(need, dtype=torch.uint8, device="cuda") for _ in range(2))
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def bwd(w, inv_t):
+        grads.zero_()
+        _lib.check(lib.ccr_inbatch_ce_bwd(vp(qb), vp(pb), vp(nb), vp(lse), B, dim, inv_t, 1.0, vp(grads[0]), vp(grads[1]), vp(grads[2]), vp(w), need, stream), "bwd")
+        torch.cuda.synchronize()
+        return grads.clone()
+
+    _lib.check(lib.ccr_inbatch_ce_fwd(vp(qb), vp(pb), vp(nb), B, dim, 20.0, vp(loss), vp(lse), vp(ws), need, stream), "fwd")
+    good = bwd(ws, 20.0)
+    assert torch.isfinite(good).all() and good.abs().max() > 0
+    assert torch.isnan(bwd(scratch, 20.0)).all()          # never written by a forward
+    assert torch.isnan(bwd(ws, 10.0)).all()               # another temperature's logits
+    _lib.check(lib.ccr_inbatch_ce_fwd(vp(qb), vp(pb), vp(nb), B, dim, 10.0, vp(loss), vp(lse), vp(ws), need, stream), "fwd")
+    assert torch.isnan(bwd(ws, 20.0)).all()               # the workspace has been reused by another forward since
+    assert torch.isfinite(bwd(ws, 10.0)).all()

@@ -1,34 +1,48 @@
 #!/bin/bash
-# PMC passes over the BM25 kernels of tools/exp_bm25_tile.py --cfgs 0 (500 k documents x 2 000 queries x top-1001): bytes fetched from beyond
-# the L2 (FETCH_SIZE, doubled per the guide's gfx950 correction), bytes written, L2 hits / misses.  bash tools/pmc_bm25.sh -> gpurun_out/pmc_bm25.txt
+# PMC passes over the BM25 kernels of tools/one_bm25.py (the bench line's workload: 500 k documents x 2 000 queries x top-1001): bytes fetched
+# from beyond the L2 (FETCH_SIZE, doubled per the guide's gfx950 correction), bytes written, L2 hits / misses -- separate passes, kernel trace
+# only.  bash tools/pmc_bm25.sh -> gpurun_out/pmc_bm25/summary.txt + summary.json (copy to profiles/rNN_bm25_pmc.{txt,json})
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_bm25; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for pass in "FETCH_SIZE" "WRITE_SIZE GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   tag=$(echo $pass | tr ' ' '_')
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/$tag -- python3 $ROOT/tools/exp_bm25_tile.py --cfgs 0 > $OUT/$tag.log 2>&1 || tail -3 $OUT/$tag.log
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/$tag -- python3 $ROOT/tools/one_bm25.py --reps 3 > $OUT/$tag.log 2>&1 || tail -3 $OUT/$tag.log
 done
-python3 - $OUT <<'PY'
-import csv, glob, sys, collections
+python3 - $OUT <<'PY' | tee $OUT/summary.txt
+import csv, glob, json, sys, collections
 out = sys.argv[1]
-tot = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+per = collections.defaultdict(lambda: collections.defaultdict(list))   # kernel -> counter -> per-dispatch values
 for f in glob.glob(out + "/*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "bm25_" in k:
+        if "bm25_" in k and "contrib" not in k and "check" not in k and "mark" not in k:
             name = k.split("(")[0].replace("void ", "").replace("ccr::", "")
-            tot[name][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(name, r["Counter_Name"])] += 1
-for name, c in sorted(tot.items()):
+            per[name][r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+# one_bm25.py: a 64-query warm-up call, then `reps` full calls -> the LAST dispatch of every kernel belongs to a full call
+call = {"kernels": {}}
+fabric = 0.0
+for name, c in sorted(per.items()):
     print(name)
+    rec = {}
     for cn, v in sorted(c.items()):
-        n = cnt[(name, cn)]
-        print(f"   {cn:18s} per launch {v / n:14.4g}   (launches {n})")
-    if "FETCH_SIZE" in c:
-        print(f"   read from beyond the L2 per launch = FETCH_SIZE x 2 KiB = {c['FETCH_SIZE'] / cnt[(name, 'FETCH_SIZE')] * 2 * 1024 / 1e9:.3f} GB")
-    if "WRITE_SIZE" in c:
-        print(f"   written per launch = WRITE_SIZE x 1 KiB = {c['WRITE_SIZE'] / cnt[(name, 'WRITE_SIZE')] * 1024 / 1e9:.3f} GB")
-    if "TCC_HIT_sum" in c:
-        h, m = c["TCC_HIT_sum"], c["TCC_MISS_sum"]
-        print(f"   L2 hit rate {h / (h + m):.3f}")
+        last = sorted(v)[-1][1]
+        rec[cn] = last
+        print(f"   {cn:18s} last launch {last:14.6g}   (launches {len(v)})")
+    if "FETCH_SIZE" in rec:
+        rec["read_beyond_l2_bytes"] = rec["FETCH_SIZE"] * 2 * 1024
+        fabric += rec["read_beyond_l2_bytes"]
+        print(f"   read from beyond the L2 = FETCH_SIZE x 2 KiB = {rec['read_beyond_l2_bytes'] / 1e9:.3f} GB")
+    if "WRITE_SIZE" in rec:
+        rec["written_bytes"] = rec["WRITE_SIZE"] * 1024
+        fabric += rec["written_bytes"]
+        print(f"   written = WRITE_SIZE x 1 KiB = {rec['written_bytes'] / 1e9:.3f} GB")
+    if "TCC_HIT_sum" in rec:
+        rec["l2_hit_rate"] = rec["TCC_HIT_sum"] / (rec["TCC_HIT_sum"] + rec["TCC_MISS_sum"])
+        print(f"   L2 hit rate {rec['l2_hit_rate']:.3f}")
+    call["kernels"][name] = rec
+call["fabric_bytes_per_call"] = fabric
+print(f"fabric traffic of one call (all kernels, read x 2 KiB + written x 1 KiB): {fabric / 1e9:.3f} GB")
+json.dump(call, open(out + "/summary.json", "w"), indent=1)
 PY
