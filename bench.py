@@ -331,9 +331,10 @@ def inbatch_side_run(dev, B=1024, d=768, iters=50):
         out[name] = round((time.perf_counter() - t0) / iters * 1e3, 4)
         out[name.replace("_ms", "_loss")] = round(float(loss), 6)
     out["steps_per_s"] = round(1e3 / out["hip_ms"], 1)
-    # the library calls alone: bf16 operands resident, HIP events on the stream they are launched on
+    # the library calls alone (the calls the autograd function makes: fp32 blocks resident -> one-launch bf16 pack + forward, then the
+    # backward), HIP events on the stream they are launched on
     lib = _lib.load()
-    qb, pb, nb = (t.to(torch.bfloat16).contiguous() for t in (q, p, n))
+    packed = torch.empty(3, B, d, dtype=torch.bfloat16, device=dev)
     loss_t, lse = torch.empty(1, device=dev), torch.empty(B, device=dev)
     grads = [torch.empty(B, d, device=dev) for _ in range(3)]
     ws = torch.empty(int(lib.ccr_inbatch_ce_workspace_bytes(B, d)), dtype=torch.uint8, device=dev)
@@ -341,8 +342,8 @@ def inbatch_side_run(dev, B=1024, d=768, iters=50):
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
     def kernels():
-        _lib.check(lib.ccr_inbatch_ce_fwd(ptr(qb), ptr(pb), ptr(nb), B, d, 20.0, ptr(loss_t), ptr(lse), ptr(ws), ws.numel(), stream))
-        _lib.check(lib.ccr_inbatch_ce_bwd(ptr(qb), ptr(pb), ptr(nb), ptr(lse), B, d, 20.0, 1.0, ptr(grads[0]), ptr(grads[1]), ptr(grads[2]),
+        _lib.check(lib.ccr_inbatch_ce_fwd_f32(ptr(q), ptr(p), ptr(n), B, d, 20.0, ptr(packed), ptr(loss_t), ptr(lse), ptr(ws), ws.numel(), stream))
+        _lib.check(lib.ccr_inbatch_ce_bwd(ptr(packed[0]), ptr(packed[1]), ptr(packed[2]), ptr(lse), B, d, 20.0, 1.0, ptr(grads[0]), ptr(grads[1]), ptr(grads[2]),
                                           ptr(ws), ws.numel(), stream))
     for _ in range(5):
         kernels()
@@ -355,7 +356,7 @@ def inbatch_side_run(dev, B=1024, d=768, iters=50):
     kms = e0.elapsed_time(e1) / iters
     flops = 3 * 2 * 2.0 * B * B * d          # 2 x 2 B^2 d forward (two logit blocks), x 3 with the backward (dQ over 2B keys, dP, dN) = 9.66 GFLOP
     out["kernels_ms"] = round(kms, 4)
-    out["roofline"] = {"bound": "launch latency (4 dependent kernels of microseconds of MFMA work each)", "kernel": "inbatch_fwd_kernel + inbatch_prep_kernel + inbatch_gemm3_kernel",
+    out["roofline"] = {"bound": "launch latency (4 dependent kernels of microseconds of MFMA work each)", "kernel": "inbatch_pack3_kernel + inbatch_fwd_kernel<FRAG> + inbatch_prep_kernel + inbatch_gemm3_kernel",
                        "achieved": round(flops / (kms * 1e-3) / 1e12, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                        "frac": round(flops / (kms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4), "flops_per_step": flops,
                        "launch_floor_ms": round(3 * 0.0019 + 0.0015, 4),

@@ -18,6 +18,8 @@
 //         contraction index contiguous; (2) inbatch_gemm3_kernel then reads every MFMA fragment straight from L2 -- no LDS staging,
 //         no barrier inside the K loop -- one workgroup per 32 x 64 output tile, its four waves taking a quarter of K each and
 //         adding their partial tiles through LDS in wave order.  Deterministic, no atomics.
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "ccr_common.h"
@@ -47,6 +49,10 @@ __device__ __forceinline__ unsigned int drain_and_take_ticket(unsigned int *tick
 // grid = (query tiles of 32, key splits), block = one wave.
 //   pm / pl / pd [splits][B]: partial max, sum, diagonal; S [2B][ldS]: the scaled logits (row = key, column = query)
 //   tile_ticket [query tiles] + loss_ticket [1] + tile_part [query tiles] doubles: zeroed by the caller's memset
+// FRAG (the fp32 entry point, B % 32 == 0, dim % 128 == 0): Q points at the FRAGMENT-MAJOR copy of [Q ; P ; N] the pack kernel left in
+// the workspace (3B rows, contraction index = dim; layout: frag_major below) -- every operand load of a wave is one contiguous KiB
+// instead of 16 bytes from each of 32 rows (32 cache lines per instruction: what bounded this kernel at 52 us).
+template <bool FRAG>
 __global__ __launch_bounds__(64) void inbatch_fwd_kernel(const uint16_t *__restrict__ Q, const uint16_t *__restrict__ P,
                                                         const uint16_t *__restrict__ N, int B, int dim, float inv_t, int splits,
                                                         float *__restrict__ pm, float *__restrict__ pl, float *__restrict__ pd,
@@ -62,12 +68,16 @@ __global__ __launch_bounds__(64) void inbatch_fwd_kernel(const uint16_t *__restr
     const int t_lo = (int)((int64_t)s * ktiles / splits), t_hi = (int)((int64_t)(s + 1) * ktiles / splits);
     const int i = i0 + l31;
     const int iq = i < B ? i : B - 1;
-    const uint16_t *qrow = Q + (int64_t)iq * dim + 8 * h;
+    // FRAG: row block rb of the 3B-row matrix starts at rb (dim / 64) 2 048 elements; inside a 64-wide chunk k-step ks is at ks 512 + lane 8,
+    // so the 8 k-steps of a 128-wide chunk c are at c 4 096 + u 512 (u = 0 .. 7)
+    const uint16_t *qrow = FRAG ? Q + (int64_t)blockIdx.x * (dim / 64) * 2048 + lane * 8 : Q + (int64_t)iq * dim + 8 * h;
+    constexpr int KSTEP = FRAG ? 512 : 16;      // elements between consecutive k-steps of a lane
+    constexpr int KCHUNK = FRAG ? 4096 : 128;   // ... and between 128-wide chunks
     float m = -INFINITY, l = 0.f, dg = -INFINITY;
     for (int t = t_lo; t < t_hi; ++t) {
         int jr = t * 32 + l31;
         if (jr > 2 * B - 1) jr = 2 * B - 1;
-        const uint16_t *krow = key_row(P, N, B, jr, dim) + 8 * h;
+        const uint16_t *krow = FRAG ? Q + (int64_t)(B / 32 + t) * (dim / 64) * 2048 + lane * 8 : key_row(P, N, B, jr, dim) + 8 * h;
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -77,11 +87,11 @@ __global__ __launch_bounds__(64) void inbatch_fwd_kernel(const uint16_t *__restr
         const int nfull = dim / 128;
         bf16x8 a[2][8], b[2][8];
         auto load = [&](int set, int c) {
-            const int kk = (c < nfull ? c : nfull - 1) * 128;
+            const int kk = (c < nfull ? c : nfull - 1) * KCHUNK;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                a[set][u] = *reinterpret_cast<const bf16x8 *>(krow + kk + 16 * u);
-                b[set][u] = *reinterpret_cast<const bf16x8 *>(qrow + kk + 16 * u);
+                a[set][u] = *reinterpret_cast<const bf16x8 *>(krow + kk + KSTEP * u);
+                b[set][u] = *reinterpret_cast<const bf16x8 *>(qrow + kk + KSTEP * u);
             }
         };
         if (nfull > 0) {
@@ -97,7 +107,7 @@ __global__ __launch_bounds__(64) void inbatch_fwd_kernel(const uint16_t *__restr
                 }
             }
         }
-        int k0 = nfull * 128;
+        int k0 = FRAG ? dim : nfull * 128;   // (FRAG: dim % 128 == 0, no tail)
         for (; k0 < dim; k0 += 16) {
             const bf16x8 a = *reinterpret_cast<const bf16x8 *>(krow + k0);
             const bf16x8 b = *reinterpret_cast<const bf16x8 *>(qrow + k0);
@@ -395,8 +405,10 @@ __global__ __launch_bounds__(256) void inbatch_gemm3_kernel(const uint16_t *__re
 }
 
 // fp32 -> bf16 (RNE: torch's .to(bfloat16) bits) of the step's three embedding blocks in ONE launch.  grid = (chunks, 3), block = 256.
+// frag (may be null; B % 32 == 0 and dim % 64 == 0): the same values again as ONE fragment-major matrix [Q ; P ; N] of 3B rows (the
+// forward's operand layout: a thread's 8 consecutive dim elements are exactly one lane's 16 bytes of a k-step).
 __global__ __launch_bounds__(256) void inbatch_pack3_kernel(const float *__restrict__ q, const float *__restrict__ p, const float *__restrict__ n,
-                                                           int64_t count, uint16_t *__restrict__ out) {
+                                                           int64_t count, uint16_t *__restrict__ out, uint16_t *__restrict__ frag, int B, int dim) {
     const float *src = blockIdx.y == 0 ? q : (blockIdx.y == 1 ? p : n);
     uint16_t *dst = out + (int64_t)blockIdx.y * count;
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; i < count; i += (int64_t)gridDim.x * 256 * 8) {   // count % 8 == 0
@@ -407,6 +419,10 @@ __global__ __launch_bounds__(256) void inbatch_pack3_kernel(const float *__restr
         for (int e = 0; e < 4; ++e)
             w[e] = (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)f[2 * e]) | ((uint32_t)__builtin_bit_cast(uint16_t, (__bf16)f[2 * e + 1]) << 16);
         *reinterpret_cast<uint4 *>(dst + i) = make_uint4(w[0], w[1], w[2], w[3]);
+        if (frag) {
+            const int row = (int)(i / dim) + (int)blockIdx.y * B, d = (int)(i % dim);
+            *reinterpret_cast<uint4 *>(frag + frag_major(row, d, dim / 64)) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
     }
 }
 
@@ -426,14 +442,14 @@ using namespace ccr;
 
 namespace {
 // workspace: [partials 3 x 64 x B floats][S: 2B rows of ldS floats][tickets: (query tiles + 1) u32, padded][tile shares: doubles]
-//            [stamp][backward: Gk | Gq (three bf16 parts each) | QT | KT]
+//            [stamp][backward: Gk | Gq (three bf16 parts each) | QT | KT][forward, fp32 entry point: fragment-major Q ; P ; N]
 struct InbatchWs {
     float *pm, *pl, *pd, *S;
     int ldS, ldk, ldq;
     unsigned int *tile_ticket, *loss_ticket;
     double *tile_part;
     uint32_t *stamp;
-    uint16_t *Gk, *Gq, *QT, *KT;
+    uint16_t *Gk, *Gq, *QT, *KT, *Xf;
     size_t zero_bytes;   // tickets + stamp: zeroed before every forward
     size_t total;
 };
@@ -464,6 +480,7 @@ InbatchWs inbatch_ws(void *workspace, int B, int dim) {
     w.Gq = (uint16_t *)(base + off), off += up256((size_t)3 * w.ldk * w.ldq * 2);
     w.QT = (uint16_t *)(base + off), off += up256(dimp * w.ldk * 2);
     w.KT = (uint16_t *)(base + off), off += up256(dimp * w.ldq * 2);
+    w.Xf = (uint16_t *)(base + off), off += up256((size_t)3 * B * dimp * 2);   // the forward's fragment-major [Q ; P ; N] (fp32 entry point)
     w.total = off + 256;   // + 256: the caller's pointer need only be 16-byte aligned
     return w;
 }
@@ -477,8 +494,8 @@ extern "C" size_t ccr_inbatch_ce_workspace_bytes(int B, int dim) {
     return inbatch_ws(nullptr, B, dim).total;
 }
 
-extern "C" int ccr_inbatch_ce_fwd(const uint16_t *Qe, const uint16_t *Pe, const uint16_t *Ne, int B, int dim,
-                                  float inv_temperature, float *loss, float *lse, void *workspace, size_t ws_bytes, void *stream) {
+static int inbatch_fwd_impl(const uint16_t *Qe, const uint16_t *Pe, const uint16_t *Ne, bool frag, int B, int dim, float inv_temperature,
+                            float *loss, float *lse, void *workspace, size_t ws_bytes, void *stream) {
     CCR_REQUIRE(Qe && Pe && Ne && loss && lse, "ccr_inbatch_ce_fwd: null pointer");
     CCR_REQUIRE(B >= 1 && dim >= 16 && dim % 16 == 0, "ccr_inbatch_ce_fwd: B=%d dim=%d (dim %% 16 == 0)", B, dim);
     CCR_REQUIRE(((uintptr_t)Qe | (uintptr_t)Pe | (uintptr_t)Ne) % 16 == 0, "ccr_inbatch_ce_fwd: embedding pointers must be 16-byte aligned");
@@ -491,19 +508,52 @@ extern "C" int ccr_inbatch_ce_fwd(const uint16_t *Qe, const uint16_t *Pe, const 
     const int splits = pick_splits(B);
     CCR_HIP_CHECK(hipMemsetAsync(w.tile_ticket, 0, w.zero_bytes, s));   // tickets, and the stamp: no longer this workspace's logits
     dim3 grid((B + 31) / 32, splits);
-    hipLaunchKernelGGL(inbatch_fwd_kernel, grid, dim3(64), 0, s, Qe, Pe, Ne, B, dim, inv_temperature, splits, w.pm, w.pl, w.pd, w.S, w.ldS,
-                       lse, loss, w.tile_ticket, w.loss_ticket, w.tile_part, w.stamp);
+    if (frag)
+        hipLaunchKernelGGL(inbatch_fwd_kernel<true>, grid, dim3(64), 0, s, w.Xf, w.Xf, w.Xf, B, dim, inv_temperature, splits, w.pm, w.pl, w.pd, w.S, w.ldS,
+                           lse, loss, w.tile_ticket, w.loss_ticket, w.tile_part, w.stamp);
+    else
+        hipLaunchKernelGGL(inbatch_fwd_kernel<false>, grid, dim3(64), 0, s, Qe, Pe, Ne, B, dim, inv_temperature, splits, w.pm, w.pl, w.pd, w.S, w.ldS,
+                           lse, loss, w.tile_ticket, w.loss_ticket, w.tile_part, w.stamp);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
 }
 
-// pack + forward in one call (the autograd function's host path: one crossing of the C boundary per forward)
+extern "C" int ccr_inbatch_ce_fwd(const uint16_t *Qe, const uint16_t *Pe, const uint16_t *Ne, int B, int dim,
+                                  float inv_temperature, float *loss, float *lse, void *workspace, size_t ws_bytes, void *stream) {
+    return inbatch_fwd_impl(Qe, Pe, Ne, false, B, dim, inv_temperature, loss, lse, workspace, ws_bytes, stream);
+}
+
+static int launch_pack3(const float *q, const float *p, const float *n, int B, int dim, uint16_t *out, uint16_t *frag, void *stream) {
+    CCR_REQUIRE(q && p && n && out, "ccr_inbatch_pack3_bf16: null pointer");
+    CCR_REQUIRE(B >= 1 && dim >= 8 && dim % 8 == 0, "ccr_inbatch_pack3_bf16: B=%d dim=%d (dim %% 8 == 0)", B, dim);
+    CCR_REQUIRE(((uintptr_t)q | (uintptr_t)p | (uintptr_t)n | (uintptr_t)out) % 16 == 0, "ccr_inbatch_pack3_bf16: pointers must be 16-byte aligned");
+    const int64_t count = (int64_t)B * dim;
+    hipLaunchKernelGGL(inbatch_pack3_kernel, dim3((unsigned)std::min<int64_t>((count / 8 + 255) / 256, 4096), 3), dim3(256), 0, (hipStream_t)stream, q, p, n,
+                       count, out, frag, B, dim);
+    CCR_LAUNCH_CHECK();
+    return CCR_OK;
+}
+
+extern "C" int ccr_inbatch_pack3_bf16(const float *q, const float *p, const float *n, int B, int dim, uint16_t *out, void *stream) {
+    return launch_pack3(q, p, n, B, dim, out, nullptr, stream);
+}
+
+// pack + forward in one call (the autograd function's host path: one crossing of the C boundary per forward).  Where the shape allows
+// (B % 32 == 0, dim % 128 == 0) the pack also leaves the fragment-major copy the forward then reads.
 extern "C" int ccr_inbatch_ce_fwd_f32(const float *q, const float *p, const float *n, int B, int dim, float inv_temperature,
                                       uint16_t *packed, float *loss, float *lse, void *workspace, size_t ws_bytes, void *stream) {
-    const int rc = ccr_inbatch_pack3_bf16(q, p, n, B, dim, packed, stream);
+    CCR_REQUIRE(packed && workspace, "ccr_inbatch_ce_fwd_f32: null pointer");
+    CCR_REQUIRE(B >= 1 && dim >= 16 && dim % 16 == 0, "ccr_inbatch_ce_fwd_f32: B=%d dim=%d (dim %% 16 == 0)", B, dim);
+    if (ws_bytes < ccr_inbatch_ce_workspace_bytes(B, dim)) {
+        set_error("ccr_inbatch_ce_fwd_f32: workspace %zu bytes required, got %zu", ccr_inbatch_ce_workspace_bytes(B, dim), ws_bytes);
+        return CCR_ERR_WORKSPACE;
+    }
+    const bool frag = B % 32 == 0 && dim % 128 == 0 && getenv("CCR_INBATCH_ROWMAJOR") == nullptr;
+    const InbatchWs w = inbatch_ws(align256(workspace), B, dim);
+    const int rc = launch_pack3(q, p, n, B, dim, packed, frag ? w.Xf : nullptr, stream);
     if (rc != CCR_OK) return rc;
     const size_t blk = (size_t)B * dim;
-    return ccr_inbatch_ce_fwd(packed, packed + blk, packed + 2 * blk, B, dim, inv_temperature, loss, lse, workspace, ws_bytes, stream);
+    return inbatch_fwd_impl(packed, packed + blk, packed + 2 * blk, frag, B, dim, inv_temperature, loss, lse, workspace, ws_bytes, stream);
 }
 
 static int inbatch_bwd_impl(const uint16_t *Qe, const uint16_t *Pe, const uint16_t *Ne, const float *lse, int B, int dim,
@@ -529,17 +579,6 @@ static int inbatch_bwd_impl(const uint16_t *Qe, const uint16_t *Pe, const uint16
     const int nq_blocks = (B + G3_TM - 1) / G3_TM * ntn, nk_blocks = (2 * B + G3_TM - 1) / G3_TM * ntn;
     hipLaunchKernelGGL(inbatch_gemm3_kernel, dim3((unsigned)(nq_blocks + nk_blocks)), dim3(256), 0, s, w.Gq, w.Gk, w.KT, w.QT, B, dim, w.ldq, w.ldk,
                        nq_blocks, dQ, dP, dN);
-    CCR_LAUNCH_CHECK();
-    return CCR_OK;
-}
-
-extern "C" int ccr_inbatch_pack3_bf16(const float *q, const float *p, const float *n, int B, int dim, uint16_t *out, void *stream) {
-    CCR_REQUIRE(q && p && n && out, "ccr_inbatch_pack3_bf16: null pointer");
-    CCR_REQUIRE(B >= 1 && dim >= 8 && dim % 8 == 0, "ccr_inbatch_pack3_bf16: B=%d dim=%d (dim %% 8 == 0)", B, dim);
-    CCR_REQUIRE(((uintptr_t)q | (uintptr_t)p | (uintptr_t)n | (uintptr_t)out) % 16 == 0, "ccr_inbatch_pack3_bf16: pointers must be 16-byte aligned");
-    const int64_t count = (int64_t)B * dim;
-    hipLaunchKernelGGL(inbatch_pack3_kernel, dim3((unsigned)std::min<int64_t>((count / 8 + 255) / 256, 4096), 3), dim3(256), 0, (hipStream_t)stream, q, p, n,
-                       count, out);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
 }

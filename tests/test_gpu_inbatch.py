@@ -170,3 +170,21 @@ def test_backward_rejects_a_workspace_that_is_not_its_forwards():
     _lib.check(lib.ccr_inbatch_ce_fwd(vp(qb), vp(pb), vp(nb), B, dim, 10.0, vp(loss), vp(lse), vp(ws), need, stream), "fwd")
     assert torch.isnan(bwd(ws, 20.0)).all()               # the workspace has been reused by another forward since
     assert torch.isfinite(bwd(ws, 10.0)).all()
+
+
+def test_fragment_major_forward_equals_the_row_major_forward(monkeypatch):
+    """B % 32 == 0 and dim % 128 == 0: the fp32 entry point packs a fragment-major copy of [Q ; P ; N] and the forward reads its operands
+    as contiguous KiB blocks; CCR_INBATCH_ROWMAJOR=1 keeps the row-major loads.  Same contraction order: the same loss and gradient bits."""
+    from ccrec_amd import ops
+    g = torch.Generator().manual_seed(5)
+    q, p, n = (torch.randn(96, 256, generator=g).cuda() * 256 ** -0.5 for _ in range(3))
+    out = []
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("CCR_INBATCH_ROWMAJOR", env)
+        a, b, c = (t.clone().requires_grad_(True) for t in (q, p, n))
+        loss = ops.inbatch_ce(a, b, c, 20.0)
+        loss.backward()
+        out.append((loss.detach().clone(), torch.stack([a.grad, b.grad, c.grad])))
+    assert torch.equal(out[0][0].view(torch.int32), out[1][0].view(torch.int32))
+    assert torch.equal(out[0][1].view(torch.int32), out[1][1].view(torch.int32))
