@@ -120,7 +120,12 @@ def gen_rows(n, dim, seed, device, data="gaussian", chunk=262144, lo=0, hi=None)
             if ndup and m > 1:
                 dst = torch.randint(0, m, (ndup,), generator=g, device=device)
                 src = torch.randint(0, m, (ndup,), generator=g, device=device)
-                x[dst] = x[src]
+                # a destination drawn twice keeps its FIRST source: an indexed store with repeated destinations leaves the winner to
+                # the hardware, and the ranks of a sharded run would then hold different rows than the single-GPU run
+                order = torch.arange(ndup, device=device)
+                first = torch.full((m,), ndup, dtype=torch.int64, device=device).scatter_reduce_(0, dst, order, "amin")
+                keep = first[dst] == order
+                x[dst[keep]] = x[src[keep]]
         if data == "outlier" and seed == 1234:
             first = (c_lo + 499_999) // 500_000 * 500_000   # global rows 0, 500 000, ... inside this chunk
             if first < c_hi:
@@ -190,6 +195,7 @@ class Workload:
         self.shard, self.qpack = self.slots[0]["shard"], self.slots[0]["qpack"]
         self.prev = None        # the step whose search / exchange is still in flight
         self.nstep = 0
+        self.suspended_at_step = None
         self.index = self.scores = self.ids = None
         self.set_k(k)
 
@@ -212,10 +218,19 @@ class Workload:
         self.repeats = 0        # exchanges that had to be repeated (some rank's search had flagged queries: completed by finish(), gathered again)
         self.fallback_queries = 0   # short lists: queries repeated with full lists (a list was consumed to its end)
         self.wait_ms = []       # host-observed wait for each step's collective, at the time the step is completed (one step later)
+        self.host_syncs = 0     # times an exchange had to synchronise with the compute stream (0 on the pipelined path)
 
     def step(self):
         from ccrec_amd import ops
-        from ccrec_amd.dist import submit_sharded_search
+        from ccrec_amd.dist import submit_sharded_search, short_lists_pay
+        if self.world > 1 and self.k_list < self.k and not short_lists_pay(self.k, self.world):
+            # an exchange repeated too many queries (a corpus in topical order): every rank has seen the same flags and switches to
+            # full lists at this same step
+            self.suspended_at_step = self.nstep
+            self.drain()
+            counters = (self.done_stats, self.repeats, self.fallback_queries, self.wait_ms, self.host_syncs)
+            self.set_k(self.k)
+            self.done_stats, self.repeats, self.fallback_queries, self.wait_ms, self.host_syncs = counters
         b = self.slots[self.nstep % 2]
         self.nstep += 1
         ops.pack_bf16(self.corpus_f32, out=b["shard"], norm_bounds=b["bounds"], normalize=self.normalize)   # pack + norm bound of every packed row in one pass
@@ -243,6 +258,7 @@ class Workload:
             self.repeats += int(exchange.repeated)
             self.fallback_queries += exchange.fallback_queries
             self.wait_ms.append(exchange.wait_ms)
+            self.host_syncs += exchange.host_syncs
         else:
             index.finish()
         self.index, self.scores, self.ids = index, s, i
@@ -285,6 +301,7 @@ class Workload:
                 "achieved_tflops": achieved, "n_fallback_max": max(m["n_fallback"] for m in stats),
                 "rank_ms_per_step": [e / steps * 1e3 for e in per_rank], "exchange_repeats": self.repeats,
                 "fallback_queries": self.fallback_queries, "search_ms": sum(m["ms_total"] for m in stats) / len(stats),
+                "exchange_host_syncs": self.host_syncs, "short_lists_suspended_at_step": self.suspended_at_step,
                 "exchange_wait_ms": (sum(self.wait_ms) / len(self.wait_ms)) if self.wait_ms else 0.0,
                 "exchange_wait_ms_max": max(self.wait_ms) if self.wait_ms else 0.0}
 
@@ -539,6 +556,7 @@ def exchange_obj(w, r):
             "entries_per_query_per_rank": w.k_list, "message_bytes_per_rank": msg, "gathered_bytes_per_rank_per_step": msg * w.world,
             "full_list_message_bytes_per_rank": shard_message_bytes(w.queries, w.k),
             "repeated_exchanges": r["exchange_repeats"], "queries_repeated_with_full_lists": r["fallback_queries"],
+            "compute_stream_syncs_in_exchange": r["exchange_host_syncs"], "short_lists_suspended_at_step": r["short_lists_suspended_at_step"],
             "rank_ms_per_step_min": round(min(r["rank_ms_per_step"]), 3), "rank_ms_per_step_max": round(max(r["rank_ms_per_step"]), 3),
             # the per-shard search on this rank's stream (library events) vs. what the host waited for the collective of a step when it
             # completed that step one step later (0 = it had long arrived behind the next step's pack and search)

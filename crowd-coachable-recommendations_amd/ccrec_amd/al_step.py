@@ -26,7 +26,7 @@ def _bm25_on_device(device, corpus, queries):
 
 def run_rank_step(tower, tokenizer, corpus, queries, qrels, step_qids, step, results_dir, ranking_profile_bm25=None,
                   block_dict=None, landing_image=None, n_repeats=3, repeat_seed=42, encoder_kw=None, autocast=True,
-                  compat_profile=True, rank=0, world=1, group=None):
+                  compat_profile=True, rank=0, world=1, group=None, balance="tokens"):
     """-> {"ranking_profile", "mrr", "requests", "timings"}; files are written to results_dir/data_iteration_{step}/.
     timings: wall seconds of the stages (rank = encode + search; save; mrr; bm25; requests) and the corpus encoder's own statistics.
     autocast: rank inside `torch.autocast("cuda")` -- the reference's fp16 context (scripts/al_0_rank.py:125); the layer kernels run
@@ -36,7 +36,8 @@ def run_rank_step(tower, tokenizer, corpus, queries, qrels, step_qids, step, res
     further down does not lose the encode + search.
     rank / world / group: one process per GPU (torch.distributed initialised by the caller): every rank encodes and indexes its own
     block of the corpus, all ranks hold the same merged profile and MRR afterwards.  Only rank 0 writes files, and only rank 0
-    computes the BM25 ranking when none is passed in (the other ranks then return "requests": None)."""
+    computes the BM25 ranking when none is passed in (the other ranks then return "requests": None).  balance: how the corpus is cut
+    into the ranks' blocks (encode.ranking_sharded: "tokens" = equal estimated tokens per rank, "rows", or one weight per row)."""
     import time
     t_start = time.perf_counter()
     timings = {}
@@ -71,7 +72,7 @@ def run_rank_step(tower, tokenizer, corpus, queries, qrels, step_qids, step, res
             try:
                 with torch.autocast("cuda", enabled=bool(autocast)):
                     profile, ids, _ = ranking_sharded(corpus, queries, encoder, block_dict=block_dict, with_tensors=True, lazy=True,
-                                                      rank=rank, world=world, group=group)
+                                                      rank=rank, world=world, group=group, balance=balance)
                 torch.cuda.synchronize()
                 timings["rank_s"] = time.perf_counter() - t0
                 timings["corpus_encoder"] = dict(encoder.stats)      # (the corpus is encoded last: its statistics are the ones left)
@@ -97,9 +98,12 @@ def run_rank_step(tower, tokenizer, corpus, queries, qrels, step_qids, step, res
             ranking_profile_bm25 = bm25_job.result()
             timings["bm25_wait_s"] = time.perf_counter() - t0       # what was NOT hidden behind the dense ranking
             timings["bm25_since_start_s"] = time.perf_counter() - t_bm25
+        bm25_job = None
     finally:
         if bm25_pool is not None:
-            bm25_pool.shutdown(wait=True, cancel_futures=True)
+            # normal path: the job's result has been collected above.  Error path (bm25_job still set): the exception must not wait
+            # for the whole BM25 job -- drop what has not started and let the worker thread finish on its own
+            bm25_pool.shutdown(wait=bm25_job is None, cancel_futures=True)
     requests = None
     if makes_requests:
         t0 = time.perf_counter()

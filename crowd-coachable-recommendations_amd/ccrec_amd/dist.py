@@ -32,11 +32,32 @@ HEADER_WORDS = _lib.SHARD_HEADER_BYTES // 4   # the header as int32 words: magic
 PAD_ID = torch.iinfo(torch.int64).max           # padding slot (r, p) carries id PAD_ID - (r k + p): distinct, above every real id
 
 
-def shard_bounds(n_rows, world_size, rank):
-    """Contiguous, balanced row block of `rank`: [lo, hi)."""
-    base, rem = divmod(n_rows, world_size)
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
+def shard_bounds(n_rows, world_size, rank, weights=None):
+    """Contiguous row block of `rank`: [lo, hi).  weights=None: equal row counts.  weights = one non-negative cost per row (token
+    counts: the encoder's time per passage is proportional to its tokens, and the reference's DataParallel scatters every batch
+    evenly, scripts/al_0_rank.py:70-74,92): the blocks carry equal WEIGHT instead -- boundary r is the number of leading rows whose
+    total weight stays within r / world of the whole, so a corpus whose passage length follows the row order (sorted by length, one
+    source after another) still gives every rank the same encode time.  Every rank must pass the same weights."""
+    if weights is None:
+        base, rem = divmod(n_rows, world_size)
+        lo = rank * base + min(rank, rem)
+        return lo, lo + base + (1 if rank < rem else 0)
+    cuts = weighted_cuts(weights, world_size)
+    assert len(cuts) == world_size + 1 and cuts[-1] == n_rows, "weights: one per row"
+    return int(cuts[rank]), int(cuts[rank + 1])
+
+
+def weighted_cuts(weights, world_size):
+    """[0 = c_0 <= c_1 <= ... <= c_world = n]: rank r takes rows [c_r, c_r+1) (shard_bounds with weights)."""
+    import numpy as np
+    w = np.asarray(weights, dtype=np.float64)
+    assert w.ndim == 1 and (w >= 0).all(), "weights: non-negative, one per row"
+    cum = np.cumsum(w)
+    total = float(cum[-1]) if len(w) else 0.0
+    if total <= 0.0:      # nothing to balance: equal row counts
+        return [shard_bounds(len(w), world_size, r)[0] for r in range(world_size)] + [len(w)]
+    inner = np.searchsorted(cum, total * np.arange(1, world_size) / world_size, side="right")
+    return [0] + [int(c) for c in inner] + [len(w)]
 
 
 def short_list_length(k, world, sigmas=6.0):
@@ -48,15 +69,52 @@ def short_list_length(k, world, sigmas=6.0):
     return int(min(k, math.ceil(k * share + sigmas * math.sqrt(k * share * (1.0 - share))) + 8))
 
 
+SHORT_LIST_MAX_REPEAT_FRACTION = 0.05   # more queries than this repeated with full lists -> later exchanges of this (k, world) send full lists
+_SUSPENDED = {}                         # (k, world) -> the exchange statistics that suspended the short lists
+
+
+def short_lists_possible(k, world):
+    kl = short_list_length(k, world)
+    return world > 1 and kl < k and world * kl * 12 <= ops.SHORT_LIST_LDS_BYTES
+
+
 def short_lists_pay(k, world):
-    """Use the short-list exchange?  When it cuts the lists by at least a quarter and the R lists of a query fit the merge kernel's LDS.
+    """Use the short-list exchange?  When it cuts the lists by at least a quarter, the R lists of a query fit the merge kernel's LDS, and
+    it has not been SUSPENDED for this (k, world): the k / R + 6 sigma budget assumes exchangeable rows, and a corpus in topical order
+    (adjacent passages of one document) concentrates a query's top-k in few shards -- every flagged query then costs a second search
+    and a second collective.  An exchange that had to repeat more than SHORT_LIST_MAX_REPEAT_FRACTION of its queries suspends the
+    shortcut (note_short_list_outcome: every rank sees the same gathered flags, so every rank switches at the same step).
     CCREC_SHORT_LISTS=0 / 1 switches it off / forces it where it is possible (the A/B knob)."""
     kl = short_list_length(k, world)
-    possible = world > 1 and kl < k and world * kl * 12 <= ops.SHORT_LIST_LDS_BYTES
+    possible = short_lists_possible(k, world)
     env = os.environ.get("CCREC_SHORT_LISTS", "").strip()
     if env in ("0", "1"):
         return possible and env == "1"
-    return possible and 4 * kl <= 3 * k
+    return possible and 4 * kl <= 3 * k and (int(k), int(world)) not in _SUSPENDED
+
+
+def note_short_list_outcome(k, world, n_q, repeated):
+    """Called by every short-list exchange with the number of queries it had to repeat with full lists."""
+    if n_q > 0 and repeated > SHORT_LIST_MAX_REPEAT_FRACTION * n_q:
+        _SUSPENDED.setdefault((int(k), int(world)), {"queries": int(n_q), "repeated": int(repeated)})
+
+
+def short_lists_suspended(k, world):
+    return _SUSPENDED.get((int(k), int(world)))
+
+
+def resume_short_lists():
+    """Forget every suspension (a new corpus)."""
+    _SUSPENDED.clear()
+
+
+def exchange_list_length(k, world, short_lists=None, blocked=False):
+    """Entries per query and rank of an exchange for top-k -- from quantities that are IDENTICAL on every rank (k, world, the flags,
+    the module's suspension state), never from a rank's own shard size: ranks that disagreed would post collectives of different sizes."""
+    if blocked or world <= 1:
+        return int(k)
+    short = short_lists_pay(k, world) if short_lists is None else (bool(short_lists) and short_lists_possible(k, world))
+    return short_list_length(k, world) if short else int(k)
 
 
 class ShardMessage:
@@ -83,8 +141,10 @@ class ShardMessage:
         self.is_cuda = self.send.is_cuda
         # headers land here (pinned) from a side stream, so reading them never waits for work enqueued after the collective
         self.headers_host = torch.empty(self.world, HEADER_WORDS, dtype=torch.int32)
+        self.count_host = torch.zeros(1, dtype=torch.int32)      # short lists: queries the merge flagged (same route as the headers)
         if self.is_cuda:
             self.headers_host = self.headers_host.pin_memory()
+            self.count_host = self.count_host.pin_memory()
 
     # ---- writing
     def fill(self, scores, ids, row_offset, n_rows):
@@ -159,8 +219,12 @@ class ShardMessage:
 class ShardExchange:
     """One exchange in flight: submit() starts it behind the (asynchronous) search, result() completes it.  Between the two the
     caller may enqueue the next step's pack and search: nothing in here waits for work enqueued after the collective.
-    k_out > message.k: the message holds SHORT lists (module docstring); result() then verifies the merged lists and repeats the
-    queries that fail with full lists -- `queries` (this exchange's query rows) and `index` are needed for that."""
+    k_out > message.k: the message holds SHORT lists (module docstring); the merge + verification then runs on the SIDE stream right
+    behind the collective and its 4-byte flag count travels to pinned memory the way the headers do, so result() reads both after
+    waiting for the side stream's event only -- no host read behind work of a later step (r4 read count.item() on the compute stream:
+    the host could not enqueue step i + 2 before step i + 1's search had finished).  Queries that fail the verification are repeated
+    with full lists -- `queries` (this exchange's query rows) and `index` are needed for that.
+    host_syncs counts the times result() had to synchronise with the COMPUTE stream (0 on the pipelined path)."""
 
     def __init__(self, message, index=None, group=None, merge_fn=None, k_out=None, queries=None, search_fn=None, short_merge_fn=None):
         self.message, self.index, self.group, self.merge_fn = message, index, group, merge_fn
@@ -172,16 +236,31 @@ class ShardExchange:
         self.fallback_queries = 0      # short lists: queries repeated with full lists
         self.headers = None
         self.wait_ms = 0.0             # host time result() spent waiting for the collective (+ the header copy) to arrive
+        self.host_syncs = 0
+        self.side_merge = None         # (scores, ids, flags, count) of the merge the side stream ran
 
-    def submit(self):
+    def submit(self, _work=None):
+        """_work (tests): a stand-in for the collective's work handle over an already gathered `recv` -- exercises the stream-ordered
+        (RCCL) path of submit() / result() where no second GPU exists."""
         m = self.message
-        self.work = m.gather_async(self.group)
-        if m.is_cuda and dist.get_backend(self.group) == "nccl":
+        self.work = _work if _work is not None else m.gather_async(self.group)
+        if m.is_cuda and (_work is not None or dist.get_backend(self.group) == "nccl"):
             # a side stream waits for the collective and copies the R headers to pinned memory; result() waits for THAT event
             side = _side_stream(m.send.device)
+            short = self.k_out > m.k and self.short_merge_fn is None and self.merge_fn is None
+            outs = None
+            if short:   # outputs allocated on the caller's stream (its allocator pool), written by the side stream behind the collective
+                dev = m.send.device
+                outs = (torch.empty(m.n_q, self.k_out, dtype=torch.float32, device=dev), torch.empty(m.n_q, self.k_out, dtype=torch.int64, device=dev),
+                        torch.zeros(max(1, m.n_q), dtype=torch.int32, device=dev)[:m.n_q], torch.zeros(1, dtype=torch.int32, device=dev))
+                side.wait_stream(torch.cuda.current_stream(dev))     # ... after the two zero fills
             with torch.cuda.stream(side):
                 self.work.wait()
                 m.headers_host.copy_(m.all_headers, non_blocking=True)
+                if short:
+                    # (if some rank's lists turn out not to be final -- headers: n_flagged > n_covered -- this merge is discarded in result())
+                    self.side_merge = ops.merge_short_lists(m.recv, m.world, m.n_q, m.k, self.k_out, out=outs)
+                    m.count_host.copy_(self.side_merge[3], non_blocking=True)
                 self.event = torch.cuda.Event()
                 self.event.record(side)
         return self
@@ -191,12 +270,13 @@ class ShardExchange:
         m = self.message
         t0 = time.perf_counter()
         if self.event is not None:
-            self.event.synchronize()                              # the collective + the header copy, nothing later
-            torch.cuda.current_stream(m.send.device).wait_event(self.event)   # the merge reads `recv` behind the collective
+            self.event.synchronize()                              # the collective + the header copy (+ the short-list merge), nothing later
+            torch.cuda.current_stream(m.send.device).wait_event(self.event)   # later kernels read `recv` / the merged lists behind it
             words = m.headers_host
         else:
             self.work.wait()
             words = m.all_headers.cpu()
+            self.host_syncs += 1
         self.wait_ms = (time.perf_counter() - t0) * 1e3
         self.headers = m.parse_headers(words)
         if self.index is not None and getattr(self.index, "_deferred", None) is not None:
@@ -205,12 +285,19 @@ class ShardExchange:
             # some rank's lists were not final when they were exchanged.  Every rank sees the same headers, so every rank is
             # here: the flagged ranks have completed their lists in finish() above, all ranks repeat the collective.
             self.repeated = True
+            self.side_merge = None
             m.header[1:2].zero_()
             m.gather(self.group)
         if self.k_out == m.k:
             return m.merge(self.merge_fn)
-        scores, ids, flags, count = m.merge_short(self.k_out, self.headers, self.short_merge_fn)
-        self.fallback_queries = int(count.item())      # (the one host read of the short-list path: 4 bytes behind the merge)
+        if self.side_merge is not None:
+            scores, ids, flags, _ = self.side_merge
+            self.fallback_queries = int(m.count_host[0])          # arrived in pinned memory with the event above
+        else:
+            scores, ids, flags, count = m.merge_short(self.k_out, self.headers, self.short_merge_fn)
+            self.fallback_queries = int(count.item())             # (gloo / test hooks / a repeated collective: a synchronous path anyway)
+            self.host_syncs += 1
+        note_short_list_outcome(self.k_out, m.world, m.n_q, self.fallback_queries)
         if self.fallback_queries:
             # a list was consumed to its end for these queries: all ranks (same flags from the same bytes) repeat them with full lists
             which = flags.nonzero().squeeze(1)
@@ -218,6 +305,7 @@ class ShardExchange:
             s2, i2 = sharded_search(self.index, again, self.k_out, self.group, merge_fn=self.merge_fn, search_fn=self.search_fn,
                                     short_lists=False)
             scores[which], ids[which] = s2, i2
+            self.host_syncs += 1
         return scores, ids
 
 
@@ -241,12 +329,11 @@ def submit_sharded_search(index, queries_bf16, k, group=None, message=None, merg
     if message is not None:
         k_list = message.k
     else:
-        short = short_lists_pay(k, world) if short_lists is None else (bool(short_lists) and short_list_length(k, world) < k)
-        k_list = short_list_length(k, world) if short else k
-        if k_list > index.n_rows:
-            k_list = k
+        k_list = exchange_list_length(k, world, short_lists)
         message = ShardMessage(n_q, k_list, queries_bf16.device, world)
     assert (message.n_q, message.world) == (n_q, world) and message.k <= k
+    # (never re-size the lists from this rank's own shard: the ranks' collectives must agree -- tiny shards go through sharded_search)
+    assert message.k <= index.n_rows, f"shard of {index.n_rows} rows cannot fill lists of {message.k}: use sharded_search"
     index.search_shard(queries_bf16, message.k, message.send, defer=True)
     return ShardExchange(message, index, group, merge_fn, k_out=k, queries=queries_bf16).submit()
 
@@ -272,9 +359,7 @@ def sharded_search(index, queries_bf16, k, group=None, merge_fn=None, search_fn=
     if message is not None:
         k_list = message.k
     else:
-        short = block is None and (short_lists_pay(k, world) if short_lists is None else
-                                   (bool(short_lists) and short_list_length(k, world) < k and world * short_list_length(k, world) * 12 <= ops.SHORT_LIST_LDS_BYTES))
-        k_list = short_list_length(k, world) if short else k
+        k_list = exchange_list_length(k, world, short_lists, blocked=block is not None)
     direct = block is None and search_fn is None and k_list <= index.n_rows and 0 < n_q <= ops.MAX_QUERIES_PER_SEARCH
     if direct:   # the kernel writes the exchange message itself, no host round trip (larger batches are searched in pieces below)
         if message is None:

@@ -361,29 +361,47 @@ class LengthSortedEncoder:
         return out
 
 
-def encode_local_shard(encoder, corpus_ids, corpus, sim, rank, world, norm_bounds=None):
-    """This rank's contiguous block of the corpus (dist.shard_bounds) -> (bf16 shard [hi-lo, dim], lo, hi)."""
-    lo, hi = shard_bounds(len(corpus_ids), world, rank)
+def encode_local_shard(encoder, corpus_ids, corpus, sim, rank, world, norm_bounds=None, weights=None):
+    """This rank's contiguous block of the corpus (dist.shard_bounds; weights: equal-weight blocks) -> (bf16 shard [hi-lo, dim], lo, hi)."""
+    lo, hi = shard_bounds(len(corpus_ids), world, rank, weights)
     shard = encoder.encode([corpus[c] for c in corpus_ids[lo:hi]], sim=sim, norm_bounds=norm_bounds)
     return shard, lo, hi
 
 
-def ranking_sharded(corpus, queries, encoder, block_dict=None, rank=0, world=1, group=None, keep=None, with_tensors=False, lazy=False):
+def token_weights(texts, max_length, tokens_per_word=1.3, special_tokens=2):
+    """A per-text estimate of the encoder's token count that every rank can compute for the WHOLE corpus in a second or two (no
+    tokeniser run): words x tokens_per_word + the special tokens, clipped to max_length -- the quantity the encode time of a passage
+    is proportional to.  (Exact counts exist only after tokenisation, which every rank does for its own rows only.)"""
+    import numpy as np
+    words = np.fromiter((t.count(" ") + 1 if t else 0 for t in texts), dtype=np.float64, count=len(texts))
+    return np.minimum(words * tokens_per_word + special_tokens, float(max_length))
+
+
+def ranking_sharded(corpus, queries, encoder, block_dict=None, rank=0, world=1, group=None, keep=None, with_tensors=False, lazy=False,
+                    balance="tokens"):
     """Multi-GPU form of ms_marco_eval.ranking (scripts/ms_marco_eval.py:189-235): every rank encodes and indexes its
     own corpus rows, all ranks encode the (small) query set, per-shard fused top-k, one all-gather, merge.
     Returns the same rank-ordered {qid: {pid: score}} on every rank.  block_dict: each shard scores its own blocked rows
     -1e6 (ccr_search_blocked, lists of any length) before the exchange, so the merged list is the reference's.
     with_tensors: return (profile, row ids [Q, keep] int64, scores [Q, keep]) -- the device tensors behind the dicts.
-    lazy: the profile is a ranking_profile.RankingProfile over those tensors (inner dicts built when a query is read)."""
+    lazy: the profile is a ranking_profile.RankingProfile over those tensors (inner dicts built when a query is read).
+    balance: how the corpus rows are cut into the ranks' contiguous blocks.  "tokens" (default): equal ESTIMATED TOKENS per rank
+    (token_weights; the encode is ~97 % of the step and its time follows the tokens, so a corpus whose passage length follows the row
+    order would otherwise leave the step waiting for its slowest rank; the reference's DataParallel splits every batch evenly,
+    scripts/al_0_rank.py:70-74,92); "rows": equal row counts; or one weight per corpus row.  The search only needs each shard's
+    global_row_offset, so the result does not depend on the cut."""
     from .ms_marco_eval import KEEP, Retriever
     from .dist import sharded_search
     queries_ids, corpus_ids = list(queries.keys()), list(corpus.keys())
     sim = "cos" if os.environ["CCREC_SIM_TYPE"] == "cos" else "dot"
     keep = KEEP if keep is None else keep
     q_bf16 = encoder.encode([queries[q] for q in queries_ids], sim=sim)
-    lo0, hi0 = shard_bounds(len(corpus_ids), world, rank)
+    weights = None
+    if world > 1 and not (isinstance(balance, str) and balance == "rows"):
+        weights = token_weights([corpus[c] for c in corpus_ids], encoder.max_length) if isinstance(balance, str) else balance
+    lo0, hi0 = shard_bounds(len(corpus_ids), world, rank, weights)
     bounds = torch.empty(max(hi0 - lo0, 1), dtype=torch.float32, device=q_bf16.device)   # norm bound of every packed row
-    shard, lo, hi = encode_local_shard(encoder, corpus_ids, corpus, sim, rank, world, norm_bounds=bounds)
+    shard, lo, hi = encode_local_shard(encoder, corpus_ids, corpus, sim, rank, world, norm_bounds=bounds, weights=weights)
     bounds = bounds if hi > lo else None
     if world == 1:
         return Retriever(corpus_ids, shard, norm_bounds=bounds).ranking_profile(queries_ids, q_bf16, block_dict, keep, with_tensors, lazy)

@@ -519,7 +519,7 @@ def merge_shard_messages(gathered, world, n_q, k):
 SHORT_LIST_LDS_BYTES = 96 * 1024   # ccr_merge_short_lists merges a query's R lists in LDS: R * k_list * 12 bytes must fit
 
 
-def merge_short_lists(gathered, world, n_q, k_list, k_out):
+def merge_short_lists(gathered, world, n_q, k_list, k_out, out=None):
     """R gathered SHORT shard messages (k_list entries per query each) -> the k_out best of every query plus the verification of the
     shortcut (ccr_merge_short_lists): ([n_q, k_out] fp32, [n_q, k_out] int64 global ids, flags [n_q] int32 -- 1 where a shard's list
     was consumed to its end although the shard holds more rows: that query must be repeated with full lists --, n_flagged [1] int32)."""
@@ -528,10 +528,13 @@ def merge_short_lists(gathered, world, n_q, k_list, k_out):
     assert 1 <= k_list <= k_out <= world * k_list and world * k_list * 12 <= SHORT_LIST_LDS_BYTES
     stride = gathered.numel() // world
     dev = gathered.device
-    os_ = torch.empty(n_q, k_out, dtype=torch.float32, device=dev)
-    oi = torch.empty(n_q, k_out, dtype=torch.int64, device=dev)
-    flags = torch.zeros(max(1, n_q), dtype=torch.int32, device=dev)[:n_q]
-    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    if out is not None:      # (scores, ids, zeroed flags, zeroed count) allocated by the caller (dist.ShardExchange: on another stream)
+        os_, oi, flags, count = out
+    else:
+        os_ = torch.empty(n_q, k_out, dtype=torch.float32, device=dev)
+        oi = torch.empty(n_q, k_out, dtype=torch.int64, device=dev)
+        flags = torch.zeros(max(1, n_q), dtype=torch.int32, device=dev)[:n_q]
+        count = torch.zeros(1, dtype=torch.int32, device=dev)
     with _on(gathered):
         _lib.check(lib.ccr_merge_short_lists(_ptr(gathered), stride, world, n_q, k_list, k_out, _ptr(os_), _ptr(oi), _ptr(flags) if n_q else _ptr(count),
                                              _ptr(count), _stream(gathered)), "ccr_merge_short_lists")

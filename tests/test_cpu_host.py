@@ -133,6 +133,53 @@ def test_shard_bounds_partition():
         assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
 
 
+def test_shard_bounds_by_weight():
+    """shard_bounds(weights=...): contiguous blocks of equal WEIGHT (token counts).  A corpus sorted by passage length -- the case where
+    equal row counts leave the last rank with several times the tokens of the first -- gives every rank the same tokens within 2 %;
+    the blocks partition the rows; zero weights / a single heavy row / more ranks than rows stay well-formed."""
+    from ccrec_amd.dist import shard_bounds, weighted_cuts
+    from ccrec_amd.encode import token_weights
+    rs = np.random.RandomState(0)
+    lens = np.sort(np.clip(rs.lognormal(4.6, 0.6, 200_000), 8, 512).astype(np.int64))       # sorted by length: 8 .. 512 tokens
+    for world in (2, 3, 8):
+        b = [shard_bounds(len(lens), world, r, lens) for r in range(world)]
+        assert b[0][0] == 0 and b[-1][1] == len(lens) and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+        tok = np.array([lens[lo:hi].sum() for lo, hi in b], np.float64)
+        assert tok.max() / tok.min() < 1.02, tok
+        rows = np.array([shard_bounds(len(lens), world, r) for r in range(world)])
+        tok_rows = np.array([lens[lo:hi].sum() for lo, hi in rows], np.float64)
+        if world == 8:
+            assert tok_rows.max() / tok_rows.min() > 3.0          # what equal row counts would have cost
+    assert weighted_cuts(np.zeros(10), 3) == [0, 4, 7, 10]                        # nothing to balance: equal rows
+    assert weighted_cuts([0, 0, 100, 0, 0], 2)[1] in (2, 3) and weighted_cuts([1, 1], 4)[-1] == 2
+    cuts = weighted_cuts(rs.randint(1, 50, 7), 8)
+    assert cuts[0] == 0 and cuts[-1] == 7 and all(a <= b_ for a, b_ in zip(cuts, cuts[1:]))
+    # the estimate every rank computes without a tokeniser: words x 1.3 + 2, clipped to max_length
+    w = token_weights(["a b c", "", "x " * 400], 256)
+    assert w.tolist() == [3 * 1.3 + 2, 2.0, 256.0]
+
+
+def test_short_lists_are_suspended_after_an_exchange_that_repeats_too_many_queries(monkeypatch):
+    """The k / R + 6 sigma budget assumes exchangeable rows; an exchange that had to repeat more than 5 % of its queries with full lists
+    (a corpus in topical order) suspends the shortcut for that (k, world): later exchanges send full lists.  Explicit short_lists=True and
+    CCREC_SHORT_LISTS=1 still force it; resume_short_lists() forgets."""
+    from ccrec_amd import dist as cdist
+    monkeypatch.delenv("CCREC_SHORT_LISTS", raising=False)
+    cdist.resume_short_lists()
+    assert cdist.exchange_list_length(1001, 8) == 196 and cdist.exchange_list_length(1001, 8, blocked=True) == 1001
+    cdist.note_short_list_outcome(1001, 8, 3452, 100)            # 2.9 %: fine
+    assert cdist.short_lists_pay(1001, 8) and cdist.short_lists_suspended(1001, 8) is None
+    cdist.note_short_list_outcome(1001, 8, 3452, 400)            # 11.6 %
+    assert not cdist.short_lists_pay(1001, 8) and cdist.short_lists_suspended(1001, 8) == {"queries": 3452, "repeated": 400}
+    assert cdist.exchange_list_length(1001, 8) == 1001 and cdist.exchange_list_length(1001, 8, short_lists=True) == 196
+    assert cdist.short_lists_pay(1001, 4)                         # another world size is another budget
+    monkeypatch.setenv("CCREC_SHORT_LISTS", "1")
+    assert cdist.short_lists_pay(1001, 8)
+    monkeypatch.delenv("CCREC_SHORT_LISTS")
+    cdist.resume_short_lists()
+    assert cdist.short_lists_pay(1001, 8)
+
+
 def test_round_robin_negatives():
     from ccrec_amd.bbpr_loss import pick_round_robin_negatives
     table = {0: [5, 6, 7], 1: [9]}
@@ -255,8 +302,13 @@ def _short_worker(rank, world, port, n, nq, k, skew, out_dir):
     ok = ok and np.array_equal(i.numpy(), ref_i) and np.array_equal(s.numpy().view(np.uint32), ref_s.view(np.uint32))
     if skew:
         ok = ok and ex.fallback_queries == 2 and calls == [(nq, k_list), (2, k)]      # exactly the two skewed queries were repeated, with full lists
+        # 2 of 7 queries repeated: every rank has suspended the shortcut for this (k, world); the next automatic exchange sends full lists
+        ok = ok and cdist.short_lists_suspended(k, world) == {"queries": nq, "repeated": 2}
+        calls.clear()
+        s4, i4 = cdist.sharded_search(index, qrows, k, merge_fn=merge_fn, search_fn=search_fn, short_merge_fn=short_merge_fn)
+        ok = ok and np.array_equal(i4.numpy(), ref_i) and calls == [(nq, k)]
     else:
-        ok = ok and ex.fallback_queries == 0 and calls == [(nq, k_list)]
+        ok = ok and ex.fallback_queries == 0 and calls == [(nq, k_list)] and cdist.short_lists_suspended(k, world) is None
     # the same through sharded_search's own routing (short_lists=True), and switched off
     calls.clear()
     s2, i2 = cdist.sharded_search(index, qrows, k, merge_fn=merge_fn, search_fn=search_fn, short_lists=True, short_merge_fn=short_merge_fn)

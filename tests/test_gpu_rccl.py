@@ -261,3 +261,29 @@ def test_short_list_exchange_with_real_kernels_and_a_skewed_shard(tmp_path, worl
     mp.spawn(_short_rank_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert open(tmp_path / f"rank{r}.txt").read() == "ok"
+
+
+def test_bench_ranks_rehearsal_on_a_corpus_in_topical_order_suspends_the_short_lists(tmp_path):
+    """ranking()'s k = 1001 over 3 ranks on a corpus whose clusters are CONTIGUOUS row ranges (--data sorted: passages of one topic lie
+    next to each other, as in a corpus in source order): a query's top-1001 sits in one or two shards, their short lists (k / R + 6 sigma
+    entries) are consumed to their ends, and the flagged queries are repeated with full lists -- still the single-GPU ids.  Once an
+    exchange has repeated more than 5 % of its queries every rank suspends the shortcut at the same step and the later steps send full
+    lists (no second search, no second collective): the record says at which step."""
+    bench = os.path.join(ROOT, "bench.py")
+    common = ["--steps", "3", "--warmup", "1", "--rows", "180000", "--queries", "200", "--k", "1001", "--data", "sorted", "--cpu-queries", "0",
+              "--no-secondary"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CCR_BENCH_WATCHDOG="150")
+    env.pop("CCREC_SHORT_LISTS", None)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    _run_child([sys.executable, bench, "--gpus", "1", "--dump-ids", str(tmp_path / "one.pt")] + common, env, tmp_path, "one")
+    out, _ = _run_child([sys.executable, bench, "--gpus", "3", "--dist-backend", "gloo", "--same-device", "--dump-ids", str(tmp_path / "three.pt")] + common,
+                        env, tmp_path, "ranks")
+    rec = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][0])
+    a, b = torch.load(tmp_path / "one.pt"), torch.load(tmp_path / "three.pt")
+    assert a.shape == (200, 1001) and torch.equal(a, b)
+    ex = rec["exchange"]
+    from ccrec_amd.dist import short_list_length
+    # the warm-up step ran with short lists and repeated most of its queries; the timed steps ran with full lists
+    assert ex["short_lists_suspended_at_step"] == 1, ex
+    assert ex["entries_per_query_per_rank"] == 1001 > short_list_length(1001, 3) and ex["queries_repeated_with_full_lists"] == 0

@@ -665,3 +665,47 @@ def test_index_lifecycle_pending_search_workspace_adoption_and_low_rank_add_zero
     assert (low + 0) is low and (0 + low) is low and (low + None) is low
     dense = low + torch.ones(40, 5000, device="cuda")
     assert torch.allclose(dense, low.as_tensor() + 1.0)
+
+
+def test_short_list_exchange_result_never_waits_for_later_work_on_the_compute_stream():
+    """The stream-ordered (RCCL) path of ShardExchange where no second GPU exists: the gathered buffer is emulated, submit() gets a
+    stand-in work handle, and the merge + verification runs on the SIDE stream with its flag count travelling to pinned memory.  Then the
+    compute stream is kept busy for ~0.3 s AFTER submit() (the next steps' pack and search, in the pipelined loop): result() must
+    return the single-index lists without waiting for it (r4 read count.item() behind that work) -- host_syncs == 0."""
+    import time
+    from ccrec_amd import ops
+    from ccrec_amd.dist import shard_bounds, short_list_length, ShardMessage, ShardExchange, resume_short_lists
+    resume_short_lists()
+    n, nq, k, world, d = 6000, 24, 300, 3, 256
+    Db, Qb = _rand_bits(n, d, 211), _rand_bits(nq, d, 212)
+    D, Q = _bf16(Db), _bf16(Qb)
+    s1, i1 = ops.CorpusIndex(D).search(Q, k)
+    kl = short_list_length(k, world)
+    gathered = ShardMessage(nq, kl, D.device, world)
+    for r in range(world):
+        lo, hi = shard_bounds(n, world, r)
+        m = ShardMessage(nq, kl, D.device, 1)
+        ops.CorpusIndex(D[lo:hi].contiguous(), global_row_offset=lo).search_shard(Q, kl, m.send)
+        gathered.recv.view(world, -1)[r].copy_(m.send)
+    torch.cuda.synchronize()
+
+    class Arrived:                      # the collective's work handle: already complete
+        def wait(self):
+            return True
+
+    ex = ShardExchange(gathered, None, None, None, k_out=k, queries=Q).submit(_work=Arrived())
+    a = torch.randn(4096, 4096, device=D.device)
+    t0 = time.perf_counter()
+    for _ in range(60):                 # ~0.3 s of compute-stream work enqueued behind submit()
+        a = (a @ a).clamp_(-1, 1)
+    t_enqueue = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    s, i = ex.result()
+    t_result = time.perf_counter() - t0
+    busy = torch.cuda.Event()
+    busy.record()
+    still_running = not busy.query()    # the matmuls are still in flight when result() has returned
+    torch.cuda.synchronize()
+    assert ex.host_syncs == 0 and ex.fallback_queries == 0 and not ex.repeated
+    assert torch.equal(i, i1) and torch.equal(s.view(torch.int32), s1.view(torch.int32))
+    assert still_running and t_result < 0.05, (t_enqueue, t_result)
