@@ -368,13 +368,22 @@ def encode_local_shard(encoder, corpus_ids, corpus, sim, rank, world, norm_bound
     return shard, lo, hi
 
 
-def token_weights(texts, max_length, tokens_per_word=1.3, special_tokens=2):
+def token_weights(texts, max_length, tokens_per_word=1.3, special_tokens=2, tokenizer=None, sample=512):
     """A per-text estimate of the encoder's token count that every rank can compute for the WHOLE corpus in a second or two (no
-    tokeniser run): words x tokens_per_word + the special tokens, clipped to max_length -- the quantity the encode time of a passage
-    is proportional to.  (Exact counts exist only after tokenisation, which every rank does for its own rows only.)"""
+    tokeniser run over it): words x tokens_per_word + the special tokens, clipped to max_length -- the quantity the encode time of a
+    passage is proportional to.  (Exact counts exist only after tokenisation, which every rank does for its own rows only.)
+    tokenizer: the two constants are fitted on `sample` evenly spaced texts run through it (the same texts on every rank, so the same
+    weights on every rank)."""
     import numpy as np
     words = np.fromiter((t.count(" ") + 1 if t else 0 for t in texts), dtype=np.float64, count=len(texts))
-    return np.minimum(words * tokens_per_word + special_tokens, float(max_length))
+    if tokenizer is not None and len(texts) >= 2:
+        idx = np.unique(np.linspace(0, len(texts) - 1, min(len(texts), int(sample))).astype(np.int64))
+        ids = tokenizer([texts[i] for i in idx], truncation=True, padding=False, max_length=int(max_length))["input_ids"]
+        toks = np.array([len(r) for r in ids], np.float64)
+        free = toks < max_length                        # truncated texts say nothing about the slope
+        if free.sum() >= 2 and np.ptp(words[idx][free]) > 0:
+            tokens_per_word, special_tokens = np.polyfit(words[idx][free], toks[free], 1)
+    return np.clip(words * tokens_per_word + special_tokens, 1.0, float(max_length))
 
 
 def ranking_sharded(corpus, queries, encoder, block_dict=None, rank=0, world=1, group=None, keep=None, with_tensors=False, lazy=False,
@@ -386,7 +395,7 @@ def ranking_sharded(corpus, queries, encoder, block_dict=None, rank=0, world=1, 
     with_tensors: return (profile, row ids [Q, keep] int64, scores [Q, keep]) -- the device tensors behind the dicts.
     lazy: the profile is a ranking_profile.RankingProfile over those tensors (inner dicts built when a query is read).
     balance: how the corpus rows are cut into the ranks' contiguous blocks.  "tokens" (default): equal ESTIMATED TOKENS per rank
-    (token_weights; the encode is ~97 % of the step and its time follows the tokens, so a corpus whose passage length follows the row
+    (token_weights: a x words + b, clipped to max_length, a and b fitted on 512 evenly spaced texts run through the tokeniser; the encode is ~97 % of the step and its time follows the tokens, so a corpus whose passage length follows the row
     order would otherwise leave the step waiting for its slowest rank; the reference's DataParallel splits every batch evenly,
     scripts/al_0_rank.py:70-74,92); "rows": equal row counts; or one weight per corpus row.  The search only needs each shard's
     global_row_offset, so the result does not depend on the cut."""
@@ -398,7 +407,8 @@ def ranking_sharded(corpus, queries, encoder, block_dict=None, rank=0, world=1, 
     q_bf16 = encoder.encode([queries[q] for q in queries_ids], sim=sim)
     weights = None
     if world > 1 and not (isinstance(balance, str) and balance == "rows"):
-        weights = token_weights([corpus[c] for c in corpus_ids], encoder.max_length) if isinstance(balance, str) else balance
+        weights = (token_weights([corpus[c] for c in corpus_ids], encoder.max_length, tokenizer=encoder.tokenizer)
+                   if isinstance(balance, str) else balance)
     lo0, hi0 = shard_bounds(len(corpus_ids), world, rank, weights)
     bounds = torch.empty(max(hi0 - lo0, 1), dtype=torch.float32, device=q_bf16.device)   # norm bound of every packed row
     shard, lo, hi = encode_local_shard(encoder, corpus_ids, corpus, sim, rank, world, norm_bounds=bounds, weights=weights)

@@ -158,6 +158,14 @@ def test_shard_bounds_by_weight():
     w = token_weights(["a b c", "", "x " * 400], 256)
     assert w.tolist() == [3 * 1.3 + 2, 2.0, 256.0]
 
+    class Pieces:      # 2 tokens per word + 2 special tokens: the fit on a sample recovers both constants
+        def __call__(self, texts, truncation=True, padding=False, max_length=64):
+            return {"input_ids": [[0] * min(2 * (t.count(" ") + 1) + 2, max_length) for t in texts]}
+    texts = [" ".join(["w"] * n) for n in rs.randint(1, 60, 3000)]
+    w = token_weights(texts, 64, tokenizer=Pieces())
+    want = np.minimum(2.0 * np.array([t.count(" ") + 1 for t in texts]) + 2, 64)
+    assert np.abs(w - want).max() < 1e-6
+
 
 def test_short_lists_are_suspended_after_an_exchange_that_repeats_too_many_queries(monkeypatch):
     """The k / R + 6 sigma budget assumes exchangeable rows; an exchange that had to repeat more than 5 % of its queries with full lists

@@ -1,2 +1,2 @@
 mkdir -p gpurun_out/r5e
-timeout -k 10 900 python -m pytest tests/test_gpu_rccl.py tests/test_gpu_search.py -x -q -m gpu > gpurun_out/r5e/tests.log 2>&1; tail -15 gpurun_out/r5e/tests.log
+timeout -k 10 900 python -m pytest tests/test_gpu_encode.py -x -q -m gpu -k "sharded" > gpurun_out/r5e/tests.log 2>&1; tail -15 gpurun_out/r5e/tests.log
