@@ -527,6 +527,45 @@ def bm25_side_run(dev, docs=500_000, queries=2000, vocab=50_000, k=1001, cpu_que
     return out
 
 
+def small_batches_side_run(index, qpack, n_rows, dim, k=TOP_K, sizes=(1, 16, 64, 256, 512), reps=20):
+    """SURVEY 8d's small query batches (Q in {1, 16, 64, 512}; 256 = one full query tile) on the resident NQ index: search-only time
+    (the index and the packed queries exist: an interactive ranking() call against an encoded corpus), `reps` searches back to back, each
+    completed before the next starts.  Below a few hundred queries the main pass can at best stream the corpus once: `roofline` is the
+    HBM one, bytes = 2 N d per search, the main pass's duration from the library's events on the search stream.  n_q <= 64
+    runs the streaming main pass (csrc/ccr_narrow.hip), larger batches the tile kernels."""
+    out = {"workload": f"configs[1] corpus resident and indexed, top-{k}, batches of n_q queries (search only)", "unit": "ms per search", "batches": {}}
+    pmc = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r05_small_batches_pmc.json")))
+    except Exception:
+        pass
+    for nq in sizes:
+        Q = qpack[:nq].contiguous()
+        for _ in range(3):
+            index.search(Q, k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        mains = []
+        for _ in range(reps):
+            index.search(Q, k)
+            mains.append(index.last_stats()["ms_main"])
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        st = index.last_stats()
+        main = sum(mains) / len(mains)
+        bytes_ = 2.0 * n_rows * dim
+        gbs = bytes_ / (main * 1e-3) / 1e9
+        traffic = ((pmc or {}).get(str(nq)) or {}).get("fabric_bytes_main_pass")
+        out["batches"][str(nq)] = {
+            "ms_per_search": round(ms, 4), "queries_per_s": round(nq / ms * 1e3, 1), "phases_ms": phases_obj(st),
+            "main_pass": "narrow_filter_kernel (streaming: queries resident in LDS, corpus straight into the MFMA operand registers)" if st.get("ranges") == 1 and nq <= 64
+                         else "gemm_topk16_kernel<EPI_FILTER> (256-query tiles)",
+            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                         "bytes_per_search": bytes_, "main_pass_ms": round(main, 4), "traffic": traffic,
+                         "traffic_source": "offline rocprofv3 --pmc passes (profiles/r05_small_batches_pmc.json); not measured in this run" if traffic else None}}
+    return out
+
+
 def roofline_obj(r, traffic=None, traffic_source=None):
     """`achieved` = algorithmic flops of one step's main pass (2 n_q n_rows dim: every launch of the pass covers its share of the
     corpus, together exactly once) / the main pass's duration per step from the library's HIP events on the search stream."""
@@ -697,6 +736,12 @@ def main():
     if world == 1 and default_shape and not args.no_secondary:
         sec = {}
         side_steps, side_warm = min(args.steps, 5), min(args.warmup, 2)
+        # (0) SURVEY 8d's small batches on the index the last timed step built
+        try:
+            w.drain()
+            sec["small_batches"] = small_batches_side_run(w.index, w.qpack, args.rows, args.dim)
+        except Exception as e:      # a side run must never cost the line its headline
+            sec["small_batches"] = {"skipped": f"{type(e).__name__}: {e}"}
         # (a) what ranking() asks for: the same corpus at k = 1001
         w.set_k(1001)
         r2 = w.run(side_steps, max(1, side_warm), "k1001")

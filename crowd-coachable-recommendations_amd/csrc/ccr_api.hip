@@ -1088,8 +1088,9 @@ static int search_impl(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k, fl
     rc = launch_gemm_gmax(gs, p.grid, s);
     if (rc != CCR_OK) return rc;
     CCR_HIP_CHECK(hipEventRecord(ix->ev[2], s));
+    // (small batches: the streaming pass's sub-list counters are cleared by the threshold launch)
     rc = launch_threshold(gmax, (int64_t)p.sample_tiles * GROUPS_PER_TILE, n_q, p.nq_pad, p.opt_rank ? p.opt_rank : k, qnorm, ix->dmax_bits,
-                          ix->dim, ix->tile_norm, p.sample_stride, thr, delta, s);
+                          ix->dim, ix->tile_norm, p.sample_stride, thr, delta, s, p.narrow ? cnt : nullptr, p.narrow ? NARROW_SUBLISTS : 0);
     if (rc != CCR_OK) return rc;
 
     // main pass -> candidates
@@ -1114,7 +1115,7 @@ static int search_impl(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k, fl
     CCR_HIP_CHECK(hipEventRecord(ix->ev[3], s));
     if (p.narrow) {
         // small batch: the corpus is STREAMED past query rows resident in LDS (ccr_narrow.hip); two atomically filled sub-lists per query
-        CCR_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)n_q * NARROW_SUBLISTS * 4, s));
+        // (their counters were cleared by launch_threshold)
         NarrowArgs na;
         memset(&na, 0, sizeof(na));
         na.D = ix->D;

@@ -44,7 +44,7 @@ int launch_tile_norms(const float *row_bounds, int64_t rows, uint32_t *tile_bits
 // thr[q] = tau_q (lower bound of the k-th largest exact score), cq[q] = gamma ||q|| (margin per unit of row norm)
 int launch_threshold(const float *gmax, int64_t n_groups, int n_q, int nq_pad, int k, const float *qnorm,
                      const uint32_t *dmax_bits, int dim, const float *tile_norm, int64_t sample_stride, float *thr, float *cq,
-                     hipStream_t s);
+                     hipStream_t s, uint32_t *zero_cnt = nullptr, int zero_per_query = 0);   // zero_cnt: n_q x zero_per_query counters to clear on the way
 int select_compact_entries(int dim, int ranges, int rescore_cap, int64_t want);
 // thr (device, [n_q], may be null): the thresholds the main pass filtered with.  The select VERIFIES them -- the k-th largest lower
 // bound L of the candidates must reach thr[q], else rows below an over-estimated threshold may be missing: the query is flagged
