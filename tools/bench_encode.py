@@ -70,10 +70,13 @@ def main():
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--max-length", type=int, default=200)
     ap.add_argument("--batch", type=int, default=512)
+    ap.add_argument("--autocast", default="bf16", choices=["bf16", "fp16"],
+                    help="the autocast type around the encode: fp16 is the reference's torch.cuda.amp.autocast() (scripts/al_0_rank.py:8,125)")
     ap.add_argument("--fused", default="auto", choices=["auto", "off"],
                     help="sorted modes: encoder layers on the library's attention / add + LayerNorm kernels (auto) or as torch modules (off); "
                          "the extra mode name sorted_modules always runs the torch modules")
     args = ap.parse_args()
+    ac_dtype = torch.float16 if args.autocast == "fp16" else torch.bfloat16
     from transformers import BertConfig, BertModel
     from ccrec_amd.item_tower import NaiveItemTower
     from ccrec_amd.encode import LengthSortedEncoder
@@ -97,7 +100,7 @@ def main():
     def reference_style(padding):
         nonlocal texts
         out = []
-        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        with torch.no_grad(), torch.autocast("cuda", dtype=ac_dtype):
             for lo in range(0, len(texts), args.batch):
                 toks = tok(texts[lo:lo + args.batch], truncation=True, padding=padding, max_length=args.max_length, return_tensors="pt")
                 emb = tower(**{k: v.cuda() for k, v in toks.items()}, output_step="mean_pooling")
@@ -110,7 +113,7 @@ def main():
                                   chunk_texts=chunk or args.chunk_texts, host_threads=threads or args.host_threads,
                                   host_processes=args.host_processes if procs is None else procs,
                                   fused=(args.fused == "auto") if fused is None else fused)
-        with torch.autocast("cuda", dtype=torch.bfloat16):
+        with torch.autocast("cuda", dtype=ac_dtype):
             shard = enc.encode(texts, sim="dot")
         enc.close()
         st = dict(enc.stats)

@@ -10,11 +10,12 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "crowd-coachable-recommendations_amd")]
 from ccrec_amd import ops
 
 B, L, lo, H = (int(v) for v in (sys.argv[1:5] + ["482", "136", "129", "12"][len(sys.argv) - 1:]))
+DTYPE = torch.float16 if os.environ.get("ATT_DTYPE", "bf16") == "fp16" else torch.bfloat16   # fp16: the layer type under the reference's autocast
 torch.manual_seed(0)
 lens = torch.randint(lo, L + 1, (B,), dtype=torch.int32, device="cuda")
-qkv = torch.randn(B * L, 3 * H * 64, device="cuda").to(torch.bfloat16)
+qkv = torch.randn(B * L, 3 * H * 64, device="cuda").to(DTYPE)
 start = torch.arange(B, dtype=torch.int32, device="cuda") * L
-out = torch.empty(B * L, H * 64, dtype=torch.bfloat16, device="cuda")
+out = torch.empty(B * L, H * 64, dtype=DTYPE, device="cuda")
 for _ in range(5):
     ops.attention(qkv, start, lens, H, max_len=L, pad_len=L, out=out)
 torch.cuda.synchronize()
