@@ -311,7 +311,7 @@ class Workload:
         torch.cuda.empty_cache()
 
 
-def inbatch_side_run(dev, B=1024, d=768, iters=50):
+def inbatch_side_run(dev, B=1024, d=768, iters=200):
     """configs[4]: the in-batch-negative contrastive step (bbpr.py:205-212) at B = 1024, d = 768: forward + backward of the HIP loss
     (ccr_inbatch_ce_fwd/bwd: three kernel launches) next to the reference's torch formulation (mm, mm, cat, scale, CrossEntropyLoss +
     autograd) on this GPU, in fp32 and -- the comparator that matches this library's bf16 operands -- under autocast(bf16).
@@ -338,7 +338,7 @@ def inbatch_side_run(dev, B=1024, d=768, iters=50):
 
     out = {"workload": f"configs[4]: in-batch-negative loss forward + backward, B = {B}, d = {d}, inv_temperature 20"}
     for name, fn in (("hip_ms", ours), ("torch_fp32_ms", lambda: ref(torch.float32)), ("torch_bf16_autocast_ms", lambda: ref(torch.bfloat16))):
-        for _ in range(5):
+        for _ in range(30):     # (the first steps of a variant pay its module loads and the allocator's first blocks)
             loss = fn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()

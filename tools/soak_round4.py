@@ -139,9 +139,10 @@ def soak_short_lists(c):
     assert ok
 
 
-narrow = 0
-for c in range(cases):
-    narrow += int(soak_streaming(c))
-    soak_bm25(c)
-    soak_short_lists(c)
-print(f"all {cases} cases of each kind equal their exact paths; streaming kernel used in {narrow} of {cases}")
+if __name__ == "__main__":
+    narrow = 0
+    for c in range(cases):
+        narrow += int(soak_streaming(c))
+        soak_bm25(c)
+        soak_short_lists(c)
+    print(f"all {cases} cases of each kind equal their exact paths; streaming kernel used in {narrow} of {cases}")
