@@ -49,6 +49,7 @@ Knobs read_knobs() {
     kn.narrow = env_int("CCR_NARROW", -1);
     kn.narrow_nt = env_int("CCR_NARROW_NT", 0);
     kn.narrow_grid = env_int("CCR_NARROW_GRID", 0);
+    kn.narrow_groups = env_int("CCR_NARROW_GROUPS", NARROW_MAX_GROUPS);
     return kn;
 }
 
@@ -288,9 +289,13 @@ static Plan make_plan_for(int64_t n_rows, int dim, int n_q, int k, int flags, in
         int64_t sample_big = pinned ? sample : sample_for(sample_div / 2);
         if (sample_big * 4 > p.full_tiles) sample_big = sample;
         // small batches: the first main pass is the streaming kernel (ccr_narrow.hip) when the query rows fit its LDS image
+        // (65 .. 128 queries: two groups of <= 64 on paired workgroups that walk the same rows)
         int nqt = n_q <= 16 ? 1 : (n_q <= 32 ? 2 : 4);
-        const bool narrow = kn.narrow != 0 && n_q <= NARROW_MAX_Q && dim % TILE_K == 0 && narrow_lds_bytes(nqt, dim) <= (size_t)160 * 1024;
+        const int ngroups = n_q <= NARROW_MAX_Q ? 1 : 2;
+        const bool narrow = kn.narrow != 0 && n_q <= NARROW_MAX_Q * std::min(std::max(kn.narrow_groups, 1), NARROW_MAX_GROUPS) && dim % TILE_K == 0 &&
+                            narrow_lds_bytes(nqt, dim) <= (size_t)160 * 1024 && (ngroups == 1 || num_cu >= 16);
         p.narrow = narrow ? nqt : 0;
+        p.narrow_groups = narrow ? ngroups : 1;
         const MainPassChoice choice = choose_main_pass(p, k, sample, sample_alt, sample_big, kn, narrow);
         sample = choice.sample;
         const int64_t R = choice.ranges;
@@ -1130,11 +1135,13 @@ static int search_impl(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k, fl
         na.cand = cand;
         na.cnt = cnt;
         na.cap = p.first_lay.cap[0];
+        na.groups = p.narrow_groups;
         // one workgroup (8 waves x 12 KiB of loads in flight) per CU: measured at NQ 6.2 / 6.2 / 6.0 TB/s of corpus bytes at n_q = 1 / 16 / 64;
         // two or four per CU -- the 16- and 32-query images would fit -- stream no faster (6.2 / 5.9 TB/s at 1 / 16)
         int ngrid = ix->knobs.narrow_grid > 0 ? ix->knobs.narrow_grid : ix->num_cu;
         const int64_t blocks = (ix->n_rows + 16 * NARROW_WAVES - 1) / (16 * NARROW_WAVES);
         if ((int64_t)ngrid > blocks) ngrid = (int)std::max<int64_t>(1, blocks);
+        if (p.narrow_groups == 2) ngrid = std::max(16, ngrid / 16 * 16);   // whole sets of eight (b, b + 8) pairs; a pair shares its row stream
         rc = launch_narrow_filter(na, p.narrow, ngrid, ix->knobs.narrow_nt != 0, s);
     } else {
         rc = run_main_pass(ix, p, gm, cand, cnt, thr, delta, p.item_b ? (uint32_t *)(ws + p.off_top) : nullptr, n_q, k, true, s);

@@ -97,6 +97,7 @@ struct Plan {
     // small query batches (n_q <= 64, query rows resident in LDS): the FIRST main pass is the streaming kernel (ccr_narrow.hip) with
     // its own list layout -- one range, two sub-lists per query; the retry pass of flagged queries keeps the tile kernels' layout above
     int narrow;           // 0, or the query tiles of 16 the streaming kernel computes (1, 2, 4)
+    int narrow_groups;    // 1, or 2: 65 .. 128 queries as two groups of <= 64, each streamed by half of the workgroups (pairs on one XCD)
     int first_nsub;       // sub-lists per query the first main pass fills (ranges * sublists, or 2) ...
     int first_sp;         // ... per cell (sublists, or 2) ...
     CandLayout first_lay; // ... and where they are (cand, or one segment of narrow capacity)

@@ -1487,7 +1487,7 @@ int launch_tile_norms(const float *row_bounds, int64_t rows, uint32_t *tile_bits
     return CCR_OK;
 }
 
-// The same thresholds for a SMALL batch (the streaming main pass, n_q <= 64): threshold_kernel gives a query 16 threads, which walk its
+// The same thresholds for a SMALL batch (the streaming main pass, n_q <= 128): threshold_kernel gives a query 16 threads, which walk its
 // ~4 000 sampled lower bounds four times from global memory -- 70 us for ONE query, a tenth of the whole search.  Here a workgroup
 // per query: the lower bounds are staged in LDS once (every load independent, one round trip), the four radix passes read LDS.
 // zero_cnt (may be null): the streaming pass's sub-list counters of this query are cleared here instead of by a memset node.
@@ -1526,7 +1526,7 @@ int launch_threshold(const float *gmax, int64_t n_groups, int n_q, int nq_pad, i
                      hipStream_t s, uint32_t *zero_cnt, int zero_per_query) {
     // small batches: a workgroup per query (needs k <= n_groups -- the planner samples >= 2k groups -- and the bounds in 64 KiB of LDS);
     // *zero_cnt tells the caller whether its counters have been cleared here
-    if (n_q <= 64 && n_groups >= k && n_groups <= 16384 && zero_per_query <= 256) {
+    if (n_q <= 128 && n_groups >= k && n_groups <= 16384 && zero_per_query <= 256) {
         if (n_groups * 4 > 32 * 1024) {
             const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&threshold_small_kernel), 64 * 1024);
             if (rc != CCR_OK) return rc;

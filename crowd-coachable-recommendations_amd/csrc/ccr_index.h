@@ -22,6 +22,7 @@ struct Knobs {
     int narrow;        // CCR_NARROW       -1 = planner's choice (n_q <= 64 whose rows fit the LDS), 0 = tile kernels only (the A/B knob)
     int narrow_nt;     // CCR_NARROW_NT    1 = the streaming kernel's corpus loads are non-temporal, 0 = default cache policy (default: 6.0 vs 5.5 TB/s at NQ)
     int narrow_grid;   // CCR_NARROW_GRID  0 = planner's choice, else workgroups of the streaming kernel
+    int narrow_groups; // CCR_NARROW_GROUPS 2 = batches of 65 .. 128 queries stream as two query groups (default), 1 = tile kernels above 64 queries (the A/B knob)
 };
 Knobs read_knobs();
 

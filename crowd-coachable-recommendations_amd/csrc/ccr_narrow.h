@@ -7,6 +7,7 @@ namespace ccr {
 constexpr int NARROW_THREADS = 512;                 // 8 waves, each streaming its own 16-row groups
 constexpr int NARROW_WAVES = NARROW_THREADS / 64;
 constexpr int NARROW_MAX_Q = 64;                    // query rows resident in LDS (4 MFMA tiles of 16)
+constexpr int NARROW_MAX_GROUPS = 2;                // query groups of <= NARROW_MAX_Q a launch serves (each group streamed by 1 / groups of the workgroups)
 constexpr int NARROW_LDS_CAP = 64;                  // records a workgroup stages per query before it flushes (overflow: straight to global)
 constexpr int NARROW_SUBLISTS = 2;                  // sub-lists per query in the candidate area: workgroups of even / odd index
 
@@ -31,6 +32,8 @@ struct NarrowArgs {
     uint2 *cand;             // candidate area: query q's cell = [cap][2] records {score bits, local row}, slot-major
     uint32_t *cnt;           // [n_q][2], zeroed by the caller
     int cap;                 // slots per sub-list
+    int groups;              // 1, or 2: workgroup b serves query group (b >> 3) & 1 (queries [64 g, 64 g + 64)) and row stream (b >> 4) * 8 + (b & 7):
+                             // blocks b and b + 8 -- one XCD -- walk the SAME rows, so the second reader finds them in that XCD's L2
 };
 
 int launch_narrow_filter(const NarrowArgs &a, int nqt, int grid, bool nt, hipStream_t s);

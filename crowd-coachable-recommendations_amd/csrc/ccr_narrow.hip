@@ -18,6 +18,11 @@
 //     LDS (one LDS atomic per hit), flushed to the candidate area once per workgroup (one global atomic per (workgroup, query)).
 // The candidate area uses the select stage's own layout with ONE range and TWO sub-lists per query (workgroups of even / odd index),
 // so select_rescore_kernel, the retry pass and the exact paths are unchanged: results are the canonical bits either way.
+// r5: 65 .. 128 queries run as TWO groups of <= 64 (NarrowArgs::groups): workgroups b and b + 8 -- the same XCD -- hold the two groups'
+// query rows and walk the SAME corpus rows, so HBM still delivers the corpus once (the partner finds the rows in the XCD's L2 or in the
+// Infinity Cache) instead of the tile kernels' full 256-query tile per corpus tile.
+#include <stdlib.h>
+
 #include "ccr_gemm_common.h"
 #include "ccr_index.h"
 #include "ccr_narrow.h"
@@ -51,6 +56,12 @@ __global__ __launch_bounds__(NARROW_THREADS) void narrow_filter_kernel(const Nar
     const int row_bytes = a.dim * 2;
     const int S = a.q_stride;                      // LDS bytes per query row (== 32 mod 256)
     constexpr int NQ = NQT * 16;
+    // query group and row stream of this workgroup (groups == 1: every workgroup serves all queries and has its own stream)
+    const int grp = a.groups == 2 ? (int)((blockIdx.x >> 3) & 1u) : 0;
+    const int stream_id = a.groups == 2 ? (int)((blockIdx.x >> 4) * 8 + (blockIdx.x & 7u)) : (int)blockIdx.x;
+    const int n_streams = a.groups == 2 ? (int)(gridDim.x >> 1) : (int)gridDim.x;
+    const int q_base = grp * NARROW_MAX_Q;
+    const int nq_here = a.n_q - q_base < NQ ? a.n_q - q_base : NQ;      // >= 1: the planner pairs groups only above NARROW_MAX_Q queries
     char *s_q = smem;
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(smem + (size_t)NQ * S);
     uint2 *s_list = reinterpret_cast<uint2 *>(smem + (size_t)NQ * S + NQ * 4);   // [NQ][NARROW_LDS_CAP]
@@ -60,7 +71,7 @@ __global__ __launch_bounds__(NARROW_THREADS) void narrow_filter_kernel(const Nar
     for (int i = tid; i < NQ * chunks; i += NARROW_THREADS) {
         const int q = i / chunks, c = i - q * chunks;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (q < a.n_q) v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(a.Q) + (size_t)q * row_bytes + c * 16);
+        if (q < nq_here) v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(a.Q) + (size_t)(q_base + q) * row_bytes + c * 16);
         *reinterpret_cast<uint4 *>(s_q + (size_t)q * S + c * 16) = v;
     }
     for (int i = tid; i < NQ; i += NARROW_THREADS) s_cnt[i] = 0u;
@@ -70,8 +81,8 @@ __global__ __launch_bounds__(NARROW_THREADS) void narrow_filter_kernel(const Nar
 #pragma unroll
     for (int qt = 0; qt < NQT; ++qt) {
         const int q = qt * 16 + l15;
-        thr[qt] = (q < a.n_q) ? a.thr[q] : __builtin_nanf("");
-        cqv[qt] = (q < a.n_q) ? a.cq[q] : 0.f;
+        thr[qt] = (q < nq_here) ? a.thr[q_base + q] : __builtin_nanf("");
+        cqv[qt] = (q < nq_here) ? a.cq[q_base + q] : 0.f;
     }
 
     // ---- this wave's stream: 16-row groups g = (i * gridDim.x + blockIdx.x) * 8 + wv, each KS = dim / 32 K-steps of 64 bytes per row,
@@ -79,8 +90,8 @@ __global__ __launch_bounds__(NARROW_THREADS) void narrow_filter_kernel(const Nar
     const int KS = a.dim / SUB_K;
     const int cpg = KS / P;                                            // chunks per group
     const int64_t n_groups = (a.n_rows + 15) / 16;
-    const int64_t g_first = (int64_t)blockIdx.x * NARROW_WAVES + wv;
-    const int64_t g_step = (int64_t)gridDim.x * NARROW_WAVES;
+    const int64_t g_first = (int64_t)stream_id * NARROW_WAVES + wv;
+    const int64_t g_step = (int64_t)n_streams * NARROW_WAVES;
     const int64_t my_groups = g_first < n_groups ? (n_groups - g_first + g_step - 1) / g_step : 0;
     const int64_t n_chunks = my_groups * cpg;
     const char *Dbytes = reinterpret_cast<const char *>(a.D);
@@ -175,9 +186,9 @@ __global__ __launch_bounds__(NARROW_THREADS) void narrow_filter_kernel(const Nar
                                 if (pos < (uint32_t)NARROW_LDS_CAP) {
                                     s_list[q * NARROW_LDS_CAP + pos] = rec;
                                 } else {   // the workgroup's staging list is full (a flooded list): straight to the candidate area
-                                    const int sl = blockIdx.x & 1;
-                                    const uint32_t gp = atomicAdd(&a.cnt[q * 2 + sl], 1u);
-                                    if (gp < (uint32_t)a.cap) a.cand[((int64_t)q * a.cap + gp) * 2 + sl] = rec;
+                                    const int sl = stream_id & 1;
+                                    const uint32_t gp = atomicAdd(&a.cnt[(q_base + q) * 2 + sl], 1u);
+                                    if (gp < (uint32_t)a.cap) a.cand[((int64_t)(q_base + q) * a.cap + gp) * 2 + sl] = rec;
                                 }
                             }
                         }
@@ -190,17 +201,17 @@ __global__ __launch_bounds__(NARROW_THREADS) void narrow_filter_kernel(const Nar
 
     // ---- flush: one block reservation per (workgroup, query), records go to sub-list (workgroup parity) of the query's cell
     __syncthreads();
-    const int sl = blockIdx.x & 1;
-    for (int q = wv; q < NQ && q < a.n_q; q += NARROW_WAVES) {
+    const int sl = stream_id & 1;
+    for (int q = wv; q < NQ && q < nq_here; q += NARROW_WAVES) {
         uint32_t n = s_cnt[q];
         if (n > (uint32_t)NARROW_LDS_CAP) n = NARROW_LDS_CAP;
         if (n == 0) continue;                               // wave-uniform
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&a.cnt[q * 2 + sl], n);
+        if (lane == 0) base = atomicAdd(&a.cnt[(q_base + q) * 2 + sl], n);
         base = __shfl(base, 0);
         for (uint32_t i = lane; i < n; i += 64) {
             const uint32_t p = base + i;
-            if (p < (uint32_t)a.cap) a.cand[((int64_t)q * a.cap + p) * 2 + sl] = s_list[q * NARROW_LDS_CAP + i];
+            if (p < (uint32_t)a.cap) a.cand[((int64_t)(q_base + q) * a.cap + p) * 2 + sl] = s_list[q * NARROW_LDS_CAP + i];
         }
     }
 }
@@ -229,6 +240,9 @@ static int launch_narrow_np(const NarrowArgs &a, int grid, bool nt, hipStream_t 
 template <int NQT>
 static int launch_narrow_n(const NarrowArgs &a, int grid, bool nt, hipStream_t s) {
     const int KS = a.dim / SUB_K;
+    // two query groups: every corpus row is pulled by two CUs (one of them from the L2 / the Infinity Cache), i.e. a CU moves twice the
+    // bytes of the one-group launch -- twice the window (24 KiB per wave in flight) keeps the pull rate per CU from binding
+    if (NQT == 4 && a.groups == 2 && KS % 24 == 0 && getenv("CCR_NARROW_P12") == nullptr) return launch_narrow_np<NQT, 24>(a, grid, nt, s);
     if (KS % 12 == 0) return launch_narrow_np<NQT, 12>(a, grid, nt, s);
     if (KS % 8 == 0) return launch_narrow_np<NQT, 8>(a, grid, nt, s);
     if (KS % 4 == 0) return launch_narrow_np<NQT, 4>(a, grid, nt, s);
@@ -237,7 +251,9 @@ static int launch_narrow_n(const NarrowArgs &a, int grid, bool nt, hipStream_t s
 }
 
 int launch_narrow_filter(const NarrowArgs &a, int nqt, int grid, bool nt, hipStream_t s) {
-    CCR_REQUIRE(a.dim % SUB_K == 0 && a.n_q >= 1 && a.n_q <= nqt * 16 && (nqt == 1 || nqt == 2 || nqt == 4), "narrow main pass: bad shape (internal)");
+    CCR_REQUIRE(a.dim % SUB_K == 0 && a.n_q >= 1 && (nqt == 1 || nqt == 2 || nqt == 4) && (a.groups == 1 || a.groups == 2) &&
+                    (a.groups == 1 ? a.n_q <= nqt * 16 : (nqt == 4 && a.n_q > NARROW_MAX_Q && a.n_q <= 2 * NARROW_MAX_Q && grid % 16 == 0)),
+                "narrow main pass: bad shape (internal)");
     CCR_REQUIRE(narrow_lds_bytes(nqt, a.dim) <= 160 * 1024, "narrow main pass: %zu bytes of LDS (internal)", narrow_lds_bytes(nqt, a.dim));
     if (nqt == 1) return launch_narrow_n<1>(a, grid, nt, s);
     if (nqt == 2) return launch_narrow_n<2>(a, grid, nt, s);

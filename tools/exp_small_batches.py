@@ -17,7 +17,7 @@ nb = torch.empty(n, device="cuda")
 D = ops.pack_bf16(gen_rows(n, d, 1234, "cuda"), norm_bounds=nb)
 Qall = ops.pack_bf16(gen_rows(1024, d, 4321, "cuda"))
 index = ops.CorpusIndex(D, norm_bounds=nb)
-for nq in (1, 16, 64, 256, 512, 1024):
+for nq in (1, 16, 64, 65, 96, 128, 129, 256, 512, 1024):
     Q = Qall[:nq].contiguous()
     for _ in range(3):
         index.search(Q, 100)
