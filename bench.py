@@ -40,7 +40,7 @@ MSMARCO_ROWS, MSMARCO_Q = 8_841_823, 6_980
 C4_ROWS, C4_Q, C4_DIM, C4_K = 50_000_000, 10_000, 1024, 1000    # BASELINE.json configs[3]
 MFMA_PEAK_TFLOPS = 2500.0   # dense bf16, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_locality.json")   # tools/exp_locality.py: separate rocprofv3 --pmc passes per workload
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r05_locality.json")   # tools/exp_locality.py: separate rocprofv3 --pmc passes per workload
 
 
 def parse():
@@ -705,7 +705,7 @@ def main():
         """(bytes per step, label) of the main pass from the committed PMC measurement of the same workload, or (None, None)."""
         try:
             rec = json.load(open(PMC_SUMMARY))[tag]
-            return rec["traffic_bytes"], (f"offline rocprofv3 --pmc passes of this workload (profiles/r04_locality.json[{tag}]: FETCH_SIZE x 2 + "
+            return rec["traffic_bytes"], (f"offline rocprofv3 --pmc passes of this workload (profiles/r05_locality.json[{tag}]: FETCH_SIZE x 2 + "
                                           f"WRITE_SIZE of the main-pass launches of one step); not measured in this run")
         except Exception:
             return None, None
