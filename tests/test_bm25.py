@@ -297,3 +297,25 @@ def test_hip_bm25_index_create_rejects_unsorted_or_out_of_range_postings():
         create(far)
     # a descent ACROSS a term boundary is the normal case and must pass (every list starts again at a low document)
     assert rows[indptr[1]] < rows[indptr[1] - 1]
+
+
+@pytest.mark.gpu
+def test_hip_bm25_more_queries_than_one_fused_batch(monkeypatch):
+    """4 500 queries: the fused path takes 4 096 rows per batch (candidate lists, sample rows and term tables are per batch), so the
+    second batch re-uses the first one's areas -- ids and score bits equal the stored-rows path's, and the first and last queries'
+    equal a single-query call's."""
+    from ccrec_amd.bm25 import BM25
+    rs = np.random.RandomState(21)
+    indptr, rows, counts, doc_k, idf = _random_postings(rs, 40_000, 300, dense_terms=4)
+    queries = [np.sort(rs.choice(300, rs.randint(1, 9), replace=False)).astype(np.int32) for _ in range(4500)]
+    monkeypatch.delenv("CCR_BM25_DENSE_SELECT", raising=False)
+    model = BM25.from_postings(indptr, rows, counts, doc_k, idf, k1=1.2)
+    s, i = model.transform_terms_topk(queries, 10)
+    st = model.last_stats()
+    assert st["path"] == "tile+fused_filter" and st["batches"] == 2, st
+    for q in (0, 4095, 4096, 4499):
+        s1, i1 = model.transform_terms_topk(queries[q:q + 1], 10)
+        assert torch.equal(i1[0], i[q]) and torch.equal(s1.view(torch.int32)[0], s.view(torch.int32)[q]), q
+    monkeypatch.setenv("CCR_BM25_DENSE_SELECT", "1")
+    s2, i2 = model.transform_terms_topk(queries, 10)
+    assert torch.equal(i, i2) and torch.equal(s.view(torch.int32), s2.view(torch.int32))
