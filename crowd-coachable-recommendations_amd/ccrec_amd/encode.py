@@ -378,11 +378,15 @@ def token_weights(texts, max_length, tokens_per_word=1.3, special_tokens=2, toke
     words = np.fromiter((t.count(" ") + 1 if t else 0 for t in texts), dtype=np.float64, count=len(texts))
     if tokenizer is not None and len(texts) >= 2:
         idx = np.unique(np.linspace(0, len(texts) - 1, min(len(texts), int(sample))).astype(np.int64))
-        ids = tokenizer([texts[i] for i in idx], truncation=True, padding=False, max_length=int(max_length))["input_ids"]
-        toks = np.array([len(r) for r in ids], np.float64)
-        free = toks < max_length                        # truncated texts say nothing about the slope
-        if free.sum() >= 2 and np.ptp(words[idx][free]) > 0:
-            tokens_per_word, special_tokens = np.polyfit(words[idx][free], toks[free], 1)
+        try:
+            ids = tokenizer([texts[i] for i in idx], truncation=True, padding=False, max_length=int(max_length))["input_ids"]
+            toks = np.array([len(r) for r in ids], np.float64)
+        except Exception:                               # a tokeniser without this call form: keep the default constants
+            toks = None
+        if toks is not None:
+            free = toks < max_length                    # truncated texts say nothing about the slope
+            if free.sum() >= 2 and np.ptp(words[idx][free]) > 0:
+                tokens_per_word, special_tokens = np.polyfit(words[idx][free], toks[free], 1)
     return np.clip(words * tokens_per_word + special_tokens, 1.0, float(max_length))
 
 

@@ -585,6 +585,7 @@ class _InBatchCE(torch.autograd.Function):
     def forward(ctx, q, p, n, inv_temperature):
         lib = require_gpu()
         B, dim = q.shape
+        assert q.is_cuda and p.shape == q.shape == n.shape and p.device == q.device == n.device, "three [B, dim] blocks on one device"
         lay = _INBATCH_LAYOUT.get((B, dim))
         if lay is None:
             ws_bytes = int(lib.ccr_inbatch_ce_workspace_bytes(B, dim))
