@@ -10,10 +10,6 @@
 //
 // Arithmetic = what autocast(bf16) does in the reference's layer: bf16 operands, fp32 scores / softmax / accumulation,
 // probabilities rounded to bf16 for the P V product, fp32 residual sum and LayerNorm.
-#include <stdlib.h>
-
-#include <algorithm>
-
 #include "ccr_common.h"
 #include "ccr_index.h"
 
@@ -81,7 +77,6 @@ constexpr int ATT_QW = 32;             // query rows per wave step (the N side o
 constexpr int ATT_KMAX = 8, ATT_VMAX = 4;   // 16-byte key pieces / value-row pairs a thread stages (all in flight at once)
 constexpr int ATT_KB = 64;         // keys per loop step (two 32-key score tiles: halves the online-softmax rescaling)
 constexpr int ATT_HEAD = 64;       // head width
-constexpr int ATT_PERSIST_DEFAULT = 0;   // workgroups per CU of the persistent form of attention_kernel (0: one workgroup per item); CCR_ATT_PERSIST overrides
 constexpr int ATT_KROW = 144;      // bytes per key row in LDS: 128 + 16, so the 16 lanes of a ds_read_b128 group hit distinct banks
 
 // LDS: K [lk_pad rows][144 B] row-major | V TRANSPOSED [64 d][2 * lk_pad + 8 B] (row stride = 8 * odd: the 32 lanes of a ds_read_b64
@@ -96,16 +91,12 @@ __host__ __device__ inline size_t attention_lds_bytes(int lk_pad) {
 // softmax row reductions are in-lane plus one exchange with lane ^ 32, and the probabilities, rounded to bf16, ARE the B
 // operand of O^T = V^T P^T (contraction index = key; the A operand V^T is read from the transposed LDS image with the
 // same key permutation: element j of lane half g <-> key 16 s + 4 g + (j & 3) + 8 (j >> 2)).
-// PERSIST (r5): a workgroup walks items (sequence, head) = blockIdx.x, + gridDim.x, ... and issues the staging loads of its NEXT item
-// before it computes the current one -- the K / V pieces wait in registers (64 VGPRs) behind the key loop, so the memory latency of the
-// staging phase (36 % of a wave's life in the one-item form: profiles/r05_attention_pmc.txt) is covered by matrix work instead of by a
-// third resident workgroup that the wave slots rarely admit.
-template <int DT, bool PERSIST>
+template <int DT>
 __global__ __launch_bounds__(ATT_MAX_THREADS) void attention_kernel(const uint16_t *__restrict__ qkv,
                                                                   const int32_t *__restrict__ seq_start,
                                                                   const int32_t *__restrict__ seq_len,
                                                                   uint16_t *__restrict__ out, int H, int pad_len, int max_len,
-                                                                  int lk_pad, float scale_log2e, int n_items) {
+                                                                  int lk_pad, float scale_log2e) {
     typedef Half16<DT> HT;
     typedef typename HT::vec8 vec8;
     typedef typename HT::elem elem;
@@ -115,235 +106,189 @@ __global__ __launch_bounds__(ATT_MAX_THREADS) void attention_kernel(const uint16
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nwaves = nthreads >> 6;
+    const int wq = (wv + blockIdx.x) % nwaves;   // the wave's first query block rotates with the head: second rounds spread over the SIMDs
+    const int b = blockIdx.y, h = blockIdx.x;
+    int len = seq_len[b];
+    if (len > max_len) len = max_len;   // the LDS image holds max_len keys: a longer entry is cut (the caller's contract: seq_len <= max_len)
+    if (len < 0) len = 0;
+    const int rows = len > pad_len ? len : pad_len;   // rows the sequence occupies in the token arrays (padding rows get zeros)
     const int HD = H * ATT_HEAD;
     const int64_t stride = 3 * (int64_t)HD;
+    const int64_t row0 = seq_start[b];
+    const uint16_t *Qg = qkv + row0 * stride + h * ATT_HEAD;
+    const uint16_t *Kg = Qg + HD;
+    const uint16_t *Vg = Qg + 2 * HD;
+    uint16_t *Og = out + row0 * HD + h * ATT_HEAD;
     const int ql = lane & 31, g = lane >> 5;
-    char *Ks = smem;
-    char *Vt = smem + (size_t)lk_pad * ATT_KROW;
-    const int VS = 2 * lk_pad + 8;
-
-    struct Item {
-        int len, rows, wq;
-        const uint16_t *Qg, *Kg, *Vg;
-        uint16_t *Og;
-    };
-    auto setup = [&](int item, Item &it) {
-        const int b = item / H, h = item - b * H;
-        int len = seq_len[b];
-        if (len > max_len) len = max_len;   // the LDS image holds max_len keys: a longer entry is cut (the caller's contract: seq_len <= max_len)
-        if (len < 0) len = 0;
-        it.len = len;
-        it.rows = len > pad_len ? len : pad_len;   // rows the sequence occupies in the token arrays (padding rows get zeros)
-        it.wq = (wv + h) % nwaves;   // the wave's first query block rotates with the head: second rounds spread over the SIMDs
-        const int64_t row0 = seq_start[b];
-        it.Qg = qkv + row0 * stride + h * ATT_HEAD;
-        it.Kg = it.Qg + HD;
-        it.Vg = it.Qg + 2 * HD;
-        it.Og = out + row0 * HD + h * ATT_HEAD;
-    };
-    // ---- staging loads of one item: K (row-major) and V (transposed, two keys per dword); rows beyond len are zeros.  Every load of the
-    // staging is issued before the first LDS store: one memory latency per item instead of one per piece.  The launcher sizes the
-    // workgroup so that a thread has at most ATT_KMAX key pieces and ATT_VMAX value pairs.
-    uint4 kreg[ATT_KMAX], va[ATT_VMAX], vb[ATT_VMAX];
-    vec8 qf[4];
-    // tt: the thread index as the staging code sees it -- an opaque copy refreshed once per item, so that the persistent form does not
-    // hoist the address arithmetic of its 16 staging pieces out of the item loop (as loop invariants they cost ~100 live registers:
-    // 256 VGPRs + 130 spilled against 116 for the one-item form)
-    int tt = tid;
-    auto load_k = [&](const Item &it) {
-#pragma unroll
-        for (int u = 0; u < ATT_KMAX; ++u) {
-            const int i = tt + u * nthreads;
-            const int r = i >> 3, c = i & 7;
-            kreg[u] = make_uint4(0u, 0u, 0u, 0u);
-            if (r < it.len) kreg[u] = *reinterpret_cast<const uint4 *>(it.Kg + (int64_t)r * stride + c * 8);
-        }
-    };
-    auto load_v = [&](const Item &it) {
-#pragma unroll
-        for (int u = 0; u < ATT_VMAX; ++u) {
-            const int i = tt + u * nthreads;
-            const int p = i >> 3, c = i & 7;
-            va[u] = vb[u] = make_uint4(0u, 0u, 0u, 0u);
-            if (2 * p < it.len) va[u] = *reinterpret_cast<const uint4 *>(it.Vg + (int64_t)(2 * p) * stride + c * 8);
-            if (2 * p + 1 < it.len) vb[u] = *reinterpret_cast<const uint4 *>(it.Vg + (int64_t)(2 * p + 1) * stride + c * 8);
-        }
-    };
-    auto load_q = [&](const Item &it, int q0w) {
-        const int q = q0w + ql;
-        const int qr = q < it.len ? q : it.len - 1;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const vec8 *>(it.Qg + (int64_t)qr * stride + 16 * s + 8 * g);
-    };
-    auto zero_rows = [&](const Item &it) {   // an empty sequence (workgroup-uniform): its padding rows get zeros, nothing is read
-        for (int q = tid; q < it.rows; q += nthreads) {
-            uint4 *dst = reinterpret_cast<uint4 *>(it.Og + (int64_t)q * HD);
+    if (len == 0) {   // an empty sequence (workgroup-uniform): its padding rows get zeros, nothing is read
+        for (int q = tid; q < rows; q += nthreads) {
+            uint4 *dst = reinterpret_cast<uint4 *>(Og + (int64_t)q * HD);
 #pragma unroll
             for (int i = 0; i < 8; ++i) dst[i] = make_uint4(0u, 0u, 0u, 0u);
         }
-    };
-
-    int item = PERSIST ? (int)blockIdx.x : (int)(blockIdx.y * H + blockIdx.x);
-    Item cur;
-    setup(item, cur);
-    if (cur.len > 0) {
-        load_k(cur);
-        load_v(cur);
-        load_q(cur, cur.wq * ATT_QW);
+        return;
     }
-    for (;;) {
-        const int next = item + (int)gridDim.x;
-        const bool more = PERSIST && next < n_items;   // workgroup-uniform
-        Item nxt = cur;
-        if (cur.len == 0) {
-            zero_rows(cur);
-            if (more) {
-                setup(next, nxt);
-                if (nxt.len > 0) load_k(nxt);
-            }
-        } else {
-            const int len = cur.len, rows = cur.rows;
-            uint16_t *Og = cur.Og;
-            const int nkb = (len + ATT_KB - 1) / ATT_KB;
-            const int nk = nkb * ATT_KB;
-#pragma unroll
-            for (int u = 0; u < ATT_KMAX; ++u) {
-                const int i = tt + u * nthreads;
-                if (i < nk * 8) *reinterpret_cast<uint4 *>(Ks + (i >> 3) * ATT_KROW + (i & 7) * 16) = kreg[u];
-            }
-#pragma unroll
-            for (int u = 0; u < ATT_VMAX; ++u) {
-                const int i = tt + u * nthreads;
-                if (i < nk * 4) {
-                    const int p = i >> 3, c = i & 7;
-                    const uint32_t a[4] = {va[u].x, va[u].y, va[u].z, va[u].w}, bb[4] = {vb[u].x, vb[u].y, vb[u].z, vb[u].w};
-                    char *dst = Vt + (size_t)(8 * c) * VS + 4 * p;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        *reinterpret_cast<uint32_t *>(dst + (size_t)(2 * j) * VS) = (a[j] & 0xffffu) | (bb[j] << 16);
-                        *reinterpret_cast<uint32_t *>(dst + (size_t)(2 * j + 1) * VS) = (a[j] >> 16) | (bb[j] & 0xffff0000u);
-                    }
-                }
-            }
-            __syncthreads();
-            if (more) {   // the next item's K / V pieces travel while this item's key loop runs
-                setup(next, nxt);
-                if (PERSIST) asm volatile("" : "+v"(tt));
-                if (nxt.len > 0) load_k(nxt);
-            }
 
-            for (int q0w = cur.wq * ATT_QW; q0w < rows; q0w += nwaves * ATT_QW) {   // wave-uniform; no barrier below
-                const int q = q0w + ql;
-                if (q0w >= len) {   // a block of padding rows only: defined output (zeros), no NaNs into the next projection
-                    if (q < rows) {
-                        uint2 *dst = reinterpret_cast<uint2 *>(Og + (int64_t)q * HD);
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) dst[i * 2 + g] = make_uint2(0u, 0u);
-                    }
-                    continue;
-                }
-                if (q0w != cur.wq * ATT_QW) load_q(cur, q0w);   // the wave's next query block (sequences beyond 32 x waves tokens)
+    char *Ks = smem;
+    char *Vt = smem + (size_t)lk_pad * ATT_KROW;
+    const int VS = 2 * lk_pad + 8;
+    const int nkb = (len + ATT_KB - 1) / ATT_KB;
+    const int nk = nkb * ATT_KB;
 
-                ef32x16 o0, o1;
+    // ---- stage K (row-major) and V (transposed, two keys per dword) of this (sequence, head); rows beyond len are zeros.
+    // Every load of the staging -- and the wave's first query fragment -- is issued before the first LDS store: one memory
+    // latency per workgroup instead of one per piece.  The launcher sizes the workgroup so that a thread has at most
+    // ATT_KMAX key pieces and ATT_VMAX value pairs.
+    uint4 kreg[ATT_KMAX], va[ATT_VMAX], vb[ATT_VMAX];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) o0[e] = o1[e] = 0.f;
-                float m = -INFINITY, lsum = 0.f;
-
-                for (int kb = 0; kb < nkb; ++kb) {
-                    ef32x16 s0, s1;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) s0[e] = s1[e] = 0.f;
-                    const char *kp = Ks + (kb * ATT_KB + ql) * ATT_KROW + g * 16;
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        const vec8 k0 = *reinterpret_cast<const vec8 *>(kp + 32 * s);
-                        const vec8 k1 = *reinterpret_cast<const vec8 *>(kp + 32 * ATT_KROW + 32 * s);
-                        s0 = HT::mfma(k0, qf[s], s0);
-                        s1 = HT::mfma(k1, qf[s], s1);
-                    }
-                    float x[32];
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        x[e] = s0[e];
-                        x[16 + e] = s1[e];
-                    }
-                    if (kb * ATT_KB + ATT_KB > len) {   // the last step: keys beyond the sequence
-#pragma unroll
-                        for (int e = 0; e < 32; ++e) {
-                            const int key = kb * ATT_KB + (e >> 4) * 32 + (e & 3) + 8 * ((e & 15) >> 2) + 4 * g;
-                            if (key >= len) x[e] = -INFINITY;
-                        }
-                    }
-                    float mx = x[0];
-#pragma unroll
-                    for (int e = 1; e < 32; ++e) mx = fmaxf(mx, x[e]);
-                    mx = fmaxf(mx, __shfl_xor(mx, 32));
-                    const float mn = fmaxf(m, mx);            // finite: every step holds at least one key < len
-                    const float alpha = __builtin_amdgcn_exp2f((m - mn) * scale_log2e);   // m = -inf on the first step: 0
-                    const float bias = -mn * scale_log2e;
-                    m = mn;
-                    float ps = 0.f;
-#pragma unroll
-                    for (int e = 0; e < 32; ++e) {
-                        x[e] = __builtin_amdgcn_exp2f(fmaf(x[e], scale_log2e, bias));
-                        ps += x[e];
-                    }
-                    lsum = fmaf(lsum, alpha, ps);
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        o0[e] *= alpha;
-                        o1[e] *= alpha;
-                    }
-#pragma unroll
-                    for (int hb = 0; hb < 2; ++hb) {
-#pragma unroll
-                        for (int s2 = 0; s2 < 2; ++s2) {
-                            vec8 pf;
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) pf[j] = (elem)x[hb * 16 + s2 * 8 + j];
-                            const int kbase = kb * ATT_KB + hb * 32 + s2 * 16 + 4 * g;
-                            const char *vp = Vt + (size_t)ql * VS + 2 * kbase;
-                            union {
-                                uint2 u[2];
-                                vec8 v;
-                            } a0, a1;
-                            a0.u[0] = *reinterpret_cast<const uint2 *>(vp);
-                            a0.u[1] = *reinterpret_cast<const uint2 *>(vp + 16);
-                            a1.u[0] = *reinterpret_cast<const uint2 *>(vp + (size_t)32 * VS);
-                            a1.u[1] = *reinterpret_cast<const uint2 *>(vp + (size_t)32 * VS + 16);
-                            o0 = HT::mfma(a0.v, pf, o0);
-                            o1 = HT::mfma(a1.v, pf, o1);
-                        }
-                    }
-                }
-
-                const float inv = 1.f / (lsum + __shfl_xor(lsum, 32));
-                if (q < len) {
-                    // O^T tile: lane -> query, register e -> head column 32 db + (e & 3) + 8 (e >> 2) + 4 g: four consecutive columns per 8-byte store
-                    uint16_t *dst = Og + (int64_t)q * HD + 4 * g;
-#pragma unroll
-                    for (int c4 = 0; c4 < 4; ++c4) {
-                        *reinterpret_cast<uint2 *>(dst + 8 * c4) =
-                            round4<elem>(o0[4 * c4] * inv, o0[4 * c4 + 1] * inv, o0[4 * c4 + 2] * inv, o0[4 * c4 + 3] * inv);
-                        *reinterpret_cast<uint2 *>(dst + 32 + 8 * c4) =
-                            round4<elem>(o1[4 * c4] * inv, o1[4 * c4 + 1] * inv, o1[4 * c4 + 2] * inv, o1[4 * c4 + 3] * inv);
-                    }
-                } else if (q < rows) {
-                    uint2 *dst = reinterpret_cast<uint2 *>(Og + (int64_t)q * HD);
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) dst[i * 2 + g] = make_uint2(0u, 0u);
-                }
-            }   // query blocks of this wave
-        }
-        if (!more) break;
-        if (nxt.len > 0) {
-            load_v(nxt);
-            load_q(nxt, nxt.wq * ATT_QW);
-        }
-        __syncthreads();   // every wave is done with this item's LDS image before the next one's stores
-        item = next;
-        cur = nxt;
+    for (int u = 0; u < ATT_KMAX; ++u) {
+        const int i = tid + u * nthreads;
+        const int r = i >> 3, c = i & 7;
+        kreg[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (r < len) kreg[u] = *reinterpret_cast<const uint4 *>(Kg + (int64_t)r * stride + c * 8);
     }
+#pragma unroll
+    for (int u = 0; u < ATT_VMAX; ++u) {
+        const int i = tid + u * nthreads;
+        const int p = i >> 3, c = i & 7;
+        va[u] = vb[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (2 * p < len) va[u] = *reinterpret_cast<const uint4 *>(Vg + (int64_t)(2 * p) * stride + c * 8);
+        if (2 * p + 1 < len) vb[u] = *reinterpret_cast<const uint4 *>(Vg + (int64_t)(2 * p + 1) * stride + c * 8);
+    }
+    vec8 qf[4];
+    {
+        const int q = wq * ATT_QW + ql;
+        const int qr = q < len ? q : len - 1;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const vec8 *>(Qg + (int64_t)qr * stride + 16 * s + 8 * g);
+    }
+#pragma unroll
+    for (int u = 0; u < ATT_KMAX; ++u) {
+        const int i = tid + u * nthreads;
+        if (i < nk * 8) *reinterpret_cast<uint4 *>(Ks + (i >> 3) * ATT_KROW + (i & 7) * 16) = kreg[u];
+    }
+#pragma unroll
+    for (int u = 0; u < ATT_VMAX; ++u) {
+        const int i = tid + u * nthreads;
+        if (i < nk * 4) {
+            const int p = i >> 3, c = i & 7;
+            const uint32_t a[4] = {va[u].x, va[u].y, va[u].z, va[u].w}, bb[4] = {vb[u].x, vb[u].y, vb[u].z, vb[u].w};
+            char *dst = Vt + (size_t)(8 * c) * VS + 4 * p;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                *reinterpret_cast<uint32_t *>(dst + (size_t)(2 * j) * VS) = (a[j] & 0xffffu) | (bb[j] << 16);
+                *reinterpret_cast<uint32_t *>(dst + (size_t)(2 * j + 1) * VS) = (a[j] >> 16) | (bb[j] & 0xffff0000u);
+            }
+        }
+    }
+    __syncthreads();
+
+    for (int q0w = wq * ATT_QW; q0w < rows; q0w += nwaves * ATT_QW) {   // wave-uniform; no barrier below
+        const int q = q0w + ql;
+        if (q0w >= len) {   // a block of padding rows only: defined output (zeros), no NaNs into the next projection
+            if (q < rows) {
+                uint2 *dst = reinterpret_cast<uint2 *>(Og + (int64_t)q * HD);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) dst[i * 2 + g] = make_uint2(0u, 0u);
+            }
+            continue;
+        }
+        if (q0w != wq * ATT_QW) {   // the wave's next query block (sequences beyond 32 x waves tokens)
+            const int qr = q < len ? q : len - 1;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const vec8 *>(Qg + (int64_t)qr * stride + 16 * s + 8 * g);
+        }
+
+        ef32x16 o0, o1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o0[e] = o1[e] = 0.f;
+        float m = -INFINITY, lsum = 0.f;
+
+        for (int kb = 0; kb < nkb; ++kb) {
+            ef32x16 s0, s1;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s0[e] = s1[e] = 0.f;
+            const char *kp = Ks + (kb * ATT_KB + ql) * ATT_KROW + g * 16;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const vec8 k0 = *reinterpret_cast<const vec8 *>(kp + 32 * s);
+                const vec8 k1 = *reinterpret_cast<const vec8 *>(kp + 32 * ATT_KROW + 32 * s);
+                s0 = HT::mfma(k0, qf[s], s0);
+                s1 = HT::mfma(k1, qf[s], s1);
+            }
+            float x[32];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                x[e] = s0[e];
+                x[16 + e] = s1[e];
+            }
+            if (kb * ATT_KB + ATT_KB > len) {   // the last step: keys beyond the sequence
+#pragma unroll
+                for (int e = 0; e < 32; ++e) {
+                    const int key = kb * ATT_KB + (e >> 4) * 32 + (e & 3) + 8 * ((e & 15) >> 2) + 4 * g;
+                    if (key >= len) x[e] = -INFINITY;
+                }
+            }
+            float mx = x[0];
+#pragma unroll
+            for (int e = 1; e < 32; ++e) mx = fmaxf(mx, x[e]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mn = fmaxf(m, mx);            // finite: every step holds at least one key < len
+            const float alpha = __builtin_amdgcn_exp2f((m - mn) * scale_log2e);   // m = -inf on the first step: 0
+            const float bias = -mn * scale_log2e;
+            m = mn;
+            float ps = 0.f;
+#pragma unroll
+            for (int e = 0; e < 32; ++e) {
+                x[e] = __builtin_amdgcn_exp2f(fmaf(x[e], scale_log2e, bias));
+                ps += x[e];
+            }
+            lsum = fmaf(lsum, alpha, ps);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                o0[e] *= alpha;
+                o1[e] *= alpha;
+            }
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    vec8 pf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[j] = (elem)x[hb * 16 + s2 * 8 + j];
+                    const int kbase = kb * ATT_KB + hb * 32 + s2 * 16 + 4 * g;
+                    const char *vp = Vt + (size_t)ql * VS + 2 * kbase;
+                    union {
+                        uint2 u[2];
+                        vec8 v;
+                    } a0, a1;
+                    a0.u[0] = *reinterpret_cast<const uint2 *>(vp);
+                    a0.u[1] = *reinterpret_cast<const uint2 *>(vp + 16);
+                    a1.u[0] = *reinterpret_cast<const uint2 *>(vp + (size_t)32 * VS);
+                    a1.u[1] = *reinterpret_cast<const uint2 *>(vp + (size_t)32 * VS + 16);
+                    o0 = HT::mfma(a0.v, pf, o0);
+                    o1 = HT::mfma(a1.v, pf, o1);
+                }
+            }
+        }
+
+        const float inv = 1.f / (lsum + __shfl_xor(lsum, 32));
+        if (q < len) {
+            // O^T tile: lane -> query, register e -> head column 32 db + (e & 3) + 8 (e >> 2) + 4 g: four consecutive columns per 8-byte store
+            uint16_t *dst = Og + (int64_t)q * HD + 4 * g;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                *reinterpret_cast<uint2 *>(dst + 8 * c4) =
+                    round4<elem>(o0[4 * c4] * inv, o0[4 * c4 + 1] * inv, o0[4 * c4 + 2] * inv, o0[4 * c4 + 3] * inv);
+                *reinterpret_cast<uint2 *>(dst + 32 + 8 * c4) =
+                    round4<elem>(o1[4 * c4] * inv, o1[4 * c4 + 1] * inv, o1[4 * c4 + 2] * inv, o1[4 * c4 + 3] * inv);
+            }
+        } else if (q < rows) {
+            uint2 *dst = reinterpret_cast<uint2 *>(Og + (int64_t)q * HD);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dst[i * 2 + g] = make_uint2(0u, 0u);
+        }
+    }   // query blocks of this wave
 }
 
 // One wave per row of dim = 256 * C elements; lane owns elements 4 * (64 c + lane) .. + 3 of every 256-element slice.
@@ -540,10 +485,7 @@ static int attention_any(const uint16_t *qkv, const int32_t *seq_start, const in
     const size_t lds = attention_lds_bytes(lk_pad);
     // the opt-in is cached per (kernel, device) whatever the size: ask for the kernel's maximum once (512 keys), not for this call's
     // image -- length-sorted batches start with the shortest texts
-    // CCR_ATT_PERSIST = workgroups per CU of the persistent form (0: one workgroup per item)
-    static const int persist = getenv("CCR_ATT_PERSIST") ? atoi(getenv("CCR_ATT_PERSIST")) : ATT_PERSIST_DEFAULT;
-    const int rc = persist > 0 ? ensure_dynamic_lds(reinterpret_cast<const void *>(&attention_kernel<DT, true>), attention_lds_bytes(512))
-                               : ensure_dynamic_lds(reinterpret_cast<const void *>(&attention_kernel<DT, false>), attention_lds_bytes(512));
+    const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&attention_kernel<DT>), attention_lds_bytes(512));
     if (rc != CCR_OK) return rc;
     int waves = (max_len + ATT_QW - 1) / ATT_QW;   // one wave per 32 query rows, at most 8 (longer sequences: the waves loop)
     if (waves > ATT_MAX_THREADS / 64) waves = ATT_MAX_THREADS / 64;
@@ -553,22 +495,8 @@ static int attention_any(const uint16_t *qkv, const int32_t *seq_start, const in
     // fit either way and 7-8 waves are faster)
     if (lk_pad == 192 && waves > 4) waves = 4;
     CCR_REQUIRE(lk_pad * 8 <= ATT_KMAX * 64 * waves && lk_pad * 4 <= ATT_VMAX * 64 * waves, "ccr_attention: staging bound (internal)");
-    const int n_items = n_heads * n_seq;
-    if (persist > 0) {
-        static int num_cu = 0;
-        if (num_cu == 0) {
-            int dev = 0;
-            CCR_HIP_CHECK(hipGetDevice(&dev));
-            CCR_HIP_CHECK(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
-            if (num_cu <= 0) num_cu = 256;
-        }
-        const int grid = std::min(n_items, num_cu * persist);
-        hipLaunchKernelGGL((attention_kernel<DT, true>), dim3(grid), dim3(64 * waves), lds, stream, qkv, seq_start, seq_len, out, n_heads, pad_len,
-                           max_len, lk_pad, scale * 1.4426950408889634f, n_items);
-    } else {
-        hipLaunchKernelGGL((attention_kernel<DT, false>), dim3(n_heads, n_seq), dim3(64 * waves), lds, stream, qkv, seq_start, seq_len, out, n_heads,
-                           pad_len, max_len, lk_pad, scale * 1.4426950408889634f, n_items);
-    }
+    hipLaunchKernelGGL(attention_kernel<DT>, dim3(n_heads, n_seq), dim3(64 * waves), lds, stream, qkv, seq_start, seq_len, out,
+                       n_heads, pad_len, max_len, lk_pad, scale * 1.4426950408889634f);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
 }
