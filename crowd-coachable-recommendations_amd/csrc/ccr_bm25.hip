@@ -95,7 +95,7 @@ struct Bm25Term {        // one distinct term of a query row
 };
 constexpr int BM25_TILE_WAVES = 4;
 constexpr int BM25_TILE_GROUP = 4;           // terms whose first steps are in flight together
-constexpr int BM25_MAX_TILE_TERMS = 64;      // lane r <-> term r; longer queries take the round kernels
+constexpr int BM25_MAX_TILE_TERMS = 256;     // lane r <-> terms r, 64 + r, 128 + r, 192 + r; longer queries take the round kernels
 
 __device__ __forceinline__ int64_t readlane64(int64_t v, int l) {
     const int lo = __builtin_amdgcn_readlane((int)(uint32_t)v, l), hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
@@ -117,7 +117,10 @@ constexpr int BM25_LIST_CAP = 16384;         // candidate records per row (128 K
 // TABLE: the index holds the FINISHED contribution of every posting (ccr_bm25_index_set_idf: (tf idf_t)(k1 + 1) / (tf + K_d) evaluated once, by
 // the same fp64 operations in the same order, so the same bits) and the queries use the index's idf: a posting is 4 + 8 coalesced bytes and
 // one add -- no K_d gather (64 scattered 8-byte requests per wave and step), no fp64 division (~30 instructions per posting).
-template <int T, int U, int MODE, bool TABLE>
+// G: lane r keeps the cursors of terms r, 64 + r, ... 64 (G - 1) + r of the row (G = 1: queries of up to 64 distinct terms; G = 4: up to 256 --
+// product descriptions as queries, the reference's prime_pantry set-up: scripts/ms_marco_eval.py:56-57); the groups are walked in order, so
+// the adds of a cell keep the ascending term order.
+template <int T, int U, int MODE, bool TABLE, int G>
 __global__ __launch_bounds__(256) void bm25_tile_kernel(const Bm25Term *__restrict__ terms, const int32_t *__restrict__ row_ptr, int n_rows,
                                                        const int32_t *__restrict__ doc_ids, const float *__restrict__ tf,
                                                        const double *__restrict__ doc_k, const double *__restrict__ contrib, double k1p1,
@@ -139,26 +142,31 @@ __global__ __launch_bounds__(256) void bm25_tile_kernel(const Bm25Term *__restri
         const int row = (int)(item % (uint32_t)n_rows), run = (int)(item / (uint32_t)n_rows);
         const int trow = row_map ? (int)row_map[row] : row;   // the row of the term table
         const int t0 = row_ptr[trow], nt = row_ptr[trow + 1] - t0;
-        int64_t cur = 0, end = 0;
-        double idf = 0.0;
-        if (lane < nt) {
-            const Bm25Term t = terms[t0 + lane];
-            cur = t.begin, end = t.end, idf = t.idf;
-        }
+        int64_t cur[G], end[G];
+        double idf[G];
+        int nd[G];   // the next document of the lane's term of group gq
         const int64_t run_base = (int64_t)run * run_stride_docs;
         const int64_t run_end = run_base + (int64_t)run_tiles * T < n_docs ? run_base + (int64_t)run_tiles * T : n_docs;
-        if (run > 0) {   // first posting of every term at or behind the run's first document
-            int64_t lo = cur, hi = end;
-            while (__ballot(lo < hi) != 0ull) {
-                const int64_t mid = lo + ((hi - lo) >> 1);
-                if (lo < hi) {
-                    if ((int64_t)doc_ids[mid] < run_base) lo = mid + 1;
-                    else hi = mid;
-                }
+#pragma unroll
+        for (int gq = 0; gq < G; ++gq) {
+            cur[gq] = 0, end[gq] = 0, idf[gq] = 0.0;
+            if (64 * gq + lane < nt) {
+                const Bm25Term t = terms[t0 + 64 * gq + lane];
+                cur[gq] = t.begin, end[gq] = t.end, idf[gq] = t.idf;
             }
-            cur = lo;
+            if (run > 0) {   // first posting of every term at or behind the run's first document
+                int64_t lo = cur[gq], hi = end[gq];
+                while (__ballot(lo < hi) != 0ull) {
+                    const int64_t mid = lo + ((hi - lo) >> 1);
+                    if (lo < hi) {
+                        if ((int64_t)doc_ids[mid] < run_base) lo = mid + 1;
+                        else hi = mid;
+                    }
+                }
+                cur[gq] = lo;
+            }
+            nd[gq] = cur[gq] < end[gq] ? doc_ids[cur[gq]] : 0x7fffffff;
         }
-        int nd = cur < end ? doc_ids[cur] : 0x7fffffff;   // the next document of the lane's term
         float *out_row = MODE == BM25_SAMPLE ? scores + ((int64_t)row * n_runs + run) * T : scores + (int64_t)row * n_docs;
         float thr = 0.f;
         bool odd = false;
@@ -171,7 +179,6 @@ __global__ __launch_bounds__(256) void bm25_tile_kernel(const Bm25Term *__restri
             // was the whole kernel).  A slot without a term repeats slot 0's addresses: every wave issues the same number of loads, so
             // the wait in front of slot b is a plain count.  The values are pinned behind the loads: left alone, hipcc sinks the load of
             // a value into the `if (in)` that uses it -- a second dependent round trip per step.
-            unsigned long long act = __ballot(nd < tile_end);
             constexpr int NB = BM25_TILE_GROUP;
             // (addresses = a wave-uniform 64-bit base + a 32-bit lane offset: the loads take the scalar-base form, no 64-bit lane arithmetic)
             auto fetch = [&](int32_t(&dd)[U], double(&cc)[U], float(&ff)[U], int64_t c0, int64_t e0) {
@@ -187,6 +194,9 @@ __global__ __launch_bounds__(256) void bm25_tile_kernel(const Bm25Term *__restri
                     else ff[u] = pf[o];
                 }
             };
+#pragma unroll
+            for (int gq = 0; gq < G; ++gq) {
+            unsigned long long act = __ballot(nd[gq] < tile_end);
             while (act != 0ull) {
                 int32_t d[NB][U];
                 double cv[NB][U];
@@ -200,7 +210,7 @@ __global__ __launch_bounds__(256) void bm25_tile_kernel(const Bm25Term *__restri
                     if (act != 0ull) {
                         rr[b] = __builtin_amdgcn_readfirstlane(__builtin_ctzll(act));
                         act &= act - 1ull;
-                        cc[b] = readlane64(cur, rr[b]), ee[b] = readlane64(end, rr[b]);
+                        cc[b] = readlane64(cur[gq], rr[b]), ee[b] = readlane64(end[gq], rr[b]);
                     }
                     fetch(d[b], cv[b], f[b], cc[b], ee[b]);
                 }
@@ -210,7 +220,7 @@ __global__ __launch_bounds__(256) void bm25_tile_kernel(const Bm25Term *__restri
                     const int r = rr[b];
                     int64_t c = cc[b];
                     const int64_t e = ee[b];
-                    const double w = __longlong_as_double(readlane64(__double_as_longlong(idf), r));
+                    const double w = __longlong_as_double(readlane64(__double_as_longlong(idf[gq]), r));
                     int cnt;
                     for (;;) {
                         cnt = 0;
@@ -259,9 +269,10 @@ __global__ __launch_bounds__(256) void bm25_tile_kernel(const Bm25Term *__restri
                             next = u_sel == u ? v : next;
                         }
                     }
-                    if (lane == r) cur = c, nd = next;
+                    if (lane == r) cur[gq] = c, nd[gq] = next;
                 }
             }
+            }   // term groups
             if (MODE == BM25_FILTER) {
                 // the tile against tau: the same test as the r4 collect pass (score >= tau, and > 0 when tau <= 0: a BM25 row is mostly
                 // exact zeros).  Two walks over the tile's LDS image -- count, then write -- instead of 16 live scores per lane: the
@@ -622,7 +633,7 @@ Bm25Sample bm25_sample_plan(const ccr_bm25_index *ix, int k) {
 //     4 096) a 128-KiB candidate list and a sample row, plus fp32 score rows for `redo_rows` rows at a time (the rows the filter could
 //     not finish; ~1 GiB);
 //   stored (small corpora, k beyond the candidate lists, CCR_BM25_DENSE_SELECT): fp32 score rows of the whole batch (~8 GiB of them),
-//     exact dense selection of every row; the round kernels (queries of more than 64 distinct terms, CCR_BM25_TILE=-1) keep their fp64
+//     exact dense selection of every row; the round kernels (queries of more than 256 distinct terms, CCR_BM25_TILE=-1) keep their fp64
 //     accumulator rows beside them (up to 256 rows).
 struct Bm25Layout {
     bool tile, fused;
@@ -673,6 +684,7 @@ struct Bm25TileArgs {
     int64_t sample_every;       // SAMPLE: one piece of T documents out of this many
     int sample_pieces;
     bool table;                 // the queries use the index's idf: finished contributions instead of tf / K_d
+    int max_terms;              // of the batch: up to 64 -> one cursor group per lane, up to 256 -> four
 };
 
 template <int T, int U, int MODE>
@@ -699,14 +711,18 @@ int launch_bm25_tile(const ccr_bm25_index *ix, const Bm25TileArgs &a, hipStream_
     }
     const int64_t items = runs * m;
     const unsigned grid = (unsigned)std::min<int64_t>((items + BM25_TILE_WAVES - 1) / BM25_TILE_WAVES, (int64_t)ix->num_cu * wgs_per_cu);
-    if (a.table)
-        hipLaunchKernelGGL((bm25_tile_kernel<T, U, MODE, true>), dim3(grid), dim3(64 * BM25_TILE_WAVES), 0, s, a.terms, a.row_ptr, m, ix->doc_ids, ix->tf,
-                           ix->doc_k, ix->contrib, ix->k1 + 1.0, ix->n_docs, run_tiles, (int)runs, stride, a.ticket, a.scores, a.row_map, a.tau, a.list,
-                           a.list_cnt, a.odd_cnt);
-    else
-        hipLaunchKernelGGL((bm25_tile_kernel<T, U, MODE, false>), dim3(grid), dim3(64 * BM25_TILE_WAVES), 0, s, a.terms, a.row_ptr, m, ix->doc_ids, ix->tf,
-                           ix->doc_k, ix->contrib, ix->k1 + 1.0, ix->n_docs, run_tiles, (int)runs, stride, a.ticket, a.scores, a.row_map, a.tau, a.list,
-                           a.list_cnt, a.odd_cnt);
+#define CCR_BM25_LAUNCH(TAB, GG)                                                                                                                  \
+    hipLaunchKernelGGL((bm25_tile_kernel<T, U, MODE, TAB, GG>), dim3(grid), dim3(64 * BM25_TILE_WAVES), 0, s, a.terms, a.row_ptr, m, ix->doc_ids, \
+                       ix->tf, ix->doc_k, ix->contrib, ix->k1 + 1.0, ix->n_docs, run_tiles, (int)runs, stride, a.ticket, a.scores, a.row_map,     \
+                       a.tau, a.list, a.list_cnt, a.odd_cnt)
+    if (a.max_terms <= 64) {
+        if (a.table) CCR_BM25_LAUNCH(true, 1);
+        else CCR_BM25_LAUNCH(false, 1);
+    } else {
+        if (a.table) CCR_BM25_LAUNCH(true, 4);
+        else CCR_BM25_LAUNCH(false, 4);
+    }
+#undef CCR_BM25_LAUNCH
     CCR_LAUNCH_CHECK();
     return CCR_OK;
 }
@@ -817,7 +833,7 @@ extern "C" int ccr_bm25_search(const ccr_bm25_index *ix, const int64_t *q_ptr_ho
             rp[m] = n;
             CCR_HIP_CHECK(hipMemcpyAsync(d_terms, blob.data(), blob.size(), hipMemcpyHostToDevice, s));
             const int32_t *d_row_ptr = reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(d_terms) + ptr_off);
-            Bm25TileArgs a = {d_terms, d_row_ptr, m, ctl + 1, scores, nullptr, tau, cand_list, list_cnt, odd_cnt, S.every, S.n_pieces, table};
+            Bm25TileArgs a = {d_terms, d_row_ptr, m, ctl + 1, scores, nullptr, tau, cand_list, list_cnt, odd_cnt, S.every, S.n_pieces, table, max_terms};
             if (L.fused) {
                 // sample pieces -> tau per row -> every tile against tau -> sort the lists
                 a.scores = sample;

@@ -402,7 +402,8 @@ int ccr_rank_metrics(const int64_t *ids, int n_q, int k, const int64_t *qrel_ptr
  *   score(q, d) = sum_t ascending (tf * idf_t) * (k1 + 1) / (tf + doc_k[d]) in fp64, rounded once to fp32;
  *   out_scores / out_ids [n_q][k] in the order (score desc, document index asc); documents without any query term
  *   score 0 and follow in index order, as a stable sort of the reference's dense score vector would leave them.
- *   Queries of up to 64 distinct terms run the document-tile scorer (fp64 accumulators in LDS); from ~30 k documents up the top-k
+ *   Queries of up to 256 distinct terms run the document-tile scorer (fp64 accumulators in LDS; one cursor group per lane up to 64 terms,
+ *   four up to 256); from ~30 k documents up the top-k
  *   filter is fused into it (a sampled threshold per query, the documents that pass leave the tile's registers as candidate records,
  *   verified; rows the filter cannot finish are scored again with their fp32 rows stored and ranked exactly), so no [n_q][n_docs]
  *   score row exists and the workspace is ~130 KiB per query + 1 GiB.  Smaller corpora and CCR_BM25_DENSE_SELECT=1 store the fp32 rows

@@ -212,7 +212,7 @@ def _random_postings(rs, n_docs, n_terms, dense_terms):
 def test_hip_bm25_tile_scorer_equals_the_round_kernels(n_docs, k, monkeypatch):
     """The document-tile scorer (a wave per run of tiles, fp64 accumulators in LDS, cursors per term) against the round kernels with
     their fp64 rows in HBM (CCR_BM25_TILE=-1), ids and score bits: corpora that are not a multiple of the tile, smaller than one tile,
-    exactly one tile; queries of 0, 1, 64 (the tile scorer's limit) and 65+ terms (round kernels); terms without postings; a single
+    exactly one tile; queries of 0, 1, 64 (one cursor group), 65 / 200 (four groups) and 257 terms (round kernels); terms without postings; a single
     query (every run is one tile: a binary search per tile and term); the other tile shapes."""
     from ccrec_amd.bm25 import BM25
     rs = np.random.RandomState(n_docs % 1000)
@@ -248,12 +248,19 @@ def test_hip_bm25_tile_scorer_equals_the_round_kernels(n_docs, k, monkeypatch):
     plain.idf = idf * 1.25
     s2, i2 = plain.transform_terms_topk(queries[:30], k)
     assert torch.equal(i, i2) and torch.equal(s.view(torch.int32), s2.view(torch.int32))
-    # 65 terms in one query of the batch: the whole call takes the round kernels, same results for the other queries
+    # 65 and 200 distinct terms in a query (product descriptions as queries: the reference's prime_pantry set-up): four cursor groups per
+    # lane, still the tile scorer; 257 terms: the whole call takes the round kernels -- same results for the other queries either way
     monkeypatch.setenv("CCR_BM25_TILE", "0")
     model = BM25.from_postings(indptr, rows, counts, doc_k, idf, k1=1.2)
     long_q = np.sort(rs.choice(n_terms, 65, replace=False)).astype(np.int32)
-    s, i = model.transform_terms_topk(queries[:20] + [long_q], k)
+    longer_q = np.sort(rs.choice(n_terms, 200, replace=False)).astype(np.int32)
+    s, i = model.transform_terms_topk(queries[:20] + [long_q, longer_q], k)
+    assert model.last_stats()["path"].startswith("tile+")
     assert torch.equal(i[:20].cpu(), results["-1"][1][:20]) and torch.equal(s.view(torch.int32)[:20].cpu(), results["-1"][0][:20])
+    too_long = np.sort(rs.choice(n_terms, 257, replace=False)).astype(np.int32)
+    s2, i2 = model.transform_terms_topk(queries[:20] + [long_q, longer_q, too_long], k)
+    assert model.last_stats()["path"] == "rounds+stored_rows"
+    assert torch.equal(i2[:22], i) and torch.equal(s2.view(torch.int32)[:22], s.view(torch.int32))
     # the oracle's arithmetic on one row: fp64 sums in ascending term order, rounded once
     q = queries[3]
     acc = np.zeros(n_docs)
