@@ -758,7 +758,7 @@ extern "C" int ccr_bm25_search(const ccr_bm25_index *ix, const int64_t *q_ptr_ho
                 MAX_K);
     if (n_q == 0) return CCR_OK;
     int max_terms = 0;
-    bool table = ix->contrib != nullptr;   // ... and every query weight is the index's idf of that term, bit for bit
+    bool use_table = ix->contrib != nullptr;   // ... and every query weight is the index's idf of that term, bit for bit
     for (int q = 0; q < n_q; ++q) {
         const int64_t a = q_ptr_host[q], b = q_ptr_host[q + 1];
         CCR_REQUIRE(a <= b, "ccr_bm25_search: q_ptr not monotone at query %d", q);
@@ -767,7 +767,7 @@ extern "C" int ccr_bm25_search(const ccr_bm25_index *ix, const int64_t *q_ptr_ho
             CCR_REQUIRE(q_terms_host && q_idf_host, "ccr_bm25_search: null term arrays");
             CCR_REQUIRE(q_terms_host[i] >= 0 && q_terms_host[i] < ix->n_terms, "ccr_bm25_search: term id %d out of range", q_terms_host[i]);
             CCR_REQUIRE(i == a || q_terms_host[i] > q_terms_host[i - 1], "ccr_bm25_search: terms of query %d not strictly ascending", q);
-            if (table && memcmp(&q_idf_host[i], &ix->idf[q_terms_host[i]], 8) != 0) table = false;
+            if (use_table && memcmp(&q_idf_host[i], &ix->idf[q_terms_host[i]], 8) != 0) use_table = false;
         }
     }
     const Bm25Layout L = bm25_layout(ix, n_q, max_terms, k);
@@ -777,7 +777,7 @@ extern "C" int ccr_bm25_search(const ccr_bm25_index *ix, const int64_t *q_ptr_ho
     }
     hipStream_t s = (hipStream_t)stream;
     const int rows = L.rows;
-    ix->stats[0] = (L.fused ? 2 : (L.tile ? 1 : 0)) + (L.tile && table ? 4 : 0), ix->stats[1] = 0, ix->stats[2] = (n_q + rows - 1) / rows, ix->stats[3] = L.fused ? L.sample.rank : 0;
+    ix->stats[0] = (L.fused ? 2 : (L.tile ? 1 : 0)) + (L.tile && use_table ? 4 : 0), ix->stats[1] = 0, ix->stats[2] = (n_q + rows - 1) / rows, ix->stats[3] = L.fused ? L.sample.rank : 0;
     char *ws = (char *)workspace;
     double *acc = (double *)ws;                                  // round kernels only
     float *scores = (float *)(ws + L.scores_off);                // stored: [rows][n_docs]; fused: [redo_rows][n_docs]
@@ -833,7 +833,7 @@ extern "C" int ccr_bm25_search(const ccr_bm25_index *ix, const int64_t *q_ptr_ho
             rp[m] = n;
             CCR_HIP_CHECK(hipMemcpyAsync(d_terms, blob.data(), blob.size(), hipMemcpyHostToDevice, s));
             const int32_t *d_row_ptr = reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(d_terms) + ptr_off);
-            Bm25TileArgs a = {d_terms, d_row_ptr, m, ctl + 1, scores, nullptr, tau, cand_list, list_cnt, odd_cnt, S.every, S.n_pieces, table, max_terms};
+            Bm25TileArgs a = {d_terms, d_row_ptr, m, ctl + 1, scores, nullptr, tau, cand_list, list_cnt, odd_cnt, S.every, S.n_pieces, use_table, max_terms};
             if (L.fused) {
                 // sample pieces -> tau per row -> every tile against tau -> sort the lists
                 a.scores = sample;
