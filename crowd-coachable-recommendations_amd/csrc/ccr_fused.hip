@@ -1527,8 +1527,8 @@ int launch_threshold(const float *gmax, int64_t n_groups, int n_q, int nq_pad, i
     // small batches: a workgroup per query (needs k <= n_groups -- the planner samples >= 2k groups -- and the bounds in 64 KiB of LDS);
     // *zero_cnt tells the caller whether its counters have been cleared here
     if (n_q <= 128 && n_groups >= k && n_groups <= 16384 && zero_per_query <= 256) {
-        if (n_groups * 4 > 32 * 1024) {
-            const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&threshold_small_kernel), 64 * 1024);
+        if (n_groups * 4 > 32 * 1024) {   // (the kernel's static LDS sits on top of the dynamic part: opt in with head room)
+            const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&threshold_small_kernel), 72 * 1024);
             if (rc != CCR_OK) return rc;
         }
         hipLaunchKernelGGL(threshold_small_kernel, dim3(n_q), dim3(256), (size_t)n_groups * 4, s, gmax, (int)n_groups, nq_pad, k, qnorm, dmax_bits,
