@@ -108,6 +108,13 @@ def test_msmarco_config_shard_and_full_properties():
     print(st)
     assert st["path"] == 1 and st["n_fallback"] == 0
     _check_against_oracle(D, Q, s, i, k, sub)
+    # small batches against the same index: the streaming main pass (one query group up to 64 queries, two up to 128) with its
+    # thresholds from the per-query kernel (8,640 sampled groups here: its LDS image needs the dynamic-LDS opt-in) -- the full batch's bits
+    for nq_small in (1, 16, 100):
+        ss, si = index.search(Q[:nq_small].contiguous(), k)
+        st_s = index.last_stats()
+        assert st_s["path"] == 1 and (st_s["ranges"], st_s["sublists"]) == (1, 2) and st_s["n_fallback"] == 0, st_s
+        assert torch.equal(si, i[:nq_small]) and torch.equal(ss.view(torch.int32), s[:nq_small].view(torch.int32))
     # rank 3 of 8: rows [lo, hi) of the same corpus; the shard's list must be the full list restricted to the shard
     from ccrec_amd.dist import shard_bounds
     lo, hi = shard_bounds(n, 8, 3)
