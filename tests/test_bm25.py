@@ -326,3 +326,51 @@ def test_hip_bm25_more_queries_than_one_fused_batch(monkeypatch):
     monkeypatch.setenv("CCR_BM25_DENSE_SELECT", "1")
     s2, i2 = model.transform_terms_topk(queries, 10)
     assert torch.equal(i, i2) and torch.equal(s.view(torch.int32), s2.view(torch.int32))
+
+
+@pytest.mark.gpu
+def test_hip_bm25_workspace_sizes(monkeypatch):
+    """ccr_bm25_search_workspace_bytes_k sizes the workspace for one k: without the [queries][documents] score rows where the filter is fused
+    (~130 KiB per query + the redo area), with them otherwise; ccr_bm25_search_workspace_bytes is the k-agnostic upper bound and a
+    workspace of that size serves any k; a workspace that is too small is refused with CCR_ERR_WORKSPACE, not overrun."""
+    import ctypes
+    from ccrec_amd import _lib
+    from ccrec_amd.bm25 import BM25
+    rs = np.random.RandomState(33)
+    n_docs = 200_000
+    indptr, rows, counts, doc_k, idf = _random_postings(rs, n_docs, 200, dense_terms=3)
+    monkeypatch.delenv("CCR_BM25_DENSE_SELECT", raising=False)
+    model = BM25.from_postings(indptr, rows, counts, doc_k, idf, k1=1.2)
+    lib, h = model._lib, model._h
+    n_big = 3000                                                                      # 2.4 GB of score rows
+    fused = int(lib.ccr_bm25_search_workspace_bytes_k(h, n_big, 12, 100))
+    stored = int(lib.ccr_bm25_search_workspace_bytes_k(h, n_big, 12, 10_000))         # k beyond the candidate lists: score rows
+    anyk = int(lib.ccr_bm25_search_workspace_bytes(h, n_big, 12))
+    assert stored >= n_big * n_docs * 4 and anyk >= max(fused, stored)
+    assert fused <= n_big * 160 * 1024 + (1 << 30) + n_big * 12 * 64 + (1 << 20) < stored          # lists 128 KiB + sample 16 KiB per query, 1 GiB of redo rows
+    n_q = 300
+    queries = [np.sort(rs.choice(200, rs.randint(1, 12), replace=False)).astype(np.int32) for _ in range(n_q)]
+    mt = max(len(t) for t in queries)
+    fused = int(lib.ccr_bm25_search_workspace_bytes_k(h, n_q, mt, 100))
+    anyk = int(lib.ccr_bm25_search_workspace_bytes(h, n_q, mt))
+    s, i = model.transform_terms_topk(queries, 100)
+    # the same search through the C ABI with the k-agnostic workspace, and with one that is 4 KiB short
+    q_ptr = np.zeros(n_q + 1, np.int64)
+    q_ptr[1:] = np.cumsum([len(t) for t in queries])
+    q_terms = np.concatenate(queries).astype(np.int32)
+    q_idf = np.ascontiguousarray(model.idf[q_terms], np.float64)
+    out_s = torch.empty(n_q, 100, dtype=torch.float32, device="cuda")
+    out_i = torch.empty(n_q, 100, dtype=torch.int64, device="cuda")
+    vp = ctypes.c_void_p
+    stream = vp(torch.cuda.current_stream().cuda_stream)
+
+    def call(nbytes):
+        ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        return lib.ccr_bm25_search(h, q_ptr.ctypes.data_as(vp), q_terms.ctypes.data_as(vp), q_idf.ctypes.data_as(vp), n_q, 100, out_s.data_ptr(),
+                                   out_i.data_ptr(), ws.data_ptr(), ws.numel(), stream)
+
+    assert call(anyk) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out_i, i) and torch.equal(out_s.view(torch.int32), s.view(torch.int32))
+    rc = call(fused - 4096)
+    assert rc != 0 and "workspace" in lib.ccr_last_error().decode()
