@@ -57,7 +57,11 @@ def weighted_cuts(weights, world_size):
     if total <= 0.0:      # nothing to balance: equal row counts
         return [shard_bounds(len(w), world_size, r)[0] for r in range(world_size)] + [len(w)]
     inner = np.searchsorted(cum, total * np.arange(1, world_size) / world_size, side="right")
-    return [0] + [int(c) for c in inner] + [len(w)]
+    cuts = [0] + [int(c) for c in inner] + [len(w)]
+    if len(w) >= world_size:      # one heavy row must not leave a rank without rows (an empty shard cannot fill an exchange message)
+        for r in range(1, world_size):
+            cuts[r] = min(max(cuts[r], cuts[r - 1] + 1), len(w) - (world_size - r))
+    return cuts
 
 
 def short_list_length(k, world, sigmas=6.0):

@@ -152,6 +152,8 @@ def test_shard_bounds_by_weight():
             assert tok_rows.max() / tok_rows.min() > 3.0          # what equal row counts would have cost
     assert weighted_cuts(np.zeros(10), 3) == [0, 4, 7, 10]                        # nothing to balance: equal rows
     assert weighted_cuts([0, 0, 100, 0, 0], 2)[1] in (2, 3) and weighted_cuts([1, 1], 4)[-1] == 2
+    assert weighted_cuts([1000, 1, 1, 1], 4) == [0, 1, 2, 3, 4] and weighted_cuts([1, 1, 1, 1000], 4) == [0, 1, 2, 3, 4]   # no rank without rows
+    assert weighted_cuts([5, 0, 0, 0, 0, 5], 3) in ([0, 1, 2, 6], [0, 1, 5, 6])
     cuts = weighted_cuts(rs.randint(1, 50, 7), 8)
     assert cuts[0] == 0 and cuts[-1] == 7 and all(a <= b_ for a, b_ in zip(cuts, cuts[1:]))
     # the estimate every rank computes without a tokeniser: words x 1.3 + 2, clipped to max_length
