@@ -291,7 +291,11 @@ static Plan make_plan_for(int64_t n_rows, int dim, int n_q, int k, int flags, in
         // small batches: the first main pass is the streaming kernel (ccr_narrow.hip) when the query rows fit its LDS image
         // (65 .. 128 queries: two groups of <= 64 on paired workgroups that walk the same rows)
         int nqt = n_q <= 16 ? 1 : (n_q <= 32 ? 2 : 4);
-        const int ngroups = n_q <= NARROW_MAX_Q ? 1 : 2;
+        int ngroups = n_q <= NARROW_MAX_Q ? 1 : 2;
+        // 65 .. 96 queries: ONE group of six query tiles where their rows fit the LDS (dim <= 768) -- every corpus row is pulled once
+        if (n_q > NARROW_MAX_Q && n_q <= 96 && kn.narrow_groups >= 2 && dim % TILE_K == 0 && narrow_lds_bytes(6, dim) <= (size_t)160 * 1024 &&
+            env_int("CCR_NARROW_WIDE", 1) != 0)
+            nqt = 6, ngroups = 1;
         const bool narrow = kn.narrow != 0 && n_q <= NARROW_MAX_Q * std::min(std::max(kn.narrow_groups, 1), NARROW_MAX_GROUPS) && dim % TILE_K == 0 &&
                             narrow_lds_bytes(nqt, dim) <= (size_t)160 * 1024 && (ngroups == 1 || num_cu >= 16);
         p.narrow = narrow ? nqt : 0;

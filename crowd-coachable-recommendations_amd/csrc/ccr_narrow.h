@@ -9,6 +9,8 @@ constexpr int NARROW_WAVES = NARROW_THREADS / 64;
 constexpr int NARROW_MAX_Q = 64;                    // query rows resident in LDS (4 MFMA tiles of 16)
 constexpr int NARROW_MAX_GROUPS = 2;                // query groups of <= NARROW_MAX_Q a launch serves (each group streamed by 1 / groups of the workgroups)
 constexpr int NARROW_LDS_CAP = 64;                  // records a workgroup stages per query before it flushes (overflow: straight to global)
+constexpr int NARROW_LDS_CAP_WIDE = 8;              // ... with 96 resident query rows (6 tiles: 147 KiB of the 160 at dim 768)
+__host__ __device__ constexpr int narrow_lds_cap(int nqt) { return nqt > 4 ? NARROW_LDS_CAP_WIDE : NARROW_LDS_CAP; }
 constexpr int NARROW_SUBLISTS = 2;                  // sub-lists per query in the candidate area: workgroups of even / odd index
 
 // LDS bytes per resident query row: >= the row, == 32 (mod 256): the 16 lanes of every ds_read_b128 group (rows l15, chunks lq) then

@@ -45,7 +45,8 @@ __device__ __forceinline__ bf16x8 stream_load(const char *p) {
         return *reinterpret_cast<const bf16x8 *>(p);
 }
 
-// NQT: query tiles of 16 (1, 2, 4); P: loads in flight per wave = K-steps per chunk (divides dim / 32)
+// NQT: query tiles of 16 (1, 2, 4; 6 = 65 .. 96 queries in one group, with a short staging list per query); P: loads in flight per wave =
+// K-steps per chunk (divides dim / 32)
 template <int NQT, int P, bool NT>
 __global__ __launch_bounds__(NARROW_THREADS) void narrow_filter_kernel(const NarrowArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -56,6 +57,7 @@ __global__ __launch_bounds__(NARROW_THREADS) void narrow_filter_kernel(const Nar
     const int row_bytes = a.dim * 2;
     const int S = a.q_stride;                      // LDS bytes per query row (== 32 mod 256)
     constexpr int NQ = NQT * 16;
+    constexpr int LCAP = narrow_lds_cap(NQT);
     // query group and row stream of this workgroup (groups == 1: every workgroup serves all queries and has its own stream)
     const int grp = a.groups == 2 ? (int)((blockIdx.x >> 3) & 1u) : 0;
     const int stream_id = a.groups == 2 ? (int)((blockIdx.x >> 4) * 8 + (blockIdx.x & 7u)) : (int)blockIdx.x;
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(NARROW_THREADS) void narrow_filter_kernel(const Nar
     const int nq_here = a.n_q - q_base < NQ ? a.n_q - q_base : NQ;      // >= 1: the planner pairs groups only above NARROW_MAX_Q queries
     char *s_q = smem;
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(smem + (size_t)NQ * S);
-    uint2 *s_list = reinterpret_cast<uint2 *>(smem + (size_t)NQ * S + NQ * 4);   // [NQ][NARROW_LDS_CAP]
+    uint2 *s_list = reinterpret_cast<uint2 *>(smem + (size_t)NQ * S + NQ * 4);   // [NQ][LCAP]
 
     // ---- query rows -> LDS (rows beyond n_q: zeros; their thresholds are NaN, nothing of theirs is ever recorded)
     const int chunks = row_bytes / 16;
@@ -183,8 +185,8 @@ __global__ __launch_bounds__(NARROW_THREADS) void narrow_filter_kernel(const Nar
                             if (v >= t && doc < a.n_rows) {
                                 const uint32_t pos = atomicAdd(&s_cnt[q], 1u);
                                 const uint2 rec = make_uint2(__float_as_uint(v), (uint32_t)doc);
-                                if (pos < (uint32_t)NARROW_LDS_CAP) {
-                                    s_list[q * NARROW_LDS_CAP + pos] = rec;
+                                if (pos < (uint32_t)LCAP) {
+                                    s_list[q * LCAP + pos] = rec;
                                 } else {   // the workgroup's staging list is full (a flooded list): straight to the candidate area
                                     const int sl = stream_id & 1;
                                     const uint32_t gp = atomicAdd(&a.cnt[(q_base + q) * 2 + sl], 1u);
@@ -204,21 +206,21 @@ __global__ __launch_bounds__(NARROW_THREADS) void narrow_filter_kernel(const Nar
     const int sl = stream_id & 1;
     for (int q = wv; q < NQ && q < nq_here; q += NARROW_WAVES) {
         uint32_t n = s_cnt[q];
-        if (n > (uint32_t)NARROW_LDS_CAP) n = NARROW_LDS_CAP;
+        if (n > (uint32_t)LCAP) n = LCAP;
         if (n == 0) continue;                               // wave-uniform
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(&a.cnt[(q_base + q) * 2 + sl], n);
         base = __shfl(base, 0);
         for (uint32_t i = lane; i < n; i += 64) {
             const uint32_t p = base + i;
-            if (p < (uint32_t)a.cap) a.cand[((int64_t)(q_base + q) * a.cap + p) * 2 + sl] = s_list[q * NARROW_LDS_CAP + i];
+            if (p < (uint32_t)a.cap) a.cand[((int64_t)(q_base + q) * a.cap + p) * 2 + sl] = s_list[q * LCAP + i];
         }
     }
 }
 
 size_t narrow_lds_bytes(int nqt, int dim) {
     const int S = narrow_query_stride(dim);
-    return (size_t)nqt * 16 * S + (size_t)nqt * 16 * 4 + (size_t)nqt * 16 * NARROW_LDS_CAP * 8;
+    return (size_t)nqt * 16 * S + (size_t)nqt * 16 * 4 + (size_t)nqt * 16 * narrow_lds_cap(nqt) * 8;
 }
 
 template <int NQT, int P>
@@ -251,12 +253,13 @@ static int launch_narrow_n(const NarrowArgs &a, int grid, bool nt, hipStream_t s
 }
 
 int launch_narrow_filter(const NarrowArgs &a, int nqt, int grid, bool nt, hipStream_t s) {
-    CCR_REQUIRE(a.dim % SUB_K == 0 && a.n_q >= 1 && (nqt == 1 || nqt == 2 || nqt == 4) && (a.groups == 1 || a.groups == 2) &&
+    CCR_REQUIRE(a.dim % SUB_K == 0 && a.n_q >= 1 && (nqt == 1 || nqt == 2 || nqt == 4 || nqt == 6) && (a.groups == 1 || a.groups == 2) &&
                     (a.groups == 1 ? a.n_q <= nqt * 16 : (nqt == 4 && a.n_q > NARROW_MAX_Q && a.n_q <= 2 * NARROW_MAX_Q && grid % 16 == 0)),
                 "narrow main pass: bad shape (internal)");
     CCR_REQUIRE(narrow_lds_bytes(nqt, a.dim) <= 160 * 1024, "narrow main pass: %zu bytes of LDS (internal)", narrow_lds_bytes(nqt, a.dim));
     if (nqt == 1) return launch_narrow_n<1>(a, grid, nt, s);
     if (nqt == 2) return launch_narrow_n<2>(a, grid, nt, s);
+    if (nqt == 6) return launch_narrow_n<6>(a, grid, nt, s);
     return launch_narrow_n<4>(a, grid, nt, s);
 }
 

@@ -186,14 +186,15 @@ def test_estimated_thresholds_are_verified_and_exact(case, monkeypatch):
 @pytest.mark.parametrize("n,nq,d,k", [(70_001, 1, 768, 100), (70_001, 16, 768, 100), (70_001, 17, 768, 10), (300_007, 33, 768, 1001),
                                       (300_007, 64, 768, 100), (40_000, 64, 1024, 300), (40_000, 5, 32, 7), (123_457, 40, 256, 64),
                                       (9_000, 64, 768, 1), (300_007, 65, 768, 100), (123_457, 128, 768, 1001), (70_001, 100, 256, 10),
-                                      (40_000, 128, 1024, 100), (3_000, 90, 768, 50)])
+                                      (40_000, 128, 1024, 100), (3_000, 90, 768, 50), (300_007, 80, 768, 100), (70_001, 96, 256, 1001)])
 def test_streaming_main_pass_of_small_batches(n, nq, d, k, monkeypatch):
     """n_q <= 64: the first main pass is the streaming kernel (csrc/ccr_narrow.hip: query rows resident in LDS, the corpus straight
     into the MFMA operand registers, no barrier; one range x two atomically filled sub-lists per query).  Same canonical bits as the
     tile kernels (CCR_NARROW=0) and as the exact dense path; rows that are no multiple of 16 (tail group), every query-tile count
     (16 / 32 / 64 rows resident), dim 32 ... 1024 (64 x 1 024-wide rows do not fit the LDS image: the planner keeps the tile kernels
     there), exact ties, and a norm-outlier row (per-tile margins).  65 .. 128 queries (r5): two groups of <= 64 on paired workgroups
-    that walk the same rows (65 = one query in the second group; a 3 000-row corpus: fewer 128-row blocks than workgroups)."""
+    that walk the same rows (a 3 000-row corpus: fewer 128-row blocks than workgroups) -- or, up to 96 queries where six query
+    tiles fit the LDS (dim <= 768), ONE group with a short staging list per query."""
     from ccrec_amd import ops
     g = torch.Generator().manual_seed(n + nq + d)
     D = torch.randn(n, d, generator=g) / d ** 0.5
