@@ -20,11 +20,11 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 dev = "cuda"
 
 
-def soak_streaming(c):
-    rs = np.random.RandomState(4000 + c)
+def soak_streaming(c, nq_lo=1, nq_hi=65):
+    rs = np.random.RandomState(4000 + c + 1000 * nq_lo)
     n = int(rs.randint(20_000, 1_500_000))
     d = int(rs.choice([64, 128, 256, 384, 768, 1024]))
-    nq = int(rs.randint(1, 65))
+    nq = int(rs.randint(nq_lo, nq_hi))
     k = int(rs.choice([1, 10, 100, 500, 1001, 2500]))
     k = min(k, n)
     ncl = int(rs.choice([1, 16, 512]))

@@ -7,7 +7,7 @@
       fp64 torch formulation on the same bf16-rounded operands: loss 2e-5, gradients 2e-4 (the tolerances of tests/test_gpu_inbatch.py),
       and bit-identical on a second run;
   (c) the streaming main pass of small batches (its thresholds now come from threshold_small_kernel) against the exact dense path
-      (tools/soak_round4.py's cases).
+      (tools/soak_round4.py's cases), and the same for batches of 65 .. 128 queries (six resident query tiles / two query groups).
   python tools/soak_round5.py [cases]"""
 import os
 import sys
@@ -114,11 +114,12 @@ def soak_inbatch(c):
     assert ok
 
 
-redone = narrow = 0
+redone = narrow = narrow_wide = 0
 for c in range(cases):
     redone += soak_bm25(c)
     soak_inbatch(c)
     narrow += int(r4.soak_streaming(c))
+    narrow_wide += int(r4.soak_streaming(c, 65, 129))        # six resident query tiles (<= 96 queries) / two query groups (<= 128)
 for v in ("CCR_BM25_TILE", "CCR_BM25_TABLE", "CCR_BM25_REDO_ROWS", "CCR_BM25_DENSE_SELECT"):
     os.environ.pop(v, None)
-print(f"all {cases} cases of each kind agree with their independent paths; BM25 rows through the redo path: {redone}; streaming kernel used in {narrow} of {cases}")
+print(f"all {cases} cases of each kind agree with their independent paths; BM25 rows through the redo path: {redone}; streaming kernel used in {narrow} of {cases} small and {narrow_wide} of {cases} 65 .. 128-query batches")
