@@ -64,12 +64,43 @@ def weighted_cuts(weights, world_size):
     return cuts
 
 
-def short_list_length(k, world, sigmas=6.0):
-    """Entries per query a rank sends in the short-list exchange: the share of a global top-k that one of `world` equal shards of
-    exchangeable rows holds is Binomial(k, 1/world); mean + 6 sigma + 8 is exceeded by some shard with probability < 1e-8 per query."""
+def agreed_cuts(n_rows, world_size, weights=None, group=None, device=None):
+    """The world + 1 shard boundaries EVERY rank uses: rank 0 computes them and broadcasts them as int64 (one tiny collective).
+    Computing them per rank is not enough once the blocks follow weights: a float cumsum + searchsorted over weights that differ by
+    one ulp between ranks (another BLAS / thread count behind the polyfit, another tokenizer build, a caller's own array) moves a
+    boundary on one rank only -- rank r's hi != rank r + 1's lo, rows silently dropped or encoded twice under wrong row offsets
+    (round-5 advisor, medium).  Every rank still VALIDATES what it received: monotone, [0 .. n_rows], world + 1 entries.
+    device: where the collective's tensor lives (a cuda device under RCCL; None = cpu for gloo)."""
+    if weights is None:
+        local = [shard_bounds(n_rows, world_size, r)[0] for r in range(world_size)] + [int(n_rows)]
+    else:
+        local = weighted_cuts(weights, world_size)
+    if world_size <= 1 or not (dist.is_available() and dist.is_initialized()):
+        return [int(c) for c in local]
+    if device is None and dist.get_backend(group) == "nccl":
+        device = torch.device("cuda", torch.cuda.current_device())
+    t = torch.tensor(local, dtype=torch.int64, device=device if device is not None else "cpu")
+    dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    cuts = [int(c) for c in t.cpu().tolist()]
+    assert len(cuts) == world_size + 1 and cuts[0] == 0 and cuts[-1] == int(n_rows) and all(a <= b for a, b in zip(cuts, cuts[1:])), \
+        f"shard cuts {cuts} do not tile [0, {n_rows})"
+    return cuts
+
+
+def largest_share(cuts):
+    """Largest fraction of the corpus rows one rank holds (1 / world for equal row counts)."""
+    n = int(cuts[-1])
+    return max(b - a for a, b in zip(cuts, cuts[1:])) / n if n > 0 else 1.0
+
+
+def short_list_length(k, world, sigmas=6.0, share=None):
+    """Entries per query a rank sends in the short-list exchange: the share of a global top-k that one of `world` shards of
+    exchangeable rows holds is Binomial(k, share); mean + 6 sigma + 8 is exceeded by some shard with probability < 1e-8 per query.
+    share: the LARGEST row share of a rank (largest_share(cuts); default 1 / world = equal row counts) -- token-balanced cuts give
+    unequal row counts (3.1x on a length-sorted corpus), and the rank with the most rows holds the most of a query's top-k."""
     if world <= 1:
         return int(k)
-    share = 1.0 / world
+    share = 1.0 / world if share is None else min(1.0, max(float(share), 1.0 / world))
     return int(min(k, math.ceil(k * share + sigmas * math.sqrt(k * share * (1.0 - share))) + 8))
 
 
@@ -77,20 +108,20 @@ SHORT_LIST_MAX_REPEAT_FRACTION = 0.05   # more queries than this repeated with f
 _SUSPENDED = {}                         # (k, world) -> the exchange statistics that suspended the short lists
 
 
-def short_lists_possible(k, world):
-    kl = short_list_length(k, world)
+def short_lists_possible(k, world, share=None):
+    kl = short_list_length(k, world, share=share)
     return world > 1 and kl < k and world * kl * 12 <= ops.SHORT_LIST_LDS_BYTES
 
 
-def short_lists_pay(k, world):
+def short_lists_pay(k, world, share=None):
     """Use the short-list exchange?  When it cuts the lists by at least a quarter, the R lists of a query fit the merge kernel's LDS, and
     it has not been SUSPENDED for this (k, world): the k / R + 6 sigma budget assumes exchangeable rows, and a corpus in topical order
     (adjacent passages of one document) concentrates a query's top-k in few shards -- every flagged query then costs a second search
     and a second collective.  An exchange that had to repeat more than SHORT_LIST_MAX_REPEAT_FRACTION of its queries suspends the
     shortcut (note_short_list_outcome: every rank sees the same gathered flags, so every rank switches at the same step).
     CCREC_SHORT_LISTS=0 / 1 switches it off / forces it where it is possible (the A/B knob)."""
-    kl = short_list_length(k, world)
-    possible = short_lists_possible(k, world)
+    kl = short_list_length(k, world, share=share)
+    possible = short_lists_possible(k, world, share)
     env = os.environ.get("CCREC_SHORT_LISTS", "").strip()
     if env in ("0", "1"):
         return possible and env == "1"
@@ -112,13 +143,14 @@ def resume_short_lists():
     _SUSPENDED.clear()
 
 
-def exchange_list_length(k, world, short_lists=None, blocked=False):
+def exchange_list_length(k, world, short_lists=None, blocked=False, share=None):
     """Entries per query and rank of an exchange for top-k -- from quantities that are IDENTICAL on every rank (k, world, the flags,
-    the module's suspension state), never from a rank's own shard size: ranks that disagreed would post collectives of different sizes."""
+    the module's suspension state, the largest row share of the AGREED cuts), never from a rank's own shard size: ranks that
+    disagreed would post collectives of different sizes."""
     if blocked or world <= 1:
         return int(k)
-    short = short_lists_pay(k, world) if short_lists is None else (bool(short_lists) and short_lists_possible(k, world))
-    return short_list_length(k, world) if short else int(k)
+    short = short_lists_pay(k, world, share) if short_lists is None else (bool(short_lists) and short_lists_possible(k, world, share))
+    return short_list_length(k, world, share=share) if short else int(k)
 
 
 class ShardMessage:
@@ -258,6 +290,8 @@ class ShardExchange:
                 outs = (torch.empty(m.n_q, self.k_out, dtype=torch.float32, device=dev), torch.empty(m.n_q, self.k_out, dtype=torch.int64, device=dev),
                         torch.zeros(max(1, m.n_q), dtype=torch.int32, device=dev)[:m.n_q], torch.zeros(1, dtype=torch.int32, device=dev))
                 side.wait_stream(torch.cuda.current_stream(dev))     # ... after the two zero fills
+                for t in outs:                                       # written by the side stream: an exchange dropped between submit() and
+                    t.record_stream(side)                            # result() must not hand these blocks back to the pool while the merge is pending
             with torch.cuda.stream(side):
                 self.work.wait()
                 m.headers_host.copy_(m.all_headers, non_blocking=True)
@@ -323,7 +357,7 @@ def _side_stream(device):
     return _SIDE[key]
 
 
-def submit_sharded_search(index, queries_bf16, k, group=None, message=None, merge_fn=None, short_lists=None):
+def submit_sharded_search(index, queries_bf16, k, group=None, message=None, merge_fn=None, short_lists=None, share=None):
     """Asynchronous per-shard search straight into a packed message + the all-gather behind it -> ShardExchange (call
     .result() for the merged lists).  short_lists: None = short_lists_pay(k, world) (and the shard holds k_list rows); a `message`
     built for k_list < k entries selects the short-list exchange by itself.  Needs min(k, k_list) <= index.n_rows (sharded_search
@@ -333,7 +367,7 @@ def submit_sharded_search(index, queries_bf16, k, group=None, message=None, merg
     if message is not None:
         k_list = message.k
     else:
-        k_list = exchange_list_length(k, world, short_lists)
+        k_list = exchange_list_length(k, world, short_lists, share=share)
         message = ShardMessage(n_q, k_list, queries_bf16.device, world)
     assert (message.n_q, message.world) == (n_q, world) and message.k <= k
     # (never re-size the lists from this rank's own shard: the ranks' collectives must agree -- tiny shards go through sharded_search)
@@ -343,12 +377,14 @@ def submit_sharded_search(index, queries_bf16, k, group=None, message=None, merg
 
 
 def sharded_search(index, queries_bf16, k, group=None, merge_fn=None, search_fn=None, message=None, block=None, n_total=None,
-                   short_lists=None, short_merge_fn=None):
+                   short_lists=None, short_merge_fn=None, share=None):
     """index: this rank's CorpusIndex (built with global_row_offset = its shard's first row).
     message: optional reusable ShardMessage(n_q, k or short_list_length(k, world), device, world) -- the search then writes straight into it.
     block: (ptr, idx) CSR of per-query blocked GLOBAL row ids (the same on every rank; each shard applies its own part).
     n_total: rows of the whole corpus; k is clamped to it (a corpus smaller than k cannot fill k ranks).
     short_lists: None = automatic (short_lists_pay), False = always full lists, True = short lists wherever k_list < k.
+    share: the largest row share of a rank under the cuts every rank agreed on (largest_share(agreed_cuts(...))): sizes the short lists
+    for unequal shards; None = equal row counts.
     search_fn / merge_fn / short_merge_fn: test hooks (CPU stand-ins for the per-shard search and the merges)."""
     if n_total is not None:
         k = min(k, int(n_total))
@@ -363,7 +399,7 @@ def sharded_search(index, queries_bf16, k, group=None, merge_fn=None, search_fn=
     if message is not None:
         k_list = message.k
     else:
-        k_list = exchange_list_length(k, world, short_lists, blocked=block is not None)
+        k_list = exchange_list_length(k, world, short_lists, blocked=block is not None, share=share)
     direct = block is None and search_fn is None and k_list <= index.n_rows and 0 < n_q <= ops.MAX_QUERIES_PER_SEARCH
     if direct:   # the kernel writes the exchange message itself, no host round trip (larger batches are searched in pieces below)
         if message is None:

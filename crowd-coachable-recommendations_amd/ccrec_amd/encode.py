@@ -361,9 +361,10 @@ class LengthSortedEncoder:
         return out
 
 
-def encode_local_shard(encoder, corpus_ids, corpus, sim, rank, world, norm_bounds=None, weights=None):
-    """This rank's contiguous block of the corpus (dist.shard_bounds; weights: equal-weight blocks) -> (bf16 shard [hi-lo, dim], lo, hi)."""
-    lo, hi = shard_bounds(len(corpus_ids), world, rank, weights)
+def encode_local_shard(encoder, corpus_ids, corpus, sim, rank, world, norm_bounds=None, weights=None, cuts=None):
+    """This rank's contiguous block of the corpus (dist.shard_bounds; weights: equal-weight blocks; cuts: the world + 1 boundaries every
+    rank agreed on -- dist.agreed_cuts -- take precedence) -> (bf16 shard [hi-lo, dim], lo, hi)."""
+    lo, hi = (int(cuts[rank]), int(cuts[rank + 1])) if cuts is not None else shard_bounds(len(corpus_ids), world, rank, weights)
     shard = encoder.encode([corpus[c] for c in corpus_ids[lo:hi]], sim=sim, norm_bounds=norm_bounds)
     return shard, lo, hi
 
@@ -413,13 +414,18 @@ def ranking_sharded(corpus, queries, encoder, block_dict=None, rank=0, world=1, 
     if world > 1 and not (isinstance(balance, str) and balance == "rows"):
         weights = (token_weights([corpus[c] for c in corpus_ids], encoder.max_length, tokenizer=encoder.tokenizer)
                    if isinstance(balance, str) else balance)
-    lo0, hi0 = shard_bounds(len(corpus_ids), world, rank, weights)
+    # ONE set of boundaries for all ranks: rank 0's, broadcast as int64 (weights that differ by an ulp between ranks would otherwise move
+    # a boundary on one rank only: rows dropped or encoded twice).  The short lists are sized from the largest row share of these cuts.
+    from .dist import agreed_cuts, largest_share, resume_short_lists
+    cuts = agreed_cuts(len(corpus_ids), world, weights, group=group, device=q_bf16.device if q_bf16.is_cuda else None)
+    lo0, hi0 = cuts[rank], cuts[rank + 1]
     bounds = torch.empty(max(hi0 - lo0, 1), dtype=torch.float32, device=q_bf16.device)   # norm bound of every packed row
-    shard, lo, hi = encode_local_shard(encoder, corpus_ids, corpus, sim, rank, world, norm_bounds=bounds, weights=weights)
+    shard, lo, hi = encode_local_shard(encoder, corpus_ids, corpus, sim, rank, world, norm_bounds=bounds, cuts=cuts)
     bounds = bounds if hi > lo else None
     if world == 1:
         return Retriever(corpus_ids, shard, norm_bounds=bounds).ranking_profile(queries_ids, q_bf16, block_dict, keep, with_tensors, lazy)
     index = ops.CorpusIndex(shard, global_row_offset=lo, norm_bounds=bounds)
+    resume_short_lists()     # a new corpus: a suspension earned on another corpus's row order does not carry over (same call on every rank)
     n = len(corpus_ids)
     block = None
     if block_dict is not None:   # every rank passes the whole lists; a shard applies the ids that fall inside it
@@ -432,7 +438,7 @@ def ranking_sharded(corpus, queries, encoder, block_dict=None, rank=0, world=1, 
             assert -1 not in rows, "block id not found"
             lists.append(rows)
         block = block_csr(lists, n)
-    scores, ids = sharded_search(index, q_bf16, min(n, keep), group=group, block=block, n_total=n)
+    scores, ids = sharded_search(index, q_bf16, min(n, keep), group=group, block=block, n_total=n, share=largest_share(cuts))
     from .ranking_profile import RankingProfile
     profile = RankingProfile(queries_ids, corpus_ids, ids, scores)
     if not lazy:

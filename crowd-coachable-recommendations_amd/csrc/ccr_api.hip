@@ -1172,6 +1172,19 @@ static int search_impl(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k, fl
         (void)hipFree(stamps);
     }
 
+#ifdef CCR_DIAGNOSTICS
+    if (ix->knobs.gemm_dbg != 0 && ix->knobs.gemm_dbg != 16) {
+        // timing-only ablation of the main pass: its candidates are meaningless, so nothing is selected or re-done -- the outputs are
+        // zeroed and the main pass's time by the library's own events goes to stderr (diagnostic library only)
+        CCR_HIP_CHECK(hipMemsetAsync(out_scores, 0, (size_t)n_q * k * 4, s));
+        CCR_HIP_CHECK(hipStreamSynchronize(s));
+        float ms = 0.f;
+        CCR_HIP_CHECK(hipEventElapsedTime(&ms, ix->ev[3], ix->ev[4]));
+        fprintf(stderr, "[ccr diag] CCR_GEMM_DBG=%d main pass %.4f ms (%d launches)\n", ix->knobs.gemm_dbg, ms, p.item_a ? 3 : 1);
+        ix->pending.active = false;
+        return CCR_OK;
+    }
+#endif
     rc = launch_select_rescore(cand, cnt, p.first_nsub, p.first_sp, n_q, p.nq_pad, p.first_lay, k, p.rescore_cap, p.select_compact, ix->n_rows, thr, delta,
                                ix->tile_norm, ix->row_norm, ix->dmax_bits, Q_bf16, ix->D, ix->dim,
                                ix->id_out, out_scores, out_ids, flag_count, flag_list, stat_cand, nullptr, s);

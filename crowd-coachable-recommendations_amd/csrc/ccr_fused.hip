@@ -56,6 +56,12 @@ __device__ __forceinline__ float load_uniform_f32(const float *p) {
 //        u-1 were retired (lgkmcnt(0)) before its barrier A_{u-1}, and for both groups that
 //        barrier instance precedes every mem(u).
 
+// s_waitcnt vmcnt(N) with a compile-time N
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 __device__ __forceinline__ unsigned long long stamp() {
     unsigned long long t;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
@@ -436,6 +442,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
     const int lq = lane >> 4;  // 0..3: K chunk of the operand fragments, row quad of the accumulator
     const bool g1 = (wv >= 4);
     const int KS2 = TAIL ? (a.dim + SUB_K - 1) / SUB_K : a.dim / SUB_K;
+    // DBG (diagnostic instantiations only, WRONG results): 4 no DMA at all, 8 no MFMA, 32 corpus-only DMA (the query region of the ring stays
+    // zero), 64 query-only DMA (the corpus region stays zero), 128 thresholds +inf (the complete kernel without a single hit: the baseline
+    // of the others, whose zero scores never pass); the counted waits follow the pieces a wave issues per sub-stage
+    constexpr bool DMA_D = !(DBG & 4) && !(DBG & 64);
+    constexpr bool DMA_Q = !(DBG & 4) && !(DBG & 32);
+    constexpr int PIECES = (DMA_D ? 2 : 0) + (DMA_Q ? 2 : 0);
+    if constexpr ((DBG & (4 | 32 | 64)) != 0) {
+        for (int i = tid; i < RING * SUB_BYTES / 16; i += GEMM_THREADS) reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+    }
 
     const int srow = wv * 16 + (lane >> 2);  // + piece*128
     const int schunk = (lane & 3) ^ (((srow >> 2) & 1) << 1);
@@ -479,6 +495,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
                 cqv[qt] = (q < a.n_q) ? a.cq[q] : 0.f;
                 clist[qt] = a.cand + seg_base + ((int64_t)(r - seg_r0) * a.nq_pad + q) * 8 * cap + (wd * 4 + lq);   // slot-major cell
             }
+            if constexpr ((DBG & 128) != 0) {   // everything runs, nothing passes the filter: the baseline of the ablations
+#pragma unroll
+                for (int qt = 0; qt < 4; ++qt) thr[qt] = INFINITY;
+            }
             asm volatile("" : "+v"(thr[0]), "+v"(thr[1]), "+v"(thr[2]), "+v"(thr[3]), "+v"(cqv[0]), "+v"(cqv[1]), "+v"(cqv[2]), "+v"(cqv[3]));
         }
         const uint16_t *qsrc[2];
@@ -517,10 +537,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
                 for (int i = 0; i < 2; ++i)
                     glds16(in ? (const void *)(qsrc[i] + k0) : (const void *)g_zero_chunk, buf + SUB_Q_REGION + (i * 512 + wv * 64) * 16);
             } else {
+                if constexpr (DMA_D) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) glds16(dsrc[i] + k0, buf + (i * 512 + wv * 64) * 16);
+                    for (int i = 0; i < 2; ++i) glds16(dsrc[i] + k0, buf + (i * 512 + wv * 64) * 16);
+                }
+                if constexpr (DMA_Q) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) glds16(qsrc[i] + k0, buf + SUB_Q_REGION + (i * 512 + wv * 64) * 16);
+                    for (int i = 0; i < 2; ++i) glds16(qsrc[i] + k0, buf + SUB_Q_REGION + (i * 512 + wv * 64) * 16);
+                }
             }
             ++iu;
             if (++iks == KS2) {
@@ -584,9 +608,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
         const int npro = U < 3 ? (int)U : 3;
         for (int i = 0; i < npro; ++i) issue();
         if (npro == 3)
-            CCR_WAIT_VM(8);
+            wait_vm<2 * PIECES>();
         else if (npro == 2)
-            CCR_WAIT_VM(4);
+            wait_vm<PIECES>();
         else
             CCR_WAIT_VM(0);
         CCR_BARRIER();
@@ -604,7 +628,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
             }
             if (u + 1 < U) {
                 if (u + 2 < U)
-                    CCR_WAIT_VM(4);
+                    wait_vm<PIECES>();
                 else
                     CCR_WAIT_VM(0);
             }
@@ -617,7 +641,24 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
             if (u + 3 < U) issue();
             CCR_WAIT_LGKM0();
             CCR_BARRIER();
-            if (cks == 0) {
+            if constexpr ((DBG & 8) != 0) {   // no matrix work: keep the operands alive, skip the MFMAs
+#pragma unroll
+                for (int dt = 0; dt < 8; ++dt) asm volatile("" ::"v"(af[dt]));
+#pragma unroll
+                for (int qt = 0; qt < 4; ++qt) asm volatile("" ::"v"(bfr[qt]));
+                if (cks == 0) {
+#pragma unroll
+                    for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+                        for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[dt][qt][e] = -1e30f;
+                }
+#pragma unroll
+                for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+                    for (int qt = 0; qt < 4; ++qt) asm volatile("" : "+v"(acc[dt][qt]));   // opaque: the filter trees stay
+            } else if (cks == 0) {
                 const f32x4v z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int dt = 0; dt < 8; ++dt)
@@ -1458,6 +1499,19 @@ static int launch_gemm(const GemmArgs &a, int grid, hipStream_t s) {
 
 int launch_gemm_filter(const GemmArgs &a, int grid, hipStream_t s) { return launch_gemm<EPI_FILTER>(a, grid, s); }
 int launch_gemm16_filter(const GemmArgs &a, int grid, hipStream_t s) {
+#ifdef CCR_DIAGNOSTICS
+    // timing-only ablations of the 16x16x32 main pass (CCR_GEMM_DBG; WRONG results): diagnostic library only (make DIAG=1)
+    switch (a.dbg) {
+        case 4: return launch_kernel(&gemm_topk16_kernel<EPI_FILTER, 4>, RING * (size_t)SUB_BYTES, a, grid, s);
+        case 8: return launch_kernel(&gemm_topk16_kernel<EPI_FILTER, 8>, RING * (size_t)SUB_BYTES, a, grid, s);
+        case 12: return launch_kernel(&gemm_topk16_kernel<EPI_FILTER, 12>, RING * (size_t)SUB_BYTES, a, grid, s);
+        case 32: return launch_kernel(&gemm_topk16_kernel<EPI_FILTER, 32>, RING * (size_t)SUB_BYTES, a, grid, s);
+        case 40: return launch_kernel(&gemm_topk16_kernel<EPI_FILTER, 40>, RING * (size_t)SUB_BYTES, a, grid, s);
+        case 64: return launch_kernel(&gemm_topk16_kernel<EPI_FILTER, 64>, RING * (size_t)SUB_BYTES, a, grid, s);
+        case 128: return launch_kernel(&gemm_topk16_kernel<EPI_FILTER, 128>, RING * (size_t)SUB_BYTES, a, grid, s);
+        default: break;   // 0 or unknown: the production kernel
+    }
+#endif
     if (a.dim % SUB_K != 0) return launch_kernel(&gemm_topk16_kernel<EPI_FILTER, 0, true>, RING * (size_t)SUB_BYTES, a, grid, s);
     return launch_kernel(&gemm_topk16_kernel<EPI_FILTER, 0>, RING * (size_t)SUB_BYTES, a, grid, s);
 }

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Timing-only ablations of the 16x16x32 main pass.  Runs ON THE GPU BOX against the DIAGNOSTIC library
+(tools/build_diag.sh -> crowd-coachable-recommendations_amd/lib_diag/libccr_hip.so; its CCR_GEMM_DBG modes return WRONG results and
+exist in no shipped build).  One process per variant (the knob is read at index creation; the library is loaded once per process),
+NQ shape, CCR_PROGRESSIVE=0 (ONE launch: comparable items) and the default three-launch plan.
+
+  python3 tools/exp_main_pass_ablation.py [outfile]        # driver
+  python3 tools/exp_main_pass_ablation.py --one            # one variant (environment set by the driver)
+"""
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "crowd-coachable-recommendations_amd")
+VARIANTS = [
+    (0, "production kernel (hits recorded)"),
+    (128, "complete kernel, thresholds +inf (no hit): BASELINE of the rows below"),
+    (4, "no DMA at all (ring zero-filled once)"),
+    (32, "corpus-only DMA (query region of the ring left zero; 2 pieces per wave and sub-stage)"),
+    (64, "query-only DMA (corpus region left zero; 2 pieces per wave and sub-stage)"),
+    (8, "DMA + LDS reads + barriers + filter trees, no MFMA"),
+    (40, "corpus-only DMA, no MFMA"),
+    (12, "LDS reads + barriers + filter trees only (no DMA, no MFMA)"),
+]
+
+
+def one():
+    sys.path[:0] = [ROOT, PKG]
+    import torch
+    from ccrec_amd import _lib
+    _lib.LIB_PATH = os.path.join(PKG, "lib_diag", "libccr_hip.so")
+    from ccrec_amd import ops
+    n, nq, d, k = int(os.environ.get("ABL_ROWS", 2681468)), int(os.environ.get("ABL_QUERIES", 3452)), 768, 100
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    D = torch.empty(n, d, dtype=torch.bfloat16, device="cuda")
+    for lo in range(0, n, 1 << 19):
+        hi = min(n, lo + (1 << 19))
+        D[lo:hi] = (torch.randn(hi - lo, d, generator=g, device="cuda") / d ** 0.5).to(torch.bfloat16)
+    Q = (torch.randn(nq, d, generator=g, device="cuda") / d ** 0.5).to(torch.bfloat16)
+    ix = ops.CorpusIndex(D)
+    dbg = int(os.environ.get("CCR_GEMM_DBG", "0"))
+    ms = []
+    for it in range(8):
+        ix.search(Q, k)
+        torch.cuda.synchronize()
+        if dbg == 0:
+            ms.append(ix.last_stats()["ms_main"])
+    if dbg == 0:
+        for m in ms:
+            print(f"[ccr diag] CCR_GEMM_DBG=0 main pass {m:.4f} ms", file=sys.stderr)
+
+
+def main():
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r06_main_pass_ablation.txt")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    lines = ["# tools/exp_main_pass_ablation.py: gemm_topk16_kernel<EPI_FILTER>, NQ 2,681,468 x 768 x 3,452 queries, top-100, one box, diagnostic library",
+             "# main-pass time by the library's own HIP events (ms), median of the last 5 of 8 searches per process"]
+    for plan, env_plan in (("single launch (CCR_PROGRESSIVE=0)", {"CCR_PROGRESSIVE": "0"}), ("default plan (three launches, thresholds re-tightened)", {})):
+        lines.append(f"## {plan}")
+        base = None
+        for dbg, what in VARIANTS:
+            env = dict(os.environ, CCR_GEMM_DBG=str(dbg), CCR_MFMA16="1", **env_plan)
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one"], env=env, capture_output=True, text=True, timeout=900)
+            vals = [float(m) for m in re.findall(r"main pass ([0-9.]+) ms", r.stderr)]
+            if r.returncode != 0 or len(vals) < 6:
+                lines.append(f"dbg={dbg:3d}  FAILED rc={r.returncode} {r.stderr[-300:]!r}")
+                continue
+            v = sorted(vals[-5:])[2]
+            if dbg == 128:
+                base = v
+            rel = f"  ({v / base:5.3f} of baseline)" if base and dbg not in (0, 128) else ""
+            lines.append(f"dbg={dbg:3d}  {v:8.3f} ms{rel}   {what}")
+            print(lines[-1], flush=True)
+    open(out, "w").write("\n".join(lines) + "\n")
+    print("wrote", out)
+
+
+if __name__ == "__main__":
+    one() if "--one" in sys.argv else main()
