@@ -24,6 +24,9 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+#ifndef CCR_QDIRECT_DEFAULT
+#define CCR_QDIRECT_DEFAULT 0   // 16x16x32 main pass: query fragments through the LDS ring (0) or straight from global memory (1 / 3 / 4 / 5)
+#endif
 // ------------------------------------------------------------------ planner
 // Query-block groups per XCD set: the smallest divisor of qblocks among {1,2,4,8} that keeps one XCD's
 // query rows (qblocks / groups blocks of 256 rows) within ~3 MiB of its 4-MiB L2.
@@ -41,6 +44,7 @@ Knobs read_knobs() {
     kn.sample_div = env_int("CCR_SAMPLE_DIV", 0);
     kn.gemm_dbg = env_int("CCR_GEMM_DBG", 0);
     kn.stagger = env_int("CCR_GEMM_STAGGER", 1);
+    kn.qdirect = env_int("CCR_QDIRECT", CCR_QDIRECT_DEFAULT);
     kn.max_lists = env_int("CCR_MAX_LISTS", 0);
     kn.ranges = env_int("CCR_RANGES", 0);
     kn.item_swap = env_int("CCR_ITEM_SWAP", 0);
@@ -688,6 +692,7 @@ static int margin_for_rows(const ccr_index *ix, const uint16_t *Qc, const float 
         g.store = scratch;
         g.store_pitch = pitch;
         g.stagger = 1;
+        g.qdirect = ix->knobs.qdirect;
         int rc = (ix->knobs.mfma16 >= 0 ? ix->knobs.mfma16 : CCR_MFMA16_DEFAULT) ? launch_gemm16_store(g, grid, s) : launch_gemm_store(g, grid, s);
         if (rc != CCR_OK) return rc;
         rc = launch_margin_select(scratch, pitch, ix->n_rows, k, ix->dim, g.Q, ix->D, ix->tile_norm, ix->row_norm, ix->dmax_bits,
@@ -892,6 +897,7 @@ static int search_complete(ccr_index *ix) {
                 g.qblocks = pad2 / TILE_Q;
                 g.qgroups = pick_qgroups(g.qblocks, ix->dim, ix->knobs);
                 g.stagger = ix->knobs.stagger;
+                g.qdirect = ix->knobs.qdirect;
                 g.n_vt = p.tiles;
                 g.tile_stride = 1;
                 g.ranges = p.ranges;
@@ -1082,8 +1088,10 @@ static int search_impl(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k, fl
     g.qgroups = p.qgroups;
 #ifdef CCR_DIAGNOSTICS
     g.dbg = ix->knobs.gemm_dbg;
+    g.dbg_pitch = env_int("CCR_DBG_PITCH", ix->dim);
 #endif
     g.stagger = ix->knobs.stagger;
+    g.qdirect = ix->knobs.qdirect;
 
     // sample pass -> group maxima -> thresholds
     GemmArgs gs = g;
@@ -1275,6 +1283,7 @@ extern "C" int ccr_scores(const ccr_index *ix, const uint16_t *Q_bf16, int n_q, 
     g.item_end = INT32_MAX;
     g.store = out;
     g.stagger = 1;
+    g.qdirect = ix->knobs.qdirect;
     const int grid = std::max(NUM_XCD, ix->num_cu / NUM_XCD * NUM_XCD);
     if (ix->knobs.mfma16 >= 0 ? ix->knobs.mfma16 : CCR_MFMA16_DEFAULT) return launch_gemm16_store(g, grid, (hipStream_t)stream);
     return launch_gemm_store(g, grid, (hipStream_t)stream);

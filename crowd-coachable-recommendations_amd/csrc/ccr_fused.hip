@@ -444,7 +444,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
     const int KS2 = TAIL ? (a.dim + SUB_K - 1) / SUB_K : a.dim / SUB_K;
     // DBG (diagnostic instantiations only, WRONG results): 4 no DMA at all, 8 no MFMA, 32 corpus-only DMA (the query region of the ring stays
     // zero), 64 query-only DMA (the corpus region stays zero), 128 thresholds +inf (the complete kernel without a single hit: the baseline
-    // of the others, whose zero scores never pass); the counted waits follow the pieces a wave issues per sub-stage
+    // of the others, whose zero scores never pass), 256 every DMA piece reads whole 128-byte lines (8 rows x 128 B; garbage operands: use 384 = 256 + 128);
+    // the counted waits follow the pieces a wave issues per sub-stage
     constexpr bool DMA_D = !(DBG & 4) && !(DBG & 64);
     constexpr bool DMA_Q = !(DBG & 4) && !(DBG & 32);
     constexpr int PIECES = (DMA_D ? 2 : 0) + (DMA_Q ? 2 : 0);
@@ -501,12 +502,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
             }
             asm volatile("" : "+v"(thr[0]), "+v"(thr[1]), "+v"(thr[2]), "+v"(thr[3]), "+v"(cqv[0]), "+v"(cqv[1]), "+v"(cqv[2]), "+v"(cqv[3]));
         }
-        const uint16_t *qsrc[2];
+        const uint16_t *qsrc[(DBG & 256) ? 4 : 2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int qrow = q0 + i * 128 + srow;
+        for (int i = 0; i < ((DBG & 256) ? 4 : 2); ++i) {
+            int qrow = q0 + ((DBG & 256) ? i * 64 + wv * 8 + (lane >> 3) : i * 128 + srow);
             if (qrow > a.n_q - 1) qrow = a.n_q - 1;
-            qsrc[i] = a.Q + (int64_t)qrow * a.dim + schunk * 8;
+            if constexpr ((DBG & 1024) != 0) {
+                const int last = (int)(((int64_t)a.n_q * a.dim - a.dim) / a.dbg_pitch);
+                if (qrow > last) qrow = last;
+                qsrc[i] = a.Q + (int64_t)qrow * a.dbg_pitch + schunk * 8;
+            } else
+            qsrc[i] = a.Q + (int64_t)qrow * a.dim + ((DBG & 256) ? (lane & 7) : schunk) * 8;
         }
 
         f32x4v acc[8][4];
@@ -514,14 +520,20 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
 
         int64_t iu = 0, it = 0;
         int iks = 0;
-        const uint16_t *dsrc[2];
+        const uint16_t *dsrc[(DBG & 256) ? 4 : 2];
         auto tile_ptrs = [&]() {
             const int64_t row0 = (r + it * a.ranges) * a.tile_stride * TILE_DOCS;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                int64_t drow = row0 + i * 128 + srow;
+            for (int i = 0; i < ((DBG & 256) ? 4 : 2); ++i) {
+                // DBG 256 (timing only): a piece reads 8 rows x 128 B (whole cache lines) instead of 16 rows x 64 B; the LDS image is garbage
+                int64_t drow = row0 + ((DBG & 256) ? i * 64 + wv * 8 + (lane >> 3) : i * 128 + srow);
                 if (drow > a.n_rows - 1) drow = a.n_rows - 1;
-                dsrc[i] = a.D + drow * a.dim + schunk * 8;
+                if constexpr ((DBG & 1024) != 0) {   // timing only: the traffic of rows at another PITCH (a.dbg_pitch elements), kept inside the array
+                    const int64_t last = (a.n_rows * a.dim - a.dim) / a.dbg_pitch;
+                    if (drow > last) drow = last;
+                    dsrc[i] = a.D + drow * a.dbg_pitch + schunk * 8;
+                } else
+                dsrc[i] = a.D + drow * a.dim + ((DBG & 256) ? (lane & 7) : schunk) * 8;
             }
         };
         tile_ptrs();
@@ -536,6 +548,33 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
                     glds16(in ? (const void *)(qsrc[i] + k0) : (const void *)g_zero_chunk, buf + SUB_Q_REGION + (i * 512 + wv * 64) * 16);
+            } else if constexpr ((DBG & 512) != 0) {
+                // DBG 512 (timing only): the traffic of a K-TILED layout -- the 16 KiB a sub-stage takes from the corpus tile (and from the
+                // query block) are ONE contiguous block, every piece one contiguous KiB: piece (iks * 16 + i * 8 + wv) of the tile's /
+                // block's 384 contiguous KiB in the row-major arrays.  Every byte is still requested exactly once; operands are garbage.
+                const int64_t row0 = (r + it * a.ranges) * a.tile_stride * TILE_DOCS;
+                const int64_t dtile = (int64_t)(a.n_rows - row0 < TILE_DOCS ? a.n_rows - row0 : TILE_DOCS) * a.dim * 2;   // bytes of this tile
+                const int64_t qblk = (int64_t)(a.n_q - q0 < TILE_Q ? a.n_q - q0 : TILE_Q) * a.dim * 2;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    int64_t o = (int64_t)(iks * 16 + i * 8 + wv) * 1024;
+                    if (o > dtile - 1024) o = dtile - 1024;
+                    glds16(reinterpret_cast<const char *>(a.D + row0 * a.dim) + o + lane * 16, buf + (i * 512 + wv * 64) * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    int64_t o = (int64_t)(iks * 16 + i * 8 + wv) * 1024;
+                    if (o > qblk - 1024) o = qblk - 1024;
+                    glds16(reinterpret_cast<const char *>(a.Q + (int64_t)q0 * a.dim) + o + lane * 16, buf + SUB_Q_REGION + (i * 512 + wv * 64) * 16);
+                }
+            } else if constexpr ((DBG & 256) != 0) {
+                // even sub-stage: rows 0 .. 127 of the tile, K [k0, k0 + 64); odd: rows 128 .. 255, the same K range: every byte of the tile
+                // is still requested exactly once, now as whole 128-byte lines
+                const int ofs = (iks & ~1) * SUB_K, hf = (iks & 1) * 2;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) glds16((hf ? dsrc[(i + 2) & 3] : dsrc[i]) + ofs, buf + (i * 512 + wv * 64) * 16);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) glds16((hf ? qsrc[(i + 2) & 3] : qsrc[i]) + ofs, buf + SUB_Q_REGION + (i * 512 + wv * 64) * 16);
             } else {
                 if constexpr (DMA_D) {
 #pragma unroll
@@ -689,6 +728,300 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
             }
             CCR_BARRIER();
         }
+        if (pending) epilogue(pending_vt, pending_nt);
+        if (!g1) CCR_BARRIER();
+
+        if (EPI == EPI_FILTER) {
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt)
+                a.cnt[((int64_t)r * a.nq_pad + q0 + wq * 64 + qt * 16 + l15) * 8 + wd * 4 + lq] = ncand[qt];
+        }
+        __syncthreads();
+    }
+}
+
+// =============================================================================================
+// QUERY-DIRECT form of the 16x16x32 main pass (round 6).  The ablation of the kernel above (profiles/r06_main_pass_ablation.txt:
+// full 11.35 ms, corpus-only DMA 8.0, no DMA 7.75) says that the LDS-DMA *issue* -- four 1-KiB pieces per wave and sub-stage, two of
+// them the query slice that is re-streamed for every corpus tile -- is what keeps the mem phase longer than the partner's MFMA phase.
+// Here the ring carries the CORPUS alone (two pieces per wave and sub-stage) and a lane fetches its four B-operand fragments -- 16 bytes
+// of query row (q0 + wq*64 + qt*16 + l15) at K chunk lq: exactly what v_mfma_f32_16x16x32_bf16 wants in SrcB -- straight from global
+// memory (the item's query block stays in the XCD's L2) one sub-stage ahead: no LDS round trip for the queries, no ds_read for them.
+//   QD = 1  fragments of u + 1 requested at the TAIL of the MFMA phase of u (behind the 32 MFMAs), ONE register set
+//   QD = 3  requested BETWEEN the MFMAs of u: query tile qt's eight MFMAs, then qt's next fragment, ONE register set
+//   QD = 4 / 5  the same two placements with TWO register sets: the fragments of u + 2 are requested during u
+// vmcnt order per wave, one set: ... DMA(u+2)[2] | Q(u)[4] | DMA(u+3)[2] | Q(u+1)[4] ...: `vmcnt(2)` before barrier A_u confirms Q(u) and, being
+// older, this wave's DMA of u + 1 AND u + 2 (a sub-stage of corpus has one period to land).  Two sets: ... Q(u)[4] | DMA(u+2)[2] Q(u+1)[4] DMA(u+3)[2]:
+// `vmcnt(8)` confirms Q(u) and the DMA of u + 1 -- the prefetch distance of the kernel above.
+// Same ring protocol, same ping-pong, same epilogues and candidate layout as gemm_topk16_kernel; dim % 32 == 0 only.
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+
+template <int EPI, int QD>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16q_kernel(const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wd = wv >> 2;
+    const int wq = wv & 3;
+    const int l15 = lane & 15;
+    const int lq = lane >> 4;
+    const bool g1 = (wv >= 4);
+    const int KS2 = a.dim / SUB_K;
+
+    const int srow = wv * 16 + (lane >> 2);  // + piece*128
+    const int schunk = (lane & 3) ^ (((srow >> 2) & 1) << 1);
+    const int cofs = ((lq ^ (((lane >> 2) & 1) << 1)) << 4);
+    const int a_base = (wd * 128 + l15) * 64 + cofs;                // + dt*1024
+
+    const int xcd = blockIdx.x & (NUM_XCD - 1);
+    const int jx = blockIdx.x >> 3;
+    const int per_x = gridDim.x >> 3;
+    const int qg = xcd % a.qgroups;
+    const int rc = xcd / a.qgroups;
+    const int nrc = NUM_XCD / a.qgroups;
+    const int qb_per = a.qblocks / a.qgroups;
+    const int count_x = (a.ranges / nrc) * qb_per;
+    const int item_end = a.item_end < count_x ? a.item_end : count_x;
+
+    for (int item = a.item_begin + jx; item < item_end; item += per_x) {
+        const int n_rl = a.ranges / nrc;
+        const int rl = a.item_swap ? item % n_rl : item / qb_per;
+        const int qb = qg * qb_per + (a.item_swap ? item / n_rl : item % qb_per);
+        const int r = rc + nrc * rl;
+        const int64_t ntile = (a.n_vt - r + a.ranges - 1) / a.ranges;
+        if (ntile <= 0) continue;
+        const int q0 = qb * TILE_Q;
+
+        float thr[4] = {0.f, 0.f, 0.f, 0.f}, cqv[4] = {0.f, 0.f, 0.f, 0.f};
+        uint32_t ncand[4] = {0u, 0u, 0u, 0u};
+        uint2 *clist[4] = {nullptr, nullptr, nullptr, nullptr};
+        int cap = 0;
+        if (EPI == EPI_FILTER) {
+            int seg_r0;
+            long long seg_base;
+            cand_segment(a.lay, r, cap, seg_r0, seg_base);
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt) {
+                const int q = q0 + wq * 64 + qt * 16 + l15;
+                thr[qt] = (q < a.n_q) ? a.thr[q] : __builtin_nanf("");
+                cqv[qt] = (q < a.n_q) ? a.cq[q] : 0.f;
+                clist[qt] = a.cand + seg_base + ((int64_t)(r - seg_r0) * a.nq_pad + q) * 8 * cap + (wd * 4 + lq);
+            }
+            asm volatile("" : "+v"(thr[0]), "+v"(thr[1]), "+v"(thr[2]), "+v"(thr[3]), "+v"(cqv[0]), "+v"(cqv[1]), "+v"(cqv[2]), "+v"(cqv[3]));
+        }
+        // this lane's four query rows (B fragments): byte offsets from a.Q, K chunk lq folded in (n_q * dim * 2 < 2^31: checked by the launcher)
+        uint32_t qoff[4];
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+            int q = q0 + wq * 64 + qt * 16 + l15;
+            if (q > a.n_q - 1) q = a.n_q - 1;
+            qoff[qt] = (uint32_t)q * (uint32_t)(a.dim * 2) + (uint32_t)(lq * 16);
+        }
+        // The fragment loads and their waits are inline asm on purpose: hipcc's own wait for a C++ load is `vmcnt(0)` in front of the
+        // first MFMA (it cannot bound the conditional DMA issue in between), which drains the ring every sub-stage.  The asm load
+        // updates its destination in place ("+v": one physical register set across the loop), the counted wait names the same
+        // registers, so nothing reads them in between.
+        const char *qbase = reinterpret_cast<const char *>(a.Q);
+        auto ldq = [&](u32x4v &dst, int qt, int ks) {   // ks: K sub-stage inside the tile (wave-uniform)
+            const char *sb = qbase + ks * (SUB_K * 2);
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dst) : "v"(qoff[qt]), "s"(sb));
+        };
+#define CCR_WAIT_VM_Q(n, b) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])::"memory")
+
+        f32x4v acc[8][4];
+        const int64_t U = ntile * KS2;
+
+        int64_t iu = 0, it = 0;
+        int iks = 0;
+        const uint16_t *dsrc[2];
+        auto tile_ptrs = [&]() {
+            const int64_t row0 = (r + it * a.ranges) * a.tile_stride * TILE_DOCS;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int64_t drow = row0 + i * 128 + srow;
+                if (drow > a.n_rows - 1) drow = a.n_rows - 1;
+                dsrc[i] = a.D + drow * a.dim + schunk * 8;
+            }
+        };
+        tile_ptrs();
+        auto issue = [&]() {   // the corpus slice of one sub-stage: two 1-KiB pieces per wave
+            char *buf = smem + (int)(iu & (RING - 1)) * SUB_BYTES;
+            const int k0 = iks * SUB_K;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) glds16(dsrc[i] + k0, buf + (i * 512 + wv * 64) * 16);
+            ++iu;
+            if (++iks == KS2) {
+                iks = 0;
+                ++it;
+                tile_ptrs();
+            }
+        };
+
+        auto epilogue = [&](int64_t vt, float nt) __attribute__((always_inline)) {
+            const int64_t row_base = vt * a.tile_stride * TILE_DOCS + wd * 128 + 4 * lq;  // + dt*16 + e
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt) {
+                if (EPI == EPI_FILTER) {
+                    float sub[8];
+#pragma unroll
+                    for (int dt = 0; dt < 8; ++dt)
+                        sub[dt] = fmaxf(fmaxf(acc[dt][qt][0], acc[dt][qt][1]), fmaxf(acc[dt][qt][2], acc[dt][qt][3]));
+                    const float t = fmaf(-cqv[qt], nt, thr[qt]);
+                    const float mall = fmaxf(fmaxf(fmaxf(sub[0], sub[1]), fmaxf(sub[2], sub[3])),
+                                             fmaxf(fmaxf(sub[4], sub[5]), fmaxf(sub[6], sub[7])));
+                    if (__ballot(mall >= t) != 0ull) {
+#pragma unroll
+                        for (int dt = 0; dt < 8; ++dt) {
+                            if (sub[dt] >= t) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const float v = acc[dt][qt][e];
+                                    const int64_t doc = row_base + dt * 16 + e;
+                                    if (v >= t && doc < a.n_rows) {
+                                        if (ncand[qt] < (uint32_t)cap)
+                                            clist[qt][ncand[qt] * 8] = make_uint2(__float_as_uint(v), (uint32_t)doc);
+                                        ++ncand[qt];
+                                    }
+                                }
+                            }
+                        }
+                    }
+                } else {  // EPI_STORE
+                    const int q = q0 + wq * 64 + qt * 16 + l15;
+                    const int64_t pitch = a.store_pitch ? a.store_pitch : a.n_rows;
+                    if (q < a.n_q) {
+                        float *dst = a.store + (int64_t)q * pitch;
+#pragma unroll
+                        for (int dt = 0; dt < 8; ++dt) {
+                            const int64_t doc = row_base + dt * 16;
+                            if ((pitch & 3) == 0 && doc + 3 < a.n_rows) {
+                                *reinterpret_cast<float4 *>(dst + doc) =
+                                    make_float4(acc[dt][qt][0], acc[dt][qt][1], acc[dt][qt][2], acc[dt][qt][3]);
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    if (doc + e < a.n_rows) dst[doc + e] = acc[dt][qt][e];
+                            }
+                        }
+                    }
+                }
+            }
+        };
+
+        // ---- prologue: the fragments of sub-stage 0 (and 1) first -- oldest in vmcnt -- then up to three sub-stages of corpus DMA
+        constexpr bool TWO = (QD >= 4);          // two register sets: fragments requested TWO sub-stages ahead
+        constexpr bool INTER = (QD == 3 || QD == 5);   // requested between the MFMAs (query tile by query tile) instead of behind them
+        u32x4v bq[4] = {}, bq2[4] = {};
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) ldq(bq[qt], qt, 0);
+        if constexpr (TWO) {
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt) ldq(bq2[qt], qt, KS2 > 1 ? 1 : 0);
+        }
+        // The DMA issue is UNCONDITIONAL (three sub-stages here, one per sub-stage in the loop -- the last three of an item fetch clamped
+        // rows into ring buffers nobody reads again): every counted wait below is then ONE straight-line statement.  A wait inside a branch
+        // makes hipcc merge the fragment registers of the two paths with copies, and it places such copies IN FRONT of the wait.
+        for (int i = 0; i < 3; ++i) issue();
+        if constexpr (TWO)
+            CCR_WAIT_VM_Q(2, bq);   // Q(0) Q(1) DMA(0) DMA(1) | DMA(2): sub-stage 1 has landed too, so that vmcnt(8) is enough at u = 0
+        else
+            CCR_WAIT_VM_Q(4, bq);   // Q(0) DMA(0) | DMA(1) DMA(2)
+        CCR_BARRIER();
+        if (g1) CCR_BARRIER();
+
+        int cks = 0;
+        int64_t ct = 0;
+        bool pending = false;
+        int64_t pending_vt = 0;
+        float pending_nt = 0.f;
+        // one sub-stage; cur = the fragments of u (requested one -- TWO: two -- sub-stages ago), nxt = where this sub-stage's requests go
+        // (ONE set: cur itself, for u + 1; TWO: cur as well -- it is free once the MFMAs of u are issued -- for u + 2, while the other
+        // set holds u + 1 in flight)
+        auto substage = [&](int64_t u, u32x4v (&cur)[4]) __attribute__((always_inline)) {
+            if (pending) {
+                epilogue(pending_vt, pending_nt);
+                pending = false;
+            }
+            int nks = cks + (TWO ? 2 : 1);   // K sub-stage (inside its tile) of the fragments requested during u
+            if (nks >= KS2) nks -= KS2;
+            if (nks >= KS2) nks = 0;        // (KS2 == 1)
+            const char *buf = smem + (int)(u & (RING - 1)) * SUB_BYTES;
+            bf16x8 af[8];
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) af[dt] = *reinterpret_cast<const bf16x8 *>(buf + a_base + dt * 1024);
+            issue();   // sub-stage u + 3 (past the item's end: see the prologue)
+            // confirm, before this wave's barrier A_u: the fragments of u and -- older in vmcnt -- this wave's corpus DMA of u + 1
+            if constexpr (TWO)
+                CCR_WAIT_VM_Q(8, cur);   // ... Q(u) | DMA(u+2)[2] Q(u+1)[4] DMA(u+3)[2]
+            else
+                CCR_WAIT_VM_Q(2, cur);   // ... DMA(u+2)[2] Q(u) | DMA(u+3)[2]
+            CCR_WAIT_LGKM0();
+            CCR_BARRIER();
+            if constexpr (INTER) {   // query tile by query tile; a tile's next fragment is requested as soon as its MFMAs are issued
+#pragma unroll
+                for (int qt = 0; qt < 4; ++qt) {
+                    if (cks == 0) {
+                        const f32x4v z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int dt = 0; dt < 8; ++dt) acc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[dt], __builtin_bit_cast(bf16x8, cur[qt]), z, 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int dt = 0; dt < 8; ++dt) acc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[dt], __builtin_bit_cast(bf16x8, cur[qt]), acc[dt][qt], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    ldq(cur[qt], qt, nks);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                if (cks == 0) {
+                    const f32x4v z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+                        for (int qt = 0; qt < 4; ++qt)
+                            acc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[dt], __builtin_bit_cast(bf16x8, cur[qt]), z, 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+                        for (int qt = 0; qt < 4; ++qt)
+                            acc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[dt], __builtin_bit_cast(bf16x8, cur[qt]), acc[dt][qt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int qt = 0; qt < 4; ++qt) ldq(cur[qt], qt, nks);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (++cks == KS2) {
+                cks = 0;
+                const int64_t vt_done = r + ct * a.ranges;
+                const float nt_done = EPI == EPI_FILTER ? load_uniform_f32(a.tile_norm + vt_done * a.tile_stride) : 0.f;
+                if (g1) {
+                    epilogue(vt_done, nt_done);
+                } else {
+                    pending = true;
+                    pending_vt = vt_done;
+                    pending_nt = nt_done;
+                }
+                ++ct;
+            }
+            CCR_BARRIER();
+        };
+        if constexpr (TWO) {
+            int64_t u = 0;
+            for (; u + 1 < U; u += 2) {
+                substage(u, bq);
+                substage(u + 1, bq2);
+            }
+            if (u < U) substage(u, bq);
+        } else {
+            for (int64_t u = 0; u < U; ++u) substage(u, bq);
+        }
+        // The DMA and the fragments requested past the item's end land here, unused.  The wait NAMES the fragment registers: they stay
+        // allocated until nothing is in flight into them (hipcc would otherwise hand them to the epilogue below as temporaries).
+        if constexpr (TWO) CCR_WAIT_VM_Q(0, bq2);
+        CCR_WAIT_VM_Q(0, bq);
         if (pending) epilogue(pending_vt, pending_nt);
         if (!g1) CCR_BARRIER();
 
@@ -1498,6 +1831,21 @@ static int launch_gemm(const GemmArgs &a, int grid, hipStream_t s) {
 }
 
 int launch_gemm_filter(const GemmArgs &a, int grid, hipStream_t s) { return launch_gemm<EPI_FILTER>(a, grid, s); }
+// query-direct forms (a.qdirect = 1 / 3 / 4 / 5: gemm_topk16q_kernel); dim % 32 == 0 and a query block of less than 2^31 bytes
+template <int EPI>
+static int launch_gemm16q(const GemmArgs &a, int grid, hipStream_t s) {
+    const size_t lds = RING * (size_t)SUB_BYTES;
+    switch (a.qdirect) {
+        case 1: return launch_kernel(&gemm_topk16q_kernel<EPI, 1>, lds, a, grid, s);
+        case 3: return launch_kernel(&gemm_topk16q_kernel<EPI, 3>, lds, a, grid, s);
+        case 4: return launch_kernel(&gemm_topk16q_kernel<EPI, 4>, lds, a, grid, s);
+        default: return launch_kernel(&gemm_topk16q_kernel<EPI, 5>, lds, a, grid, s);
+    }
+}
+static bool qdirect_ok(const GemmArgs &a) {
+    return a.qdirect > 0 && a.dim % SUB_K == 0 && (int64_t)a.n_q * a.dim * 2 < (int64_t)1 << 31;
+}
+
 int launch_gemm16_filter(const GemmArgs &a, int grid, hipStream_t s) {
 #ifdef CCR_DIAGNOSTICS
     // timing-only ablations of the 16x16x32 main pass (CCR_GEMM_DBG; WRONG results): diagnostic library only (make DIAG=1)
@@ -1509,13 +1857,18 @@ int launch_gemm16_filter(const GemmArgs &a, int grid, hipStream_t s) {
         case 40: return launch_kernel(&gemm_topk16_kernel<EPI_FILTER, 40>, RING * (size_t)SUB_BYTES, a, grid, s);
         case 64: return launch_kernel(&gemm_topk16_kernel<EPI_FILTER, 64>, RING * (size_t)SUB_BYTES, a, grid, s);
         case 128: return launch_kernel(&gemm_topk16_kernel<EPI_FILTER, 128>, RING * (size_t)SUB_BYTES, a, grid, s);
+        case 384: return launch_kernel(&gemm_topk16_kernel<EPI_FILTER, 384>, RING * (size_t)SUB_BYTES, a, grid, s);
+        case 640: return launch_kernel(&gemm_topk16_kernel<EPI_FILTER, 640>, RING * (size_t)SUB_BYTES, a, grid, s);
+        case 1152: return launch_kernel(&gemm_topk16_kernel<EPI_FILTER, 1152>, RING * (size_t)SUB_BYTES, a, grid, s);
         default: break;   // 0 or unknown: the production kernel
     }
 #endif
+    if (qdirect_ok(a)) return launch_gemm16q<EPI_FILTER>(a, grid, s);
     if (a.dim % SUB_K != 0) return launch_kernel(&gemm_topk16_kernel<EPI_FILTER, 0, true>, RING * (size_t)SUB_BYTES, a, grid, s);
     return launch_kernel(&gemm_topk16_kernel<EPI_FILTER, 0>, RING * (size_t)SUB_BYTES, a, grid, s);
 }
 int launch_gemm16_store(const GemmArgs &a, int grid, hipStream_t s) {
+    if (qdirect_ok(a)) return launch_gemm16q<EPI_STORE>(a, grid, s);
     if (a.dim % SUB_K != 0) return launch_kernel(&gemm_topk16_kernel<EPI_STORE, 0, true>, RING * (size_t)SUB_BYTES, a, grid, s);
     return launch_kernel(&gemm_topk16_kernel<EPI_STORE, 0>, RING * (size_t)SUB_BYTES, a, grid, s);
 }

@@ -14,6 +14,7 @@ struct Knobs {
     int sample_div;    // CCR_SAMPLE_DIV   0 = planner's choice, else the pinned sample fraction 1/div
     int gemm_dbg;      // CCR_GEMM_DBG     timing-only ablations of the main pass (WRONG results when non-zero)
     int stagger;       // CCR_GEMM_STAGGER 0 = both wave groups of the 32x32x16 kernel in phase
+    int qdirect;       // CCR_QDIRECT      16x16x32 main pass: 0 = queries through the LDS ring, 1 / 3 / 4 / 5 = query fragments straight from global memory
     int ranges;        // CCR_RANGES       0 = planner's choice, else the pinned range count (rounded to a multiple of 8)
     int item_swap;     // CCR_ITEM_SWAP    1 = co-resident workgroups share the query block instead of the corpus range (honoured with CCR_PROGRESSIVE=0)
     int optimistic;    // CCR_OPTIMISTIC   -1 = planner's choice, 0 = conservative thresholds only, 1 = estimated thresholds wherever the sample allows

@@ -119,3 +119,60 @@ def run_child_with_evidence(cmd, env, tmp_path, tag, limit=240):
     return stdout, stderr
 
 
+
+
+# ---------------------------------------------------------------------------------------------- goldens g18 / g19 (shared with tools/make_golden.py)
+class GoldenTokenizer:
+    """Deterministic whitespace tokenizer with the HF call shapes the reference uses (padding=True | "max_length" | False, truncation,
+    max_length, return_tensors="pt"): id = 4 + crc32(word) % (vocab - 4); [CLS] = 1, [SEP] = 2, [PAD] = 0.  (No Python hash(): the golden
+    generator and the tests must tokenise alike in every process.)"""
+    pad_token_id = 0
+
+    def __init__(self, vocab=64):
+        self.vocab = int(vocab)
+
+    def __call__(self, texts, truncation=True, padding=True, max_length=32, return_tensors="pt", **kw):
+        import zlib
+        import torch
+        ids = [[1] + [4 + zlib.crc32(w.encode()) % (self.vocab - 4) for w in t.split()][: max_length - 2] + [2] for t in texts]
+        if padding is False:
+            return {"input_ids": ids, "attention_mask": [[1] * len(r) for r in ids]}
+        L = max_length if padding == "max_length" else max(len(r) for r in ids)
+        out = torch.zeros(len(ids), L, dtype=torch.int64)
+        mask = torch.zeros(len(ids), L, dtype=torch.int64)
+        for r, row in enumerate(ids):
+            out[r, :len(row)] = torch.tensor(row)
+            mask[r, :len(row)] = 1
+        return {"input_ids": out, "attention_mask": mask}
+
+
+def numpy_seeded_bert(cfg, seed):
+    """A transformers BertModel whose every parameter is drawn from numpy's RandomState(seed) in named_parameters() order (the same
+    bits on every host and torch build -- torch's own CPU normal sampler depends on the vector width): weights N(0, 0.05) with the
+    query / key projections x 6 (softmaxes that are not uniform), LayerNorm weights U(0.6, 1.4), biases N(0, 0.05); every value
+    rounded to a bf16-exact fp32.  eval() mode."""
+    import torch
+    from transformers import BertConfig, BertModel
+    model = BertModel(BertConfig(**cfg)).eval()
+    rs = np.random.RandomState(seed)
+    with torch.no_grad():
+        for name, prm in model.named_parameters():
+            shape = tuple(prm.shape)
+            if "LayerNorm.weight" in name:
+                v = rs.uniform(0.6, 1.4, shape)
+            else:
+                v = rs.standard_normal(shape) * 0.05
+                if "attention.self.query.weight" in name or "attention.self.key.weight" in name:
+                    v = v * 6.0
+            prm.copy_(torch.from_numpy(v.astype(np.float32)).to(torch.bfloat16).float())
+    return model
+
+
+G18_CFG = dict(vocab_size=64, hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128, max_position_embeddings=40)
+G19_CFG = dict(vocab_size=64, hidden_size=768, num_hidden_layers=1, num_attention_heads=12, intermediate_size=128, max_position_embeddings=24)
+
+
+def golden_texts(n, seed, longest=20, words=150):
+    rs = np.random.RandomState(seed)
+    vocab = [f"w{i}" for i in range(words)]
+    return [" ".join(rs.choice(vocab, rs.randint(1, longest + 1))) for _ in range(n)]

@@ -230,16 +230,17 @@ def _worker(rank, world, port, n, nq, k, out_dir):
         return torch.from_numpy(s), torch.from_numpy(i)
 
     if n >= k:
-        s, i = sharded_search(Shard(), None, k, merge_fn=merge_fn, search_fn=search_fn)
+        # (short_lists=False: the FULL-list protocol -- at world 8 the automatic choice would be short lists, which have their own test)
+        s, i = sharded_search(Shard(), None, k, merge_fn=merge_fn, search_fn=search_fn, short_lists=False)
         ref_i, ref_s = orc.canonical_search(Qb, Db, k)
         ok = np.array_equal(i.numpy(), ref_i) and np.array_equal(s.numpy(), ref_s)
     else:
         # the whole corpus holds fewer than k rows: n_total clamps k; without it the tail is (-inf, distinct pad ids) --
         # every output slot written, never uninitialised memory
         ref_i, ref_s = orc.canonical_search(Qb, Db, n)
-        s, i = sharded_search(Shard(), None, k, merge_fn=merge_fn, search_fn=search_fn, n_total=n)
+        s, i = sharded_search(Shard(), None, k, merge_fn=merge_fn, search_fn=search_fn, n_total=n, short_lists=False)
         ok = tuple(i.shape) == (nq, n) and np.array_equal(i.numpy(), ref_i) and np.array_equal(s.numpy(), ref_s)
-        s, i = sharded_search(Shard(), None, k, merge_fn=merge_fn, search_fn=search_fn)
+        s, i = sharded_search(Shard(), None, k, merge_fn=merge_fn, search_fn=search_fn, short_lists=False)
         ok = ok and tuple(i.shape) == (nq, k) and np.array_equal(i.numpy()[:, :n], ref_i) and np.array_equal(s.numpy()[:, :n], ref_s)
         tail_i, tail_s = i.numpy()[:, n:], s.numpy()[:, n:]
         ok = ok and bool(np.isneginf(tail_s).all()) and bool((tail_i > 2 ** 62).all())
@@ -255,6 +256,15 @@ def test_sharded_search_gloo_world2(tmp_path, n, k):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, n, 6, k, str(tmp_path)), nprocs=2, join=True)
     for r in range(2):
+        assert open(tmp_path / f"rank{r}.txt").read() == "ok"
+
+
+@pytest.mark.parametrize("n,k", [(1600, 100), (30, 8)])   # world 8: the target world size; 30 rows: shards of 3-4 rows < k
+def test_sharded_search_gloo_world8(tmp_path, n, k):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(8, port, n, 6, k, str(tmp_path)), nprocs=8, join=True)
+    for r in range(8):
         assert open(tmp_path / f"rank{r}.txt").read() == "ok"
 
 
@@ -340,6 +350,20 @@ def test_short_list_exchange_gloo(tmp_path, world, skew):
     port = _free_port()
     mp.spawn(_short_worker, args=(world, port, 2400, 7, 300, skew, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
+        assert open(tmp_path / f"rank{r}.txt").read() == "ok"
+
+
+@pytest.mark.parametrize("k,n,skew", [(1001, 16800, False), (1001, 16800, True), (100, 2400, False), (100, 2400, True)])
+def test_short_list_exchange_gloo_world8(tmp_path, k, n, skew):
+    """The same exchange at the TARGET world size, eight ranks over gloo: ranking()'s k = 1001 -> k_list = 196 entries per rank and query,
+    k = 100 -> 41; eight headers parsed on every rank; with two queries whose whole top-k sits in the last shard exactly those two
+    are repeated with full lists (a matched second collective on eight ranks) and the shortcut is suspended afterwards."""
+    import torch.multiprocessing as mp
+    from ccrec_amd.dist import short_list_length
+    assert short_list_length(k, 8) == (196 if k == 1001 else 41)
+    port = _free_port()
+    mp.spawn(_short_worker, args=(8, port, n, 7, k, skew, str(tmp_path)), nprocs=8, join=True)
+    for r in range(8):
         assert open(tmp_path / f"rank{r}.txt").read() == "ok"
 
 
@@ -468,13 +492,126 @@ def _flag_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_exchange_repeats_on_every_rank_when_one_rank_flags(tmp_path, world):
     import torch.multiprocessing as mp
     port = _free_port()
     mp.spawn(_flag_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert open(tmp_path / f"rank{r}.txt").read() == "ok"
+
+def _cuts_worker(rank, world, port, out_dir):
+    """Every rank computes its OWN cuts from weights that differ by one part in 1e9 on rank 1 (another BLAS behind the polyfit, a
+    caller's array): the local cuts disagree, agreed_cuts() hands every rank rank 0's."""
+    import json
+    import torch.distributed as dist
+    sys.path[:0] = [ROOT, PKG]
+    from ccrec_amd.dist import agreed_cuts, largest_share, weighted_cuts
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    w = np.ones(10)
+    if rank == 1:
+        w[0] += 1e-9                    # cum[4] now exceeds half the total: the local boundary moves from 5 to 4
+    local = weighted_cuts(w, world)
+    cuts = agreed_cuts(10, world, w)
+    rows = agreed_cuts(11, world)       # no weights: equal row counts, still one answer for all
+    json.dump({"local": local, "agreed": cuts, "rows": rows, "share": largest_share(cuts)}, open(os.path.join(out_dir, f"rank{rank}.json"), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_cuts_are_agreed_on_not_computed_per_rank(tmp_path):
+    """Round-5 advisor (medium): token-balanced cuts come from a float cumsum + searchsorted over weights every rank computes for
+    itself; a one-ulp difference moves a boundary on one rank only (rows dropped or encoded twice under wrong row offsets).
+    agreed_cuts(): rank 0's boundaries, broadcast as int64, validated on every rank."""
+    import json
+    import torch.multiprocessing as mp
+    mp.spawn(_cuts_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (json.load(open(tmp_path / f"rank{r}.json")) for r in range(2))
+    assert r0["local"] == [0, 5, 10] and r1["local"] == [0, 4, 10]          # the hazard is real: the ranks' own cuts differ
+    assert r0["agreed"] == r1["agreed"] == [0, 5, 10] and r0["rows"] == r1["rows"] == [0, 6, 11]
+    assert r0["share"] == 0.5
+    # unequal shards size the short lists from the largest row share (advisor, low): 8 ranks, one holding 30 % of the rows
+    from ccrec_amd import dist as cdist
+    assert cdist.short_list_length(1001, 8) == 196 and cdist.short_list_length(1001, 8, share=0.30) == 396
+    assert cdist.short_list_length(1001, 8, share=0.01) == 196              # never below the equal-shard budget
+    assert cdist.exchange_list_length(1001, 8, share=0.30) == 396 and cdist.exchange_list_length(1001, 8, share=0.9) == 1001
+    assert cdist.largest_share([0, 3, 4, 10]) == 0.6
+
+
+def _bench_worker(rank, world, port, data, out_dir):
+    """bench.Workload -- the pipelined step loop, set_k, the exchange record -- on eight gloo ranks with the oracle-backed stand-ins
+    of tests/cpu_stand_ins.py in place of the device ops (no GPU here; the product has no CPU path: this rehearses CONTROL FLOW)."""
+    import json
+    import torch.distributed as dist
+    sys.path[:0] = [ROOT, PKG, os.path.join(ROOT, "tests")]
+    import cpu_stand_ins
+    index_cls = cpu_stand_ins.install()
+    import bench
+    from ccrec_amd import dist as cdist
+    from oracle import oracle as orc
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    rows, queries, dim = 8 * 1100, 24, 64
+    if data == "skewed":
+        # three of the 24 queries find 300 strongly aligned rows inside the LAST shard (a corpus in topical order): that shard's short
+        # list is consumed to its end for them (k_list 41 / 196), 3 / 24 > 5 % of the queries -> the shortcut is suspended
+        iid = bench.gen_rows
+
+        def gen_rows(n, d, seed, device, data_="gaussian", chunk=262144, lo=0, hi=None):
+            x = iid(n, d, seed, device, "gaussian")
+            if seed == 1234:
+                q = iid(queries, d, 4321, device, "gaussian")
+                for j, qi in enumerate((0, 7, 13)):
+                    blk = slice(n - 1000 + 300 * j, n - 1000 + 300 * (j + 1))
+                    x[blk] = 3.0 * q[qi] + 0.2 * x[blk]
+            return x[lo:n if hi is None else hi].clone()
+        bench.gen_rows = gen_rows
+        data = "gaussian"
+        skewed = True
+    else:
+        skewed = False
+    full = orc.pack_bf16(bench.gen_rows(rows, dim, 1234, "cpu", data).numpy())
+    qb = orc.pack_bf16(bench.gen_rows(queries, dim, 4321, "cpu", data).numpy())
+    rec = {}
+    w = bench.Workload(rows, queries, dim, 100, data, "cpu", rank, world, "gloo")
+    for k in (100, 1001):
+        if k != w.k:
+            w.set_k(k)
+        k_list0 = w.k_list
+        r = w.run(3, 1, f"k{k}")
+        ref_i, ref_s = orc.canonical_search(qb, full, k)
+        ex = bench.exchange_obj(w, r)
+        rec[str(k)] = {"ids_equal": bool(np.array_equal(w.ids.numpy(), ref_i)),
+                       "scores_equal": bool(np.array_equal(w.scores.numpy().view(np.uint32), ref_s.view(np.uint32))),
+                       "k_list_first": k_list0, "k_list_last": w.k_list, "entries": ex["entries_per_query_per_rank"], "n_ranks_seen": ex["n_ranks_seen"],
+                       "repeated_queries": ex["queries_repeated_with_full_lists"], "suspended_at": ex["short_lists_suspended_at_step"],
+                       "message_bytes": ex["message_bytes_per_rank"], "searches": list(index_cls.calls)}
+        index_cls.calls.clear()
+    json.dump(rec, open(os.path.join(out_dir, f"rank{rank}.json"), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("data", ["gaussian", "skewed"])
+def test_bench_step_loop_rehearsal_world8_gloo(tmp_path, data):
+    """`bench.py --gpus 8`'s step loop at world 8: eight gloo processes, a CPU-sized corpus (8,800 x 64, 24 queries),
+    top-100 (k_list 41) and top-1001 (k_list 196).  Every rank ends with the single-index oracle lists; iid rows never repeat a
+    query; a corpus in topical order (--data sorted) repeats queries with full lists and every rank suspends the shortcut at the
+    same step (the k_list of the last step is then k itself; "skewed": three queries with 300 aligned rows inside the last shard)."""
+    import json
+    import torch.multiprocessing as mp
+    mp.spawn(_bench_worker, args=(8, _free_port(), data, str(tmp_path)), nprocs=8, join=True)
+    recs = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(8)]
+    for k, kl in (("100", 41), ("1001", 196)):
+        for r in recs:
+            assert r[k]["ids_equal"] and r[k]["scores_equal"] and r[k]["n_ranks_seen"] == 8 and r[k]["k_list_first"] == kl
+        assert len({(r[k]["k_list_last"], r[k]["suspended_at"], r[k]["repeated_queries"]) for r in recs}) == 1   # every rank took the same branches
+        if data == "gaussian":
+            assert recs[0][k]["repeated_queries"] == 0 and recs[0][k]["suspended_at"] is None and recs[0][k]["k_list_last"] == kl
+            assert all(c == [24, kl] for c in recs[0][k]["searches"])
+        if data == "skewed":   # the warm-up step repeats the three skewed queries with full lists; every rank then switches to full lists
+            assert recs[0][k]["suspended_at"] is not None and recs[0][k]["k_list_last"] == int(k)
+            assert [24, kl] in recs[0][k]["searches"] or recs[0][k]["searches"][-1] == [24, int(k)]
+
 
 def test_committed_bench_line_has_the_contract_fields():
     """The NEWEST default bench line committed under profiles/ (a real MI355X run of `python bench.py`: profiles/rNN_bench<i>.json)

@@ -131,3 +131,54 @@ def test_generate_ranking_profile_length_sorted_route_gives_the_same_ranking():
     finally:
         del os.environ["CCREC_LENGTH_SORTED"]
     assert all(list(c[q]) == list(b[q]) for q in queries)
+
+
+@pytest.mark.parametrize("tag,sim", [("dot", "dot"), ("cos_block", "cos")])
+def test_generate_ranking_profile_against_the_references_own_function_golden_g18(golden_dir, monkeypatch, tag, sim):
+    """Golden g18: the reference's generate_ranking_profile (scripts/al_oracle_agent.py:83-129), run by tools/make_golden.py on a local
+    numpy-seeded encoder.  The product's function on the same texts, tokenizer and weights:
+      * feeds the search the embeddings the reference's embedding_func produced (queries first, then the corpus in dict order; fp32
+        noise of another BLAS only: 2e-5 of the largest value);
+      * returns, bit for bit, the oracle's canonical ranking of ITS embeddings (ids and score bits);
+      * and that profile is the reference's: scores within the bf16 rounding of the rows (2^-7 ||q|| ||d||), ids equal at every rank
+        the reference separates by more than twice that, blocked passages last at -1e6 (cos + block_dict case)."""
+    from helpers import G18_CFG, GoldenTokenizer, assert_rank_close, canonicalise, numpy_seeded_bert
+    from ccrec_amd.al_rank import generate_ranking_profile
+    from ccrec_amd.item_tower import NaiveItemTower
+    g = np.load(os.path.join(golden_dir, "g18_ranking_profile_fn.npz"))
+    monkeypatch.setenv("CCREC_SIM_TYPE", sim)
+    monkeypatch.setenv("CCREC_EMBEDDING_TYPE", "mean_pooling")
+    monkeypatch.setenv("CCREC_MAX_LENGTH", str(int(g["max_length"])))
+    corpus = {f"p{j}": str(t) for j, t in enumerate(g["corpus_texts"])}
+    queries = {f"q{i}": str(t) for i, t in enumerate(g["query_texts"])}
+    block = {q: [f"p{int(j)}" for j in g["block"][i]] for i, q in enumerate(queries)} if tag == "cos_block" else None
+
+    class Recording(NaiveItemTower):
+        record = []
+
+        def forward(self, *a, **k):
+            out = super().forward(*a, **k)
+            self.record.append(out.detach().float().cpu().numpy())
+            return out
+
+    Recording.record = []
+    tower = Recording(numpy_seeded_bert(G18_CFG, int(g["seed"])), torch.nn.LayerNorm(64, elementwise_affine=False))
+    prof = generate_ranking_profile(tower, "unused", corpus, queries, block_dict=block, tokenizer=GoldenTokenizer(64))
+    rec = Recording.record
+    Eq, Ed = rec[0], np.concatenate(rec[1:], 0)
+    ref_q, ref_d = g[f"{tag}_query_emb"], g[f"{tag}_corpus_emb"]
+    assert Eq.shape == ref_q.shape and Ed.shape == ref_d.shape
+    np.testing.assert_allclose(Eq, ref_q, rtol=0, atol=2e-5 * np.abs(ref_q).max())
+    np.testing.assert_allclose(Ed, ref_d, rtol=0, atol=2e-5 * np.abs(ref_d).max())
+    blk = [r.tolist() for r in g["block"]] if block is not None else None
+    can_i, can_s = orc.canonical_ranking(Eq, Ed, sim, block=blk)
+    got_i = np.array([[int(p[1:]) for p in prof[q]] for q in queries])
+    got_s = np.array([list(prof[q].values()) for q in queries], np.float32)
+    assert list(prof) == list(queries)
+    assert np.array_equal(got_i, can_i) and np.array_equal(got_s.view(np.uint32), can_s.view(np.uint32))
+    ri, rs = canonicalise(g[f"{tag}_ids"], g[f"{tag}_scores"])
+    bound = 2.0 ** -7 * (float((np.linalg.norm(ref_q, axis=1)[:, None] * np.linalg.norm(ref_d, axis=1)[None, :]).max()) if sim == "dot" else 1.0)
+    assert_rank_close(got_i, got_s, ri, rs, tol=bound)
+    if block is not None:
+        for i, q in enumerate(queries):
+            assert [p for p in prof[q]][-4:] == sorted(block[q], key=lambda p: int(p[1:])) and all(prof[q][p] == -1e6 for p in block[q])

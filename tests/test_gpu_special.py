@@ -703,3 +703,45 @@ def test_two_host_threads_search_their_own_indices_concurrently():
         th.join(timeout=300)
     assert not any(th.is_alive() for th in threads), "a search thread did not finish"
     assert not errors, errors
+
+
+@pytest.mark.parametrize("sim", ["dot", "cos"])
+def test_bertbpr_transform_against_the_references_own_methods_golden_g19(golden_dir, monkeypatch, sim):
+    """Golden g19: the reference's BertBPR.get_all_embeddings and BertBPR.transform (src/ccrec/models/bbpr.py:466-550), bound to a
+    __new__-built instance by tools/make_golden.py (toy tokenizer with the class's own padding="max_length" kw, a numpy-seeded 768-wide
+    BertModel).  The product's BertBPR on the same titles / weights / index maps: the packed embeddings are the reference's fp32 rows
+    rounded to bf16 (up to fp32 noise of another BLAS), and transform(D)'s scores are the reference's dense matrix within the bf16
+    rounding of the rows (2^-7 ||u|| ||v||; cos: 2^-7), with the same arg-max item per user wherever the reference separates its two
+    best items by more than twice that."""
+    import os
+    import pandas as pd
+    from helpers import G19_CFG, GoldenTokenizer, numpy_seeded_bert
+    from ccrec_amd.bbpr_transform import BertBPR, LowRankScore
+    from ccrec_amd.item_tower import NaiveItemTower
+    g = np.load(os.path.join(golden_dir, "g19_bertbpr_transform.npz"))
+    monkeypatch.setenv("CCREC_SIM_TYPE", sim)
+    monkeypatch.setenv("CCREC_EMBEDDING_TYPE", "mean_pooling")
+    titles = [str(t) for t in g["titles"]]
+    n_items = len(titles)
+    item_df = pd.DataFrame({"TITLE": titles}, index=[f"i{j}" for j in range(n_items)])
+    tower = NaiveItemTower(numpy_seeded_bert(G19_CFG, int(g["seed"])), torch.nn.LayerNorm(768, elementwise_affine=False)).cuda()
+    bb = BertBPR(item_df, tower, GoldenTokenizer(64), max_length=int(g["max_length"]), batch_size=32)
+    E = g["all_emb"]
+    emb = bb.get_all_embeddings(tower, 32)
+    assert emb.shape == (n_items, 768) and emb.dtype == torch.bfloat16
+    want = E / np.maximum(np.linalg.norm(E, axis=1, keepdims=True), 1e-12) if sim == "cos" else E
+    got = emb.float().cpu().numpy()
+    assert np.all(np.abs(got - want) <= 2.0 ** -8 * np.abs(want) + 2e-5 * np.abs(want).max())
+    users = [[f"i{int(p)}"] for p in g["i_to_ptr"]]
+    items = [f"i{int(j)}" for j in g["j_to_ptr"]]
+    S = bb.transform(_Dataset(users, items, None))
+    assert isinstance(S, LowRankScore) and S.shape == (11, 70)
+    ref = g[f"scores_{sim}"]
+    ours = S.as_tensor().cpu().numpy()
+    U, V = E[g["i_to_ptr"]], E[g["j_to_ptr"]]
+    bound = 2.0 ** -7 * ((np.linalg.norm(U, axis=1)[:, None] * np.linalg.norm(V, axis=1)[None, :]) if sim == "dot" else np.ones_like(ref)) + 1e-6
+    assert np.all(np.abs(ours - ref) <= bound)
+    top_s, top_i = S.topk(1)
+    srt = np.sort(ref, axis=1)
+    clear = (srt[:, -1] - srt[:, -2]) > 2 * bound.max()
+    assert np.array_equal(top_i.cpu().numpy()[clear, 0], ref.argmax(1)[clear]) and clear.sum() >= 3

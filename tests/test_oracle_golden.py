@@ -213,3 +213,42 @@ def test_mrr_beir_known_answers():
     rel = [{1}, {2}, {3}]
     assert [orc.mrr(ids, rel, k, n_qrels=4) for k in (1, 3, 10)] == [got["MRR@1"], got["MRR@3"], got["MRR@10"]]
     assert orc.mrr(ids, rel, 10) == round((0.5 + 1 + 0.25) / 3, 5)
+
+
+@pytest.mark.parametrize("tag,sim", [("dot", "dot"), ("cos_block", "cos")])
+def test_generate_ranking_profile_golden_g18(golden_dir, tag, sim):
+    """Golden g18 = the reference's OWN generate_ranking_profile (scripts/al_oracle_agent.py:83-129, its source executed by
+    tools/make_golden.py) on a local seeded encoder: the profile it returned is what the oracle's ranking gives on the embeddings its
+    embedding_func produced (the function adds tokeniser + tower + DataParallel around ranking(), nothing numeric)."""
+    g = _load(golden_dir, "g18_ranking_profile_fn.npz")
+    Eq, Ed = g[f"{tag}_query_emb"], g[f"{tag}_corpus_emb"]
+    assert Eq.shape == (7, 64) and Ed.shape == (260, 64) and g[f"{tag}_ids"].shape == (7, 260)
+    block = [r.tolist() for r in g["block"]] if tag == "cos_block" else None
+    ids, sc = orc.reference_ranking(Eq, Ed, 512, sim, block=block)
+    ci, cs = canonicalise(ids, sc)
+    ri, rs = canonicalise(g[f"{tag}_ids"], g[f"{tag}_scores"])
+    assert_rank_close(ci, cs, ri, rs, tol=1e-6)
+    # the canonical (bf16) path: within the bf16 tolerance of the reference's fp32 scores; blocked passages last at -1e6
+    ids2, sc2 = orc.canonical_ranking(Eq, Ed, sim, block=block)
+    scale = float(np.abs(rs[rs > -1e5]).max())
+    assert_rank_close(ids2, sc2, ri, rs, tol=1e-2 * max(1.0, scale))
+    if block is not None:
+        for q, b in enumerate(block):
+            assert set(ids2[q, -len(b):].tolist()) == set(b) and np.all(sc2[q, -len(b):] == np.float32(-1e6))
+
+
+def test_bertbpr_transform_golden_g19(golden_dir):
+    """Golden g19 = the reference's OWN BertBPR.get_all_embeddings / transform (src/ccrec/models/bbpr.py:466-550): the dense score matrix it
+    returned is all_emb[i_to_ptr] @ all_emb[j_to_ptr].T (dot) / the cosine of the same rows -- the restatement the product's transform
+    is compared with."""
+    g = _load(golden_dir, "g19_bertbpr_transform.npz")
+    E, i_ptr, j_ptr = g["all_emb"], g["i_to_ptr"], g["j_to_ptr"]
+    assert E.shape == (90, 768) and g["scores_dot"].shape == (11, 70)
+    U, V = E[i_ptr], E[j_ptr]
+    np.testing.assert_allclose(U.astype(np.float64) @ V.astype(np.float64).T, g["scores_dot"], rtol=0, atol=2e-5 * np.abs(g["scores_dot"]).max())
+    np.testing.assert_allclose(orc.reference_cos_sim(U, V), g["scores_cos"], rtol=0, atol=2e-6)
+    # canonical bf16 path against the reference's fp32 values: bf16 rounding of both operands (2^-8 relative per row, norm-scaled)
+    for sim in ("dot", "cos"):
+        got = orc.canonical_scores(orc.pack(U, sim), orc.pack(V, sim))
+        bound = (np.linalg.norm(U, axis=1)[:, None] * np.linalg.norm(V, axis=1)[None, :]) if sim == "dot" else 1.0
+        assert np.all(np.abs(got - g[f"scores_{sim}"]) <= 2.0 ** -7 * bound + 1e-6)

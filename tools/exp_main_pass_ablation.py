@@ -14,9 +14,13 @@ import sys
 
 ROOT = os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "crowd-coachable-recommendations_amd")
+PITCH = [(1152, f"thresholds +inf, DMA addresses generated with a row pitch of {p} elements ({2 * p} B) instead of 768 (1536 B)", {"CCR_DBG_PITCH": str(p)})
+         for p in (768, 784, 800, 832, 896, 1024)]
 VARIANTS = [
     (0, "production kernel (hits recorded)"),
     (128, "complete kernel, thresholds +inf (no hit): BASELINE of the rows below"),
+    (384, "thresholds +inf, every DMA piece reads whole 128-byte lines (8 rows x 128 B instead of 16 rows x 64 B; same bytes, same pieces)"),
+    (640, "thresholds +inf, the traffic of a K-TILED layout: every piece ONE contiguous KiB, a sub-stage's 16 + 16 KiB contiguous (same bytes, same pieces)"),
     (4, "no DMA at all (ring zero-filled once)"),
     (32, "corpus-only DMA (query region of the ring left zero; 2 pieces per wave and sub-stage)"),
     (64, "query-only DMA (corpus region left zero; 2 pieces per wave and sub-stage)"),
@@ -53,15 +57,15 @@ def one():
 
 
 def main():
-    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r06_main_pass_ablation.txt")
+    out = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else os.path.join(ROOT, "gpurun_out", "r06_main_pass_ablation.txt")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     lines = ["# tools/exp_main_pass_ablation.py: gemm_topk16_kernel<EPI_FILTER>, NQ 2,681,468 x 768 x 3,452 queries, top-100, one box, diagnostic library",
              "# main-pass time by the library's own HIP events (ms), median of the last 5 of 8 searches per process"]
     for plan, env_plan in (("single launch (CCR_PROGRESSIVE=0)", {"CCR_PROGRESSIVE": "0"}), ("default plan (three launches, thresholds re-tightened)", {})):
         lines.append(f"## {plan}")
         base = None
-        for dbg, what in VARIANTS:
-            env = dict(os.environ, CCR_GEMM_DBG=str(dbg), CCR_MFMA16="1", **env_plan)
+        for dbg, what, *more in ([v for v in VARIANTS if v[0] in (0, 128)] + PITCH if "--pitch" in sys.argv else VARIANTS):
+            env = dict(os.environ, CCR_GEMM_DBG=str(dbg), CCR_MFMA16="1", **env_plan, **(more[0] if more else {}))
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one"], env=env, capture_output=True, text=True, timeout=900)
             vals = [float(m) for m in re.findall(r"main pass ([0-9.]+) ms", r.stderr)]
             if r.returncode != 0 or len(vals) < 6:

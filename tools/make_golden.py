@@ -27,6 +27,9 @@ Fixtures:
   G14 low-rank + sparse prior: _assign_topk / evaluate_item_rec / score_op on
       ElementWiseExpression(add, [U @ V.T, sparse]) -- the post-fit expression of bbpr.py:592-595 (reranking_prior 1e5)
   G15 _assign_topk on MatMulExpressions of width 300 and 50 (any factor width: score_array.py:320-339)
+  G16 NaiveItemTower around a real BertModel; G17 ranking() with cos + block lists + truncation
+  G18 generate_ranking_profile (scripts/al_oracle_agent.py:83-129, the function's own source executed) -- SURVEY 8a row a1
+  G19 BertBPR.get_all_embeddings / BertBPR.transform (src/ccrec/models/bbpr.py:466-550, bound to a __new__-built instance) -- row a9
 """
 import contextlib
 import importlib.abc
@@ -527,6 +530,102 @@ def g_sparse_prior():
     print("g14_sparse_prior", metrics, ops_low, ops_sum)
 
 
+def g_ranking_profile_fn():
+    """g18: the reference's OWN generate_ranking_profile (scripts/al_oracle_agent.py:83-129; twin of al_0_rank.py:69-105),
+    its source executed in a prepared namespace the g10 / g11 way (the script is not importable: it parses argv at import):
+    AutoTokenizer.from_pretrained -> the deterministic toy tokenizer of tests/helpers.py, the model a `_BertMT`-shaped object whose
+    .item_tower is the reference's NaiveItemTower around a local numpy-seeded BertModel, DataParallel = the reference's cached-replica
+    class (no devices here: it calls the module), ranking = the reference's, EvaluateRetrieval -> an inert stub (beir is absent: the MRR
+    print is not part of the fixture).  Cases: dot without blocks, cos with a block_dict.  Stored: texts, the seed / config of the
+    encoder, the fp32 embeddings the reference's embedding_func produced, and the returned rank-ordered profile (ids + scores)."""
+    import types
+    import warnings
+    mod = _import_reference("dot")
+    sys.path.insert(0, os.path.join(os.path.dirname(OUT)))
+    from helpers import G18_CFG, GoldenTokenizer, golden_texts, numpy_seeded_bert
+    from ccrec.models.item_tower import NaiveItemTower
+    from ccrec.util.data_parallel import DataParallel
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    src = _reference_lines("scripts/al_oracle_agent.py", "def generate_ranking_profile(", "# %%")
+    res = {"config": np.array(json.dumps(G18_CFG)), "seed": 18, "max_length": 24}
+    corpus = {f"p{j}": t for j, t in enumerate(golden_texts(260, 181))}
+    queries = {f"q{i}": t for i, t in enumerate(golden_texts(7, 182, longest=8))}
+    rs = np.random.RandomState(183)
+    block = {q: [f"p{int(j)}" for j in rs.choice(260, 4, replace=False)] for q in queries}
+    res["corpus_texts"], res["query_texts"] = np.array(list(corpus.values())), np.array(list(queries.values()))
+    res["block"] = np.array([[int(p[1:]) for p in block[q]] for q in queries])
+    for tag, sim, blk in (("dot", "dot", None), ("cos_block", "cos", block)):
+        os.environ["CCREC_SIM_TYPE"] = sim
+        os.environ["CCREC_EMBEDDING_TYPE"] = "mean_pooling"
+        os.environ["CCREC_MAX_LENGTH"] = "24"
+        tower = NaiveItemTower(numpy_seeded_bert(G18_CFG, 18), torch.nn.LayerNorm(64, elementwise_affine=False))
+        recorded = []
+        fwd = tower.forward
+
+        def recording(*a, _f=fwd, **k):
+            out = _f(*a, **k)
+            recorded.append(out.detach().float().numpy().copy())
+            return out
+        tower.forward = recording
+        auto_tok = types.SimpleNamespace(from_pretrained=lambda name: GoldenTokenizer(64))
+        evaluator = type("EvaluateRetrieval", (), {"__init__": lambda self, *a: None, "evaluate_custom": lambda self, *a, **k: {}})
+        save_to = os.path.join(OUT, "_g18_tmp.pt")
+        ns = dict(torch=torch, os=os, warnings=warnings, AutoTokenizer=auto_tok, DataParallel=DataParallel, ranking=mod.ranking,
+                  EvaluateRetrieval=evaluator)
+        exec(compile(src, "al_oracle_agent.py[generate_ranking_profile]", "exec"), ns)
+        with contextlib.redirect_stdout(io.StringIO()):
+            prof = ns["generate_ranking_profile"](types.SimpleNamespace(item_tower=tower), "unused", corpus, queries, {}, save_to, blk)
+        assert torch.load(save_to) == prof
+        os.remove(save_to)
+        emb = np.concatenate(recorded, 0)           # ranking() encodes the queries first, then the corpus
+        res[f"{tag}_query_emb"], res[f"{tag}_corpus_emb"] = emb[:len(queries)], emb[len(queries):]
+        res[f"{tag}_ids"] = np.array([[int(p[1:]) for p in prof[q]] for q in queries], np.int64)
+        res[f"{tag}_scores"] = np.array([list(prof[q].values()) for q in queries], np.float32)
+        assert list(prof) == list(queries)
+    np.savez_compressed(os.path.join(OUT, "g18_ranking_profile_fn.npz"), **res)
+    print("g18_ranking_profile_fn", res["dot_ids"].shape, res["cos_block_scores"][0, :3])
+
+
+def g_bertbpr_transform():
+    """g19: the reference's OWN BertBPR.get_all_embeddings and BertBPR.transform (src/ccrec/models/bbpr.py:466-550), bound
+    methods of a `BertBPR.__new__` instance (the constructor downloads a tokenizer and builds Lightning loggers): item_titles, the toy
+    tokenizer with the class's own tokenizer_kw (padding="max_length", bbpr.py:359-364), model.item_tower = the reference's
+    NaiveItemTower around a local numpy-seeded 768-wide BertModel (get_all_embeddings allocates [n, 768]), `_get_data_module` -> an
+    object with the i_to_ptr / j_to_ptr index maps of bbpr.py:287-293.  Stored: titles, index maps, the [n_items, 768] fp32 embeddings
+    and the dense score matrices (dot and cos) the reference returned."""
+    import types
+    import pandas as pd
+    _import_reference("dot")
+    sys.path.insert(0, os.path.join(os.path.dirname(OUT)))
+    from helpers import G19_CFG, GoldenTokenizer, golden_texts, numpy_seeded_bert
+    from ccrec.models.bbpr import BertBPR
+    from ccrec.models.item_tower import NaiveItemTower
+    n_items = 90
+    titles = golden_texts(n_items, 191, longest=12)
+    rs = np.random.RandomState(192)
+    i_to_ptr = [int(x) for x in rs.choice(n_items, 11, replace=False)]
+    j_to_ptr = [int(x) for x in rs.permutation(n_items)[:70]]
+    res = {"config": np.array(json.dumps(G19_CFG)), "seed": 19, "max_length": 16, "titles": np.array(titles),
+           "i_to_ptr": np.array(i_to_ptr), "j_to_ptr": np.array(j_to_ptr)}
+    os.environ["CCREC_EMBEDDING_TYPE"] = "mean_pooling"
+    for sim in ("dot", "cos"):
+        os.environ["CCREC_SIM_TYPE"] = sim
+        bb = BertBPR.__new__(BertBPR)
+        bb.item_titles = pd.Series(titles, index=[f"i{j}" for j in range(n_items)])
+        bb.tokenizer = GoldenTokenizer(64)
+        bb.tokenizer_kw = dict(padding="max_length", return_tensors="pt", max_length=16, truncation=True)
+        bb.model = types.SimpleNamespace(item_tower=NaiveItemTower(numpy_seeded_bert(G19_CFG, 19), torch.nn.LayerNorm(768, elementwise_affine=False)))
+        bb._get_data_module = lambda D: types.SimpleNamespace(i_to_ptr=i_to_ptr, j_to_ptr=j_to_ptr)
+        with contextlib.redirect_stdout(io.StringIO()):
+            if sim == "dot":
+                res["all_emb"] = bb.get_all_embeddings(bb.model.item_tower, 32).numpy()
+            S = bb.transform(None)
+        res[f"scores_{sim}"] = np.asarray(S.as_tensor("cpu").numpy(), np.float32)
+        assert res[f"scores_{sim}"].shape == (11, 70)
+    np.savez_compressed(os.path.join(OUT, "g19_bertbpr_transform.npz"), **res)
+    print("g19_bertbpr_transform", res["all_emb"].shape, res["scores_dot"][0, :3], res["scores_cos"][0, :3])
+
+
 def main():
     """No arguments: every fixture.  `make_golden.py g10 g11`: only the named groups (g1 = all ranking fixtures)."""
     os.makedirs(OUT, exist_ok=True)
@@ -534,7 +633,7 @@ def main():
     groups = [("g1", lambda: g_ranking(_import_reference("dot"))), ("g6", g_item_tower), ("g7", g_contrastive),
               ("g8", g_assign_topk), ("g9", g_pack), ("g10", g_requests), ("g11", g_train_data), ("g12", g_bm25), ("g13", g_item_rec), ("g14", g_sparse_prior),
               ("g15", g_assign_topk_odd_width), ("g16", lambda: (_import_reference("dot"), g_item_tower_bert())[1]),
-              ("g17", lambda: g_ranking_cos_block(_import_reference("dot")))]
+              ("g17", lambda: g_ranking_cos_block(_import_reference("dot"))), ("g18", g_ranking_profile_fn), ("g19", g_bertbpr_transform)]
     for name, fn in groups:
         if not want or name in want:
             fn()
