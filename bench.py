@@ -548,7 +548,7 @@ def small_batches_side_run(index, qpack, n_rows, dim, k=TOP_K, sizes=(1, 16, 64,
     out = {"workload": f"configs[1] corpus resident and indexed, top-{k}, batches of n_q queries (search only)", "unit": "ms per search", "batches": {}}
     pmc = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r05_small_batches_pmc.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r06_small_batches_pmc.json")))   # tools/pmc_small_batches_json.sh
     except Exception:
         pass
     for nq in sizes:
@@ -575,7 +575,7 @@ def small_batches_side_run(index, qpack, n_rows, dim, k=TOP_K, sizes=(1, 16, 64,
                          else "gemm_topk16_kernel<EPI_FILTER> (256-query tiles)",
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                          "bytes_per_search": bytes_, "main_pass_ms": round(main, 4), "traffic": traffic,
-                         "traffic_source": "offline rocprofv3 --pmc passes (profiles/r05_small_batches_pmc.json); not measured in this run" if traffic else None}}
+                         "traffic_source": "offline rocprofv3 --pmc passes (profiles/r06_small_batches_pmc.json: FETCH_SIZE x 2 + WRITE_SIZE of one search's main-pass launches); not measured in this run" if traffic else None}}
     return out
 
 

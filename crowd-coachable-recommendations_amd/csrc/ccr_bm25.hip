@@ -797,7 +797,8 @@ extern "C" int ccr_bm25_search(const ccr_bm25_index *ix, const int64_t *q_ptr_ho
         if (rc1 != CCR_OK) return rc1;
         const int rc3 = ensure_dynamic_lds(reinterpret_cast<const void *>(&bm25_topk_kernel<512, true>), (size_t)BM25_TOPK_SMALL * 12);
         if (rc3 != CCR_OK) return rc3;
-        const int rc2 = ensure_dynamic_lds(reinterpret_cast<const void *>(&bm25_threshold_kernel), (size_t)BM25_SAMPLE_MAX * 4);
+        // (the kernel's static LDS -- histogram + control words, ~1 KiB -- sits on top of the dynamic part: opt in with head room)
+        const int rc2 = ensure_dynamic_lds(reinterpret_cast<const void *>(&bm25_threshold_kernel), (size_t)BM25_SAMPLE_MAX * 4 + 2048);
         if (rc2 != CCR_OK) return rc2;
     }
     if (!L.tile) CCR_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)rows * ix->n_docs * 8, s));

@@ -576,13 +576,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
 #pragma unroll
                 for (int i = 0; i < 2; ++i) glds16((hf ? qsrc[(i + 2) & 3] : qsrc[i]) + ofs, buf + SUB_Q_REGION + (i * 512 + wv * 64) * 16);
             } else {
+                // DBG 2048 / 4096 / 8192 (timing AND results stay right): cache policy sc1 / sc0 / sc0 sc1 on every piece
+                constexpr int AUX = ((DBG & 2048) ? 16 : 0) | ((DBG & 4096) ? 1 : 0) | ((DBG & 8192) ? 17 : 0);
                 if constexpr (DMA_D) {
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) glds16(dsrc[i] + k0, buf + (i * 512 + wv * 64) * 16);
+                    for (int i = 0; i < 2; ++i) glds16_aux<AUX>(dsrc[i] + k0, buf + (i * 512 + wv * 64) * 16);
                 }
                 if constexpr (DMA_Q) {
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) glds16(qsrc[i] + k0, buf + SUB_Q_REGION + (i * 512 + wv * 64) * 16);
+                    for (int i = 0; i < 2; ++i) glds16_aux<AUX>(qsrc[i] + k0, buf + SUB_Q_REGION + (i * 512 + wv * 64) * 16);
                 }
             }
             ++iu;
@@ -741,7 +743,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
 }
 
 // =============================================================================================
-// QUERY-DIRECT form of the 16x16x32 main pass (round 6).  The ablation of the kernel above (profiles/r06_main_pass_ablation.txt:
+// QUERY-DIRECT form of the 16x16x32 main pass (round 6) -- an EXPERIMENT kept for the record, compiled only into the diagnostic library
+// (make DIAG=1 / tools/build_diag.sh, CCR_QDIRECT = 1 / 3 / 4 / 5).  Exact (every form returns the production kernel's ids and score bits)
+// and 38-48 % SLOWER: NQ main pass 16.8-18.2 ms against 12.1 (profiles/r06_qdirect_ab.txt).  Why: what bounds the main pass is the CU's
+// vector-memory pipeline (L1 / TCP miss handling: ~0.3 64-byte requests per clock, profiles/r06_main_pass_memory_pipeline_pmc.txt), not the
+// LDS-DMA issue; fragments fetched straight into registers are requested by BOTH waves that share a query quarter, so the CU moves
+// 16 + 32 KiB per sub-stage through that pipeline instead of 16 + 16.
+#ifdef CCR_DIAGNOSTICS
+// (The reasoning it was built on, before the measurement.)  The ablation of the kernel above (profiles/r06_main_pass_ablation.txt:
 // full 11.35 ms, corpus-only DMA 8.0, no DMA 7.75) says that the LDS-DMA *issue* -- four 1-KiB pieces per wave and sub-stage, two of
 // them the query slice that is re-streamed for every corpus tile -- is what keeps the mem phase longer than the partner's MFMA phase.
 // Here the ring carries the CORPUS alone (two pieces per wave and sub-stage) and a lane fetches its four B-operand fragments -- 16 bytes
@@ -1033,6 +1042,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16q_kernel(const Gem
         __syncthreads();
     }
 }
+#endif   // CCR_DIAGNOSTICS
 
 // ---------------------------------------------------------------------------------------------
 // bf16 row norms (fp32 accumulate; used only for error margins, inflated by the caller).  With tile_bits (the index's own
@@ -1831,7 +1841,8 @@ static int launch_gemm(const GemmArgs &a, int grid, hipStream_t s) {
 }
 
 int launch_gemm_filter(const GemmArgs &a, int grid, hipStream_t s) { return launch_gemm<EPI_FILTER>(a, grid, s); }
-// query-direct forms (a.qdirect = 1 / 3 / 4 / 5: gemm_topk16q_kernel); dim % 32 == 0 and a query block of less than 2^31 bytes
+#ifdef CCR_DIAGNOSTICS
+// query-direct forms (a.qdirect = 1 / 3 / 4 / 5: gemm_topk16q_kernel; diagnostic library only); dim % 32 == 0 and a query block of less than 2^31 bytes
 template <int EPI>
 static int launch_gemm16q(const GemmArgs &a, int grid, hipStream_t s) {
     const size_t lds = RING * (size_t)SUB_BYTES;
@@ -1845,6 +1856,7 @@ static int launch_gemm16q(const GemmArgs &a, int grid, hipStream_t s) {
 static bool qdirect_ok(const GemmArgs &a) {
     return a.qdirect > 0 && a.dim % SUB_K == 0 && (int64_t)a.n_q * a.dim * 2 < (int64_t)1 << 31;
 }
+#endif
 
 int launch_gemm16_filter(const GemmArgs &a, int grid, hipStream_t s) {
 #ifdef CCR_DIAGNOSTICS
@@ -1860,15 +1872,22 @@ int launch_gemm16_filter(const GemmArgs &a, int grid, hipStream_t s) {
         case 384: return launch_kernel(&gemm_topk16_kernel<EPI_FILTER, 384>, RING * (size_t)SUB_BYTES, a, grid, s);
         case 640: return launch_kernel(&gemm_topk16_kernel<EPI_FILTER, 640>, RING * (size_t)SUB_BYTES, a, grid, s);
         case 1152: return launch_kernel(&gemm_topk16_kernel<EPI_FILTER, 1152>, RING * (size_t)SUB_BYTES, a, grid, s);
+        case 2176: return launch_kernel(&gemm_topk16_kernel<EPI_FILTER, 2176>, RING * (size_t)SUB_BYTES, a, grid, s);
+        case 4224: return launch_kernel(&gemm_topk16_kernel<EPI_FILTER, 4224>, RING * (size_t)SUB_BYTES, a, grid, s);
+        case 8320: return launch_kernel(&gemm_topk16_kernel<EPI_FILTER, 8320>, RING * (size_t)SUB_BYTES, a, grid, s);
         default: break;   // 0 or unknown: the production kernel
     }
 #endif
+#ifdef CCR_DIAGNOSTICS
     if (qdirect_ok(a)) return launch_gemm16q<EPI_FILTER>(a, grid, s);
+#endif
     if (a.dim % SUB_K != 0) return launch_kernel(&gemm_topk16_kernel<EPI_FILTER, 0, true>, RING * (size_t)SUB_BYTES, a, grid, s);
     return launch_kernel(&gemm_topk16_kernel<EPI_FILTER, 0>, RING * (size_t)SUB_BYTES, a, grid, s);
 }
 int launch_gemm16_store(const GemmArgs &a, int grid, hipStream_t s) {
+#ifdef CCR_DIAGNOSTICS
     if (qdirect_ok(a)) return launch_gemm16q<EPI_STORE>(a, grid, s);
+#endif
     if (a.dim % SUB_K != 0) return launch_kernel(&gemm_topk16_kernel<EPI_STORE, 0, true>, RING * (size_t)SUB_BYTES, a, grid, s);
     return launch_kernel(&gemm_topk16_kernel<EPI_STORE, 0>, RING * (size_t)SUB_BYTES, a, grid, s);
 }

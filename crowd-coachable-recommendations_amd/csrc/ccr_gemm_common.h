@@ -16,6 +16,13 @@ __device__ __forceinline__ void glds16(const void *gsrc, char *lds_wave_base) {
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
+// the same with a cache-policy immediate (aux: 1 = sc0, 2 = nt, 16 = sc1): diagnostic instantiations only
+template <int AUX>
+__device__ __forceinline__ void glds16_aux(const void *gsrc, char *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, AUX);
+}
+
 // K is walked in 32-element sub-stages through a ring of four 32-KiB LDS buffers:
 // [256 corpus rows x 64 B][256 query rows x 64 B] per sub-stage
 constexpr int SUB_K = 32;

@@ -374,3 +374,21 @@ def test_hip_bm25_workspace_sizes(monkeypatch):
     assert torch.equal(out_i, i) and torch.equal(out_s.view(torch.int32), s.view(torch.int32))
     rc = call(fused - 4096)
     assert rc != 0 and "workspace" in lib.ccr_last_error().decode()
+
+
+@pytest.mark.gpu
+def test_hip_bm25_largest_sample_the_threshold_kernel_holds_in_lds(monkeypatch):
+    """1,048,576 documents = 1,024 pieces of 1,024 documents, one of every 64 sampled: 16 pieces x 1,024 = 16,384 sampled scores per
+    row = BM25_SAMPLE_MAX, i.e. exactly the 64 KiB of dynamic LDS bm25_threshold_kernel opts in to, under its static histogram
+    (round-5 advisor: the full-size case had no test; the opt-in now carries head room).  The fused selection equals the stored-rows
+    selection bit for bit."""
+    import bench
+    model, qs, df, _ = bench.bm25_workload(docs=1_048_576, queries=48, vocab=30_000)
+    monkeypatch.delenv("CCR_BM25_DENSE_SELECT", raising=False)
+    s, i = model.transform_terms_topk(qs, 1001)
+    st = model.last_stats()
+    assert st["path"] == "tile+fused_filter"
+    monkeypatch.setenv("CCR_BM25_DENSE_SELECT", "1")
+    s2, i2 = model.transform_terms_topk(qs, 1001)
+    assert model.last_stats()["path"] == "tile+stored_rows"
+    assert torch.equal(i, i2) and torch.equal(s.view(torch.int32), s2.view(torch.int32))

@@ -16,6 +16,7 @@ ROOT = os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.p
 PKG = os.path.join(ROOT, "crowd-coachable-recommendations_amd")
 PITCH = [(1152, f"thresholds +inf, DMA addresses generated with a row pitch of {p} elements ({2 * p} B) instead of 768 (1536 B)", {"CCR_DBG_PITCH": str(p)})
          for p in (768, 784, 800, 832, 896, 1024)]
+POLICY = [(2176, "thresholds +inf, cache policy sc1 on every DMA piece"), (4224, "thresholds +inf, sc0 on every piece"), (8320, "thresholds +inf, sc0 sc1 on every piece")]
 VARIANTS = [
     (0, "production kernel (hits recorded)"),
     (128, "complete kernel, thresholds +inf (no hit): BASELINE of the rows below"),
@@ -64,7 +65,7 @@ def main():
     for plan, env_plan in (("single launch (CCR_PROGRESSIVE=0)", {"CCR_PROGRESSIVE": "0"}), ("default plan (three launches, thresholds re-tightened)", {})):
         lines.append(f"## {plan}")
         base = None
-        for dbg, what, *more in ([v for v in VARIANTS if v[0] in (0, 128)] + PITCH if "--pitch" in sys.argv else VARIANTS):
+        for dbg, what, *more in ([v for v in VARIANTS if v[0] in (0, 128)] + (PITCH if "--pitch" in sys.argv else POLICY) if ("--pitch" in sys.argv or "--policy" in sys.argv) else VARIANTS):
             env = dict(os.environ, CCR_GEMM_DBG=str(dbg), CCR_MFMA16="1", **env_plan, **(more[0] if more else {}))
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one"], env=env, capture_output=True, text=True, timeout=900)
             vals = [float(m) for m in re.findall(r"main pass ([0-9.]+) ms", r.stderr)]

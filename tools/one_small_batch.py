@@ -20,4 +20,5 @@ index = ops.CorpusIndex(D, norm_bounds=nb)
 for _ in range(4):
     index.search(Q, 100)
 torch.cuda.synchronize()
+print("searches 4")
 print(index.last_stats())
