@@ -10,6 +10,8 @@
 //
 // Arithmetic = what autocast(bf16) does in the reference's layer: bf16 operands, fp32 scores / softmax / accumulation,
 // probabilities rounded to bf16 for the P V product, fp32 residual sum and LayerNorm.
+#include <stdlib.h>
+
 #include "ccr_common.h"
 #include "ccr_index.h"
 
@@ -79,11 +81,16 @@ constexpr int ATT_KB = 64;         // keys per loop step (two 32-key score tiles
 constexpr int ATT_HEAD = 64;       // head width
 constexpr int ATT_KROW = 144;      // bytes per key row in LDS: 128 + 16, so the 16 lanes of a ds_read_b128 group hit distinct banks
 
-// LDS: K [lk_pad rows][144 B] row-major | V TRANSPOSED [64 d][2 * lk_pad + 8 B] (row stride = 8 * odd: the 32 lanes of a ds_read_b64
-// group, one d each, hit distinct banks).  lk_pad = longest sequence rounded up to 64.
+// LDS: K [lk_pad rows][144 B] row-major | V.  TR = true (r6, the default): V stays ROW-MAJOR, [lk_pad keys][128 B], staged with
+// ds_write_b128 as it arrives, the 64-byte halves of a row swapped on rows whose index has bit 1 set; the V^T fragments of the second
+// MFMA come from ds_read_b64_tr_b16 (guide T10: a 16-lane group reads a 4-key x 16-column block and receives it column-major), whose
+// 32-lane half then touches 4 rows x 64 B on 64 distinct banks.  TR = false (r3-r5, CCR_ATT_TR=0): V TRANSPOSED [64 d][2 * lk_pad + 8 B],
+// written two keys per dword (23 % of the LDS-active cycles were bank-conflict cycles of those stores, profiles/r05_attention_pmc.txt).
+// lk_pad = longest sequence rounded up to 64.
 __host__ __device__ inline size_t attention_lds_bytes(int lk_pad) {
-    return (size_t)lk_pad * ATT_KROW + (size_t)ATT_HEAD * (2 * (size_t)lk_pad + 8);
+    return (size_t)lk_pad * ATT_KROW + (size_t)ATT_HEAD * (2 * (size_t)lk_pad + 8);   // (the row-major image needs 512 bytes less)
 }
+typedef short es16x4 __attribute__((ext_vector_type(4)));
 
 // S^T = K Q^T on v_mfma_f32_32x32x16_bf16: A = 32 keys (lane & 31) x 8 head columns (8 * (lane >> 5) + j), B = 32 queries
 // likewise -- both operands are 16 contiguous bytes of a row, no transposition.  C layout: lane -> query (lane & 31),
@@ -91,7 +98,7 @@ __host__ __device__ inline size_t attention_lds_bytes(int lk_pad) {
 // softmax row reductions are in-lane plus one exchange with lane ^ 32, and the probabilities, rounded to bf16, ARE the B
 // operand of O^T = V^T P^T (contraction index = key; the A operand V^T is read from the transposed LDS image with the
 // same key permutation: element j of lane half g <-> key 16 s + 4 g + (j & 3) + 8 (j >> 2)).
-template <int DT>
+template <int DT, bool TR>
 __global__ __launch_bounds__(ATT_MAX_THREADS) void attention_kernel(const uint16_t *__restrict__ qkv,
                                                                   const int32_t *__restrict__ seq_start,
                                                                   const int32_t *__restrict__ seq_len,
@@ -172,16 +179,29 @@ __global__ __launch_bounds__(ATT_MAX_THREADS) void attention_kernel(const uint16
         const int i = tid + u * nthreads;
         if (i < nk * 4) {
             const int p = i >> 3, c = i & 7;
-            const uint32_t a[4] = {va[u].x, va[u].y, va[u].z, va[u].w}, bb[4] = {vb[u].x, vb[u].y, vb[u].z, vb[u].w};
-            char *dst = Vt + (size_t)(8 * c) * VS + 4 * p;
+            if constexpr (TR) {   // rows 2p and 2p + 1 as they came: one ds_write_b128 each; 64-byte halves swapped where bit 1 of the row is set
+                char *dst = Vt + (size_t)(2 * p) * 128 + ((c ^ ((p & 1) << 2)) << 4);
+                *reinterpret_cast<uint4 *>(dst) = va[u];
+                *reinterpret_cast<uint4 *>(dst + 128) = vb[u];
+            } else {
+                const uint32_t a[4] = {va[u].x, va[u].y, va[u].z, va[u].w}, bb[4] = {vb[u].x, vb[u].y, vb[u].z, vb[u].w};
+                char *dst = Vt + (size_t)(8 * c) * VS + 4 * p;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                *reinterpret_cast<uint32_t *>(dst + (size_t)(2 * j) * VS) = (a[j] & 0xffffu) | (bb[j] << 16);
-                *reinterpret_cast<uint32_t *>(dst + (size_t)(2 * j + 1) * VS) = (a[j] >> 16) | (bb[j] & 0xffff0000u);
+                for (int j = 0; j < 4; ++j) {
+                    *reinterpret_cast<uint32_t *>(dst + (size_t)(2 * j) * VS) = (a[j] & 0xffffu) | (bb[j] << 16);
+                    *reinterpret_cast<uint32_t *>(dst + (size_t)(2 * j + 1) * VS) = (a[j] >> 16) | (bb[j] & 0xffff0000u);
+                }
             }
         }
     }
     __syncthreads();
+    // TR: this lane's part of every transposed read.  A 16-lane group fetches a block of 4 keys x 16 head columns: lane 4 qq + pp of the
+    // group supplies the address of key row (base + qq), columns 4 pp .. 4 pp + 3 (8 bytes) and receives column (lane & 15), keys base .. + 3.
+    // Groups 0 / 1 of a 32-lane half take columns 0-15 / 16-31 (the lane's own column d = lane & 31); key base = ... + 4 g (multiple of 4),
+    // so bit 1 of the row index is bit 1 of qq: the half swap is a per-lane constant.
+    const int tr_qq = (lane & 15) >> 2, tr_pp = lane & 3;
+    const int tr_off = (4 * g + tr_qq) * 128 + ((32 * ((lane >> 4) & 1) + 8 * tr_pp) ^ (((tr_qq >> 1) & 1) << 6));
+    const int tr_other = (tr_off ^ 64) - tr_off;   // +64 or -64
 
     for (int q0w = wq * ATT_QW; q0w < rows; q0w += nwaves * ATT_QW) {   // wave-uniform; no barrier below
         const int q = q0w + ql;
@@ -256,18 +276,35 @@ __global__ __launch_bounds__(ATT_MAX_THREADS) void attention_kernel(const uint16
                     vec8 pf;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) pf[j] = (elem)x[hb * 16 + s2 * 8 + j];
-                    const int kbase = kb * ATT_KB + hb * 32 + s2 * 16 + 4 * g;
-                    const char *vp = Vt + (size_t)ql * VS + 2 * kbase;
-                    union {
-                        uint2 u[2];
-                        vec8 v;
-                    } a0, a1;
-                    a0.u[0] = *reinterpret_cast<const uint2 *>(vp);
-                    a0.u[1] = *reinterpret_cast<const uint2 *>(vp + 16);
-                    a1.u[0] = *reinterpret_cast<const uint2 *>(vp + (size_t)32 * VS);
-                    a1.u[1] = *reinterpret_cast<const uint2 *>(vp + (size_t)32 * VS + 16);
-                    o0 = HT::mfma(a0.v, pf, o0);
-                    o1 = HT::mfma(a1.v, pf, o1);
+                    if constexpr (TR) {
+                        // keys kbase .. + 3 and kbase + 8 .. + 11 (kbase = kb * 64 + hb * 32 + s2 * 16 + 4 g) of this lane's column d (a0) and d + 32 (a1)
+                        typedef __attribute__((address_space(3))) es16x4 *lds_tr_ptr;
+                        const char *vp = Vt + (size_t)(kb * ATT_KB + hb * 32 + s2 * 16) * 128 + tr_off;
+                        union {
+                            es16x4 h[2];
+                            vec8 v;
+                        } a0, a1;
+                        a0.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(vp));
+                        a0.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(vp + 8 * 128));
+                        const char *vq = vp + tr_other;   // columns d + 32: the other 64-byte half of the same rows
+                        a1.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(vq));
+                        a1.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(vq + 8 * 128));
+                        o0 = HT::mfma(a0.v, pf, o0);
+                        o1 = HT::mfma(a1.v, pf, o1);
+                    } else {
+                        const int kbase = kb * ATT_KB + hb * 32 + s2 * 16 + 4 * g;
+                        const char *vp = Vt + (size_t)ql * VS + 2 * kbase;
+                        union {
+                            uint2 u[2];
+                            vec8 v;
+                        } a0, a1;
+                        a0.u[0] = *reinterpret_cast<const uint2 *>(vp);
+                        a0.u[1] = *reinterpret_cast<const uint2 *>(vp + 16);
+                        a1.u[0] = *reinterpret_cast<const uint2 *>(vp + (size_t)32 * VS);
+                        a1.u[1] = *reinterpret_cast<const uint2 *>(vp + (size_t)32 * VS + 16);
+                        o0 = HT::mfma(a0.v, pf, o0);
+                        o1 = HT::mfma(a1.v, pf, o1);
+                    }
                 }
             }
         }
@@ -485,7 +522,12 @@ static int attention_any(const uint16_t *qkv, const int32_t *seq_start, const in
     const size_t lds = attention_lds_bytes(lk_pad);
     // the opt-in is cached per (kernel, device) whatever the size: ask for the kernel's maximum once (512 keys), not for this call's
     // image -- length-sorted batches start with the shortest texts
-    const int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&attention_kernel<DT>), attention_lds_bytes(512));
+    static const bool tr = [] {
+        const char *e = getenv("CCR_ATT_TR");      // A/B knob: 0 = the transposed-image kernel of rounds 3-5
+        return !(e && atoi(e) == 0);
+    }();
+    const int rc = ensure_dynamic_lds(tr ? reinterpret_cast<const void *>(&attention_kernel<DT, true>) : reinterpret_cast<const void *>(&attention_kernel<DT, false>),
+                                      attention_lds_bytes(512));
     if (rc != CCR_OK) return rc;
     int waves = (max_len + ATT_QW - 1) / ATT_QW;   // one wave per 32 query rows, at most 8 (longer sequences: the waves loop)
     if (waves > ATT_MAX_THREADS / 64) waves = ATT_MAX_THREADS / 64;
@@ -495,8 +537,12 @@ static int attention_any(const uint16_t *qkv, const int32_t *seq_start, const in
     // fit either way and 7-8 waves are faster)
     if (lk_pad == 192 && waves > 4) waves = 4;
     CCR_REQUIRE(lk_pad * 8 <= ATT_KMAX * 64 * waves && lk_pad * 4 <= ATT_VMAX * 64 * waves, "ccr_attention: staging bound (internal)");
-    hipLaunchKernelGGL(attention_kernel<DT>, dim3(n_heads, n_seq), dim3(64 * waves), lds, stream, qkv, seq_start, seq_len, out,
-                       n_heads, pad_len, max_len, lk_pad, scale * 1.4426950408889634f);
+    if (tr)
+        hipLaunchKernelGGL((attention_kernel<DT, true>), dim3(n_heads, n_seq), dim3(64 * waves), lds, stream, qkv, seq_start, seq_len, out,
+                           n_heads, pad_len, max_len, lk_pad, scale * 1.4426950408889634f);
+    else
+        hipLaunchKernelGGL((attention_kernel<DT, false>), dim3(n_heads, n_seq), dim3(64 * waves), lds, stream, qkv, seq_start, seq_len, out,
+                           n_heads, pad_len, max_len, lk_pad, scale * 1.4426950408889634f);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
 }
