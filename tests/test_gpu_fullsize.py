@@ -1,9 +1,10 @@
 """Full-size (BASELINE.json configs[1]: NQ 2,681,468 x 768, 3,452 queries, top-100) property tests.
 The CPU oracle cannot score 9.3e9 pairs in seconds, so parity is established through size-independent
 properties: every returned score is the canonical score of its id (oracle, C), lists are in canonical
-order, and on a query subsample an fp32 BLAS sweep of the WHOLE corpus finds every row that could
-possibly belong to the top-k; those are re-scored canonically by the oracle and must reproduce the
-GPU list bit for bit."""
+order, for EVERY query an independent fp32 sweep of the whole corpus (torch's matmul on the device) finds
+no missing row that beats the k-th score by more than 1e-4, and on a query subsample an fp32 BLAS sweep
+of the WHOLE corpus finds every row that could possibly belong to the top-k; those are re-scored
+canonically by the oracle and must reproduce the GPU list bit for bit."""
 import numpy as np
 import pytest
 import torch
@@ -58,11 +59,32 @@ def test_nq_config_properties():
         cs = orc.canonical_scores_pairs(Qb[q:q + 1], Db, cand[None, :])[0]
         o = np.lexsort((cand, -cs.astype(np.float64)))[:k]
         assert np.array_equal(cand[o], i_np[q]) and np.array_equal(cs[o], s_np[q])
+    # (3b) completeness for EVERY query up to the 1e-4 band (an independent fp32 sweep of the whole corpus on the device)
+    _completeness_sweep_all_queries(D, Q, s)
     # (4) idempotence of the shard merge: merging the list with itself shifted by n keeps the original
     gi = torch.stack([i, i + n])
     gs = torch.stack([s, s - 1.0])
     ms, mi = ops.merge_topk(gs, gi)
     assert torch.equal(mi, i) and torch.equal(ms, s)
+
+
+def _completeness_sweep_all_queries(D, Q, s, chunk=65536):
+    """EVERY query (not a subsample): no row that beats the list's k-th score by more than 1.1e-4 is missing from the list.  torch's own
+    fp32 matmul (independent of this library's kernels; error ~1e-6 on these O(1) scores) sweeps the whole shard chunk by chunk on the
+    device and counts, per query, the rows above k-th + 1e-4 +- 1e-5; the list's own count of such entries must lie between the two.
+    (Rows inside the 1e-4 band around the cut are settled exactly on the query subsample, by the oracle.)"""
+    Qf = Q.float()
+    kth = s[:, -1].float()
+    hi_thr, lo_thr = (kth + 1.1e-4)[None, :], (kth + 0.9e-4)[None, :]
+    above_hi = torch.zeros(Q.shape[0], dtype=torch.int64, device=Q.device)
+    above_lo = torch.zeros_like(above_hi)
+    for lo in range(0, D.shape[0], chunk):
+        a = D[lo:lo + chunk].float() @ Qf.T                       # [chunk, n_q] fp32
+        above_hi += (a > hi_thr).sum(0)
+        above_lo += (a > lo_thr).sum(0)
+    in_list = (s > (kth + 1e-4)[:, None]).sum(1)
+    bad = ((above_hi > in_list) | (in_list > above_lo)).nonzero().flatten()
+    assert bad.numel() == 0, f"queries {bad[:8].tolist()}: rows above the cut {above_hi[bad[:8]].tolist()} / {above_lo[bad[:8]].tolist()}, in the list {in_list[bad[:8]].tolist()}"
 
 
 def _check_against_oracle(D, Q, s, i, k, sub, offset=0):
@@ -71,6 +93,7 @@ def _check_against_oracle(D, Q, s, i, k, sub, offset=0):
     torch's own matmul, chunked on the device -- pre-selects every row within 1e-4 of the k-th score; the oracle re-scores
     those canonically and its canonical order must reproduce the list)."""
     n = D.shape[0]
+    _completeness_sweep_all_queries(D, Q, s)
     s_np, i_np = s.cpu().numpy(), i.cpu().numpy() - offset
     ds = np.diff(s_np.astype(np.float64), axis=1)
     assert (ds <= 0).all()
