@@ -164,6 +164,25 @@ def cpu_baseline(corpus_bf16, queries_bf16, nq_sample, k, gpu_ids):
             "best_effort_sample": f"{nq2} queries, fp32 matmul + torch.topk({k}) in blocks of 64 queries ({dt2:.1f} s)"}
 
 
+def completeness_all_queries(corpus_bf16, queries_bf16, scores, chunk=65536):
+    """Untimed check over EVERY query of the step's result (the CPU leg re-computes a bounded sample only): an independent fp32 sweep of
+    the whole packed corpus -- torch's own matmul, chunk by chunk on the device -- counts, per query, the rows above the list's k-th
+    score + 1e-4 (+- 1e-5); a list that missed such a row would hold fewer of them than the sweep finds.  -> the record for the JSON line."""
+    Qf = queries_bf16.float()
+    kth = scores[:, -1].float()
+    hi_thr, lo_thr = (kth + 1.1e-4)[None, :], (kth + 0.9e-4)[None, :]
+    above_hi = torch.zeros(Qf.shape[0], dtype=torch.int64, device=Qf.device)
+    above_lo = torch.zeros_like(above_hi)
+    for lo in range(0, corpus_bf16.shape[0], chunk):
+        a = corpus_bf16[lo:lo + chunk].float() @ Qf.T
+        above_hi += (a > hi_thr).sum(0)
+        above_lo += (a > lo_thr).sum(0)
+    in_list = (scores > (kth + 1e-4)[:, None]).sum(1)
+    bad = int(((above_hi > in_list) | (in_list > above_lo)).sum())
+    return {"queries_checked": int(Qf.shape[0]), "queries_with_a_missing_row_above_the_cut": bad,
+            "rule": "fp32 torch.matmul sweep of the whole corpus on the device: rows scoring above the list's k-th score + 1e-4 must all be in the list"}
+
+
 class Workload:
     """One configuration of the hot path on this rank: resident fp32 inputs, packed buffers, the step closure.
 
@@ -744,6 +763,11 @@ def main():
         out["exchange"] = exchange_obj(w, r)
     if args.dump_ids and rank == 0:
         torch.save(w.ids.cpu(), args.dump_ids)
+    if rank == 0 and world == 1:
+        try:     # every query of the last timed step against an independent sweep (beside the CPU leg's bounded sample)
+            out["all_queries_check"] = completeness_all_queries(w.shard, w.qpack, w.scores)
+        except Exception as e:
+            out["all_queries_check"] = {"skipped": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and args.cpu_queries > 0:
         out["cpu_baseline"] = cpu_baseline(w.shard, w.qpack, min(args.cpu_queries, args.queries), args.k, w.ids)
     elif rank == 0:
