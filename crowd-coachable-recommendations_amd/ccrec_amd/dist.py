@@ -77,8 +77,11 @@ def agreed_cuts(n_rows, world_size, weights=None, group=None, device=None):
         local = weighted_cuts(weights, world_size)
     if world_size <= 1 or not (dist.is_available() and dist.is_initialized()):
         return [int(c) for c in local]
-    if device is None and dist.get_backend(group) == "nccl":
-        device = torch.device("cuda", torch.cuda.current_device())
+    # the collective's tensor lives where the backend moves bytes: a cuda device under RCCL ("nccl"), the host under gloo
+    if dist.get_backend(group) == "nccl":
+        device = device if device is not None and torch.device(device).type == "cuda" else torch.device("cuda", torch.cuda.current_device())
+    else:
+        device = None
     t = torch.tensor(local, dtype=torch.int64, device=device if device is not None else "cpu")
     dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
     cuts = [int(c) for c in t.cpu().tolist()]
