@@ -18,6 +18,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -50,9 +52,9 @@ __device__ __forceinline__ void wait_vm() {
 
 // accumulator tiles: AGPR class for the first 64, VGPR class for the last 32
 __device__ __forceinline__ void mfma_a(f32x4 &c, bf16x8 a, bf16x8 b) { asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b)); }
-__device__ __forceinline__ void mfma_a0(f32x4 &c, bf16x8 a, bf16x8 b) { asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b)); }
+__device__ __forceinline__ void mfma_a0(f32x4 &c, bf16x8 a, bf16x8 b) { asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&a"(c) : "v"(a), "v"(b)); }
 __device__ __forceinline__ void mfma_v(f32x4 &c, bf16x8 a, bf16x8 b) { asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b)); }
-__device__ __forceinline__ void mfma_v0(f32x4 &c, bf16x8 a, bf16x8 b) { asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b)); }
+__device__ __forceinline__ void mfma_v0(f32x4 &c, bf16x8 a, bf16x8 b) { asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b)); }
 __device__ __forceinline__ void zero_a(f32x4 &c) {
     asm("v_accvgpr_write_b32 %0, 0\n\tv_accvgpr_write_b32 %1, 0\n\tv_accvgpr_write_b32 %2, 0\n\tv_accvgpr_write_b32 %3, 0" : "=a"(c[0]), "=a"(c[1]), "=a"(c[2]), "=a"(c[3]));
 }
@@ -63,6 +65,14 @@ __device__ __forceinline__ f32x4 from_a(const f32x4 &c) {   // AGPR tile -> VGPR
         : "a"(c[0]), "a"(c[1]), "a"(c[2]), "a"(c[3]));
     return r;
 }
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ void lds_read(u32x4 &dst, uint32_t addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF)); }
+template <int... Is, class F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, Is...>, F f) { (f(std::integral_constant<int, Is>{}), ...); }
+#define SEQ(n) std::make_integer_sequence<int, n>{}
+__device__ __forceinline__ bf16x8 bits(const u32x4 &x) { return __builtin_bit_cast(bf16x8, x); }
 
 struct Args {
     const uint16_t *D, *Q;
@@ -214,6 +224,171 @@ __global__ __launch_bounds__(256, 1) void big_tile_kernel(const Args a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Variant 2: the SAME tile as a software-pipelined single-wave stream.  A K step's 96 MFMAs run in two halves -- corpus tiles dt 0-3,
+// then dt 4-7 -- and the operand registers are refilled IN PLACE from the next K step's ring slot as they fall free: af[0..3] behind the
+// first half, bq[qt] behind the four MFMAs of query tile qt in the second half, af[4..7] at the end (the next step needs them only in ITS
+// second half).  The rendezvous of K step u + 1 (own DMA landed -> barrier) sits between the halves of step u; the ten DMA pieces of
+// step u + 3 go out between the query tiles of the second half.  No operand double buffer: 249 VGPRs are in use as it is.
+__global__ __launch_bounds__(256, 1) void big_tile_pipe_kernel(const Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wd = wv >> 1, wq = wv & 1;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int cofs = ((lq ^ (((lane >> 2) & 1) << 1)) << 4);
+    const int a_base = (wd * 128 + l15) * 64 + cofs;
+    const int b_base = QREG + (wq * 192 + l15) * 64 + cofs;
+    const int prow = lane >> 2;
+    const int xcd = blockIdx.x & (NXCD - 1), jx = blockIdx.x >> 3, per_x = gridDim.x >> 3;
+    const int n_rl = a.ranges / NXCD;
+    const int items = n_rl * a.qblocks;
+    for (int item = jx; item < items; item += per_x) {
+        const int rl = item / a.qblocks, qb = item % a.qblocks;
+        const int r = xcd + NXCD * rl;
+        const int64_t ntile = (a.n_vt - r + a.ranges - 1) / a.ranges;
+        if (ntile <= 0) continue;
+        const int q0 = qb * TQ;
+        const uint32_t lane_off = (uint32_t)(prow * (DIM * 2) + (((lane & 3) ^ (((prow >> 2) & 1) << 1)) << 4));
+        int64_t it = 0;
+        int iks = 0;
+        int64_t iu = 0;
+        const char *qblk = reinterpret_cast<const char *>(a.Q) + (int64_t)q0 * (DIM * 2);
+        auto issue_piece = [&](int i) __attribute__((always_inline)) {
+            char *buf = smem + (int)(iu % RINGB) * SUB;
+            int64_t vt = r + it * a.ranges;
+            if (vt > a.n_vt - 1) vt = a.n_vt - 1;
+            const char *dtile = reinterpret_cast<const char *>(a.D) + vt * (int64_t)TD * (DIM * 2);
+            const int kb = iks * 64;
+            const int p = wv * 10 + i;
+            const char *base = (p < TD / 16 ? dtile + (int64_t)p * 16 * (DIM * 2) : qblk + (int64_t)(p - TD / 16) * 16 * (DIM * 2)) + kb;
+            glds16(base + lane_off, buf + p * 1024);
+        };
+        auto advance = [&]() __attribute__((always_inline)) {
+            ++iu;
+            if (++iks == KS2) {
+                iks = 0;
+                ++it;
+            }
+        };
+        f32x4 acc_a[8][8], acc_v[8][4];
+        auto zero_all = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) {
+#pragma unroll
+                for (int qt = 0; qt < 8; ++qt) zero_a(acc_a[dt][qt]);
+#pragma unroll
+                for (int qt = 0; qt < 4; ++qt) acc_v[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        auto mm = [&](auto first, int dt, int qt, bf16x8 fa, bf16x8 fb) __attribute__((always_inline)) {
+            if constexpr (decltype(first)::value) {      // the first K step of a tile: C = 0 (no zeroing pass)
+                if (qt < 8)
+                    mfma_a0(acc_a[dt][qt < 8 ? qt : 0], fa, fb);
+                else
+                    mfma_v0(acc_v[dt][qt >= 8 ? qt - 8 : 0], fa, fb);
+            } else {
+                if (qt < 8)
+                    mfma_a(acc_a[dt][qt < 8 ? qt : 0], fa, fb);
+                else
+                    mfma_v(acc_v[dt][qt >= 8 ? qt - 8 : 0], fa, fb);
+            }
+        };
+        zero_all();
+        const int64_t U = ntile * KS2;
+        for (int j = 0; j < 3; ++j) {          // K steps 0, 1, 2 into the three ring slots
+#pragma unroll
+            for (int i = 0; i < 10; ++i) issue_piece(i);
+            advance();
+        }
+        wait_vm<20>();                          // this wave's pieces of K step 0
+        BARRIER();
+        // (Operand reads as inline asm with hand-counted lgkmcnt waits -- the step's own af[4..7] requested first thing, the top wait leaving
+        // exactly those in flight -- measured SLOWER: 13.9 ms against 11.7 with hipcc's own waits; so did a peeled first K step with C = 0
+        // instead of the zeroing pass: 13.2 ms.)
+        bf16x8 af[8], bq[12];
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) af[dt] = *reinterpret_cast<const bf16x8 *>(smem + a_base + dt * 1024);
+#pragma unroll
+        for (int qt = 0; qt < 12; ++qt) bq[qt] = *reinterpret_cast<const bf16x8 *>(smem + b_base + qt * 1024);
+        int cks = 0;
+        int64_t ct = 0;
+        const auto first = std::false_type{};
+        // (ONE flat loop over the K steps with the tile's epilogue behind a counter: the same body in a (tile, K step) loop nest runs 13.7 ms
+        // against 11.7 -- hipcc's waits and placement differ)
+        for (int64_t u = 0; u < U; ++u) {
+            // ---- first half: corpus tiles 0-3 x all query tiles
+#pragma unroll
+            for (int qt = 0; qt < 12; ++qt)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) mm(first, dt, qt, af[dt], bq[qt]);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- rendezvous of K step u + 1: its pieces have landed (those of u + 2 may be in flight); every wave has read ALL of slot u
+            wait_vm<10>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            BARRIER();
+            const char *nxt = smem + (int)((u + 1) % RINGB) * SUB;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) af[dt] = *reinterpret_cast<const bf16x8 *>(nxt + a_base + dt * 1024);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- second half: corpus tiles 4-7, query tile by query tile; behind each: its next fragment, and a DMA piece of K step u + 3
+#pragma unroll
+            for (int qt = 0; qt < 12; ++qt) {
+#pragma unroll
+                for (int dt = 4; dt < 8; ++dt) mm(first, dt, qt, af[dt], bq[qt]);
+                __builtin_amdgcn_sched_barrier(0);
+                bq[qt] = *reinterpret_cast<const bf16x8 *>(nxt + b_base + qt * 1024);
+                if (qt < 10) issue_piece(qt);       // into the slot of u (free since the barrier above)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            advance();
+#pragma unroll
+            for (int dt = 4; dt < 8; ++dt) af[dt] = *reinterpret_cast<const bf16x8 *>(nxt + a_base + dt * 1024);
+            __builtin_amdgcn_sched_barrier(0);
+            if (++cks == KS2) {
+                cks = 0;
+                float m = -INFINITY;
+#pragma unroll
+                for (int qt = 0; qt < 8; ++qt) {
+                    float mq = -INFINITY;
+#pragma unroll
+                    for (int dt = 0; dt < 8; ++dt) {
+                        const f32x4 c = from_a(acc_a[dt][qt]);
+                        mq = fmaxf(mq, fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3])));
+                    }
+                    m = fmaxf(m, mq);
+                }
+#pragma unroll
+                for (int qt = 0; qt < 4; ++qt) {
+                    float mq = -INFINITY;
+#pragma unroll
+                    for (int dt = 0; dt < 8; ++dt) {
+                        const f32x4 c = acc_v[dt][qt];
+                        mq = fmaxf(mq, fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3])));
+                    }
+                    m = fmaxf(m, mq);
+                }
+                if (m >= a.thr) a.out[(size_t)TD * TQ + blockIdx.x * 256 + tid] = m;
+                if (a.check && item == 0 && blockIdx.x == 0 && ct == 0) {
+#pragma unroll
+                    for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+                        for (int qt = 0; qt < 12; ++qt) {
+                            const f32x4 c = qt < 8 ? from_a(acc_a[dt][qt < 8 ? qt : 0]) : acc_v[dt][qt >= 8 ? qt - 8 : 0];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                a.out[(size_t)(wd * 128 + dt * 16 + 4 * lq + e) * TQ + wq * 192 + qt * 16 + l15] = c[e];
+                        }
+                }
+                ++ct;
+                zero_all();     // (a peeled first K step with C = 0 instead: 13.2 ms against 11.7 -- twice the loop body)
+            }
+        }
+        wait_vm<0>();
+        __syncthreads();
+    }
+}
+
 __global__ void fill_kernel(uint16_t *p, int64_t n, uint32_t seed) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         uint32_t x = (uint32_t)i * 2654435761u ^ seed;
@@ -252,6 +427,7 @@ int main(int argc, char **argv) {
     const size_t lds = (size_t)RINGB * SUB;
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&big_tile_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&big_tile_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&big_tile_pipe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     std::vector<uint16_t> hD((size_t)TD * DIM), hQ((size_t)TQ * DIM);
     std::vector<float> hO((size_t)TD * TQ);
     CK(hipMemcpy(hD.data(), D, hD.size() * 2, hipMemcpyDeviceToHost));
@@ -267,12 +443,14 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    for (int variant = 0; variant < 2; ++variant) {
+    for (int variant = 0; variant < 3; ++variant) {
         auto launch = [&]() {
             if (variant == 0)
                 hipLaunchKernelGGL(big_tile_kernel<0>, dim3(256), dim3(256), lds, 0, a);
-            else
+            else if (variant == 1)
                 hipLaunchKernelGGL(big_tile_kernel<1>, dim3(256), dim3(256), lds, 0, a);
+            else
+                hipLaunchKernelGGL(big_tile_pipe_kernel, dim3(256), dim3(256), lds, 0, a);
         };
         a.check = 1;
         CK(hipMemset(out, 0xff, (size_t)TD * TQ * 4));
@@ -302,7 +480,7 @@ int main(int argc, char **argv) {
             CK(hipEventElapsedTime(&ms, e0, e1));
             const double flops = 2.0 * n_rows * (double)n_q * DIM;
             printf("variant %d (%s): %.3f ms per pass = %.0f TFLOP/s of algorithmic work (%.3f of 2.5 PF); padded queries %d\n", variant,
-                   variant ? "DMA pieces spread between the MFMAs" : "DMA issue in front of the K step", ms / 5, flops / (ms / 5 * 1e-3) / 1e12,
+                   variant == 2 ? "software-pipelined: operands refilled in place behind the MFMAs" : variant ? "DMA pieces spread between the MFMAs" : "DMA issue in front of the K step", ms / 5, flops / (ms / 5 * 1e-3) / 1e12,
                    flops / (ms / 5 * 1e-3) / 2.5e15, a.qblocks * TQ);
         }
     }
