@@ -182,3 +182,23 @@ def test_generate_ranking_profile_against_the_references_own_function_golden_g18
     if block is not None:
         for i, q in enumerate(queries):
             assert [p for p in prof[q]][-4:] == sorted(block[q], key=lambda p: int(p[1:])) and all(prof[q][p] == -1e6 for p in block[q])
+
+
+def test_replica_cache_on_a_real_device():
+    """src/ccrec/util/data_parallel.py:8-20 on the one device this box has (the >1-device path needs a multi-GPU node: only the CPU test with
+    a faked broadcast covers it): cache_replicas() really broadcasts the tower to cuda:0 -- a detached copy, not the module itself --,
+    replicate() hands that stored copy back, the forward through the wrapper equals the module's, and the wrapper keeps working
+    inside generate_ranking_profile's embedding_func (scripts/al_0_rank.py:92, 98-101)."""
+    from ccrec_amd.replica_cache import DataParallel
+    tower = _tower().cuda()
+    dp = DataParallel(tower, device_ids=[0])
+    assert dp.cache_replicas() is dp and list(dp._by_device) == [0]
+    copy0 = dp._by_device[0]
+    assert copy0 is not tower and dp.replicate(tower, [0])[0] is copy0
+    p_src, p_cpy = next(tower.cls_model.parameters()), next(copy0.cls_model.parameters())
+    assert p_cpy.device.type == "cuda" and p_cpy.is_leaf and torch.equal(p_src, p_cpy)      # detach=True: a leaf, not a view into an autograd graph
+    tok = ToyTokenizer()(["w1 w2 w3", "w4"], max_length=16)
+    with torch.no_grad():
+        a = dp(**{k: v.cuda() for k, v in tok.items()}, output_step="mean_pooling")
+        b = tower(**{k: v.cuda() for k, v in tok.items()}, output_step="mean_pooling")
+    assert torch.equal(a, b)
