@@ -1089,6 +1089,8 @@ static int search_impl(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k, fl
 #ifdef CCR_DIAGNOSTICS
     g.dbg = ix->knobs.gemm_dbg;
     g.dbg_pitch = env_int("CCR_DBG_PITCH", ix->dim);
+    g.dbg_alloc_rows = getenv("CCR_DBG_ALLOC_ROWS") ? atoll(getenv("CCR_DBG_ALLOC_ROWS")) : 0;
+    g.dbg_alloc_q = env_int("CCR_DBG_ALLOC_Q", 0);
 #endif
     g.stagger = ix->knobs.stagger;
     g.qdirect = ix->knobs.qdirect;

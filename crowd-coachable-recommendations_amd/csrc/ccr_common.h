@@ -137,6 +137,8 @@ struct GemmArgs {
     int dbg;              // timing-only ablations (CCR_GEMM_DBG; results are WRONG when non-zero)
     int stagger;          // 32x32x16 kernel: 1 = the two wave groups run one barrier interval apart (production), 0 = in phase
     int item_swap;        // experiment (CCR_ITEM_SWAP, single-launch plans only): co-resident workgroups share the query block, not the range
+    int64_t dbg_alloc_rows;   // diagnostic library, with dbg_pitch: rows the array behind D holds (CCR_DBG_ALLOC_ROWS)
+    int dbg_alloc_q;      // ... and the rows the array behind Q holds (CCR_DBG_ALLOC_Q)
     int dbg_pitch;        // diagnostic library, CCR_GEMM_DBG & 1024: row pitch (elements) the DMA addresses are generated with
     int qdirect;          // 16x16x32 kernel: 0 = queries through the LDS ring, 1 / 3 / 4 / 5 = query fragments straight from global memory (gemm_topk16q_kernel)
 };

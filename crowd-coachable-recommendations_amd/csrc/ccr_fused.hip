@@ -508,7 +508,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
             int qrow = q0 + ((DBG & 256) ? i * 64 + wv * 8 + (lane >> 3) : i * 128 + srow);
             if (qrow > a.n_q - 1) qrow = a.n_q - 1;
             if constexpr ((DBG & 1024) != 0) {
-                const int last = (int)(((int64_t)a.n_q * a.dim - a.dim) / a.dbg_pitch);
+                const int last = (int)(((int64_t)(a.dbg_alloc_q > a.n_q ? a.dbg_alloc_q : a.n_q) * a.dim - a.dim) / a.dbg_pitch);
                 if (qrow > last) qrow = last;
                 qsrc[i] = a.Q + (int64_t)qrow * a.dbg_pitch + schunk * 8;
             } else
@@ -529,7 +529,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
                 int64_t drow = row0 + ((DBG & 256) ? i * 64 + wv * 8 + (lane >> 3) : i * 128 + srow);
                 if (drow > a.n_rows - 1) drow = a.n_rows - 1;
                 if constexpr ((DBG & 1024) != 0) {   // timing only: the traffic of rows at another PITCH (a.dbg_pitch elements), kept inside the array
-                    const int64_t last = (a.n_rows * a.dim - a.dim) / a.dbg_pitch;
+                    // (a.dbg_alloc_rows: rows of `dim` elements the array behind D really holds -- the experiment hands the index the first
+                    // n_rows = alloc * dim / pitch rows of a larger array, so that no address is clamped)
+                    const int64_t last = ((a.dbg_alloc_rows > a.n_rows ? a.dbg_alloc_rows : a.n_rows) * a.dim - a.dim) / a.dbg_pitch;
                     if (drow > last) drow = last;
                     dsrc[i] = a.D + drow * a.dbg_pitch + schunk * 8;
                 } else

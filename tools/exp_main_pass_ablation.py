@@ -17,6 +17,15 @@ PKG = os.path.join(ROOT, "crowd-coachable-recommendations_amd")
 PITCH = [(1152, f"thresholds +inf, DMA addresses generated with a row pitch of {p} elements ({2 * p} B) instead of 768 (1536 B)", {"CCR_DBG_PITCH": str(p)})
          for p in (768, 784, 800, 832, 896, 1024)]
 POLICY = [(2176, "thresholds +inf, cache policy sc1 on every DMA piece"), (4224, "thresholds +inf, sc0 on every piece"), (8320, "thresholds +inf, sc0 sc1 on every piece")]
+# --pitch2: the honest form -- the index is given the first n * 768 / pitch rows of the n-row array (CCR_DBG_ALLOC_ROWS = n), so that NO
+# address is clamped; each pitch is compared with the plain kernel on the same number of rows
+N_FULL = 2681468
+PITCH2 = []
+for _p in (768, 832, 896, 1024):
+    _rows = N_FULL * 768 // _p // 256 * 256
+    PITCH2.append((128, f"{_rows} rows at the array's own pitch (baseline of the next row)", {"ABL_USE_ROWS": str(_rows)}))
+    PITCH2.append((1152, f"{_rows} rows, DMA addresses with a row pitch of {2 * _p} B (no clamping: the array holds {N_FULL} rows)",
+                   {"ABL_USE_ROWS": str(_rows), "CCR_DBG_PITCH": str(_p), "CCR_DBG_ALLOC_ROWS": str(N_FULL), "CCR_DBG_ALLOC_Q": str(3452 * _p // 768 + 8)}))
 VARIANTS = [
     (0, "production kernel (hits recorded)"),
     (128, "complete kernel, thresholds +inf (no hit): BASELINE of the rows below"),
@@ -43,8 +52,10 @@ def one():
     for lo in range(0, n, 1 << 19):
         hi = min(n, lo + (1 << 19))
         D[lo:hi] = (torch.randn(hi - lo, d, generator=g, device="cuda") / d ** 0.5).to(torch.bfloat16)
-    Q = (torch.randn(nq, d, generator=g, device="cuda") / d ** 0.5).to(torch.bfloat16)
-    ix = ops.CorpusIndex(D)
+    nq_alloc = int(os.environ.get("CCR_DBG_ALLOC_Q", nq))      # --pitch2: the query array holds more rows than are searched (no clamping)
+    Q = (torch.randn(max(nq, nq_alloc), d, generator=g, device="cuda") / d ** 0.5).to(torch.bfloat16)[:nq]
+    use = int(os.environ.get("ABL_USE_ROWS", n))      # --pitch2: the index sees the first `use` rows of the n-row array
+    ix = ops.CorpusIndex(D[:use])
     dbg = int(os.environ.get("CCR_GEMM_DBG", "0"))
     ms = []
     for it in range(8):
@@ -65,7 +76,7 @@ def main():
     for plan, env_plan in (("single launch (CCR_PROGRESSIVE=0)", {"CCR_PROGRESSIVE": "0"}), ("default plan (three launches, thresholds re-tightened)", {})):
         lines.append(f"## {plan}")
         base = None
-        for dbg, what, *more in ([v for v in VARIANTS if v[0] in (0, 128)] + (PITCH if "--pitch" in sys.argv else POLICY) if ("--pitch" in sys.argv or "--policy" in sys.argv) else VARIANTS):
+        for dbg, what, *more in (PITCH2 if "--pitch2" in sys.argv else [v for v in VARIANTS if v[0] in (0, 128)] + (PITCH if "--pitch" in sys.argv else POLICY) if ("--pitch" in sys.argv or "--policy" in sys.argv or "--pitch2" in sys.argv) else VARIANTS):
             env = dict(os.environ, CCR_GEMM_DBG=str(dbg), CCR_MFMA16="1", **env_plan, **(more[0] if more else {}))
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one"], env=env, capture_output=True, text=True, timeout=900)
             vals = [float(m) for m in re.findall(r"main pass ([0-9.]+) ms", r.stderr)]
@@ -76,6 +87,8 @@ def main():
             if dbg == 128:
                 base = v
             rel = f"  ({v / base:5.3f} of baseline)" if base and dbg not in (0, 128) else ""
+            if dbg == 128:
+                base = v
             lines.append(f"dbg={dbg:3d}  {v:8.3f} ms{rel}   {what}")
             print(lines[-1], flush=True)
     open(out, "w").write("\n".join(lines) + "\n")
