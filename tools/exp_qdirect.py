@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Same-box A/B of the query-direct forms of the 16x16x32 main pass (CCR_QDIRECT = 0 ring / 1 / 3 / 4 / 5, csrc/ccr_fused.hip
-gemm_topk16q_kernel) on the PRODUCTION library.  Runs ON THE GPU BOX.  One process per variant; every variant must return the ids and
+gemm_topk16q_kernel; since the measurement the kernel is compiled into the DIAGNOSTIC library only: tools/build_diag.sh first).  Runs ON THE GPU BOX.  One process per variant; every variant must return the ids and
 score bits of variant 0 (the canonical results do not depend on the main pass).
 
   python3 tools/exp_qdirect.py [outfile] [--rows N --queries Q --k K]"""
@@ -20,6 +20,9 @@ def arg(name, dflt):
 def one():
     sys.path[:0] = [ROOT, PKG]
     import torch
+    from ccrec_amd import _lib
+    if os.environ.get("QD_DIAG_LIB", "1") == "1":     # the query-direct kernels are compiled into the DIAGNOSTIC library only (tools/build_diag.sh)
+        _lib.LIB_PATH = os.path.join(PKG, "lib_diag", "libccr_hip.so")
     from ccrec_amd import ops
     n, nq, d, k = arg("--rows", 2681468), arg("--queries", 3452), 768, arg("--k", 100)
     g = torch.Generator(device="cuda").manual_seed(1234)
