@@ -92,7 +92,7 @@ def test_shard_message_through_rccl_world1():
 from helpers import run_child_with_evidence as _run_child   # noqa: E402  (a child that overruns FAILS the test, with evidence)
 
 
-@pytest.mark.parametrize("world,rows,launcher", [(2, 200000, "plain"), (2, 200000, "torchrun"), (3, 200003, "plain")])
+@pytest.mark.parametrize("world,rows,launcher", [(2, 200000, "plain"), (2, 200000, "torchrun"), (3, 200003, "plain"), (4, 200005, "torchrun")])
 def test_bench_ranks_rehearsal_in_fresh_processes(tmp_path, world, rows, launcher):
     """The N > 1 branch of bench.py as the driver launches it -- `python bench.py --gpus N` (bench.py starts its own ranks as a
     child torch.distributed.run) and the explicit `python -m torch.distributed.run ... bench.py --gpus N` -- rehearsed on this
