@@ -41,7 +41,8 @@ class SearchStats(ctypes.Structure):
                 ("n_candidates", ctypes.c_int64), ("ms_sample", ctypes.c_float), ("ms_threshold", ctypes.c_float),
                 ("ms_main", ctypes.c_float), ("ms_select", ctypes.c_float), ("ms_fallback", ctypes.c_float),
                 ("ms_total", ctypes.c_float), ("n_retried", ctypes.c_int32), ("n_dense", ctypes.c_int32),
-                ("main_launches", ctypes.c_int32), ("opt_rank", ctypes.c_int32)]
+                ("main_launches", ctypes.c_int32), ("opt_rank", ctypes.c_int32), ("main_tile_queries", ctypes.c_int32),
+                ("reserved0", ctypes.c_int32)]
 
 
 class CcrError(RuntimeError):

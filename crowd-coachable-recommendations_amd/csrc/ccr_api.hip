@@ -51,18 +51,19 @@ Knobs read_knobs() {
     kn.optimistic = env_int("CCR_OPTIMISTIC", -1);
     kn.opt_rank = env_int("CCR_OPT_RANK", 0);
     kn.narrow = env_int("CCR_NARROW", -1);
+    kn.wide = env_int("CCR_WIDE", -1);
     kn.narrow_nt = env_int("CCR_NARROW_NT", 0);
     kn.narrow_grid = env_int("CCR_NARROW_GRID", 0);
     kn.narrow_groups = env_int("CCR_NARROW_GROUPS", NARROW_MAX_GROUPS);
     return kn;
 }
 
-static int pick_qgroups(int qblocks, int dim, const Knobs &kn) {
+static int pick_qgroups(int qblocks, int dim, const Knobs &kn, int tile_q = TILE_Q) {
     {
         const int v = kn.qgroups;
         if ((v == 1 || v == 2 || v == 4 || v == 8) && qblocks % v == 0) return v;
     }
-    const size_t block_bytes = (size_t)TILE_Q * dim * 2;
+    const size_t block_bytes = (size_t)tile_q * dim * 2;
     int best = 1;
     for (int gq = 1; gq <= NUM_XCD; gq *= 2) {
         if (qblocks % gq) continue;
@@ -157,16 +158,18 @@ static int optimistic_rank(int k, int64_t sample, int64_t tiles, const Knobs &kn
 
 static MainPassChoice choose_main_pass(const Plan &p, int k, int64_t sample_a, int64_t sample_b, int64_t sample_c, const Knobs &kn,
                                        bool single_only = false) {
-    const int nrc = NUM_XCD / p.qgroups, qb_per = p.qblocks / p.qgroups, per_x = p.grid / NUM_XCD;
+    const int nrc = NUM_XCD / p.main_qgroups, qb_per = p.main_qblocks / p.main_qgroups, per_x = p.grid / NUM_XCD;
+    // a 256 x 384 tile in units of the 256 x 256 tile the other terms were measured in (1.5x the multiply-adds at ~1.09x the rate)
+    const double tile_cost = p.tile_q == WIDE_Q ? 1.37 : 1.0;
     // the select stage walks ranges x sublists sub-lists per query: 1 024 with its 256-thread form, 2 048 with the 1 024-thread
     // form large k uses anyway (rescore_cap > 512)
     int64_t max_lists = p.rescore_cap > 512 ? 2048 : 1024;
     // one or two query blocks: 128 ranges x 8 sub-lists would leave half of the workgroups without a work item (n_q = 1: main pass
     // 1.34 ms instead of 0.7) -- the select stage's wide form walks 2 048 sub-lists, and its cost does not matter for so few queries
-    if ((max_lists / p.sublists) * p.qblocks < p.grid) max_lists = 2048;
+    if ((max_lists / p.sublists) * p.main_qblocks < p.grid) max_lists = 2048;
     if (kn.max_lists >= 64 && kn.max_lists < max_lists) max_lists = kn.max_lists;
     const int64_t r_hi = std::min<int64_t>(max_lists / p.sublists, round_up(std::max<int64_t>(1, p.tiles / 8), NUM_XCD));
-    const int64_t target = std::min<int64_t>(r_hi, round_up(std::max<int64_t>(NUM_XCD, (int64_t)p.grid * 6 / p.qblocks), NUM_XCD));
+    const int64_t target = std::min<int64_t>(r_hi, round_up(std::max<int64_t>(NUM_XCD, (int64_t)p.grid * 6 / p.main_qblocks), NUM_XCD));
     const bool prog_on = kn.progressive != 0 && !single_only;   // 0: single launch (the streaming kernel of small batches has no phases)
     const int max_phases = kn.max_phases;        // 2: at most one re-tightening
     const double qscale = (double)p.nq_pad / 3584.0;
@@ -199,7 +202,7 @@ static MainPassChoice choose_main_pass(const Plan &p, int k, int64_t sample_a, i
         for (int64_t R = r_lo; R <= std::min(r_hi, target * 2); R += NUM_XCD) {
             if (kn.ranges > 0 && R != std::min<int64_t>(r_hi, std::max<int64_t>(r_lo, round_up(kn.ranges, NUM_XCD)))) continue;
             const int64_t items = R / nrc * qb_per;
-            const double item_cost = (double)((p.tiles + R - 1) / R) + 0.15;   // + pipeline fill per item
+            const double item_cost = ((double)((p.tiles + R - 1) / R) + 0.15) * tile_cost;   // + pipeline fill per item
             auto rounds = [&](int64_t n) { return (double)((n + per_x - 1) / per_x); };
             const double common = smp_cost + select_per_range * (double)R + 1e-3 * std::abs((double)(R - target));
             const double single = rounds(items) * item_cost + hit_w * survivors(0.0, 0.0) + common;
@@ -247,6 +250,9 @@ static Plan make_plan_for(int64_t n_rows, int dim, int n_q, int k, int flags, in
     memset(&p, 0, sizeof(p));
     p.nq_pad = (int)round_up(n_q, TILE_Q);
     p.qblocks = p.nq_pad / TILE_Q;
+    p.tile_q = TILE_Q;
+    p.main_qblocks = p.qblocks;
+    p.main_qgroups = 1;
     p.tiles = (n_rows + TILE_DOCS - 1) / TILE_DOCS;
     p.full_tiles = n_rows / TILE_DOCS;
     p.grid = std::max(NUM_XCD, num_cu / NUM_XCD * NUM_XCD);
@@ -304,6 +310,22 @@ static Plan make_plan_for(int64_t n_rows, int dim, int n_q, int k, int flags, in
                             narrow_lds_bytes(nqt, dim) <= (size_t)160 * 1024 && (ngroups == 1 || num_cu >= 16);
         p.narrow = narrow ? nqt : 0;
         p.narrow_groups = narrow ? ngroups : 1;
+        // the main pass's tile: 256 x 384 (gemm_topk16w_kernel: -17 % bytes per flop through the L1 miss path that bounds the 256 x 256
+        // kernel, measured ~9 % faster per flop) where its padding does not eat the gain -- 3 452 queries: nine blocks of 384 = 3 456
+        // against fourteen of 256 = 3 584; 512 queries stay on two 256-blocks
+        p.tile_q = TILE_Q;
+        p.main_qblocks = p.qblocks;
+        if (!narrow && p.mfma16 && dim % 32 == 0 && kn.wide != 0) {
+            const int wb = (n_q + WIDE_Q - 1) / WIDE_Q;
+            if (kn.wide == 1 || (double)wb * WIDE_Q * 0.915 < (double)p.qblocks * TILE_Q) {
+                p.tile_q = WIDE_Q;
+                p.main_qblocks = wb;
+                p.nq_pad = (int)round_up(std::max<int64_t>(n_q, (int64_t)wb * WIDE_Q), TILE_Q);   // the counters of every block's columns exist
+                p.qblocks = p.nq_pad / TILE_Q;
+                p.qgroups = pick_qgroups(p.qblocks, dim, kn);
+            }
+        }
+        p.main_qgroups = pick_qgroups(p.main_qblocks, dim, kn, p.tile_q);
         const MainPassChoice choice = choose_main_pass(p, k, sample, sample_alt, sample_big, kn, narrow);
         sample = choice.sample;
         const int64_t R = choice.ranges;
@@ -315,7 +337,7 @@ static Plan make_plan_for(int64_t n_rows, int dim, int n_q, int k, int flags, in
         p.item_b = choice.item_b;
         p.opt_rank = choice.opt_rank;
         // ranges that hold items of a phase: the candidate segments (a range started in phase A keeps phase A's capacity)
-        const int nrc_p = NUM_XCD / p.qgroups, qb_per_p = p.qblocks / p.qgroups;
+        const int nrc_p = NUM_XCD / p.main_qgroups, qb_per_p = p.main_qblocks / p.main_qgroups;
         const int64_t items_p = R / nrc_p * qb_per_p;
         const int64_t RA = p.item_a ? std::min<int64_t>(R, (int64_t)nrc_p * ((p.item_a + qb_per_p - 1) / qb_per_p)) : 0;
         const int64_t RB = p.item_b ? std::min<int64_t>(R, (int64_t)nrc_p * ((p.item_b + qb_per_p - 1) / qb_per_p)) : 0;
@@ -722,7 +744,7 @@ static int run_main_pass(const ccr_index *ix, const Plan &p, GemmArgs gm, uint2 
             const int full = rl_full * nrc * p.sublists, partial = part ? (rl_full + 1) * nrc * p.sublists : 0;
             const bool more = bounds[ph] < items && ph < 3;   // another re-tightening follows this phase
             const int rc = launch_threshold_update(cand, cnt, full, partial, part, prev_full, prev_part, prev_blocks, qb_per, p.sublists, n_q,
-                                                   p.nq_pad, p.cand, k, cq, ix->tile_norm, top, updates > 0, more, thr, s);
+                                                   p.nq_pad, p.cand, k, cq, ix->tile_norm, top, updates > 0, more, thr, s, p.tile_q);
             if (rc != CCR_OK) return rc;
             prev_full = full;
             prev_part = partial;
@@ -731,7 +753,8 @@ static int run_main_pass(const ccr_index *ix, const Plan &p, GemmArgs gm, uint2 
         }
         gm.item_begin = done;
         gm.item_end = bounds[ph];
-        const int rc = p.mfma16 ? launch_gemm16_filter(gm, p.grid, s) : launch_gemm_filter(gm, p.grid, s);
+        const int rc = p.tile_q == WIDE_Q ? launch_gemm16w_filter(gm, p.grid, s)
+                                          : (p.mfma16 ? launch_gemm16_filter(gm, p.grid, s) : launch_gemm_filter(gm, p.grid, s));
         if (rc != CCR_OK) return rc;
         done = bounds[ph];
     }
@@ -785,6 +808,7 @@ static int search_complete(ccr_index *ix) {
     ix->stats.sublists = p.narrow ? p.first_sp : p.sublists;
     ix->stats.main_launches = 1 + (p.item_a ? 1 : 0) + (p.item_b ? 1 : 0);
     ix->stats.opt_rank = p.opt_rank;
+    ix->stats.main_tile_queries = p.narrow ? 0 : p.tile_q;
     ix->stats.n_candidates = (int64_t)host.ncand;
     const int begin = 0;
     ix->stats.n_dense = 0;
@@ -1119,6 +1143,8 @@ static int search_impl(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k, fl
     gm.ranges = p.ranges;
     gm.thr = thr;
     gm.cnt = cnt;
+    gm.qblocks = p.main_qblocks;   // (blocks of p.tile_q queries; the sample pass above walks blocks of TILE_Q)
+    gm.qgroups = p.main_qgroups;
     gm.item_swap = (ix->knobs.item_swap && !p.item_a) ? 1 : 0;   // the phases' "ranges completed so far" needs the default order
     unsigned long long *stamps = nullptr;   // CCR_GEMM_DBG=16: in-kernel cycle stamps of the main pass (diagnostic build only)
 #ifdef CCR_DIAGNOSTICS

@@ -39,6 +39,7 @@ void set_error(const char *fmt, ...);
 // ---- geometry of the fused MFMA path (one definition for kernels and planner)
 constexpr int TILE_DOCS = 256;      // corpus rows per GEMM tile
 constexpr int TILE_Q = 256;         // queries per GEMM tile
+constexpr int WIDE_Q = 384;         // ... of the 256 x 384 form of the main pass (gemm_topk16w_kernel)
 constexpr int TILE_K = 32;          // K granularity of the fused kernels (one LDS sub-stage = 32 bf16 = 64 B per row): dim % 32 == 0
 constexpr int GEMM_THREADS = 512;   // 8 waves: 2 (doc halves) x 4 (query quarters)
 constexpr int GROUPS_PER_TILE = 16; // group maxima per (sample tile, query): 2 wave rows x 4 MFMA tiles x 2 lane halves
@@ -75,8 +76,11 @@ __host__ __device__ __forceinline__ long long cand_sublist(const CandLayout &L, 
 
 struct Plan {
     int fused;            // 1 = fused MFMA path usable
-    int nq_pad;           // n_q rounded up to TILE_Q
-    int qblocks;          // nq_pad / TILE_Q
+    int nq_pad;           // n_q rounded up to TILE_Q (256 x 384 main pass: at least main_qblocks * 384)
+    int qblocks;          // nq_pad / TILE_Q: the query blocks of the sample pass (and of every 256 x 256 kernel)
+    int tile_q;           // queries per tile of the MAIN pass: TILE_Q, or 384 (gemm_topk16w_kernel)
+    int main_qblocks;     // query blocks of the main pass: ceil(n_q / tile_q)
+    int main_qgroups;     // ... and their groups over the XCDs (divides main_qblocks)
     int64_t tiles;        // ceil(n_rows / TILE_DOCS)
     int64_t full_tiles;   // floor(n_rows / TILE_DOCS)
     int sample_tiles;     // tiles scored by the threshold pass

@@ -745,6 +745,246 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
 }
 
 // =============================================================================================
+// WIDE form of the 16x16x32 main pass (round 6): a 256 x 384 tile on the same eight waves.
+// Why: the 256 x 256 kernel is bound by the CU's L1 miss path (~48 cycles per 1-KiB LDS-DMA piece, 32 pieces per K step of
+// 32 against 1 070 cycles of MFMA).  A wave tile of 128 x 96 -- 192 accumulator registers of the wave's 256 -- takes (256 + 384) x 64 B
+// per K step for 1.5x the multiply-adds: -17 % bytes per flop through that path, 14 instead of 18 operand reads per 48 MFMAs, and a
+// query count like 3 452 pads to 3 456 (nine blocks) instead of 3 584.  Same occupancy (two waves per SIMD), same ping-pong of the two
+// wave groups, same LDS image and swizzle, same candidate layout (8 sub-lists per (range, query): wave row x lane >> 4).
+//   registers: 192 accumulators + 8 corpus fragments (32) + 3 query fragments (12; the other three are refilled IN PLACE behind the
+//     MFMAs of the first three query tiles) -- so nothing else may live in registers across the K loop: the thresholds and margin
+//     coefficients of the block's 384 queries and the sub-list counters sit in LDS, candidate addresses are rebuilt on a hit, and the
+//     DMA source of every piece is a wave-uniform base + one clamped per-lane offset computed at issue;
+//   ring: three 40-KiB slots (80 KiB in flight), 5 LDS-DMA pieces per wave and K step; + 3 KiB thresholds + 12 KiB counters = 135 KiB;
+//   protocol (K step u, both groups, g1 one barrier behind): [filter of a finished tile] 8 + 3 ds_read_b128 of u | DMA of u + 2 into the
+//     slot of u - 1 | own DMA of u + 1 landed (vmcnt) | lgkmcnt(0) | barrier A | 48 MFMAs with the three refills | lgkmcnt(0) | barrier B.
+//     RAW: a wave confirms its pieces of u + 1 before its barrier A_u, every reader of u + 1 starts behind a later barrier instance.
+//     WAR: the slot of u - 1 is rewritten in mem(u); every wave's reads of u - 1 (refills included) were retired before its barrier
+//     B_{u-1}, which for both groups precedes every mem(u).
+// dim % 32 == 0 only (the planner keeps the 256 x 256 kernel elsewhere).  DBG 128 (diagnostic library): thresholds +inf.
+constexpr int WIDE_SUB_BYTES = (TILE_DOCS + WIDE_Q) * SUB_K * 2;   // 40960
+constexpr int WIDE_Q_REGION = TILE_DOCS * SUB_K * 2;               // 16384
+constexpr int WIDE_RING = 3;
+constexpr int WIDE_PIECES = 5;                                     // 40 pieces of 1 KiB per K step over 8 waves
+constexpr int WIDE_QT = 6;                                         // query tiles of 16 per wave
+constexpr size_t WIDE_LDS = (size_t)WIDE_RING * WIDE_SUB_BYTES + WIDE_Q * 8 + (size_t)(GEMM_THREADS / 64) * WIDE_QT * 64 * 4;
+
+template <int DBG>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16w_kernel(const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *s_tc = reinterpret_cast<float2 *>(smem + WIDE_RING * WIDE_SUB_BYTES);          // [384] {tau_q, cq} of the item's query block
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(smem + WIDE_RING * WIDE_SUB_BYTES + WIDE_Q * 8);   // [wave][query tile][lane]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wd = wv >> 2;
+    const int wq = wv & 3;
+    const int l15 = lane & 15;
+    const int lq = lane >> 4;
+    const bool g1 = (wv >= 4);
+    const int KS2 = a.dim / SUB_K;
+    const uint32_t pitch = (uint32_t)a.dim * 2u;    // bytes per row
+
+    const int prow = lane >> 2;                     // row of a DMA piece this lane fetches a 16-byte chunk of
+    const uint32_t chunk_off = (uint32_t)(((lane & 3) ^ (((prow >> 2) & 1) << 1)) << 4);
+    const int cofs = ((lq ^ (((lane >> 2) & 1) << 1)) << 4);
+    const int a_base = (wd * 128 + l15) * 64 + cofs;                   // + dt * 1024
+    const int b_base = WIDE_Q_REGION + (wq * 96 + l15) * 64 + cofs;   // + qt * 1024
+    uint32_t *my_cnt = s_cnt + (wv * WIDE_QT) * 64 + lane;             // + qt * 64
+
+    const int xcd = blockIdx.x & (NUM_XCD - 1);
+    const int jx = blockIdx.x >> 3;
+    const int per_x = gridDim.x >> 3;
+    const int qg = xcd % a.qgroups;
+    const int rc = xcd / a.qgroups;
+    const int nrc = NUM_XCD / a.qgroups;
+    const int qb_per = a.qblocks / a.qgroups;
+    const int count_x = (a.ranges / nrc) * qb_per;
+    const int item_end = a.item_end < count_x ? a.item_end : count_x;
+
+    for (int item = a.item_begin + jx; item < item_end; item += per_x) {
+        const int n_rl = a.ranges / nrc;
+        const int rl = a.item_swap ? item % n_rl : item / qb_per;
+        const int qb = qg * qb_per + (a.item_swap ? item / n_rl : item % qb_per);
+        const int r = rc + nrc * rl;
+        const int64_t ntile = (a.n_vt - r + a.ranges - 1) / a.ranges;
+        if (ntile <= 0) continue;
+        const int q0 = qb * WIDE_Q;
+
+        int cap, seg_r0;
+        long long seg_base;
+        cand_segment(a.lay, r, cap, seg_r0, seg_base);   // this range's segment of the candidate area (wave-uniform)
+        if (tid < WIDE_Q) {
+            const int q = q0 + tid;
+            float t = (q < a.n_q) ? a.thr[q] : __builtin_nanf("");
+            if constexpr ((DBG & 128) != 0) t = INFINITY;
+            s_tc[tid] = make_float2(t, (q < a.n_q) ? a.cq[q] : 0.f);
+        }
+#pragma unroll
+        for (int qt = 0; qt < WIDE_QT; ++qt) my_cnt[qt * 64] = 0u;
+        // (the first read of s_tc is behind at least one barrier; the vector loads above are complete before the first DMA piece is counted)
+        CCR_WAIT_VM(0);
+
+        const int qlimit = (a.n_q - 1 - q0 < WIDE_Q - 1) ? a.n_q - 1 - q0 : WIDE_Q - 1;   // last valid row of the query block
+        const char *qblk = reinterpret_cast<const char *>(a.Q) + (int64_t)q0 * pitch;
+
+        f32x4v acc[8][WIDE_QT];
+        const int64_t U = ntile * KS2;
+        int64_t iu = 0, it = 0;
+        int iks = 0;
+        auto issue = [&]() __attribute__((always_inline)) {
+            char *buf = smem + (int)(iu % WIDE_RING) * WIDE_SUB_BYTES;
+            const int64_t row0 = (r + it * a.ranges) * a.tile_stride * TILE_DOCS;
+            const int dlimit = (a.n_rows - 1 - row0 < TILE_DOCS - 1) ? (int)(a.n_rows - 1 - row0) : TILE_DOCS - 1;   // last valid row of the tile
+            const char *dtile = reinterpret_cast<const char *>(a.D) + row0 * pitch;
+            const uint32_t kb = (uint32_t)iks * (SUB_K * 2);
+            // (opaque: the per-piece offsets are rebuilt at every issue -- hoisted out of the K loop they would cost ten registers the
+            // accumulators need)
+            int pr = prow;
+            uint32_t co = chunk_off;
+            asm volatile("" : "+v"(pr), "+v"(co));
+#pragma unroll
+            for (int i = 0; i < WIDE_PIECES; ++i) {
+                const int p = wv * WIDE_PIECES + i;              // wave-uniform: image rows p * 16 .. + 15 (0-255 corpus, 256-639 queries)
+                const bool is_d = p < TILE_DOCS / 16;
+                const int prow0 = is_d ? p * 16 : (p - TILE_DOCS / 16) * 16;
+                const int limit = is_d ? dlimit : qlimit;
+                int row = prow0 + pr;
+                row = row < limit ? row : limit;                 // rows beyond the end re-read the last row (their scores are never recorded)
+                const char *base = is_d ? dtile : qblk;
+                glds16(base + ((uint32_t)row * pitch + co + kb), buf + p * 1024);
+            }
+            ++iu;
+            if (++iks == KS2) {
+                iks = 0;
+                ++it;
+            }
+        };
+
+        auto epilogue = [&](int64_t vt, float nt) __attribute__((always_inline)) {   // nt: norm bound of the tile's rows (wave-uniform)
+            // (opaque lane coordinates: every address below is rebuilt here instead of living in registers across the K loop)
+            int l15o = l15, lqo = lq;
+            asm volatile("" : "+v"(l15o), "+v"(lqo));
+            const int64_t row_base = vt * a.tile_stride * TILE_DOCS + wd * 128 + 4 * lqo;  // + dt*16 + e
+#pragma unroll
+            for (int qt = 0; qt < WIDE_QT; ++qt) {
+                float sub[8];
+#pragma unroll
+                for (int dt = 0; dt < 8; ++dt)
+                    sub[dt] = fmaxf(fmaxf(acc[dt][qt][0], acc[dt][qt][1]), fmaxf(acc[dt][qt][2], acc[dt][qt][3]));
+                const float2 tc = s_tc[wq * 96 + qt * 16 + l15o];
+                const float t = fmaf(-tc.y, nt, tc.x);   // per-tile margin: mfma + cq * ||d|| >= tau_q with ||d|| <= nt
+                const float mall = fmaxf(fmaxf(fmaxf(sub[0], sub[1]), fmaxf(sub[2], sub[3])),
+                                         fmaxf(fmaxf(sub[4], sub[5]), fmaxf(sub[6], sub[7])));
+                if (__ballot(mall >= t) != 0ull) {
+                    const int q = q0 + wq * 96 + qt * 16 + l15o;
+                    uint2 *clist = a.cand + seg_base + ((int64_t)(r - seg_r0) * a.nq_pad + q) * 8 * cap + (wd * 4 + lqo);   // slot-major cell
+                    uint32_t *cn = s_cnt + (wv * WIDE_QT + qt) * 64 + lqo * 16 + l15o;
+#pragma unroll
+                    for (int dt = 0; dt < 8; ++dt) {
+                        if (sub[dt] >= t) {  // rare, divergent: 4 rows to test
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float v = acc[dt][qt][e];
+                                const int64_t doc = row_base + dt * 16 + e;
+                                if (v >= t && doc < a.n_rows) {
+                                    const uint32_t n = *cn;
+                                    if (n < (uint32_t)cap) clist[(size_t)n * 8] = make_uint2(__float_as_uint(v), (uint32_t)doc);
+                                    *cn = n + 1u;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        };
+
+        const int npro = U < 2 ? (int)U : 2;
+        for (int i = 0; i < npro; ++i) issue();
+        if (npro == 2)
+            wait_vm<WIDE_PIECES>();
+        else
+            CCR_WAIT_VM(0);
+        CCR_BARRIER();
+        if (g1) CCR_BARRIER();
+
+        int cks = 0;
+        int64_t ct = 0;
+        bool pending = false;
+        int64_t pending_vt = 0;
+        float pending_nt = 0.f;
+        for (int64_t u = 0; u < U; ++u) {
+            if (pending) {
+                epilogue(pending_vt, pending_nt);
+                pending = false;
+            }
+            const char *buf = smem + (int)(u % WIDE_RING) * WIDE_SUB_BYTES;
+            bf16x8 af[8], bfr[3];
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) af[dt] = *reinterpret_cast<const bf16x8 *>(buf + a_base + dt * 1024);
+#pragma unroll
+            for (int qt = 0; qt < 3; ++qt) bfr[qt] = *reinterpret_cast<const bf16x8 *>(buf + b_base + qt * 1024);
+            if (u + 2 < U) {
+                issue();                       // K step u + 2 into the slot of u - 1
+                wait_vm<WIDE_PIECES>();        // own pieces of u + 1 have landed
+            } else {
+                CCR_WAIT_VM(0);
+            }
+            CCR_WAIT_LGKM0();
+            CCR_BARRIER();
+            if (cks == 0) {
+                const f32x4v z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int qt = 0; qt < WIDE_QT; ++qt) {
+#pragma unroll
+                    for (int dt = 0; dt < 8; ++dt) acc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[dt], bfr[qt % 3], z, 0, 0, 0);
+                    if (qt < 3) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        bfr[qt] = *reinterpret_cast<const bf16x8 *>(buf + b_base + (qt + 3) * 1024);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int qt = 0; qt < WIDE_QT; ++qt) {
+#pragma unroll
+                    for (int dt = 0; dt < 8; ++dt)
+                        acc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[dt], bfr[qt % 3], acc[dt][qt], 0, 0, 0);
+                    if (qt < 3) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        bfr[qt] = *reinterpret_cast<const bf16x8 *>(buf + b_base + (qt + 3) * 1024);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            if (++cks == KS2) {
+                cks = 0;
+                // (the tile's norm bound: a SCALAR load + wait right here, behind the MFMAs just issued)
+                const int64_t vt_done = r + ct * a.ranges;
+                const float nt_done = load_uniform_f32(a.tile_norm + vt_done * a.tile_stride);
+                if (g1) {
+                    epilogue(vt_done, nt_done);
+                } else {
+                    pending = true;
+                    pending_vt = vt_done;
+                    pending_nt = nt_done;
+                }
+                ++ct;
+            }
+            CCR_WAIT_LGKM0();   // the refills of this K step are retired before the barrier that frees its slot
+            CCR_BARRIER();
+        }
+        if (pending) epilogue(pending_vt, pending_nt);
+        if (!g1) CCR_BARRIER();
+
+#pragma unroll
+        for (int qt = 0; qt < WIDE_QT; ++qt)
+            a.cnt[((int64_t)r * a.nq_pad + q0 + wq * 96 + qt * 16 + l15) * 8 + wd * 4 + lq] = my_cnt[qt * 64];
+        __syncthreads();
+    }
+}
+
+// =============================================================================================
 // QUERY-DIRECT form of the 16x16x32 main pass (round 6) -- an EXPERIMENT kept for the record, compiled only into the diagnostic library
 // (make DIAG=1 / tools/build_diag.sh, CCR_QDIRECT = 1 / 3 / 4 / 5).  Exact (every form returns the production kernel's ids and score bits)
 // and 38-48 % SLOWER: NQ main pass 16.8-18.2 ms against 12.1 (profiles/r06_qdirect_ab.txt).  Why: what bounds the main pass is the CU's
@@ -1279,7 +1519,7 @@ __global__ __launch_bounds__(256) void threshold_update_kernel(const uint2 *__re
                                                               const CandLayout lay, int k, int compact,
                                                               const float *__restrict__ cq, const float *__restrict__ tile_norm,
                                                               uint32_t *__restrict__ top, int top_in, int top_out,
-                                                              float *__restrict__ thr) {
+                                                              float *__restrict__ thr, int tile_q) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_val[];   // [compact] orderable lower bounds of the candidates found so far
     __shared__ uint32_t s_hist[256];
     __shared__ uint32_t s_ctl[4];
@@ -1289,7 +1529,7 @@ __global__ __launch_bounds__(256) void threshold_update_kernel(const uint2 *__re
     const int q = blockIdx.x;
     // sub-lists complete so far: those of the fully scored ranges, plus one more row of ranges for the queries whose block
     // (position inside its XCD group) was already scored in the partially finished one
-    const int qpos = (q / TILE_Q) % qb_per;
+    const int qpos = (q / tile_q) % qb_per;
     const int nsub = qpos < part_blocks ? nsub_part : nsub_full;
     uint32_t *top_n = top;
     uint32_t *top_v = top ? top + nq_pad + (int64_t)q * k : nullptr;
@@ -1886,6 +2126,17 @@ int launch_gemm16_filter(const GemmArgs &a, int grid, hipStream_t s) {
     if (a.dim % SUB_K != 0) return launch_kernel(&gemm_topk16_kernel<EPI_FILTER, 0, true>, RING * (size_t)SUB_BYTES, a, grid, s);
     return launch_kernel(&gemm_topk16_kernel<EPI_FILTER, 0>, RING * (size_t)SUB_BYTES, a, grid, s);
 }
+// the 256 x 384 form (a.qblocks counts blocks of WIDE_Q queries; dim % 32 == 0)
+int launch_gemm16w_filter(const GemmArgs &a, int grid, hipStream_t s) {
+    if (a.dim % SUB_K != 0 || a.dim < SUB_K) {
+        set_error("launch_gemm16w_filter: dim %d is not a multiple of %d", a.dim, SUB_K);
+        return CCR_ERR_INVALID;
+    }
+#ifdef CCR_DIAGNOSTICS
+    if (a.dbg == 128) return launch_kernel(&gemm_topk16w_kernel<128>, WIDE_LDS, a, grid, s);
+#endif
+    return launch_kernel(&gemm_topk16w_kernel<0>, WIDE_LDS, a, grid, s);
+}
 int launch_gemm16_store(const GemmArgs &a, int grid, hipStream_t s) {
 #ifdef CCR_DIAGNOSTICS
     if (qdirect_ok(a)) return launch_gemm16q<EPI_STORE>(a, grid, s);
@@ -1973,7 +2224,7 @@ int launch_threshold(const float *gmax, int64_t n_groups, int n_q, int nq_pad, i
 
 int launch_threshold_update(const uint2 *cand, const uint32_t *cnt, int nsub, int nsub_part, int part_blocks, int prev_nsub, int prev_part,
                             int prev_blocks, int qb_per, int sp, int n_q, int nq_pad, const CandLayout &lay, int k, const float *cq,
-                            const float *tile_norm, uint32_t *top, bool top_in, bool top_out, float *thr, hipStream_t s) {
+                            const float *tile_norm, uint32_t *top, bool top_in, bool top_out, float *thr, hipStream_t s, int tile_q) {
     if (nsub_part < nsub) nsub_part = nsub;
     if (prev_part < prev_nsub) prev_part = prev_nsub;
     if (nsub_part > 2048) {
@@ -1991,7 +2242,7 @@ int launch_threshold_update(const uint2 *cand, const uint32_t *cnt, int nsub, in
     }
     hipLaunchKernelGGL(threshold_update_kernel, dim3(n_q), dim3(256), lds, s, cand, cnt, nsub, nsub_part, part_blocks, prev_nsub, prev_part,
                        prev_blocks, qb_per > 0 ? qb_per : 1, sp, nq_pad, lay, k, compact, cq, tile_norm, top, top_in ? 1 : 0, top_out ? 1 : 0,
-                       thr);
+                       thr, tile_q > 0 ? tile_q : TILE_Q);
     CCR_LAUNCH_CHECK();
     return CCR_OK;
 }

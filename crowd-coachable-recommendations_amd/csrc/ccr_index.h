@@ -23,6 +23,7 @@ struct Knobs {
     int narrow;        // CCR_NARROW       -1 = planner's choice (n_q <= 64 whose rows fit the LDS), 0 = tile kernels only (the A/B knob)
     int narrow_nt;     // CCR_NARROW_NT    1 = the streaming kernel's corpus loads are non-temporal, 0 = default cache policy (default: 6.0 vs 5.5 TB/s at NQ)
     int narrow_grid;   // CCR_NARROW_GRID  0 = planner's choice, else workgroups of the streaming kernel
+    int wide;          // CCR_WIDE         -1 = planner's choice, 0 = 256 x 256 main-pass tiles only (the A/B knob), 1 = 256 x 384 wherever the kernel applies
     int narrow_groups; // CCR_NARROW_GROUPS 2 = batches of 65 .. 128 queries stream as two query groups (default), 1 = tile kernels above 64 queries (the A/B knob)
 };
 Knobs read_knobs();
@@ -37,6 +38,7 @@ int launch_gemm_gmax(const GemmArgs &a, int grid, hipStream_t s);
 int launch_gemm_store(const GemmArgs &a, int grid, hipStream_t s);
 int launch_gemm16_filter(const GemmArgs &a, int grid, hipStream_t s);
 int launch_gemm16_store(const GemmArgs &a, int grid, hipStream_t s);
+int launch_gemm16w_filter(const GemmArgs &a, int grid, hipStream_t s);   // 256 x 384 tiles (a.qblocks = blocks of 384 queries), dim % 32 == 0
 int launch_shard_header(const ccr_shard_header &h, void *message, hipStream_t s);   // ccr_merge.hip: the 32-byte header, by value
 int ensure_dynamic_lds(const void *kernel, size_t lds);   // per (kernel, device) opt-in to > 64 KiB of dynamic LDS
 // tile_bits (optional): bit patterns of the largest row norm of every 256-row tile, max-accumulated (zeroed by the caller)
@@ -65,9 +67,10 @@ int launch_gather_queries(const uint16_t *Q, int dim, const uint32_t *list, int 
 // nsub: sub-lists of the fully scored ranges; queries whose block position inside its XCD group is < part_blocks have nsub_part.
 // prev_*: the same at the previous re-tightening of this search (top_in: its k best lower bounds per query are in `top` and only
 // the sub-lists completed since are read); top_out: leave the k best for the next one.  top: [nq_pad + n_q * k] u32 or null.
+// tile_q: queries per block of the main pass that filled the lists (a query's block position decides which ranges it has seen).
 int launch_threshold_update(const uint2 *cand, const uint32_t *cnt, int nsub, int nsub_part, int part_blocks, int prev_nsub, int prev_part,
                             int prev_blocks, int qb_per, int sp, int n_q, int nq_pad, const CandLayout &lay, int k, const float *cq,
-                            const float *tile_norm, uint32_t *top, bool top_in, bool top_out, float *thr, hipStream_t s);
+                            const float *tile_norm, uint32_t *top, bool top_in, bool top_out, float *thr, hipStream_t s, int tile_q = TILE_Q);
 // dense exact path.  qlist: query rows to score (nullptr: q_begin + qi); out_rows: destination rows of the select
 // (nullptr: q_begin + qi); count_dev (device, may be null): only the first *count_dev - q_begin entries of the list exist
 // (the on-stream fallback chunk of an asynchronous search -- the host does not know the count yet).

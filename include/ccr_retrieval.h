@@ -72,6 +72,9 @@ typedef struct ccr_search_stats {
     int32_t main_launches;     /* launches of the main-pass kernel in this search (phases: thresholds are re-tightened between them) */
     int32_t opt_rank;          /* > 0: the thresholds were ESTIMATED (the opt_rank-th largest sampled group maximum; one launch, verified by
                                   the select stage); 0: conservative lower bounds with re-tightening */
+    int32_t main_tile_queries; /* queries per tile of the main pass: 256, or 384 (the 256 x 384 form, gemm_topk16w_kernel); 0 on the
+                                  dense path and for the streaming pass of small batches */
+    int32_t reserved0;
 } ccr_search_stats;
 
 const char *ccr_last_error(void);
