@@ -753,44 +753,51 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
 // wave groups, same LDS image and swizzle, same candidate layout (8 sub-lists per (range, query): wave row x lane >> 4).
 //   registers: 192 accumulators + 8 corpus fragments (32) + 3 query fragments (12; the other three are refilled IN PLACE behind the
 //     MFMAs of the first three query tiles) -- so nothing else may live in registers across the K loop: the thresholds and margin
-//     coefficients of the block's 384 queries and the sub-list counters sit in LDS, candidate addresses are rebuilt on a hit, and the
-//     DMA source of every piece is a wave-uniform base + one clamped per-lane offset computed at issue;
-//   ring: three 40-KiB slots (80 KiB in flight), 5 LDS-DMA pieces per wave and K step; + 3 KiB thresholds + 12 KiB counters = 135 KiB;
-//   protocol (K step u, both groups, g1 one barrier behind): [filter of a finished tile] 8 + 3 ds_read_b128 of u | DMA of u + 2 into the
-//     slot of u - 1 | own DMA of u + 1 landed (vmcnt) | lgkmcnt(0) | barrier A | 48 MFMAs with the three refills | lgkmcnt(0) | barrier B.
-//     RAW: a wave confirms its pieces of u + 1 before its barrier A_u, every reader of u + 1 starts behind a later barrier instance.
-//     WAR: the slot of u - 1 is rewritten in mem(u); every wave's reads of u - 1 (refills included) were retired before its barrier
-//     B_{u-1}, which for both groups precedes every mem(u).
+//     coefficients of the block's 384 queries and the sub-list counters sit in LDS, candidate addresses are rebuilt on a hit, the lane
+//     id is recomputed where it is needed (fresh_lane) and the DMA source of every piece is a wave-uniform base + one clamped per-lane
+//     offset computed at issue;
+//   LDS: a ring of three 40-KiB slots ([256 corpus rows x 64 B][384 query rows x 64 B]; two K steps = 80 KiB in flight) + 3 KiB
+//     thresholds + 12 KiB counters = 135 KiB; 5 LDS-DMA pieces (16 rows x 64 B = 1 KiB) per wave and K step.  A second form with
+//     separate rings -- corpus four slots deep, fetched by group 0, queries three, fetched by group 1 -- measured 2-3 % slower;
+//   protocol, K step u (A_u / B_u: the barriers in front of and behind the step's MFMAs; g1 runs one barrier behind: g1's A_u is the
+//     barrier instance of g0's B_u):
+//     mem(u): [filter of a finished tile] 8 + 3 ds_read_b128 of u | pieces of u + 2 into the slot of u - 1 | own pieces of u + 1
+//             landed (vmcnt) | lgkmcnt(0) | A_u | 48 MFMAs with the three refills | [g1: filter] | lgkmcnt(0) | B_u
+//     RAW: a wave confirms its pieces of u + 1 before its A_u; the first reader of u + 1 starts behind a later barrier instance.
+//     WAR: the slot of u - 1 is rewritten in mem(u).  Fragments read in mem(u - 1) were retired before the reader's A_{u-1}, which
+//          for both groups precedes every mem(u).  The REFILLS (query tiles 3-5 of a wave = rows 48-95 of its 96-row group) are read
+//          during the MFMAs and retired only before B_{u-1}: g1's B_{u-1} is behind the start of g0's mem(u), so GROUP 0 FETCHES NO
+//          REFILL ROW -- its waves take the 16 corpus pieces and rows 0-15 of each query group, group 1 (whose mem(u) starts behind
+//          its own B_{u-1} and behind g0's) the query rows 16-95.
 // dim % 32 == 0 only (the planner keeps the 256 x 256 kernel elsewhere).  DBG 128 (diagnostic library): thresholds +inf.
+
+// The lane id, computed where it is needed (two VALU instructions) instead of living in a register across the K loop: the wide kernel
+// has no register to spare for lane coordinates and the addresses derived from them.
+__device__ __forceinline__ int fresh_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 constexpr int WIDE_SUB_BYTES = (TILE_DOCS + WIDE_Q) * SUB_K * 2;   // 40960
 constexpr int WIDE_Q_REGION = TILE_DOCS * SUB_K * 2;               // 16384
 constexpr int WIDE_RING = 3;
 constexpr int WIDE_PIECES = 5;                                     // 40 pieces of 1 KiB per K step over 8 waves
 constexpr int WIDE_QT = 6;                                         // query tiles of 16 per wave
-constexpr size_t WIDE_LDS = (size_t)WIDE_RING * WIDE_SUB_BYTES + WIDE_Q * 8 + (size_t)(GEMM_THREADS / 64) * WIDE_QT * 64 * 4;
+constexpr int WIDE_RING_BYTES = WIDE_RING * WIDE_SUB_BYTES;        // 122880
+constexpr size_t WIDE_LDS = (size_t)WIDE_RING_BYTES + WIDE_Q * 8 + (size_t)(GEMM_THREADS / 64) * WIDE_QT * 64 * 4;   // 138240
 
 template <int DBG>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16w_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2 *s_tc = reinterpret_cast<float2 *>(smem + WIDE_RING * WIDE_SUB_BYTES);          // [384] {tau_q, cq} of the item's query block
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(smem + WIDE_RING * WIDE_SUB_BYTES + WIDE_Q * 8);   // [wave][query tile][lane]
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float2 *s_tc = reinterpret_cast<float2 *>(smem + WIDE_RING_BYTES);                     // [384] {tau_q, cq} of the item's query block
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(smem + WIDE_RING_BYTES + WIDE_Q * 8);   // [wave][query tile][lane]
+    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int wd = wv >> 2;
     const int wq = wv & 3;
-    const int l15 = lane & 15;
-    const int lq = lane >> 4;
     const bool g1 = (wv >= 4);
     const int KS2 = a.dim / SUB_K;
     const uint32_t pitch = (uint32_t)a.dim * 2u;    // bytes per row
-
-    const int prow = lane >> 2;                     // row of a DMA piece this lane fetches a 16-byte chunk of
-    const uint32_t chunk_off = (uint32_t)(((lane & 3) ^ (((prow >> 2) & 1) << 1)) << 4);
-    const int cofs = ((lq ^ (((lane >> 2) & 1) << 1)) << 4);
-    const int a_base = (wd * 128 + l15) * 64 + cofs;                   // + dt * 1024
-    const int b_base = WIDE_Q_REGION + (wq * 96 + l15) * 64 + cofs;   // + qt * 1024
-    uint32_t *my_cnt = s_cnt + (wv * WIDE_QT) * 64 + lane;             // + qt * 64
+    // (no lane coordinate lives in a register across the K loop: every use starts from fresh_lane())
 
     const int xcd = blockIdx.x & (NUM_XCD - 1);
     const int jx = blockIdx.x >> 3;
@@ -804,6 +811,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16w_kernel(const Gem
 
     for (int item = a.item_begin + jx; item < item_end; item += per_x) {
         const int n_rl = a.ranges / nrc;
+        // item order: consecutive items (the co-resident workgroups of an XCD) share a RANGE and walk its corpus tiles for different
+        // query blocks.  (Measured at NQ, nine blocks = 5 MiB of query rows per XCD against 4 MiB of L2: sharing the query block instead
+        // -- CCR_ITEM_SWAP -- main pass 12.05 ms against 11.49; blocks in two halves, all ranges x first half then x second: 11.75.)
         const int rl = a.item_swap ? item % n_rl : item / qb_per;
         const int qb = qg * qb_per + (a.item_swap ? item / n_rl : item % qb_per);
         const int r = rc + nrc * rl;
@@ -814,14 +824,18 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16w_kernel(const Gem
         int cap, seg_r0;
         long long seg_base;
         cand_segment(a.lay, r, cap, seg_r0, seg_base);   // this range's segment of the candidate area (wave-uniform)
-        if (tid < WIDE_Q) {
-            const int q = q0 + tid;
-            float t = (q < a.n_q) ? a.thr[q] : __builtin_nanf("");
-            if constexpr ((DBG & 128) != 0) t = INFINITY;
-            s_tc[tid] = make_float2(t, (q < a.n_q) ? a.cq[q] : 0.f);
-        }
+        {
+            const int ln = fresh_lane();
+            const int tid = wv * 64 + ln;
+            if (tid < WIDE_Q) {
+                const int q = q0 + tid;
+                float t = (q < a.n_q) ? a.thr[q] : __builtin_nanf("");
+                if constexpr ((DBG & 128) != 0) t = INFINITY;
+                s_tc[tid] = make_float2(t, (q < a.n_q) ? a.cq[q] : 0.f);
+            }
 #pragma unroll
-        for (int qt = 0; qt < WIDE_QT; ++qt) my_cnt[qt * 64] = 0u;
+            for (int qt = 0; qt < WIDE_QT; ++qt) s_cnt[(wv * WIDE_QT + qt) * 64 + ln] = 0u;
+        }
         // (the first read of s_tc is behind at least one barrier; the vector loads above are complete before the first DMA piece is counted)
         CCR_WAIT_VM(0);
 
@@ -829,42 +843,62 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16w_kernel(const Gem
         const char *qblk = reinterpret_cast<const char *>(a.Q) + (int64_t)q0 * pitch;
 
         f32x4v acc[8][WIDE_QT];
-        const int64_t U = ntile * KS2;
-        int64_t iu = 0, it = 0;
-        int iks = 0;
-        auto issue = [&]() __attribute__((always_inline)) {
-            char *buf = smem + (int)(iu % WIDE_RING) * WIDE_SUB_BYTES;
+        const int U = (int)(ntile * KS2);   // K steps of the item (< 2^31: tiles / ranges x dim / 32)
+        // issue state, wave-uniform and advanced incrementally (no per-step multiplies): ring slot, K step inside the tile and -- group 0 --
+        // the tile's base address and its last valid row
+        int islot = 0, iks = 0;
+        int64_t it = 0;
+        const char *dtile = nullptr;
+        int dlimit = 0;
+        auto tile_base = [&]() __attribute__((always_inline)) {
             const int64_t row0 = (r + it * a.ranges) * a.tile_stride * TILE_DOCS;
-            const int dlimit = (a.n_rows - 1 - row0 < TILE_DOCS - 1) ? (int)(a.n_rows - 1 - row0) : TILE_DOCS - 1;   // last valid row of the tile
-            const char *dtile = reinterpret_cast<const char *>(a.D) + row0 * pitch;
+            dlimit = (a.n_rows - 1 - row0 < TILE_DOCS - 1) ? (int)(a.n_rows - 1 - row0) : TILE_DOCS - 1;
+            dtile = reinterpret_cast<const char *>(a.D) + row0 * pitch;
+        };
+        tile_base();
+        // one K step's pieces of this wave (a piece = 16 image rows x 64 B): group 0, wave w: corpus rows (4 w + i) * 16 .. + 15 (i < 4) and
+        // query rows 96 w .. + 15; group 1, wave w: query rows 96 w + 16 (1 + i) .. + 15 (i < 5).  The per-lane offsets are rebuilt at every
+        // issue (hoisted out of the K loop they would cost registers the accumulators need); rows beyond the end re-read the last row
+        // (their scores are never recorded)
+        auto issue = [&]() __attribute__((always_inline)) {
+            char *buf = smem + islot * WIDE_SUB_BYTES;
             const uint32_t kb = (uint32_t)iks * (SUB_K * 2);
-            // (opaque: the per-piece offsets are rebuilt at every issue -- hoisted out of the K loop they would cost ten registers the
-            // accumulators need)
-            int pr = prow;
-            uint32_t co = chunk_off;
-            asm volatile("" : "+v"(pr), "+v"(co));
+            const int iln = fresh_lane();
+            const int pr = iln >> 2;                     // row of a DMA piece this lane fetches a 16-byte chunk of
+            const uint32_t co = (uint32_t)(((iln & 3) ^ (((pr >> 2) & 1) << 1)) << 4) + kb;
+            if (!g1) {
 #pragma unroll
-            for (int i = 0; i < WIDE_PIECES; ++i) {
-                const int p = wv * WIDE_PIECES + i;              // wave-uniform: image rows p * 16 .. + 15 (0-255 corpus, 256-639 queries)
-                const bool is_d = p < TILE_DOCS / 16;
-                const int prow0 = is_d ? p * 16 : (p - TILE_DOCS / 16) * 16;
-                const int limit = is_d ? dlimit : qlimit;
-                int row = prow0 + pr;
-                row = row < limit ? row : limit;                 // rows beyond the end re-read the last row (their scores are never recorded)
-                const char *base = is_d ? dtile : qblk;
-                glds16(base + ((uint32_t)row * pitch + co + kb), buf + p * 1024);
+                for (int i = 0; i < 4; ++i) {
+                    const int row0 = (wv * 4 + i) * 16;
+                    int row = row0 + pr;
+                    row = row < dlimit ? row : dlimit;
+                    glds16(dtile + ((uint32_t)row * pitch + co), buf + row0 * 64);
+                }
+                const int qrow0 = wv * 96;
+                int row = qrow0 + pr;
+                row = row < qlimit ? row : qlimit;
+                glds16(qblk + ((uint32_t)row * pitch + co), buf + WIDE_Q_REGION + qrow0 * 64);
+            } else {
+#pragma unroll
+                for (int i = 0; i < WIDE_PIECES; ++i) {
+                    const int qrow0 = (wv - 4) * 96 + 16 * (1 + i);
+                    int row = qrow0 + pr;
+                    row = row < qlimit ? row : qlimit;
+                    glds16(qblk + ((uint32_t)row * pitch + co), buf + WIDE_Q_REGION + qrow0 * 64);
+                }
             }
-            ++iu;
+            islot = islot == WIDE_RING - 1 ? 0 : islot + 1;
             if (++iks == KS2) {
                 iks = 0;
                 ++it;
+                if (!g1) tile_base();
             }
         };
 
         auto epilogue = [&](int64_t vt, float nt) __attribute__((always_inline)) {   // nt: norm bound of the tile's rows (wave-uniform)
-            // (opaque lane coordinates: every address below is rebuilt here instead of living in registers across the K loop)
-            int l15o = l15, lqo = lq;
-            asm volatile("" : "+v"(l15o), "+v"(lqo));
+            // (every address below is rebuilt here instead of living in registers across the K loop)
+            const int eln = fresh_lane();
+            const int l15o = eln & 15, lqo = eln >> 4;
             const int64_t row_base = vt * a.tile_stride * TILE_DOCS + wd * 128 + 4 * lqo;  // + dt*16 + e
 #pragma unroll
             for (int qt = 0; qt < WIDE_QT; ++qt) {
@@ -899,7 +933,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16w_kernel(const Gem
             }
         };
 
-        const int npro = U < 2 ? (int)U : 2;
+        const int npro = U < 2 ? U : 2;
         for (int i = 0; i < npro; ++i) issue();
         if (npro == 2)
             wait_vm<WIDE_PIECES>();
@@ -913,20 +947,27 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16w_kernel(const Gem
         bool pending = false;
         int64_t pending_vt = 0;
         float pending_nt = 0.f;
-        for (int64_t u = 0; u < U; ++u) {
+        int uslot = 0;
+        for (int u = 0; u < U; ++u) {
             if (pending) {
                 epilogue(pending_vt, pending_nt);
                 pending = false;
             }
-            const char *buf = smem + (int)(u % WIDE_RING) * WIDE_SUB_BYTES;
+            const char *abuf = smem + uslot * WIDE_SUB_BYTES;
+            const char *bbuf = abuf + WIDE_Q_REGION;
+            uslot = uslot == WIDE_RING - 1 ? 0 : uslot + 1;
+            const int ln = fresh_lane();
+            const int cofs = (((ln >> 4) ^ (((ln >> 2) & 1) << 1)) << 4);
+            const int a_base = (wd * 128 + (ln & 15)) * 64 + cofs;   // + dt * 1024
+            const int b_base = (wq * 96 + (ln & 15)) * 64 + cofs;    // + qt * 1024
             bf16x8 af[8], bfr[3];
 #pragma unroll
-            for (int dt = 0; dt < 8; ++dt) af[dt] = *reinterpret_cast<const bf16x8 *>(buf + a_base + dt * 1024);
+            for (int dt = 0; dt < 8; ++dt) af[dt] = *reinterpret_cast<const bf16x8 *>(abuf + a_base + dt * 1024);
 #pragma unroll
-            for (int qt = 0; qt < 3; ++qt) bfr[qt] = *reinterpret_cast<const bf16x8 *>(buf + b_base + qt * 1024);
+            for (int qt = 0; qt < 3; ++qt) bfr[qt] = *reinterpret_cast<const bf16x8 *>(bbuf + b_base + qt * 1024);
             if (u + 2 < U) {
-                issue();                       // K step u + 2 into the slot of u - 1
-                wait_vm<WIDE_PIECES>();        // own pieces of u + 1 have landed
+                issue();                           // pieces of u + 2 into the slot of u - 1
+                wait_vm<WIDE_PIECES>();            // own pieces of u + 1 have landed
             } else {
                 CCR_WAIT_VM(0);
             }
@@ -940,7 +981,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16w_kernel(const Gem
                     for (int dt = 0; dt < 8; ++dt) acc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[dt], bfr[qt % 3], z, 0, 0, 0);
                     if (qt < 3) {
                         __builtin_amdgcn_sched_barrier(0);
-                        bfr[qt] = *reinterpret_cast<const bf16x8 *>(buf + b_base + (qt + 3) * 1024);
+                        bfr[qt] = *reinterpret_cast<const bf16x8 *>(bbuf + b_base + (qt + 3) * 1024);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -952,7 +993,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16w_kernel(const Gem
                         acc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[dt], bfr[qt % 3], acc[dt][qt], 0, 0, 0);
                     if (qt < 3) {
                         __builtin_amdgcn_sched_barrier(0);
-                        bfr[qt] = *reinterpret_cast<const bf16x8 *>(buf + b_base + (qt + 3) * 1024);
+                        bfr[qt] = *reinterpret_cast<const bf16x8 *>(bbuf + b_base + (qt + 3) * 1024);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -971,15 +1012,18 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16w_kernel(const Gem
                 }
                 ++ct;
             }
-            CCR_WAIT_LGKM0();   // the refills of this K step are retired before the barrier that frees its slot
+            CCR_WAIT_LGKM0();   // the refills of this K step are retired before the barrier behind which group 1 rewrites their rows
             CCR_BARRIER();
         }
         if (pending) epilogue(pending_vt, pending_nt);
         if (!g1) CCR_BARRIER();
 
+        {
+            const int ln = fresh_lane();
 #pragma unroll
-        for (int qt = 0; qt < WIDE_QT; ++qt)
-            a.cnt[((int64_t)r * a.nq_pad + q0 + wq * 96 + qt * 16 + l15) * 8 + wd * 4 + lq] = my_cnt[qt * 64];
+            for (int qt = 0; qt < WIDE_QT; ++qt)
+                a.cnt[((int64_t)r * a.nq_pad + q0 + wq * 96 + qt * 16 + (ln & 15)) * 8 + wd * 4 + (ln >> 4)] = s_cnt[(wv * WIDE_QT + qt) * 64 + ln];
+        }
         __syncthreads();
     }
 }
