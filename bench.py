@@ -40,7 +40,7 @@ MSMARCO_ROWS, MSMARCO_Q = 8_841_823, 6_980
 C4_ROWS, C4_Q, C4_DIM, C4_K = 50_000_000, 10_000, 1024, 1000    # BASELINE.json configs[3]
 MFMA_PEAK_TFLOPS = 2500.0   # dense bf16, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r05_locality.json")   # tools/exp_locality.py: separate rocprofv3 --pmc passes per workload
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r06_locality.json")   # tools/exp_locality.py: separate rocprofv3 --pmc passes per workload
 
 
 def parse():
@@ -602,7 +602,8 @@ def roofline_obj(r, traffic=None, traffic_source=None):
     """`achieved` = algorithmic flops of one step's main pass (2 n_q n_rows dim: every launch of the pass covers its share of the
     corpus, together exactly once) / the main pass's duration per step from the library's HIP events on the search stream."""
     st = r["stats"]
-    return {"bound": "mfma", "kernel": ("gemm_topk16_kernel<EPI_FILTER> (main pass, v_mfma_f32_16x16x32_bf16)" if st.get("sublists") == 8
+    return {"bound": "mfma", "kernel": ("gemm_topk16w_kernel (main pass, 256 x 384 tiles, v_mfma_f32_16x16x32_bf16)" if st.get("main_tile_queries") == 384
+                                        else "gemm_topk16_kernel<EPI_FILTER> (main pass, v_mfma_f32_16x16x32_bf16)" if st.get("sublists") == 8
                                         else "gemm_topk_kernel<EPI_FILTER> (main pass, v_mfma_f32_32x32x16_bf16)"),
             "achieved": round(r["achieved_tflops"], 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(r["achieved_tflops"] / MFMA_PEAK_TFLOPS, 4),
@@ -728,7 +729,7 @@ def main():
         """(bytes per step, label) of the main pass from the committed PMC measurement of the same workload, or (None, None)."""
         try:
             rec = json.load(open(PMC_SUMMARY))[tag]
-            return rec["traffic_bytes"], (f"offline rocprofv3 --pmc passes of this workload (profiles/r05_locality.json[{tag}]: FETCH_SIZE x 2 + "
+            return rec["traffic_bytes"], (f"offline rocprofv3 --pmc passes of this workload (profiles/r06_locality.json[{tag}]: FETCH_SIZE x 2 + "
                                           f"WRITE_SIZE of the main-pass launches of one step); not measured in this run")
         except Exception:
             return None, None
@@ -756,7 +757,7 @@ def main():
         "phases_ms": dict(phases_obj(st), corpus_pack=round(pack_ms, 3)),
         "pack_kernel": {"bound": "hbm", "achieved": round(pack_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(pack_gbs / HBM_PEAK_GBS, 4)},
-        "search_stats": dict({k_: st[k_] for k_ in ("path", "n_fallback", "sample_tiles", "ranges", "sublists", "cap", "n_candidates", "opt_rank", "n_retried", "n_dense")},
+        "search_stats": dict({k_: st[k_] for k_ in ("path", "n_fallback", "sample_tiles", "ranges", "sublists", "cap", "n_candidates", "opt_rank", "n_retried", "n_dense", "main_tile_queries")},
                              candidates_per_query=round(st["n_candidates"] / max(1, args.queries), 1), n_fallback_max=r["n_fallback_max"]),
     }
     if world > 1:

@@ -311,13 +311,19 @@ static Plan make_plan_for(int64_t n_rows, int dim, int n_q, int k, int flags, in
         p.narrow = narrow ? nqt : 0;
         p.narrow_groups = narrow ? ngroups : 1;
         // the main pass's tile: 256 x 384 (gemm_topk16w_kernel: -17 % bytes per flop through the L1 miss path that bounds the 256 x 256
-        // kernel, measured ~9 % faster per flop) where its padding does not eat the gain -- 3 452 queries: nine blocks of 384 = 3 456
-        // against fourteen of 256 = 3 584; 512 queries stay on two 256-blocks
+        // kernel) where it pays.  Measured at the NQ corpus (profiles/r06_wide_*.txt), per padded multiply-add against the 256 x 256
+        // kernel: 0.92-0.96 while the query rows one XCD walks stay L2-resident (300 and 1 100 queries: main pass -31 % / -14 %, most
+        // of it the padding: one block instead of two, three instead of five), 0.97 at 5 MiB per XCD (3 452 queries: nine blocks =
+        // 3 456 columns against fourteen = 3 584: -6.5 %), and SLOWER beyond -- 4 096 queries = eleven blocks, 6 980 = nineteen: a prime
+        // block count cannot be split over the XCDs, every XCD streams all the query rows past its 4-MiB L2 (L2 hit rate 0.71 against
+        // 0.91, +3.4 % main pass) while sixteen / twenty-eight 256-blocks split into groups that fit.
         p.tile_q = TILE_Q;
         p.main_qblocks = p.qblocks;
         if (!narrow && p.mfma16 && dim % 32 == 0 && kn.wide != 0) {
             const int wb = (n_q + WIDE_Q - 1) / WIDE_Q;
-            if (kn.wide == 1 || (double)wb * WIDE_Q * 0.915 < (double)p.qblocks * TILE_Q) {
+            const double per_xcd = (double)(wb / pick_qgroups(wb, dim, kn, WIDE_Q)) * WIDE_Q * dim * 2.0;   // query bytes one XCD walks
+            const double per_flop = per_xcd <= 3.2 * 1048576.0 ? 0.95 : (per_xcd <= 5.5 * 1048576.0 ? 0.97 : 1.04);
+            if (kn.wide == 1 || (double)wb * WIDE_Q * per_flop < (double)p.qblocks * TILE_Q) {
                 p.tile_q = WIDE_Q;
                 p.main_qblocks = wb;
                 p.nq_pad = (int)round_up(std::max<int64_t>(n_q, (int64_t)wb * WIDE_Q), TILE_Q);   // the counters of every block's columns exist

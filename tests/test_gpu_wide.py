@@ -97,12 +97,19 @@ def test_wide_main_pass_equals_the_narrow_tile_and_the_dense_path(n, nq, d, k, e
 
 def test_planner_takes_the_wide_tile_where_its_padding_pays():
     """3 452 queries: nine blocks of 384 (3 456 columns) instead of fourteen of 256 (3 584); 512 queries stay on two 256-blocks; a small
-    batch keeps the streaming kernel; a dim that is no multiple of 32 keeps the 256 x 256 kernel with its zero-filled last K step."""
+    batch keeps the streaming kernel; query blocks that no XCD's L2 can hold keep the 256 x 256 kernel (its blocks split into groups);
+    a dim that is no multiple of 32 keeps the 256 x 256 kernel with its zero-filled last K step."""
     from ccrec_amd import ops
     Db = _rand_bits(70_000, 64, 1)
     index = ops.CorpusIndex(_bf16(Db))
     for nq, want in ((3452, 384), (300, 384), (512, 256), (1000, 256), (1100, 384), (64, 0)):
         index.search(_bf16(_rand_bits(nq, 64, nq)), 10, FUSED)
+        st = index.last_stats()
+        assert st["path"] == 1 and st["main_tile_queries"] == want, (nq, st)
+    # 768-dim rows: nine blocks (5 MiB of query rows per XCD) still pay, eleven -- a prime count cannot be split over the XCDs -- do not
+    index = ops.CorpusIndex(_bf16(_rand_bits(40_000, 768, 4)))
+    for nq, want in ((3452, 384), (4096, 256), (1100, 384)):
+        index.search(_bf16(_rand_bits(nq, 768, nq)), 10, FUSED)
         st = index.last_stats()
         assert st["path"] == 1 and st["main_tile_queries"] == want, (nq, st)
     Db = _rand_bits(30_000, 72, 2)

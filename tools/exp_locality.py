@@ -23,6 +23,11 @@ OUT = os.path.join(ROOT, "gpurun_out", "locality")
 PASSES = [["FETCH_SIZE"], ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"], ["GRBM_GUI_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES"]]
 
 
+def is_main_pass(name):
+    """EPI_FILTER instantiations of the tile kernels: gemm_topk_kernel<0, ..>, gemm_topk16_kernel<0, ..>, and the 256 x 384 form."""
+    return "gemm_topk16w_kernel" in name or ("gemm_topk" in name and ("<0," in name.replace(" ", "") or "<(ccr::Epi)0" in name))
+
+
 def run_plain(env, args, tag):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--cpu-queries", "0", "--no-secondary"] + args,
                        capture_output=True, text=True, env=env, timeout=600)
@@ -53,7 +58,7 @@ def run_pmc(env, args, tag, ctrs, i):
     tot = defaultdict(float)
     n_disp = 0
     for did, c in per.items():
-        if "gemm_topk" in names[did] and ("<0," in names[did].replace(" ", "") or "<(ccr::Epi)0" in names[did]):   # EPI_FILTER instantiations
+        if is_main_pass(names[did]):
             n_disp += 1
             for k, v in c.items():
                 tot[k] += v
@@ -61,7 +66,7 @@ def run_pmc(env, args, tag, ctrs, i):
     for f in kt:
         for row in csv.DictReader(open(f)):
             nm = row["Kernel_Name"]
-            if "gemm_topk" in nm and ("<0," in nm.replace(" ", "") or "<(ccr::Epi)0" in nm):
+            if is_main_pass(nm):
                 dur += (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6
     subprocess.run(["rm", "-rf", d])
     # two steps were profiled (warm-up + timed): per step
@@ -75,6 +80,7 @@ def main():
     nq, q16 = [], ["--queries", "4096"]
     variants = [
         ("nq_default", {}, nq),
+        ("nq_tile256", {"CCR_WIDE": "0"}, nq),            # round 6: the 256 x 256 kernel beside the planner's 256 x 384 choice
         ("nq_single_qg2", {"CCR_PROGRESSIVE": "0", "CCR_QGROUPS": "2"}, nq),
         ("nq_single_qg1", {"CCR_PROGRESSIVE": "0", "CCR_QGROUPS": "1"}, nq),
         ("nq_single_qg2_swap", {"CCR_PROGRESSIVE": "0", "CCR_QGROUPS": "2", "CCR_ITEM_SWAP": "1"}, nq),

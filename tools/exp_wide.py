@@ -56,6 +56,7 @@ def one():
 
 
 SETS = {
+    "ab": [{"CCR_WIDE": "0"}, {}, {"CCR_WIDE": "0"}, {}],
     "order": [{}, {"CCR_ITEM_SWAP": "1"}, {"CCR_QGROUPS": "1", "CCR_WIDE": "0", "CCR_PROGRESSIVE": "0"}, {}],
     "plans": [{"CCR_WIDE": "0"}, {}, {"CCR_OPTIMISTIC": "0"}, {"CCR_PROGRESSIVE": "0", "CCR_OPTIMISTIC": "0"}, {"CCR_WIDE": "0", "CCR_PROGRESSIVE": "0"},
               {"CCR_RANGES": "128"}, {"CCR_RANGES": "256"}, {"CCR_RANGES": "128", "CCR_OPTIMISTIC": "0"}, {"CCR_WIDE": "0"}],
