@@ -971,6 +971,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16w_kernel(const Gem
             } else {
                 CCR_WAIT_VM(0);
             }
+            // (group 0 could confirm its pieces as late as its B_u -- the barrier instance of g1's A_u --: measured 3 % slower)
             CCR_WAIT_LGKM0();
             CCR_BARRIER();
             if (cks == 0) {
