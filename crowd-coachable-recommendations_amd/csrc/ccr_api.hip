@@ -1198,7 +1198,7 @@ static int search_impl(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k, fl
         std::vector<unsigned long long> h((size_t)p.grid * 64);
         CCR_HIP_CHECK(hipMemcpyAsync(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost, s));
         CCR_HIP_CHECK(hipStreamSynchronize(s));
-        static const char *names[7] = {"barrierB+loop", "epi_hits", "dma_wait", "lds_reads+dma_issue", "barrierA", "mfma", "epi_trees"};
+        static const char *names[8] = {"barrierB+loop", "epi_hits", "dma_wait", "lds_reads+dma_issue", "barrierA", "mfma", "epi_trees|lgkm_before_A", "mfma_drain"};
         for (int grp = 0; grp < 2; ++grp) {
             double sum[8] = {0};
             int n = 0;
@@ -1206,9 +1206,9 @@ static int search_impl(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k, fl
                 for (int w = grp * 4; w < grp * 4 + 4; ++w, ++n)
                     for (int i = 0; i < 8; ++i) sum[i] += (double)h[((size_t)b * 8 + w) * 8 + i];
             double tot = 0;
-            for (int i = 0; i < 7; ++i) tot += sum[i];
+            for (int i = 0; i < 8; ++i) tot += sum[i];
             fprintf(stderr, "[ccr stamps] waves %d-%d: total %.0f cycles/wave;", grp * 4, grp * 4 + 3, tot / n);
-            for (int i = 0; i < 7; ++i) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * sum[i] / tot);
+            for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * sum[i] / tot);
             fprintf(stderr, "\n");
         }
         (void)hipFree(stamps);

@@ -778,6 +778,19 @@ __device__ __forceinline__ int fresh_lane() {
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
     return l;
 }
+// Maximum of a 16x16 MFMA tile's four registers in two VALU instructions (fmaxf() costs four: hipcc canonicalises the operands first).
+// Every VALU instruction of the filter counts: it is issued while the partner wave of the SIMD runs its MFMAs and gets a slot only now
+// and then (in-kernel stamps: the tile epilogue was 17 % of a wave's time with fmaxf trees and the first hit path).
+__device__ __forceinline__ float max4_asm(const f32x4v &c) {
+    float m;
+    asm("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32 %0, %0, %4" : "=&v"(m) : "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]));
+    return m;
+}
+__device__ __forceinline__ float max3_asm(float a, float b, float c) {
+    float m;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(a), "v"(b), "v"(c));
+    return m;
+}
 constexpr int WIDE_SUB_BYTES = (TILE_DOCS + WIDE_Q) * SUB_K * 2;   // 40960
 constexpr int WIDE_Q_REGION = TILE_DOCS * SUB_K * 2;               // 16384
 constexpr int WIDE_RING = 3;
@@ -797,7 +810,19 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16w_kernel(const Gem
     const bool g1 = (wv >= 4);
     const int KS2 = a.dim / SUB_K;
     const uint32_t pitch = (uint32_t)a.dim * 2u;    // bytes per row
-    // (no lane coordinate lives in a register across the K loop: every use starts from fresh_lane())
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // DBG 16 (diagnostic library): cycles per segment of the K loop
+    unsigned long long tprev = 0;
+    // TWO lane-dependent registers live across the K loop -- the DMA source offset of a lane inside a piece and its operand-read offset
+    // inside a slot --; everything else that depends on the lane is rebuilt from fresh_lane() where it is needed.  (VALU instructions of
+    // the memory phase are issued beside the partner wave's MFMAs and wait for a slot: 34 of them per K step for addresses were 30 % of
+    // a wave's time.)
+    uint32_t lane_src, lane_lds;
+    {
+        const int ln = fresh_lane();
+        const int pr = ln >> 2;                        // row of a DMA piece this lane fetches a 16-byte chunk of
+        lane_src = (uint32_t)pr * pitch + (uint32_t)(((ln & 3) ^ (((pr >> 2) & 1) << 1)) << 4);
+        lane_lds = (uint32_t)((ln & 15) * 64 + (((ln >> 4) ^ (((ln >> 2) & 1) << 1)) << 4));
+    }
 
     const int xcd = blockIdx.x & (NUM_XCD - 1);
     const int jx = blockIdx.x >> 3;
@@ -860,31 +885,51 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16w_kernel(const Gem
         // query rows 96 w .. + 15; group 1, wave w: query rows 96 w + 16 (1 + i) .. + 15 (i < 5).  The per-lane offsets are rebuilt at every
         // issue (hoisted out of the K loop they would cost registers the accumulators need); rows beyond the end re-read the last row
         // (their scores are never recorded)
+        // do ALL the query rows this wave fetches exist (wave-uniform, fixed for the item)?  Group 0, wave w: rows 96 w .. + 15; group 1: 96 w + 16 .. + 95
+        const bool q_whole = g1 ? ((wv - 4) * 96 + 95 <= qlimit) : (wv * 96 + 15 <= qlimit);
         auto issue = [&]() __attribute__((always_inline)) {
             char *buf = smem + islot * WIDE_SUB_BYTES;
             const uint32_t kb = (uint32_t)iks * (SUB_K * 2);
-            const int iln = fresh_lane();
-            const int pr = iln >> 2;                     // row of a DMA piece this lane fetches a 16-byte chunk of
-            const uint32_t co = (uint32_t)(((iln & 3) ^ (((pr >> 2) & 1) << 1)) << 4) + kb;
-            if (!g1) {
+            if (q_whole && (g1 || dlimit == TILE_DOCS - 1)) {
+                // every row of every piece exists: wave-uniform bases (scalar arithmetic) + ONE per-lane offset for all the pieces
+                const uint32_t voff = lane_src + kb;
+                if constexpr ((DBG & 4) == 0) {
+                    if (!g1) {
+                        if constexpr (!(DBG & 64)) {
+                            const char *rows = dtile + (size_t)(wv * 64) * pitch;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int row0 = (wv * 4 + i) * 16;
-                    int row = row0 + pr;
-                    row = row < dlimit ? row : dlimit;
-                    glds16(dtile + ((uint32_t)row * pitch + co), buf + row0 * 64);
+                            for (int i = 0; i < 4; ++i) glds16(rows + (size_t)(i * 16) * pitch + voff, buf + (wv * 4 + i) * 1024);
+                        }
+                        if constexpr (!(DBG & 32)) glds16(qblk + (size_t)(wv * 96) * pitch + voff, buf + WIDE_Q_REGION + wv * 96 * 64);
+                    } else if constexpr (!(DBG & 32)) {
+                        const char *rows = qblk + (size_t)((wv - 4) * 96 + 16) * pitch;
+                        char *dst = buf + WIDE_Q_REGION + ((wv - 4) * 96 + 16) * 64;
+#pragma unroll
+                        for (int i = 0; i < WIDE_PIECES; ++i) glds16(rows + (size_t)(i * 16) * pitch + voff, dst + i * 1024);
+                    }
                 }
-                const int qrow0 = wv * 96;
-                int row = qrow0 + pr;
-                row = row < qlimit ? row : qlimit;
-                glds16(qblk + ((uint32_t)row * pitch + co), buf + WIDE_Q_REGION + qrow0 * 64);
             } else {
+                // the last tile of the shard / the last block of the batch: rows beyond the end re-read the last row (never recorded)
+                const int iln = fresh_lane();
+                const int pr = iln >> 2;
+                const uint32_t co = (uint32_t)(((iln & 3) ^ (((pr >> 2) & 1) << 1)) << 4) + kb;
+                auto piece = [&](const char *rows, int row0, int limit, char *dst) __attribute__((always_inline)) {
+                    int row = row0 + pr;
+                    row = row < limit ? row : limit;
+                    glds16(rows + ((uint32_t)row * pitch + co), dst);
+                };
+                if constexpr ((DBG & 4) == 0) {
+                    if (!g1) {
+                        if constexpr (!(DBG & 64)) {
 #pragma unroll
-                for (int i = 0; i < WIDE_PIECES; ++i) {
-                    const int qrow0 = (wv - 4) * 96 + 16 * (1 + i);
-                    int row = qrow0 + pr;
-                    row = row < qlimit ? row : qlimit;
-                    glds16(qblk + ((uint32_t)row * pitch + co), buf + WIDE_Q_REGION + qrow0 * 64);
+                            for (int i = 0; i < 4; ++i) piece(dtile, (wv * 4 + i) * 16, dlimit, buf + (wv * 4 + i) * 1024);
+                        }
+                        if constexpr (!(DBG & 32)) piece(qblk, wv * 96, qlimit, buf + WIDE_Q_REGION + wv * 96 * 64);
+                    } else if constexpr (!(DBG & 32)) {
+#pragma unroll
+                        for (int i = 0; i < WIDE_PIECES; ++i)
+                            piece(qblk, (wv - 4) * 96 + 16 * (1 + i), qlimit, buf + WIDE_Q_REGION + ((wv - 4) * 96 + 16 * (1 + i)) * 64);
+                    }
                 }
             }
             islot = islot == WIDE_RING - 1 ? 0 : islot + 1;
@@ -899,20 +944,26 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16w_kernel(const Gem
             // (every address below is rebuilt here instead of living in registers across the K loop)
             const int eln = fresh_lane();
             const int l15o = eln & 15, lqo = eln >> 4;
-            const int64_t row_base = vt * a.tile_stride * TILE_DOCS + wd * 128 + 4 * lqo;  // + dt*16 + e
+            // candidate cell of (this range, query q0 + ql, sub-list wd * 4 + lqo): a wave-uniform base + a 32-bit byte offset
+            // (slot-major: slot n of the cell is 8 records further; 384 queries x 8 x cap <= 8192 x 8 B < 2^32)
+            char *const cbase = reinterpret_cast<char *>(a.cand + seg_base + ((int64_t)(r - seg_r0) * a.nq_pad + q0) * 8 * cap + wd * 4);
+            const uint32_t row_lo = (uint32_t)(wd * 128 + 4 * lqo);       // + dt * 16 + e: row inside the tile
+            const int64_t tile_row0 = vt * a.tile_stride * TILE_DOCS;      // wave-uniform
+            const uint32_t rows_left = a.n_rows - tile_row0 < TILE_DOCS ? (uint32_t)(a.n_rows - tile_row0) : (uint32_t)TILE_DOCS;
 #pragma unroll
             for (int qt = 0; qt < WIDE_QT; ++qt) {
                 float sub[8];
 #pragma unroll
-                for (int dt = 0; dt < 8; ++dt)
-                    sub[dt] = fmaxf(fmaxf(acc[dt][qt][0], acc[dt][qt][1]), fmaxf(acc[dt][qt][2], acc[dt][qt][3]));
+                for (int dt = 0; dt < 8; ++dt) sub[dt] = max4_asm(acc[dt][qt]);
                 const float2 tc = s_tc[wq * 96 + qt * 16 + l15o];
                 const float t = fmaf(-tc.y, nt, tc.x);   // per-tile margin: mfma + cq * ||d|| >= tau_q with ||d|| <= nt
-                const float mall = fmaxf(fmaxf(fmaxf(sub[0], sub[1]), fmaxf(sub[2], sub[3])),
-                                         fmaxf(fmaxf(sub[4], sub[5]), fmaxf(sub[6], sub[7])));
+                float mall = max3_asm(sub[0], sub[1], sub[2]);
+                mall = max3_asm(mall, sub[3], sub[4]);
+                mall = max3_asm(mall, sub[5], sub[6]);
+                mall = fmaxf(mall, sub[7]);
                 if (__ballot(mall >= t) != 0ull) {
-                    const int q = q0 + wq * 96 + qt * 16 + l15o;
-                    uint2 *clist = a.cand + seg_base + ((int64_t)(r - seg_r0) * a.nq_pad + q) * 8 * cap + (wd * 4 + lqo);   // slot-major cell
+                    const uint32_t ql = (uint32_t)(wq * 96 + qt * 16 + l15o);
+                    const uint32_t cell = (ql * 8u * (uint32_t)cap + (uint32_t)lqo) * 8u;    // byte offset of slot 0
                     uint32_t *cn = s_cnt + (wv * WIDE_QT + qt) * 64 + lqo * 16 + l15o;
 #pragma unroll
                     for (int dt = 0; dt < 8; ++dt) {
@@ -920,11 +971,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16w_kernel(const Gem
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const float v = acc[dt][qt][e];
-                                const int64_t doc = row_base + dt * 16 + e;
-                                if (v >= t && doc < a.n_rows) {
-                                    const uint32_t n = *cn;
-                                    if (n < (uint32_t)cap) clist[(size_t)n * 8] = make_uint2(__float_as_uint(v), (uint32_t)doc);
-                                    *cn = n + 1u;
+                                const uint32_t row = row_lo + dt * 16 + e;
+                                if (v >= t && row < rows_left) {
+                                    const uint32_t n = __hip_atomic_fetch_add(cn, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // lane-private cell: one ds_add_rtn
+                                    if (n < (uint32_t)cap)
+                                        *reinterpret_cast<uint2 *>(cbase + (cell + n * 64u)) = make_uint2(__float_as_uint(v), (uint32_t)tile_row0 + row);
                                 }
                             }
                         }
@@ -933,10 +984,24 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16w_kernel(const Gem
             }
         };
 
+        // pieces in flight per wave and K step: 5 (production); the DMA ablations issue 0 / 4 or 0 / 1 or 5 per group
+        auto wait_all_but_one_step = [&]() __attribute__((always_inline)) {
+            if constexpr ((DBG & 4) != 0) {
+            } else if constexpr ((DBG & 32) != 0) {
+                if (!g1) wait_vm<4>();
+            } else if constexpr ((DBG & 64) != 0) {
+                if (!g1)
+                    wait_vm<1>();
+                else
+                    wait_vm<WIDE_PIECES>();
+            } else {
+                wait_vm<WIDE_PIECES>();
+            }
+        };
         const int npro = U < 2 ? U : 2;
         for (int i = 0; i < npro; ++i) issue();
         if (npro == 2)
-            wait_vm<WIDE_PIECES>();
+            wait_all_but_one_step();
         else
             CCR_WAIT_VM(0);
         CCR_BARRIER();
@@ -948,18 +1013,19 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16w_kernel(const Gem
         int64_t pending_vt = 0;
         float pending_nt = 0.f;
         int uslot = 0;
+        if constexpr ((DBG & 16) != 0) tprev = stamp();
         for (int u = 0; u < U; ++u) {
+            CCR_STAMP(0)  // barrier B wait (+ loop overhead)
             if (pending) {
                 epilogue(pending_vt, pending_nt);
                 pending = false;
             }
+            CCR_STAMP(1)  // tile epilogue (group 0)
             const char *abuf = smem + uslot * WIDE_SUB_BYTES;
             const char *bbuf = abuf + WIDE_Q_REGION;
             uslot = uslot == WIDE_RING - 1 ? 0 : uslot + 1;
-            const int ln = fresh_lane();
-            const int cofs = (((ln >> 4) ^ (((ln >> 2) & 1) << 1)) << 4);
-            const int a_base = (wd * 128 + (ln & 15)) * 64 + cofs;   // + dt * 1024
-            const int b_base = (wq * 96 + (ln & 15)) * 64 + cofs;    // + qt * 1024
+            const int a_base = wd * 128 * 64 + (int)lane_lds;   // + dt * 1024
+            const int b_base = wq * 96 * 64 + (int)lane_lds;    // + qt * 1024
             bf16x8 af[8], bfr[3];
 #pragma unroll
             for (int dt = 0; dt < 8; ++dt) af[dt] = *reinterpret_cast<const bf16x8 *>(abuf + a_base + dt * 1024);
@@ -967,14 +1033,40 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16w_kernel(const Gem
             for (int qt = 0; qt < 3; ++qt) bfr[qt] = *reinterpret_cast<const bf16x8 *>(bbuf + b_base + qt * 1024);
             if (u + 2 < U) {
                 issue();                           // pieces of u + 2 into the slot of u - 1
-                wait_vm<WIDE_PIECES>();            // own pieces of u + 1 have landed
+                CCR_STAMP(3)  // LDS read issue + DMA issue
+                wait_all_but_one_step();           // own pieces of u + 1 have landed
             } else {
                 CCR_WAIT_VM(0);
             }
+            CCR_STAMP(2)  // DMA wait
             // (group 0 could confirm its pieces as late as its B_u -- the barrier instance of g1's A_u --: measured 3 % slower)
             CCR_WAIT_LGKM0();
+            CCR_STAMP(6)  // operand reads landed
             CCR_BARRIER();
-            if (cks == 0) {
+            CCR_STAMP(4)  // barrier A wait
+            if constexpr ((DBG & 8) != 0) {   // no matrix work: the operand reads (refills included) stay, the accumulators are opaque
+#pragma unroll
+                for (int dt = 0; dt < 8; ++dt) asm volatile("" ::"v"(af[dt]));
+#pragma unroll
+                for (int qt = 0; qt < WIDE_QT; ++qt) {
+                    asm volatile("" ::"v"(bfr[qt % 3]));
+                    if (qt < 3) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        bfr[qt] = *reinterpret_cast<const bf16x8 *>(bbuf + b_base + (qt + 3) * 1024);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if (cks == 0) {
+#pragma unroll
+                    for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+                        for (int qt = 0; qt < WIDE_QT; ++qt) acc[dt][qt] = f32x4v{-1e30f, -1e30f, -1e30f, -1e30f};
+                }
+#pragma unroll
+                for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+                    for (int qt = 0; qt < WIDE_QT; ++qt) asm volatile("" : "+v"(acc[dt][qt]));
+            } else if (cks == 0) {
                 const f32x4v z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int qt = 0; qt < WIDE_QT; ++qt) {
@@ -999,6 +1091,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16w_kernel(const Gem
                     }
                 }
             }
+            CCR_STAMP(5)  // MFMA phase (issue of the 48 MFMAs and the refills)
             if (++cks == KS2) {
                 cks = 0;
                 // (the tile's norm bound: a SCALAR load + wait right here, behind the MFMAs just issued)
@@ -1013,7 +1106,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16w_kernel(const Gem
                 }
                 ++ct;
             }
+            CCR_STAMP(1)  // tile epilogue (group 1)
             CCR_WAIT_LGKM0();   // the refills of this K step are retired before the barrier behind which group 1 rewrites their rows
+            CCR_STAMP(7)  // MFMA drain: the step's last refills / MFMAs
             CCR_BARRIER();
         }
         if (pending) epilogue(pending_vt, pending_nt);
@@ -1026,6 +1121,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16w_kernel(const Gem
                 a.cnt[((int64_t)r * a.nq_pad + q0 + wq * 96 + qt * 16 + (ln & 15)) * 8 + wd * 4 + (ln >> 4)] = s_cnt[(wv * WIDE_QT + qt) * 64 + ln];
         }
         __syncthreads();
+    }
+    if constexpr ((DBG & 16) != 0) {
+        if (fresh_lane() == 0 && a.store) {
+            unsigned long long *o = reinterpret_cast<unsigned long long *>(a.store) + ((size_t)blockIdx.x * 8 + wv) * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = seg[i];
+        }
     }
 }
 
@@ -2178,7 +2280,17 @@ int launch_gemm16w_filter(const GemmArgs &a, int grid, hipStream_t s) {
         return CCR_ERR_INVALID;
     }
 #ifdef CCR_DIAGNOSTICS
-    if (a.dbg == 128) return launch_kernel(&gemm_topk16w_kernel<128>, WIDE_LDS, a, grid, s);
+    switch (a.dbg) {   // timing-only ablations (thresholds +inf in all of them)
+        case 16: return launch_kernel(&gemm_topk16w_kernel<16>, WIDE_LDS, a, grid, s);     // cycle stamps (results stay right)
+        case 128: return launch_kernel(&gemm_topk16w_kernel<128>, WIDE_LDS, a, grid, s);
+        case 132: return launch_kernel(&gemm_topk16w_kernel<132>, WIDE_LDS, a, grid, s);   // no DMA
+        case 136: return launch_kernel(&gemm_topk16w_kernel<136>, WIDE_LDS, a, grid, s);   // no MFMA
+        case 140: return launch_kernel(&gemm_topk16w_kernel<140>, WIDE_LDS, a, grid, s);   // neither: LDS reads + barriers + filter trees
+        case 160: return launch_kernel(&gemm_topk16w_kernel<160>, WIDE_LDS, a, grid, s);   // corpus pieces only
+        case 192: return launch_kernel(&gemm_topk16w_kernel<192>, WIDE_LDS, a, grid, s);   // query pieces only
+        case 168: return launch_kernel(&gemm_topk16w_kernel<168>, WIDE_LDS, a, grid, s);   // corpus pieces only, no MFMA
+        default: break;
+    }
 #endif
     return launch_kernel(&gemm_topk16w_kernel<0>, WIDE_LDS, a, grid, s);
 }
