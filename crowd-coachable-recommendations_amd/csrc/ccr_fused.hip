@@ -1016,6 +1016,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16w_kernel(const Gem
         if constexpr ((DBG & 16) != 0) tprev = stamp();
         for (int u = 0; u < U; ++u) {
             CCR_STAMP(0)  // barrier B wait (+ loop overhead)
+            // the pieces of u + 2 go out FIRST (into the slot of u - 1, free since the barrier just passed): the L1 miss path, which bounds
+            // the pass, gets its work at the start of the phase instead of behind the filter and the operand reads (-1 %; two pieces in
+            // front of the operand reads and three behind them: +3 %)
+            if (u + 2 < U) issue();
+            __builtin_amdgcn_sched_barrier(0);
+            CCR_STAMP(3)  // DMA issue
             if (pending) {
                 epilogue(pending_vt, pending_nt);
                 pending = false;
@@ -1031,13 +1037,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16w_kernel(const Gem
             for (int dt = 0; dt < 8; ++dt) af[dt] = *reinterpret_cast<const bf16x8 *>(abuf + a_base + dt * 1024);
 #pragma unroll
             for (int qt = 0; qt < 3; ++qt) bfr[qt] = *reinterpret_cast<const bf16x8 *>(bbuf + b_base + qt * 1024);
-            if (u + 2 < U) {
-                issue();                           // pieces of u + 2 into the slot of u - 1
-                CCR_STAMP(3)  // LDS read issue + DMA issue
+            if (u + 2 < U)
                 wait_all_but_one_step();           // own pieces of u + 1 have landed
-            } else {
+            else
                 CCR_WAIT_VM(0);
-            }
             CCR_STAMP(2)  // DMA wait
             // (group 0 could confirm its pieces as late as its B_u -- the barrier instance of g1's A_u --: measured 3 % slower)
             CCR_WAIT_LGKM0();
