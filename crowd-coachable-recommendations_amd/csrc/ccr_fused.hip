@@ -430,6 +430,20 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk_kernel(const GemmAr
 //   the 16x16 fragment read pattern; brute-forced over all xor tables).
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+// Maximum of a 16x16 MFMA tile's four registers in two VALU instructions (fmaxf() costs four: hipcc canonicalises the operands first).
+// Every VALU instruction of the filter counts: it is issued while the partner wave of the SIMD runs its MFMAs and gets a slot only now
+// and then (in-kernel stamps: the tile epilogue was 17 % of a wave's time with fmaxf trees and the first hit path).
+__device__ __forceinline__ float max4_asm(const f32x4v &c) {
+    float m;
+    asm("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32 %0, %0, %4" : "=&v"(m) : "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]));
+    return m;
+}
+__device__ __forceinline__ float max3_asm(float a, float b, float c) {
+    float m;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(a), "v"(b), "v"(c));
+    return m;
+}
+
 template <int EPI, int DBG, bool TAIL = false>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -604,11 +618,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
                 if (EPI == EPI_FILTER) {
                     float sub[8];
 #pragma unroll
-                    for (int dt = 0; dt < 8; ++dt)
-                        sub[dt] = fmaxf(fmaxf(acc[dt][qt][0], acc[dt][qt][1]), fmaxf(acc[dt][qt][2], acc[dt][qt][3]));
+                    for (int dt = 0; dt < 8; ++dt) sub[dt] = max4_asm(acc[dt][qt]);   // (two VALU instructions per tile instead of fmaxf's four)
                     const float t = fmaf(-cqv[qt], nt, thr[qt]);   // per-tile margin: mfma + cq * ||d|| >= tau_q with ||d|| <= nt
-                    const float mall = fmaxf(fmaxf(fmaxf(sub[0], sub[1]), fmaxf(sub[2], sub[3])),
-                                             fmaxf(fmaxf(sub[4], sub[5]), fmaxf(sub[6], sub[7])));
+                    float mall = max3_asm(sub[0], sub[1], sub[2]);
+                    mall = max3_asm(mall, sub[3], sub[4]);
+                    mall = max3_asm(mall, sub[5], sub[6]);
+                    mall = fmaxf(mall, sub[7]);
                     if (__ballot(mall >= t) != 0ull) {
 #pragma unroll
                         for (int dt = 0; dt < 8; ++dt) {
@@ -777,19 +792,6 @@ __device__ __forceinline__ int fresh_lane() {
     int l;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
     return l;
-}
-// Maximum of a 16x16 MFMA tile's four registers in two VALU instructions (fmaxf() costs four: hipcc canonicalises the operands first).
-// Every VALU instruction of the filter counts: it is issued while the partner wave of the SIMD runs its MFMAs and gets a slot only now
-// and then (in-kernel stamps: the tile epilogue was 17 % of a wave's time with fmaxf trees and the first hit path).
-__device__ __forceinline__ float max4_asm(const f32x4v &c) {
-    float m;
-    asm("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32 %0, %0, %4" : "=&v"(m) : "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]));
-    return m;
-}
-__device__ __forceinline__ float max3_asm(float a, float b, float c) {
-    float m;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(a), "v"(b), "v"(c));
-    return m;
 }
 constexpr int WIDE_SUB_BYTES = (TILE_DOCS + WIDE_Q) * SUB_K * 2;   // 40960
 constexpr int WIDE_Q_REGION = TILE_DOCS * SUB_K * 2;               // 16384

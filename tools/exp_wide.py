@@ -58,6 +58,7 @@ def one():
 _NH = {"CCR_PROGRESSIVE": "0", "CCR_OPTIMISTIC": "0"}
 SETS = {
     "ablate": [dict(_NH, CCR_GEMM_DBG=str(v)) for v in (128, 132, 136, 140, 160, 192, 168, 128)],
+    "narrow": [{"CCR_WIDE": "0"}, {"CCR_WIDE": "0", "CCR_PROGRESSIVE": "0"}, {"CCR_WIDE": "0"}],
     "ab": [{"CCR_WIDE": "0"}, {}, {"CCR_WIDE": "0"}, {}],
     "order": [{}, {"CCR_ITEM_SWAP": "1"}, {"CCR_QGROUPS": "1", "CCR_WIDE": "0", "CCR_PROGRESSIVE": "0"}, {}],
     "plans": [{"CCR_WIDE": "0"}, {}, {"CCR_OPTIMISTIC": "0"}, {"CCR_PROGRESSIVE": "0", "CCR_OPTIMISTIC": "0"}, {"CCR_WIDE": "0", "CCR_PROGRESSIVE": "0"},
