@@ -103,7 +103,9 @@ def main():
         if a.startswith("--slice="):
             lo, hi = a.split("=")[1].split(":")
             variants = variants[int(lo):int(hi)]
-    results = json.load(open(out_file)) if os.path.isfile(out_file) else {}
+    # (gpurun_out/ does not travel to the GPU box: a sliced run continues from the committed summary of the same name under profiles/)
+    seed = os.path.join(ROOT, "profiles", os.path.basename(out_file))
+    results = json.load(open(out_file)) if os.path.isfile(out_file) else (json.load(open(seed)) if os.path.isfile(seed) else {})
     for tag, extra, args in variants:
         env = dict(os.environ, **extra)
         rec = {"env": extra, "bench_args": args}
