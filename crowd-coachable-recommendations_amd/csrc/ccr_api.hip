@@ -1154,7 +1154,7 @@ static int search_impl(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k, fl
     gm.item_swap = (ix->knobs.item_swap && !p.item_a) ? 1 : 0;   // the phases' "ranges completed so far" needs the default order
     unsigned long long *stamps = nullptr;   // CCR_GEMM_DBG=16: in-kernel cycle stamps of the main pass (diagnostic build only)
 #ifdef CCR_DIAGNOSTICS
-    const bool want_stamps = ix->knobs.gemm_dbg == 16;
+    const bool want_stamps = ix->knobs.gemm_dbg == 16 || ix->knobs.gemm_dbg == 144;
 #else
     const bool want_stamps = false;
 #endif
