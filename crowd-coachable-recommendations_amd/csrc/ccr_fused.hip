@@ -766,8 +766,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
 // per K step for 1.5x the multiply-adds: -17 % bytes per flop through that path, 14 instead of 18 operand reads per 48 MFMAs, and a
 // query count like 3 452 pads to 3 456 (nine blocks) instead of 3 584.  Same occupancy (two waves per SIMD), same ping-pong of the two
 // wave groups, same LDS image and swizzle, same candidate layout (8 sub-lists per (range, query): wave row x lane >> 4).
-//   registers: 192 accumulators + 8 corpus fragments (32) + 3 query fragments (12; the other three are refilled IN PLACE behind the
-//     MFMAs of the first three query tiles) -- so nothing else may live in registers across the K loop: the thresholds and margin
+//   registers: 192 accumulators + 8 corpus fragments (32) + 6 query fragments (24) = 248 -- so nothing else may live in registers across
+//     the K loop but two lane offsets (WIDE_BFR = 3, the first form: three query fragments, the other three refilled IN PLACE behind
+//     the MFMAs of the first three query tiles; 1.4 % slower -- the refills queue behind the partner's operand reads): the thresholds and margin
 //     coefficients of the block's 384 queries and the sub-list counters sit in LDS, candidate addresses are rebuilt on a hit, the lane
 //     id is recomputed where it is needed (fresh_lane) and the DMA source of every piece is a wave-uniform base + one clamped per-lane
 //     offset computed at issue;
@@ -776,14 +777,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16_kernel(const Gemm
 //     separate rings -- corpus four slots deep, fetched by group 0, queries three, fetched by group 1 -- measured 2-3 % slower;
 //   protocol, K step u (A_u / B_u: the barriers in front of and behind the step's MFMAs; g1 runs one barrier behind: g1's A_u is the
 //     barrier instance of g0's B_u):
-//     mem(u): [filter of a finished tile] 8 + 3 ds_read_b128 of u | pieces of u + 2 into the slot of u - 1 | own pieces of u + 1
-//             landed (vmcnt) | lgkmcnt(0) | A_u | 48 MFMAs with the three refills | [g1: filter] | lgkmcnt(0) | B_u
+//     mem(u): pieces of u + 2 into the slot of u - 1 | [g0: filter of a finished tile] | 8 + 6 ds_read_b128 of u | own pieces of u + 1
+//             landed (vmcnt) | lgkmcnt(0) | A_u | 48 MFMAs | [g1: filter] | lgkmcnt(0) | B_u
 //     RAW: a wave confirms its pieces of u + 1 before its A_u; the first reader of u + 1 starts behind a later barrier instance.
 //     WAR: the slot of u - 1 is rewritten in mem(u).  Fragments read in mem(u - 1) were retired before the reader's A_{u-1}, which
-//          for both groups precedes every mem(u).  The REFILLS (query tiles 3-5 of a wave = rows 48-95 of its 96-row group) are read
-//          during the MFMAs and retired only before B_{u-1}: g1's B_{u-1} is behind the start of g0's mem(u), so GROUP 0 FETCHES NO
-//          REFILL ROW -- its waves take the 16 corpus pieces and rows 0-15 of each query group, group 1 (whose mem(u) starts behind
-//          its own B_{u-1} and behind g0's) the query rows 16-95.
+//          for both groups precedes every mem(u).  With WIDE_BFR = 3 the REFILLS (query tiles 3-5 of a wave = rows 48-95 of its
+//          96-row group) are read during the MFMAs and retired only before B_{u-1}: g1's B_{u-1} is behind the start of g0's mem(u),
+//          so GROUP 0 FETCHES NO REFILL ROW -- its waves take the 16 corpus pieces and rows 0-15 of each query group, group 1 (whose
+//          mem(u) starts behind its own B_{u-1} and behind g0's) the query rows 16-95.  (The assignment is kept with six resident
+//          fragments: it costs nothing.)
 // dim % 32 == 0 only (the planner keeps the 256 x 256 kernel elsewhere).  DBG 128 (diagnostic library): thresholds +inf.
 
 // The lane id, computed where it is needed (two VALU instructions) instead of living in a register across the K loop: the wide kernel
@@ -815,6 +817,9 @@ constexpr int WIDE_Q_REGION = TILE_DOCS * SUB_K * 2;               // 16384
 constexpr int WIDE_RING = 3;
 constexpr int WIDE_PIECES = 5;                                     // 40 pieces of 1 KiB per K step over 8 waves
 constexpr int WIDE_QT = 6;                                         // query tiles of 16 per wave
+#ifndef WIDE_BFR
+#define WIDE_BFR 6                                                 // query fragments resident per K step: 6, or 3 + three refills (the A/B)
+#endif
 constexpr int WIDE_RING_BYTES = WIDE_RING * WIDE_SUB_BYTES;        // 122880
 constexpr size_t WIDE_LDS = (size_t)WIDE_RING_BYTES + WIDE_Q * 8 + (size_t)(GEMM_THREADS / 64) * WIDE_QT * 64 * 4;   // 138240
 
@@ -1053,11 +1058,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16w_kernel(const Gem
             uslot = uslot == WIDE_RING - 1 ? 0 : uslot + 1;
             const int a_base = wd * 128 * 64 + (int)lane_lds;   // + dt * 1024
             const int b_base = wq * 96 * 64 + (int)lane_lds;    // + qt * 1024
-            bf16x8 af[8], bfr[3];
+            bf16x8 af[8], bfr[WIDE_BFR];
 #pragma unroll
             for (int dt = 0; dt < 8; ++dt) af[dt] = *reinterpret_cast<const bf16x8 *>(abuf + a_base + dt * 1024);
 #pragma unroll
-            for (int qt = 0; qt < 3; ++qt) bfr[qt] = *reinterpret_cast<const bf16x8 *>(bbuf + b_base + qt * 1024);
+            for (int qt = 0; qt < WIDE_BFR; ++qt) bfr[qt] = *reinterpret_cast<const bf16x8 *>(bbuf + b_base + qt * 1024);
             if (u + 2 < U)
                 wait_all_but_one_step();           // own pieces of u + 1 have landed
             else
@@ -1073,8 +1078,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16w_kernel(const Gem
                 for (int dt = 0; dt < 8; ++dt) asm volatile("" ::"v"(af[dt]));
 #pragma unroll
                 for (int qt = 0; qt < WIDE_QT; ++qt) {
-                    asm volatile("" ::"v"(bfr[qt % 3]));
-                    if (qt < 3) {
+                    asm volatile("" ::"v"(bfr[qt % WIDE_BFR]));
+                    if (WIDE_BFR == 3 && qt < 3) {
                         __builtin_amdgcn_sched_barrier(0);
                         bfr[qt] = *reinterpret_cast<const bf16x8 *>(bbuf + b_base + (qt + 3) * 1024);
                         __builtin_amdgcn_sched_barrier(0);
@@ -1095,8 +1100,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16w_kernel(const Gem
 #pragma unroll
                 for (int qt = 0; qt < WIDE_QT; ++qt) {
 #pragma unroll
-                    for (int dt = 0; dt < 8; ++dt) acc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[dt], bfr[qt % 3], z, 0, 0, 0);
-                    if (qt < 3) {
+                    for (int dt = 0; dt < 8; ++dt) acc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[dt], bfr[qt % WIDE_BFR], z, 0, 0, 0);
+                    if (WIDE_BFR == 3 && qt < 3) {
                         __builtin_amdgcn_sched_barrier(0);
                         bfr[qt] = *reinterpret_cast<const bf16x8 *>(bbuf + b_base + (qt + 3) * 1024);
                         __builtin_amdgcn_sched_barrier(0);
@@ -1107,8 +1112,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_topk16w_kernel(const Gem
                 for (int qt = 0; qt < WIDE_QT; ++qt) {
 #pragma unroll
                     for (int dt = 0; dt < 8; ++dt)
-                        acc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[dt], bfr[qt % 3], acc[dt][qt], 0, 0, 0);
-                    if (qt < 3) {
+                        acc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[dt], bfr[qt % WIDE_BFR], acc[dt][qt], 0, 0, 0);
+                    if (WIDE_BFR == 3 && qt < 3) {
                         __builtin_amdgcn_sched_barrier(0);
                         bfr[qt] = *reinterpret_cast<const bf16x8 *>(bbuf + b_base + (qt + 3) * 1024);
                         __builtin_amdgcn_sched_barrier(0);
