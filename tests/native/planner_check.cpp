@@ -21,6 +21,7 @@ int main() {
     kn.mfma16 = -1;
     kn.stagger = 1;
     kn.optimistic = -1;   // the planner's choice, as in production
+    kn.wide = -1;         // 256 x 384 main-pass tiles where the planner prices them in
     const long long rows[] = {300, 9862, 70000, 335184, 1105228, 2681468, 8841823, 6250000};
     const int dims[] = {64, 768, 1024};
     const int nqs[] = {1, 40, 300, 3452, 6980, 10000};
@@ -36,16 +37,26 @@ int main() {
                     if (p.total == 0) bad += fail("empty workspace", n, d, nq, k);
                     if (!p.fused) continue;
                     ++fused;
-                    const int nrc = NUM_XCD / p.qgroups, qb_per = p.qblocks / p.qgroups, per_x = p.grid / NUM_XCD;
+                    // work items of the MAIN pass: blocks of p.tile_q queries (256, or 384 with the wide tile) in p.main_qgroups groups
+                    const int nrc = NUM_XCD / p.main_qgroups, qb_per = p.main_qblocks / p.main_qgroups, per_x = p.grid / NUM_XCD;
                     const int items = p.ranges / nrc * qb_per;
                     if (p.nq_pad % TILE_Q || p.nq_pad < nq || p.qblocks * TILE_Q != p.nq_pad) bad += fail("query padding", n, d, nq, k);
                     if (p.qblocks % p.qgroups || NUM_XCD % p.qgroups) bad += fail("query groups", n, d, nq, k);
+                    if (p.tile_q != TILE_Q && p.tile_q != WIDE_Q) bad += fail("main-pass tile", n, d, nq, k);
+                    if (p.main_qblocks != (nq + p.tile_q - 1) / p.tile_q || (long long)p.main_qblocks * p.tile_q > p.nq_pad)
+                        bad += fail("main-pass query blocks (every column of every block needs its counters)", n, d, nq, k);
+                    if (p.main_qblocks % p.main_qgroups || NUM_XCD % p.main_qgroups) bad += fail("main-pass query groups", n, d, nq, k);
+                    if (p.tile_q == WIDE_Q && (d % 32 || !p.mfma16 || p.narrow)) bad += fail("wide tile where its kernel does not apply", n, d, nq, k);
+                    // the planner's choices this round measured: nine 384-blocks at NQ, 256-blocks where the block count cannot be grouped
+                    if (d == 768 && nq == 3452 && p.tile_q != WIDE_Q) bad += fail("NQ batch not on the wide tile", n, d, nq, k);
+                    if (d == 768 && nq == 6980 && p.tile_q != TILE_Q) bad += fail("19 ungroupable 384-blocks chosen", n, d, nq, k);
+                    if (nq == 300 && d % 32 == 0 && !p.narrow && p.mfma16 && p.tile_q != WIDE_Q) bad += fail("300 queries not in one 384-block", n, d, nq, k);
                     if (p.ranges % NUM_XCD || p.ranges < NUM_XCD) bad += fail("ranges not a multiple of the XCD count", n, d, nq, k);
                     if (p.sublists != (p.mfma16 ? 8 : 4)) bad += fail("sublists", n, d, nq, k);
                     // 2 048 sub-lists is what the select stage's wide form and the threshold update walk; above 1 024 only at large k or
                     // when one or two query blocks would otherwise leave workgroups without a work item
                     if (p.ranges * p.sublists > 2048) bad += fail("too many sub-lists for the select stage", n, d, nq, k);
-                    if (p.ranges * p.sublists > 1024 && p.rescore_cap <= 512 && (1024 / p.sublists) * p.qblocks >= p.grid)
+                    if (p.ranges * p.sublists > 1024 && p.rescore_cap <= 512 && (1024 / p.sublists) * p.main_qblocks >= p.grid)
                         bad += fail("more than 1 024 sub-lists without need", n, d, nq, k);
                     if (p.item_a < 0 || p.item_b < 0 || (p.item_b && p.item_b <= p.item_a) || p.item_a > items || p.item_b > items)
                         bad += fail("phase ends", n, d, nq, k);
