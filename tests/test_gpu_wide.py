@@ -53,6 +53,9 @@ def _index(Db, wide, **kv):
     (9000, 130, 32, 5),        # ONE K step per tile
     (40000, 1153, 96, 50),     # four blocks, the last with a single row
     (40000, 770, 128, 1001),   # large k
+    (300, 200, 32, 10),        # ONE full corpus tile + 44 rows, one K step: an item is a single K step (more ranges than tiles)
+    (513, 385, 64, 5),         # two tiles and one row; a second query block of one row
+    (2048, 384, 32, 16),       # eight whole tiles, one whole block
 ])
 def test_wide_main_pass_equals_the_oracle(n, nq, d, k):
     Db, Qb = _rand_bits(n, d, n + 3), _rand_bits(nq, d, nq + 5)
