@@ -557,13 +557,14 @@ def bm25_side_run(dev, docs=500_000, queries=2000, vocab=50_000, k=1001, cpu_que
     return out
 
 
-def small_batches_side_run(index, qpack, n_rows, dim, k=TOP_K, sizes=(1, 16, 64, 128, 256, 512), reps=20):
+def small_batches_side_run(index, qpack, n_rows, dim, k=TOP_K, sizes=(1, 16, 64, 128, 256, 384, 512), reps=20):
     """SURVEY 8d's small query batches (Q in {1, 16, 64, 512}; 256 = one full query tile) on the resident NQ index: search-only time
     (the index and the packed queries exist: an interactive ranking() call against an encoded corpus), `reps` searches back to back, each
     completed before the next starts.  Below a few hundred queries the main pass can at best stream the corpus once: `roofline` is the
     HBM one, bytes = 2 N d per search, the main pass's duration from the library's events on the search stream.  n_q <= 64
     runs the streaming main pass (csrc/ccr_narrow.hip), 65 .. 128 the same kernel as two query groups on paired workgroups (every row
-    pulled twice, once of them from the L2 / the Infinity Cache), larger batches the tile kernels."""
+    pulled twice, once of them from the L2 / the Infinity Cache), larger batches the tile kernels (257 .. 384 queries: ONE block of the
+    256 x 384 form of the main pass instead of two 256-query blocks)."""
     out = {"workload": f"configs[1] corpus resident and indexed, top-{k}, batches of n_q queries (search only)", "unit": "ms per search", "batches": {}}
     pmc = None
     try:
@@ -591,7 +592,7 @@ def small_batches_side_run(index, qpack, n_rows, dim, k=TOP_K, sizes=(1, 16, 64,
             "ms_per_search": round(ms, 4), "queries_per_s": round(nq / ms * 1e3, 1), "phases_ms": phases_obj(st),
             "main_pass": ("narrow_filter_kernel (streaming: queries resident in LDS, corpus straight into the MFMA operand registers"
                           + (")" if nq <= 64 else "; two query groups on paired workgroups)")) if st.get("ranges") == 1 and st.get("sublists") == 2
-                         else "gemm_topk16_kernel<EPI_FILTER> (256-query tiles)",
+                         else ("gemm_topk16w_kernel (384-query tiles)" if st.get("main_tile_queries") == 384 else "gemm_topk16_kernel<EPI_FILTER> (256-query tiles)"),
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                          "bytes_per_search": bytes_, "main_pass_ms": round(main, 4), "traffic": traffic,
                          "traffic_source": "offline rocprofv3 --pmc passes (profiles/r06_small_batches_pmc.json: FETCH_SIZE x 2 + WRITE_SIZE of one search's main-pass launches); not measured in this run" if traffic else None}}
