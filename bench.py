@@ -213,6 +213,9 @@ class Workload:
                        "message": None} for _ in range(2)]
         self.shard, self.qpack = self.slots[0]["shard"], self.slots[0]["qpack"]
         self.prev = None        # the step whose search / exchange is still in flight
+        # the pack of step i + 1 (HBM-bound, its own buffers) runs on a side stream from the moment the main pass of step i is done: beside
+        # step i's select stage (gather- and latency-bound) instead of behind it
+        self.side = torch.cuda.Stream(device=dev) if (str(dev).startswith("cuda") and os.environ.get("CCR_BENCH_SIDE_PACK", "1") != "0") else None
         self.nstep = 0
         self.suspended_at_step = None
         self.index = self.scores = self.ids = None
@@ -252,7 +255,17 @@ class Workload:
             self.done_stats, self.repeats, self.fallback_queries, self.wait_ms, self.host_syncs = counters
         b = self.slots[self.nstep % 2]
         self.nstep += 1
-        ops.pack_bf16(self.corpus_f32, out=b["shard"], norm_bounds=b["bounds"], normalize=self.normalize)   # pack + norm bound of every packed row in one pass
+        if self.side is not None:
+            main = torch.cuda.current_stream()
+            if self.prev is not None:
+                self.prev[0].stream_wait_main_pass(self.side)   # (the slot's buffers were last read by the search TWO steps ago, long complete by then)
+            else:
+                self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):
+                ops.pack_bf16(self.corpus_f32, out=b["shard"], norm_bounds=b["bounds"], normalize=self.normalize)
+            main.wait_stream(self.side)
+        else:
+            ops.pack_bf16(self.corpus_f32, out=b["shard"], norm_bounds=b["bounds"], normalize=self.normalize)   # pack + norm bound of every packed row in one pass
         index = ops.CorpusIndex(b["shard"], global_row_offset=self.lo, norm_bounds=b["bounds"], workspace=b["ws"])
         ops.pack_bf16(self.queries_f32, out=b["qpack"], normalize=self.normalize)
         if self.world > 1:
@@ -751,7 +764,8 @@ def main():
         "config": {"workload": workload, "corpus_rows": args.rows,
                    "dim": args.dim, "queries": args.queries, "k": args.k,
                    "step": "pack corpus shard fp32->bf16 + index build + pack queries + fused MFMA score/top-k (asynchronous: the host enqueues "
-                           "step i + 1 before it completes step i)"
+                           "step i + 1 before it completes step i; the corpus pack of step i + 1 runs on a side stream from the end of step i's main "
+                           "pass, beside its select stage)"
                            + (" + RCCL all-gather of the packed shard message + merge (the exchange of step i overlaps the pack and search of step i + 1)" if world > 1 else ""),
                    "parallelism": f"row-shard x{world}"},
         "roofline": roofline_obj(r, traffic, traffic_source),

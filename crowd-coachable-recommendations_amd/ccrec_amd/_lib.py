@@ -23,6 +23,7 @@ EXPORTS = [
     "ccr_attention_bf16", "ccr_add_layernorm", "ccr_meanpool_pack_bf16_packed", "ccr_embed_layernorm", "ccr_gelu_bf16",
     "ccr_attention_half", "ccr_add_layernorm_half", "ccr_embed_layernorm_half", "ccr_gelu_half", "ccr_merge_short_lists",
     "ccr_bm25_search_workspace_bytes_k", "ccr_bm25_search_last_stats", "ccr_bm25_index_set_idf", "ccr_inbatch_pack3_bf16", "ccr_inbatch_ce_fwd_f32",
+    "ccr_search_stream_wait_main_pass",
 ]
 
 SHARD_HEADER_BYTES = 32
@@ -91,6 +92,7 @@ def load():
     lib.ccr_inbatch_ce_fwd_f32.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp, vp, vp, sz, vp]
     lib.ccr_rank_metrics.argtypes = [vp, i32, i32, vp, vp, vp, i32, vp, vp, vp]
     lib.ccr_search_finish.argtypes = [vp]
+    lib.ccr_search_stream_wait_main_pass.argtypes = [vp, vp]
     lib.ccr_scores.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.ccr_search_blocked_workspace_bytes.argtypes = [vp, i32, i32, vp]
     lib.ccr_search_blocked_workspace_bytes.restype = sz

@@ -352,6 +352,11 @@ class CorpusIndex:
             _lib.check(self._lib.ccr_search_finish(self._h), "ccr_search_finish")
         self._deferred = None
 
+    def stream_wait_main_pass(self, stream):
+        """ccr_search_stream_wait_main_pass: `stream` (a torch.cuda.Stream) waits for the main pass of this index's last search -- deferred
+        or not --: work on it that does not touch the search's buffers then runs beside the search's select stage."""
+        _lib.check(self._lib.ccr_search_stream_wait_main_pass(self._h, ctypes.c_void_p(stream.cuda_stream)), "ccr_search_stream_wait_main_pass")
+
     def search_shard(self, queries_bf16, k, message, defer=False, flags=_lib.SEARCH_DEFAULT):
         """ccr_search_shard: the search writes the packed shard message (header | scores | u32 local rows) that ONE all-gather
         moves (dist.ShardMessage.send).  `message`: uint8 cuda tensor of ccr_shard_message_bytes(n_q, k).  defer=True: no host

@@ -664,6 +664,13 @@ extern "C" size_t ccr_search_workspace_bytes(const ccr_index *ix, int n_q, int k
     return std::max({a.total, b.total, c.total}) + 256;
 }
 
+extern "C" int ccr_search_stream_wait_main_pass(const ccr_index *ix, void *stream) {
+    CCR_REQUIRE(ix, "ccr_search_stream_wait_main_pass: null index");
+    if (!ix->main_pass_recorded) return CCR_OK;   // dense path / no search yet: nothing to order against
+    CCR_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, ix->ev[4], 0));
+    return CCR_OK;
+}
+
 extern "C" int ccr_search_last_stats(const ccr_index *ix, ccr_search_stats *stats) {
     CCR_REQUIRE(ix && stats, "ccr_search_last_stats: null pointer");
     CCR_REQUIRE(!ix->pending.active, "ccr_search_last_stats: an asynchronous search is pending (call ccr_search_finish first)");
@@ -1038,6 +1045,7 @@ static int search_impl(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k, fl
     CCR_REQUIRE((uintptr_t)Q_bf16 % 16 == 0, "ccr_search: query pointer must be 16-byte aligned");
     CCR_REQUIRE(!ix->pending.active, "ccr_search: an asynchronous search is pending on this index (call ccr_search_finish first)");
     memset(&ix->stats, 0, sizeof(ix->stats));
+    ix->main_pass_recorded = false;
     if (n_q == 0) return CCR_OK;
     hipStream_t s = (hipStream_t)stream;
     ix->id_out = id_out;
@@ -1194,6 +1202,7 @@ static int search_impl(ccr_index *ix, const uint16_t *Q_bf16, int n_q, int k, fl
     }
     if (rc != CCR_OK) return rc;
     CCR_HIP_CHECK(hipEventRecord(ix->ev[4], s));
+    ix->main_pass_recorded = true;
     if (want_stamps) {
         std::vector<unsigned long long> h((size_t)p.grid * 64);
         CCR_HIP_CHECK(hipMemcpyAsync(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost, s));

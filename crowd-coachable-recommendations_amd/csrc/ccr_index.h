@@ -105,6 +105,7 @@ struct ccr_index {
     float *row_norm_own;     // the latter (per-device block cache), else null
     size_t row_bytes;
     bool have_events;
+    bool main_pass_recorded;   // ev[4] was recorded by the last search (fused path): ccr_search_stream_wait_main_pass has something to wait for
     int num_cu;
     int device;
     ccr::Knobs knobs;

@@ -230,6 +230,14 @@ int ccr_search(ccr_index *index, const uint16_t *Q_bf16, int n_q, int k, float *
                void *workspace, size_t ws_bytes, int flags, void *stream);
 int ccr_search_finish(ccr_index *index);
 int ccr_search_last_stats(const ccr_index *index, ccr_search_stats *stats /* host */);
+/*
+ * Makes `stream` wait until the MAIN PASS (the dominant kernel) of the index's last search -- possibly still pending
+ * (CCR_SEARCH_ASYNC) -- has completed on the search's stream.  Work that does not depend on that search's results and does not
+ * touch its buffers (packing the NEXT corpus shard into another buffer, the reference's next `embedding_func` batch of
+ * scripts/ms_marco_eval.py:141-149) can then run beside the search's select stage instead of behind it.  No-op when the
+ * last search took the dense path (nothing recorded).  No host synchronisation.
+ */
+int ccr_search_stream_wait_main_pass(const ccr_index *index, void *stream);
 
 /*
  * Dense score matrix of n_q queries against the shard: out [n_q][n_rows] fp32.
