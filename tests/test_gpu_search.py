@@ -709,3 +709,33 @@ def test_short_list_exchange_result_never_waits_for_later_work_on_the_compute_st
     assert ex.host_syncs == 0 and ex.fallback_queries == 0 and not ex.repeated
     assert torch.equal(i, i1) and torch.equal(s.view(torch.int32), s1.view(torch.int32))
     assert still_running and t_result < 0.05, (t_enqueue, t_result)
+
+
+def test_stream_wait_main_pass_orders_a_side_stream_behind_the_dominant_kernel():
+    """ccr_search_stream_wait_main_pass: a side stream made to wait for the main pass of a deferred search packs ANOTHER shard beside the
+    search's select stage; the search's results are those of a plain search, the pack's bits those of a pack on the main stream; after a
+    dense-path search (nothing recorded) the call is a no-op."""
+    from ccrec_amd import ops
+    n, nq, d, k = 300_000, 400, 256, 100
+    Db, Qb = _rand_bits(n, d, 301), _rand_bits(nq, d, 302)
+    index = ops.CorpusIndex(_bf16(Db))
+    Q = _bf16(Qb)
+    s0, i0 = index.search(Q, k, FUSED)
+    x = torch.randn(200_000, d, device="cuda")
+    want = ops.pack_bf16(x)
+    side = torch.cuda.Stream()
+    out = torch.empty_like(want)
+    torch.cuda.synchronize()
+    s, i = index.search(Q, k, FUSED, defer=True)
+    index.stream_wait_main_pass(side)
+    with torch.cuda.stream(side):
+        ops.pack_bf16(x, out=out)
+    torch.cuda.current_stream().wait_stream(side)
+    index.finish()
+    torch.cuda.synchronize()
+    assert torch.equal(i, i0) and torch.equal(s.view(torch.int32), s0.view(torch.int32))
+    assert torch.equal(out.view(torch.int16), want.view(torch.int16))
+    assert index.last_stats()["path"] == 1
+    index.search(Q[:3], k, DENSE)
+    index.stream_wait_main_pass(side)       # dense path: no event recorded, returns at once
+    side.synchronize()
