@@ -75,6 +75,7 @@ def test_wide_main_pass_equals_the_oracle(n, nq, d, k):
     (300_000, 1100, 256, 1001, {}),                        # estimated thresholds (large k)
     (250_003, 3452, 128, 100, {}),                         # nine blocks, several items per workgroup, partial last tile
     (200_000, 390, 768, 10, {"CCR_QGROUPS": 2}),           # two blocks as two query groups over the XCDs
+    (150_000, 3072, 768, 100, {}),                         # eight blocks: the planner's own two groups of four (4.7 MiB would not fit one L2)
 ])
 def test_wide_main_pass_equals_the_narrow_tile_and_the_dense_path(n, nq, d, k, extra):
     Db, Qb = _rand_bits(n, d, n + 11), _rand_bits(nq, d, nq + 13)
