@@ -3,7 +3,7 @@
 are multiples of 32, k from 1 to 2 500 --, clustered corpora in random or topical order, duplicate rows (mass ties), norm outliers,
 half of the cases with CCR_WIDE=1 pinned and half on the planner's choice; every case against the exact dense path of the same index,
 ids and score bits.
-  python tools/soak_wide.py [cases]"""
+  python tools/soak_wide.py [cases] [seed base]"""
 import os
 import sys
 
@@ -15,10 +15,11 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "crowd-coachable-recommendations_amd")]
 from ccrec_amd import ops  # noqa: E402
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+seed_base = int(sys.argv[2]) if len(sys.argv) > 2 else 6000      # python tools/soak_wide.py 100 7000: another hundred cases
 dev = "cuda"
 used = mism = flagged = 0
 for c in range(cases):
-    rs = np.random.RandomState(6000 + c)
+    rs = np.random.RandomState(seed_base + c)
     n = int(rs.randint(20_000, 1_500_000))
     d = int(rs.choice([32, 64, 96, 128, 256, 384, 768, 1024]))
     nq = int(rs.choice([rs.randint(130, 400), rs.randint(400, 1600), rs.randint(1600, 4000)]))
@@ -27,7 +28,7 @@ for c in range(cases):
     k = int(rs.choice([1, 10, 100, 500, 1001, 2500]))
     k = min(k, n)
     ncl = int(rs.choice([1, 16, 512]))
-    g = torch.Generator(device=dev).manual_seed(c)
+    g = torch.Generator(device=dev).manual_seed(seed_base + c)
     D = torch.randn(n, d, generator=g, device=dev) * d ** -0.5
     if ncl > 1:
         centres = torch.randn(ncl, d, generator=g, device=dev) * d ** -0.5
